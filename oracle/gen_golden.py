@@ -1,0 +1,371 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the UNMODIFIED reference (this container only).
+
+TEST INFRASTRUCTURE ONLY.  Run:   python oracle/gen_golden.py [--out tests/golden]
+
+What it does, per case:
+  1. builds the reference model (`slowfast.models.build_model`, imported from
+     /root/reference through oracle/ref_shim.py) on CPU, fp32;
+  2. loads the closed-form weights of oracle/procedural.py (`load_state_dict`, strict);
+  3. runs the reference forward (+ loss + backward) on closed-form inputs;
+  4. runs the build's CPU restatement (oracle/svit_ref.py) on the same tensors and records
+     the max-abs disagreement (the restatement is *pinned* by this);
+  5. writes small fixtures: full tensors where small, digests (oracle/procedural.digest)
+     where large.
+Only arrays / numbers produced by running the reference are written -- no reference source.
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import numpy as np
+import torch
+
+import procedural as P
+import ref_shim
+import svit_ref as R
+
+torch.set_num_threads(8)
+SMALL = 1024  # tensors up to this many elements are stored in full
+
+
+def build_reference(num_frames, crop, drop_path=0.0, dropout=0.0, extra=()):
+    cfg = ref_shim.reference_cfg(num_frames, crop, overrides=(
+        "MVIT.DROPPATH_RATE", drop_path, "MODEL.DROPOUT_RATE", dropout) + tuple(extra))
+    from slowfast.models import build_model
+    model = build_model(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = P.state_dict(shapes)
+    model.load_state_dict(sd, strict=True)
+    return cfg, model, shapes, sd
+
+
+def maxabs(a, b):
+    if a is None:  # the restatement leaves untouched params without a grad; the reference's
+        a = torch.zeros_like(b)  # 0*sum(params) touch gives them exact zeros
+    return float((a.detach().double() - b.detach().double()).abs().max())
+
+
+def relerr(a, b, floor=1e-6):
+    """max-abs error relative to the tensor's scale; `floor` keeps mathematically-zero grads
+    (e.g. attn.norm_k.bias: softmax is invariant to a per-row constant) from reading as 100%."""
+    return maxabs(a, b) / max(float(b.detach().abs().max()), floor)
+
+
+def store(arrays, digests, key, t):
+    t = t.detach()
+    if t.numel() <= SMALL:
+        arrays[key] = t.to(torch.float32).numpy()
+    digests[key] = P.digest(t)
+
+
+def run_model_case(name, num_frames, crop, batch, out_dir, manifest, backward=True,
+                   frames_path=False, eval_too=False, drop=False):
+    torch.manual_seed(0)
+    dp, do = (0.4, 0.5) if drop else (0.0, 0.0)
+    cfg, model, shapes, sd = build_reference(num_frames, crop, dp, do)
+    spec = R.make_spec(num_frames=num_frames, crop=crop, drop_path_rate=dp, dropout_rate=do)
+    assert R.param_shapes(spec) == shapes, "state_dict layout mismatch vs reference"
+    x = P.frames(batch, 1 if frames_path else num_frames, crop)
+    if frames_path:
+        x = x  # [B,3,1,S,S]: the T=1 path of a num_frames model (train_net.py:105-110)
+    y = P.labels(batch)
+    arrays, digests, agree = {}, {}, {}
+
+    # ---- reference, train mode -----------------------------------------------------
+    model.train()
+    taps_ref = {}
+    hooks = []
+    for i, blk in enumerate(model.blocks):
+        hooks.append(blk.register_forward_hook(
+            lambda m, inp, out, i=i: taps_ref.__setitem__("block%d" % i, out[0].detach())))
+    masks = {}
+    if drop:
+        from slowfast.models.common import DropPath
+        for i, blk in enumerate(model.blocks):
+            if isinstance(blk.drop_path, DropPath):
+                def grab(m, inp, out, i=i):
+                    xin, xout = inp[0].detach(), out.detach()
+                    idx = xin.flatten(1).abs().argmax(dim=1)
+                    num = xout.flatten(1).gather(1, idx[:, None])[:, 0]
+                    den = xin.flatten(1).gather(1, idx[:, None])[:, 0]
+                    masks.setdefault(i, []).append(num / den)
+                hooks.append(blk.drop_path.register_forward_hook(grab))
+        def grab_do(m, inp, out):
+            masks["dropout"] = (out.detach() != 0).float() / (1 - do)
+        hooks.append(model.head.dropout.register_forward_hook(grab_do))
+    logits, extra = model([x], {})
+    for h in hooks:
+        h.remove()
+    loss = torch.nn.functional.cross_entropy(logits, y)
+    if backward:
+        model.zero_grad()
+        loss.backward()
+
+    # ---- restatement on the same tensors -------------------------------------------
+    p = {k: v.clone().requires_grad_(backward) for k, v in sd.items()}
+    drop_scales = None
+    dropout_keep = None
+    if drop:
+        drop_scales = [None if i not in masks else (masks[i][0], masks[i][1])
+                       for i in range(spec.depth)]
+        dropout_keep = masks["dropout"]
+        for i, m in masks.items():
+            if i != "dropout":
+                arrays["dp_attn_%d" % i] = m[0].numpy()
+                arrays["dp_mlp_%d" % i] = m[1].numpy()
+        arrays["dropout_keep"] = dropout_keep.numpy().astype(np.float32) \
+            if dropout_keep.numel() <= 65 * 768 * 4 else None
+        if arrays["dropout_keep"] is None:
+            del arrays["dropout_keep"]
+    taps = {}
+    lg, ex = R.forward(p, spec, x, training=True, drop_scales=drop_scales,
+                       dropout_keep=dropout_keep, taps=taps)
+    ls = R.video_loss(lg, y)
+    if backward:
+        ls.backward()
+
+    agree["logits"] = maxabs(lg, logits)
+    agree["loss"] = maxabs(ls, loss)
+    for k in extra:
+        agree[k] = maxabs(ex[k], extra[k])
+    for i in range(spec.depth):
+        agree["block%d_rel" % i] = relerr(taps["block%d" % i], taps_ref["block%d" % i])
+    if backward:
+        worst, worst_name = 0.0, ""
+        gmax = max(float(v.grad.abs().max()) for v in model.parameters())
+        for k, v in model.named_parameters():
+            e = relerr(p[k].grad, v.grad, floor=1e-5 * gmax)
+            if e > worst:
+                worst, worst_name = e, k
+        agree["grad_rel_worst"] = worst
+        print("   worst grad:", worst_name, worst, float(dict(model.named_parameters())[worst_name].grad.abs().max()))
+
+    store(arrays, digests, "logits", logits)
+    store(arrays, digests, "loss", loss)
+    for k in extra:
+        store(arrays, digests, k, extra[k])
+    for i in range(spec.depth):
+        store(arrays, digests, "block%d" % i, taps_ref["block%d" % i])
+    if backward:
+        for k, v in model.named_parameters():
+            store(arrays, digests, "grad:" + k, v.grad)
+
+    # ---- eval mode -------------------------------------------------------------------
+    if eval_too:
+        model.eval()
+        with torch.no_grad():
+            pe, ee = model([x], {})
+            p0 = {k: v.detach() for k, v in p.items()}
+            pr, er = R.forward(p0, spec, x, training=False)
+        agree["eval_probs"] = maxabs(pr, pe)
+        store(arrays, digests, "eval_probs", pe)
+        for k in ee:
+            agree["eval_" + k] = maxabs(er[k], ee[k])
+            store(arrays, digests, "eval_" + k, ee[k])
+
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **arrays)
+    manifest["cases"][name] = {
+        "num_frames": num_frames, "crop": crop, "batch": batch, "frames_path": frames_path,
+        "drop": drop, "backward": backward, "tokens": int(taps_ref["block0"].shape[1])
+        if not spec.blocks[0].pools_q else None,
+        "restatement_vs_reference_maxabs": agree, "digests": digests,
+    }
+    print(name, "worst disagreement:", max(agree.values()), {k: "%.2e" % v for k, v in agree.items() if v > 1e-4}, flush=True)
+    return cfg, model, spec, sd, extra
+
+
+def run_op_cases(out_dir, manifest):
+    """Per-op known-answer tests taken from the reference's own functions."""
+    ref_shim.install()
+    from slowfast.models import attention as A
+    arrays, agree = {}, {}
+    # (a) attention_pool with depthwise conv, strides 1/2/4/8, and the max-pool skip
+    for s in (1, 2, 4, 8):
+        T, H, W, h, O = 2, 8, 8, 2, 3
+        x = P.tensor("kat:pool:x:%d" % s, (2, h, 1 + T * H * W + O, 96), 1.0)
+        w = P.tensor("kat:pool:w:%d" % s, (96, 1, 3, 3, 3), 0.3)
+        nw = P.tensor("kat:pool:nw", (96,), 0.2, 1.0)
+        nb = P.tensor("kat:pool:nb", (96,), 0.1)
+        conv = torch.nn.Conv3d(96, 96, 3, stride=(1, s, s), padding=1, groups=96, bias=False)
+        conv.weight.data.copy_(w)
+        norm = torch.nn.LayerNorm(96, eps=1e-6)
+        norm.weight.data.copy_(nw)
+        norm.bias.data.copy_(nb)
+        xr = x.clone().requires_grad_(True)
+        out_ref, thw = A.attention_pool(xr, conv, [T, H, W], has_cls_embed=True, norm=norm)
+        out_ref.backward(P.tensor("kat:pool:g:%d" % s, tuple(out_ref.shape), 1.0))
+        xo = x.clone().requires_grad_(True)
+        wo = w.clone().requires_grad_(True)
+        out, thw2 = R.pool_tokens(xo, (T, H, W), (1, s, s), wo, nw, nb, O)
+        out.backward(P.tensor("kat:pool:g:%d" % s, tuple(out.shape), 1.0))
+        assert tuple(thw) == tuple(thw2)
+        agree["pool_s%d" % s] = maxabs(out, out_ref)
+        agree["pool_s%d_dx" % s] = maxabs(xo.grad, xr.grad)
+        agree["pool_s%d_dw" % s] = maxabs(wo.grad, conv.weight.grad)
+        arrays["pool_s%d_out" % s] = out_ref.detach().numpy()
+        arrays["pool_s%d_dx" % s] = xr.grad.numpy()
+        arrays["pool_s%d_dw" % s] = conv.weight.grad.numpy()
+        arrays["pool_s%d_gain" % s] = R.object_gain(w, (1, s, s)).numpy()
+    T, H, W, O = 2, 8, 8, 3
+    x = P.tensor("kat:skip:x", (2, 1 + T * H * W + O, 96), 1.0)
+    mp = torch.nn.MaxPool3d((1, 3, 3), (1, 2, 2), (0, 1, 1))
+    out_ref, _ = A.attention_pool(x, mp, [T, H, W], has_cls_embed=True)
+    agree["skip"] = maxabs(R.maxpool_skip(x, (T, H, W), (1, 2, 2), O), out_ref)
+    arrays["skip_out"] = out_ref.numpy()
+    # (b) rel-pos bias incl. the interpolation branch and T'=1
+    for tag, q_thw, k_thw, rows_sp, rows_t in (
+            ("same", (2, 4, 4), (2, 4, 4), 7, 3),
+            ("kvpool", (2, 8, 8), (2, 2, 2), 15, 3),
+            ("interp", (2, 5, 5), (2, 3, 3), 7, 3),      # needs 9 rows, owns 7
+            ("t1", (1, 4, 4), (1, 2, 2), 7, 5)):         # T'=1: table 5 rows -> 1
+        Lq = q_thw[0] * q_thw[1] * q_thw[2]
+        Lk = k_thw[0] * k_thw[1] * k_thw[2]
+        q = P.tensor("kat:rel:q:" + tag, (2, 2, 1 + Lq + 3, 96), 1.0)
+        k = P.tensor("kat:rel:k:" + tag, (2, 2, 1 + Lk + 3, 96), 1.0)
+        rh = P.tensor("kat:rel:h:" + tag, (rows_sp, 96), 0.3)
+        rw = P.tensor("kat:rel:w:" + tag, (rows_sp, 96), 0.3)
+        rt = P.tensor("kat:rel:t:" + tag, (rows_t, 96), 0.3)
+        attn = torch.zeros(2, 2, 1 + Lq + 3, 1 + Lk + 3)
+        attn = A.cal_rel_pos_spatial(attn, q, k, True, q_thw, k_thw, rh, rw)
+        attn = A.cal_rel_pos_temporal(attn, q, True, q_thw, k_thw, rt)
+        bias = R.rel_pos_bias(q, q_thw, k_thw, rh, rw, rt)
+        agree["rel_" + tag] = maxabs(bias, attn[:, :, 1:1 + Lq, 1:1 + Lk])
+        assert float(attn[:, :, 0].abs().max()) == 0 and float(attn[:, :, :, 0].abs().max()) == 0
+        arrays["rel_%s_bias" % tag] = attn[:, :, 1:1 + Lq, 1:1 + Lk].numpy()
+    np.savez_compressed(os.path.join(out_dir, "ops.npz"), **arrays)
+    manifest["ops"] = {"restatement_vs_reference_maxabs": agree}
+    print("ops worst disagreement:", max(agree.values()), flush=True)
+
+
+def run_loss_optim_cases(out_dir, manifest):
+    """HAOG losses, lr policy, param groups and one clip+AdamW step on the tiny model."""
+    torch.manual_seed(0)
+    cfg, model, shapes, sd = build_reference(4, 64)
+    spec = R.make_spec(num_frames=4, crop=64, drop_path_rate=0.0, dropout_rate=0.0)
+    from slowfast.models import losses as L
+    from slowfast.models import optimizer as O
+    from slowfast.utils import lr_policy, misc
+    arrays, agree, info = {}, {}, {}
+    # image-rank step: T=1 images, HAOG losses
+    B = 3
+    x = P.frames(B, 1, 64, tag="img")
+    meta = P.haog_meta(B)
+    model.train()
+    logits, extra = model([x], {})
+    lf = L.VideoImageLoss(cfg)
+    lf._is_vid = False
+    lf.train()
+    parts = lf(logits, extra, None, meta)
+    lam = misc.get_lambdas_dict(cfg)
+    total = sum(lam[k] * v for k, v in parts.items())
+    model.zero_grad()
+    total.backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lg, ex = R.forward(p, spec, x, training=True)
+    tot, prt = R.image_loss(ex, meta, R.loss_weights(cfg.SVIT.LAMBDA_NODES, cfg.SVIT.LAMBDA_EDGES))
+    tot.backward()
+    agree["image_total"] = maxabs(tot, total)
+    for k in parts:
+        agree["image_" + k] = maxabs(prt[k], parts[k])
+        info["image_" + k] = float(parts[k].detach())
+    info["image_total"] = float(total)
+    info["lambdas"] = {k: float(v) for k, v in lam.items()}
+    worst = 0.0
+    gmax = max(float(v.grad.abs().max()) for v in model.parameters())
+    for k, v in model.named_parameters():
+        worst = max(worst, relerr(p[k].grad, v.grad, floor=1e-5 * gmax))
+    agree["image_grad_rel_worst"] = worst
+    info["image_grad_digest"] = {k: P.digest(v.grad) for k, v in model.named_parameters()
+                                 if k.startswith("head.") or k in ("cls_token", "object_queries",
+                                                                   "pos_embed_temporal")}
+    # lr policy samples
+    eps = [0.0, 0.013, 1.0, 12.5, 25.0, 49.99]
+    info["lr_epochs"] = eps
+    info["lr_values"] = [float(lr_policy.get_lr_at_epoch(cfg, e)["lr"]) for e in eps]
+    agree["lr"] = max(abs(R.cosine_lr(e, cfg.SOLVER.BASE_LR, cfg.SOLVER.COSINE_END_LR,
+                                      cfg.SOLVER.MAX_EPOCH, cfg.SOLVER.WARMUP_EPOCHS,
+                                      cfg.SOLVER.WARMUP_START_LR) - v)
+                      for e, v in zip(eps, info["lr_values"]))
+    # param groups + one clip + AdamW step (train_net.py:133-151)
+    opt = O.construct_optimizer(model, cfg)
+    wd_by_id = {}
+    for g in opt.param_groups:
+        for q in g["params"]:
+            wd_by_id[id(q)] = g["weight_decay"]
+    info["n_wd_zero"] = sum(1 for k, v in model.named_parameters() if wd_by_id[id(v)] == 0.0)
+    info["n_wd"] = sum(1 for k, v in model.named_parameters() if wd_by_id[id(v)] > 0.0)
+    for k, v in model.named_parameters():
+        assert R.weight_decay_of(k, tuple(v.shape), cfg.SOLVER.WEIGHT_DECAY) == wd_by_id[id(v)], k
+    lr = 1.5e-4
+    for g in opt.param_groups:
+        g["lr"] = lr
+    norm = torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.SOLVER.CLIP_GRAD_L2NORM)
+    opt.step()
+    pw = {k: v.detach().clone() for k, v in p.items()}
+    gr = {k: (v.grad.detach().clone() if v.grad is not None else torch.zeros_like(v)) for k, v in p.items()}
+    st = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in pw.items()}
+    n2 = R.clip_and_adamw_step(pw, gr, st, lr, 1, cfg.SOLVER.CLIP_GRAD_L2NORM,
+                               lambda n, s: R.weight_decay_of(n, s, cfg.SOLVER.WEIGHT_DECAY))
+    agree["grad_norm"] = abs(n2 - float(norm)) / float(norm)
+    info["grad_norm"] = float(norm)
+    worst = 0.0
+    for k, v in model.named_parameters():
+        worst = max(worst, maxabs(pw[k], v))
+    agree["adamw_param_maxabs"] = worst
+    info["adamw_param_digest"] = {k: P.digest(v) for k, v in model.named_parameters()
+                                  if v.numel() <= 200000}
+    info["adamw_lr"] = lr
+    np.savez_compressed(os.path.join(out_dir, "loss_optim.npz"), **arrays)
+    manifest["loss_optim"] = {"restatement_vs_reference_maxabs": agree, "info": info}
+    print("loss/optim worst disagreement:", max(agree.values()), agree, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(HERE, "..", "tests", "golden"))
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    mpath = os.path.join(args.out, "manifest.json")
+    manifest = {"cases": {}}
+    if args.only and os.path.exists(mpath):
+        manifest = json.load(open(mpath))
+    manifest.update({
+        "generator": "oracle/gen_golden.py", "torch": torch.__version__,
+        "note": "arrays/digests produced by running the unmodified reference on CPU fp32 "
+                "with the closed-form tensors of oracle/procedural.py"})
+    want = set(args.only.split(",")) if args.only else None
+
+    def on(n):
+        return want is None or n in want
+    if on("ops"):
+        run_op_cases(args.out, manifest)
+    if on("tiny"):
+        run_model_case("tiny", 4, 64, 2, args.out, manifest, eval_too=True)
+    if on("tiny_drop"):
+        run_model_case("tiny_drop", 4, 64, 4, args.out, manifest, drop=True)
+    if on("tiny_odd"):
+        run_model_case("tiny_odd", 4, 88, 2, args.out, manifest)
+    if on("tiny_frames"):
+        run_model_case("tiny_frames", 4, 64, 3, args.out, manifest, frames_path=True)
+    if on("loss_optim"):
+        run_loss_optim_cases(args.out, manifest)
+    if on("c1"):
+        run_model_case("c1", 8, 224, 1, args.out, manifest, eval_too=True)
+    if on("c2_fwd"):
+        run_model_case("c2_fwd", 16, 224, 1, args.out, manifest, backward=False)
+    if on("c2_frames"):
+        run_model_case("c2_frames", 16, 224, 2, args.out, manifest, backward=False,
+                       frames_path=True)
+    json.dump(manifest, open(mpath, "w"), indent=1, sort_keys=True)
+    print("wrote", mpath)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,180 @@
+"""The CPU restatement (oracle/svit_ref.py) replayed against the golden vectors that
+oracle/gen_golden.py took from the unmodified reference.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import procedural as P
+from oracle import svit_ref as R
+
+torch.set_num_threads(min(8, os.cpu_count() or 1))
+
+
+def close_digest(t, d, rtol=2e-4, atol=1e-6):
+    got = P.digest(t)
+    assert got["n"] == d["n"]
+    scale = max(d["absmean"], atol)
+    assert abs(got["absmean"] - d["absmean"]) <= rtol * scale + atol
+    assert abs(got["l2"] - d["l2"]) <= rtol * max(d["l2"], atol) + atol
+    assert abs(got["proj"] - d["proj"]) <= rtol * max(d["l2"], atol) + atol
+    np.testing.assert_allclose(got["head"], d["head"], rtol=0, atol=rtol * 25 * scale + atol)
+    np.testing.assert_allclose(got["strided"], d["strided"], rtol=0, atol=rtol * 25 * scale + atol)
+
+
+def run_case(case, name, golden_dir, backward):
+    spec = R.make_spec(num_frames=case["num_frames"], crop=case["crop"],
+                       drop_path_rate=0.4 if case["drop"] else 0.0,
+                       dropout_rate=0.5 if case["drop"] else 0.0)
+    sd = P.state_dict(R.param_shapes(spec))
+    p = {k: v.clone().requires_grad_(backward) for k, v in sd.items()}
+    B = case["batch"]
+    x = P.frames(B, 1 if case["frames_path"] else case["num_frames"], case["crop"])
+    y = P.labels(B)
+    arrays = np.load(os.path.join(golden_dir, name + ".npz"))
+    drop_scales = dropout_keep = None
+    if case["drop"]:
+        drop_scales = []
+        for i in range(spec.depth):
+            if "dp_attn_%d" % i in arrays:
+                drop_scales.append((torch.from_numpy(arrays["dp_attn_%d" % i]),
+                                    torch.from_numpy(arrays["dp_mlp_%d" % i])))
+            else:
+                drop_scales.append(None)
+        dropout_keep = torch.from_numpy(arrays["dropout_keep"])
+    taps = {}
+    logits, extra = R.forward(p, spec, x, training=True, drop_scales=drop_scales,
+                              dropout_keep=dropout_keep, taps=taps)
+    loss = R.video_loss(logits, y)
+    if backward:
+        loss.backward()
+    return spec, p, logits, extra, loss, taps, arrays
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_drop", "tiny_odd", "tiny_frames", "c1",
+                                  "c2_fwd", "c2_frames"])
+def test_model_case(name, manifest, golden_dir):
+    case = manifest["cases"][name]
+    for k, v in case["restatement_vs_reference_maxabs"].items():
+        assert v < 5e-3, (k, v)  # recorded when the fixtures were made (pins the restatement)
+    spec, p, logits, extra, loss, taps, arrays = run_case(case, name, golden_dir, case["backward"])
+    dg = case["digests"]
+    np.testing.assert_allclose(logits.detach().numpy(), arrays["logits"], atol=2e-4, rtol=1e-4)
+    assert abs(float(loss.detach()) - float(arrays["loss"])) < 1e-4
+    for k in ("obj_desc", "pred_bboxes", "pred_contact_state"):
+        close_digest(extra[k], dg[k])
+    for i in range(spec.depth):
+        close_digest(taps["block%d" % i], dg["block%d" % i])
+    if case["backward"]:
+        gmax = max(dg["grad:" + k]["l2"] for k in p)
+        for k, v in p.items():
+            d = dg["grad:" + k]
+            g = v.grad if v.grad is not None else torch.zeros_like(v)
+            if d["l2"] < 1e-5 * gmax:  # mathematically-zero grads (e.g. attn.norm_k.bias)
+                assert float(g.norm()) < 1e-4 * gmax
+                continue
+            close_digest(g, d, rtol=1e-3)
+            if "grad:" + k in arrays:
+                np.testing.assert_allclose(g.numpy(), arrays["grad:" + k], rtol=0,
+                                           atol=2e-3 * float(np.abs(arrays["grad:" + k]).max()) + 1e-7)
+
+
+@pytest.mark.parametrize("name", ["tiny", "c1"])
+def test_eval_mode(name, manifest, golden_dir):
+    case = manifest["cases"][name]
+    spec = R.make_spec(num_frames=case["num_frames"], crop=case["crop"], drop_path_rate=0.0,
+                       dropout_rate=0.0)
+    sd = P.state_dict(R.param_shapes(spec))
+    x = P.frames(case["batch"], case["num_frames"], case["crop"])
+    arrays = np.load(os.path.join(golden_dir, name + ".npz"))
+    with torch.no_grad():
+        probs, extra = R.forward(sd, spec, x, training=False)
+    np.testing.assert_allclose(probs.numpy(), arrays["eval_probs"], atol=1e-5)
+    np.testing.assert_allclose(probs.sum(1).numpy(), 1.0, atol=1e-5)
+    np.testing.assert_allclose(extra["pred_bboxes"].numpy(), arrays["eval_pred_bboxes"], atol=1e-5)
+    np.testing.assert_allclose(extra["pred_contact_state"].numpy(),
+                               arrays["eval_pred_contact_state"], atol=1e-5)
+
+
+def test_op_kats(golden_dir):
+    a = np.load(os.path.join(golden_dir, "ops.npz"))
+    for s in (1, 2, 4, 8):
+        T, H, W, h, O = 2, 8, 8, 2, 3
+        x = P.tensor("kat:pool:x:%d" % s, (2, h, 1 + T * H * W + O, 96), 1.0).requires_grad_(True)
+        w = P.tensor("kat:pool:w:%d" % s, (96, 1, 3, 3, 3), 0.3).requires_grad_(True)
+        nw = P.tensor("kat:pool:nw", (96,), 0.2, 1.0)
+        nb = P.tensor("kat:pool:nb", (96,), 0.1)
+        out, _ = R.pool_tokens(x, (T, H, W), (1, s, s), w, nw, nb, O)
+        out.backward(P.tensor("kat:pool:g:%d" % s, tuple(out.shape), 1.0))
+        np.testing.assert_allclose(out.detach().numpy(), a["pool_s%d_out" % s], atol=2e-5)
+        np.testing.assert_allclose(x.grad.numpy(), a["pool_s%d_dx" % s], atol=5e-5)
+        np.testing.assert_allclose(w.grad.numpy(), a["pool_s%d_dw" % s], atol=5e-4)
+        np.testing.assert_allclose(R.object_gain(w.detach(), (1, s, s)).numpy(),
+                                   a["pool_s%d_gain" % s], atol=1e-6)
+    x = P.tensor("kat:skip:x", (2, 1 + 2 * 8 * 8 + 3, 96), 1.0)
+    np.testing.assert_array_equal(R.maxpool_skip(x, (2, 8, 8), (1, 2, 2), 3).numpy(), a["skip_out"])
+    for tag, q_thw, k_thw, rows_sp, rows_t in (
+            ("same", (2, 4, 4), (2, 4, 4), 7, 3), ("kvpool", (2, 8, 8), (2, 2, 2), 15, 3),
+            ("interp", (2, 5, 5), (2, 3, 3), 7, 3), ("t1", (1, 4, 4), (1, 2, 2), 7, 5)):
+        Lq = q_thw[0] * q_thw[1] * q_thw[2]
+        q = P.tensor("kat:rel:q:" + tag, (2, 2, 1 + Lq + 3, 96), 1.0)
+        rh = P.tensor("kat:rel:h:" + tag, (rows_sp, 96), 0.3)
+        rw = P.tensor("kat:rel:w:" + tag, (rows_sp, 96), 0.3)
+        rt = P.tensor("kat:rel:t:" + tag, (rows_t, 96), 0.3)
+        bias = R.rel_pos_bias(q, q_thw, k_thw, rh, rw, rt)
+        np.testing.assert_allclose(bias.numpy(), a["rel_%s_bias" % tag], atol=2e-5)
+
+
+def test_losses_lr_optimizer(manifest):
+    lo = manifest["loss_optim"]
+    info = lo["info"]
+    for k, v in lo["restatement_vs_reference_maxabs"].items():
+        assert v < 5e-3, (k, v)
+    spec = R.make_spec(num_frames=4, crop=64, drop_path_rate=0.0, dropout_rate=0.0)
+    sd = P.state_dict(R.param_shapes(spec))
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x = P.frames(3, 1, 64, tag="img")
+    meta = P.haog_meta(3)
+    _, extra = R.forward(p, spec, x, training=True)
+    total, parts = R.image_loss(extra, meta, R.loss_weights(3.7, 0.3))
+    total.backward()
+    assert abs(float(total) - info["image_total"]) < 1e-4
+    for k, v in parts.items():
+        assert abs(float(v) - info["image_" + k]) < 1e-5
+    lam = dict(info["lambdas"])
+    # as released the consistency weight sits under a key no loss ever produces
+    assert lam.pop("video_image_boxes_l1_loss") == 1.5
+    assert lam == {k: pytest.approx(v) for k, v in R.loss_weights(3.7, 0.3).items()}
+    for k, d in info["image_grad_digest"].items():
+        close_digest(p[k].grad, d, rtol=1e-3)
+    for e, v in zip(info["lr_epochs"], info["lr_values"]):
+        assert R.cosine_lr(e) == pytest.approx(v, rel=1e-12)
+    shapes = R.param_shapes(spec)
+    assert sum(R.weight_decay_of(k, s) == 0.0 for k, s in shapes.items()) == info["n_wd_zero"] == 234
+    assert sum(R.weight_decay_of(k, s) > 0.0 for k, s in shapes.items()) == info["n_wd"] == 171
+    pw = {k: v.detach().clone() for k, v in p.items()}
+    gr = {k: (v.grad.clone() if v.grad is not None else torch.zeros_like(v)) for k, v in p.items()}
+    st = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in pw.items()}
+    norm = R.clip_and_adamw_step(pw, gr, st, info["adamw_lr"], 1)
+    assert norm == pytest.approx(info["grad_norm"], rel=1e-4)
+    for k, d in info["adamw_param_digest"].items():
+        if float(gr[k].abs().max()) < 1e-6:  # Adam amplifies rounding noise on ~zero grads
+            continue
+        close_digest(pw[k], d, rtol=2e-4, atol=2e-6)
+
+
+def test_shape_tables():
+    """token counts and rel-pos rows for the five BASELINE configs."""
+    s = R.make_spec(16, 224)
+    assert [(b.dim_in, b.dim_out, b.heads) for b in s.blocks][:4] == [
+        (96, 96, 1), (96, 192, 2), (192, 192, 2), (192, 384, 4)]
+    assert [b.stride_kv for b in s.blocks][:4] == [(1, 8, 8), (1, 4, 4), (1, 4, 4), (1, 2, 2)]
+    assert [b.rel_sp_rows for b in s.blocks] == [111, 55, 55] + [27] * 12 + [13]
+    assert all(b.rel_t_rows == 15 for b in s.blocks)
+    shapes = R.param_shapes(s)
+    assert len(shapes) == 405 and sum(int(np.prod(v)) for v in shapes.values()) == 34373560
+    s8 = R.make_spec(8, 224)
+    assert sum(int(np.prod(v)) for v in R.param_shapes(s8).values()) == 34360504
+    s5 = R.make_spec(16, 312)
+    assert [b.rel_sp_rows for b in s5.blocks][3] == 37 and s5.blocks[15].rel_sp_rows == 17
