@@ -139,15 +139,16 @@ def test_losses_lr_optimizer(manifest):
     _, extra = R.forward(p, spec, x, training=True)
     total, parts = R.image_loss(extra, meta, R.loss_weights(3.7, 0.3))
     total.backward()
-    assert abs(float(total) - info["image_total"]) < 1e-4
+    assert abs(float(total.detach()) - info["image_total"]) < 1e-4
     for k, v in parts.items():
-        assert abs(float(v) - info["image_" + k]) < 1e-5
+        assert abs(float(v.detach()) - info["image_" + k]) < 1e-5
     lam = dict(info["lambdas"])
     # as released the consistency weight sits under a key no loss ever produces
     assert lam.pop("video_image_boxes_l1_loss") == 1.5
     assert lam == {k: pytest.approx(v) for k, v in R.loss_weights(3.7, 0.3).items()}
     for k, d in info["image_grad_digest"].items():
-        close_digest(p[k].grad, d, rtol=1e-3)
+        g = p[k].grad if p[k].grad is not None else torch.zeros_like(p[k])
+        close_digest(g, d, rtol=1e-3)  # image rank: head.projection / cls grads are exact zeros
     for e, v in zip(info["lr_epochs"], info["lr_values"]):
         assert R.cosine_lr(e) == pytest.approx(v, rel=1e-12)
     shapes = R.param_shapes(spec)
