@@ -1,0 +1,197 @@
+/* libsvit_hip.so -- C ABI of the MI355X-native SViT forward/backward kernels.
+ *
+ * Drop-in boundary: the reference has no native code; every entry point
+ * below replaces an ATen op sequence of the reference's Python hot path (file:line cited
+ * per function, relative to the reference tree).  The reference-side binding is the
+ * `torch.autograd.Function` / ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions: all pointers are DEVICE pointers (hipMalloc'ed / torch CUDA tensors) unless
+ * marked host; `stream` is a hipStream_t passed as void*; every function only enqueues work
+ * on `stream` (no allocation, no synchronisation -> hipGraph-capturable) and returns 0 on
+ * success, a negative SVIT_ERR_* for argument errors, or a positive hipError_t.
+ * bf16 tensors are raw uint16 bit patterns.  Token order everywhere is
+ * [cls | patches (t,y,x row-major) | objects]; head_dim is 96.
+ */
+#ifndef SVIT_HIP_H
+#define SVIT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVIT_HEAD_DIM 96
+
+int svit_version(void);
+const char* svit_arch(void); /* "gfx950" */
+
+/* ---------------------------------------------------------------- GEMM family (K4) ---- */
+/* nn.Linear everywhere: slowfast/models/attention.py:228,230,344-349,462,546-547,561;
+ * slowfast/models/common.py:20-22,26-34; patch embed conv as implicit GEMM
+ * (slowfast/models/stem_helper.py:309-320). */
+enum {
+  SVIT_EPI_BF16 = 0,   /* out(bf16)  = acc + bias                                   */
+  SVIT_EPI_GELU = 1,   /* out2(bf16) = acc + bias ; out(bf16) = gelu_erf(out2)       */
+  SVIT_EPI_RESID = 2,  /* out(f32)   = aux(f32) + row_scale[row/rows_per_sample]*(acc+bias)
+                          (proj / fc2 + DropPath + residual, attention.py:565,570)    */
+  SVIT_EPI_F32 = 3,    /* out(f32)   = [out +] acc + bias, optional row remap         */
+  SVIT_EPI_DGELU = 4   /* out(bf16)  = acc * gelu_erf'(aux(bf16))  (fc2 dgrad)        */
+};
+typedef struct {
+  const void* A; int32_t lda;      /* bf16 [M,K] row-major                             */
+  const void* W; int32_t ldw;      /* bf16 [N,K] row-major (nn.Linear weight layout)   */
+  const float* bias;               /* f32 [N] or NULL                                  */
+  void* out; int32_t ldo;
+  void* out2; int32_t ldo2;
+  const void* aux; int32_t ldaux;
+  const float* row_scale; int32_t rows_per_sample;
+  int32_t M, N, K;                 /* N % 96 == 0, K % 32 == 0                         */
+  int32_t epilogue; int32_t accumulate;
+  int32_t remap_L, remap_N, remap_off; /* EPI_F32: out row = (r/L)*remap_N + remap_off + r%L */
+} svit_gemm_args;
+/* C[M,N] = A[M,K] * W[N,K]^T with fused epilogue (forward Linear; dgrad with W^T copy). */
+int svit_gemm_nt(const svit_gemm_args* args, void* stream);
+/* dW[N,K] (f32, atomically accumulated) += A[M,N]^T * B[M,K]  (Linear wgrad; split over M). */
+int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, float* dW, int lddw,
+                 int M, int N, int K, int splits, void* stream);
+/* dbias[N] (f32, atomically accumulated) += column sums of bf16 A[M,N]. */
+int svit_colsum_bf16(const void* A, int lda, float* out, int M, int N, void* stream);
+
+/* ------------------------------------------------------------- elementwise / casts ---- */
+int svit_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* batched fp32 [R,C] -> bf16 [C,R] transposes described by a device table of
+ * {src_off, dst_off, R, C} int64 quadruples (the W^T copies used by dgrad). */
+int svit_transpose_cast_batched(const float* src_base, void* dst_base, const int64_t* table,
+                                int n_mats, int max_tiles, void* stream);
+/* dst(bf16)[r,:] = scale[r/rows_per_sample] * src(f32)[r,:]   (DropPath backward). */
+int svit_scale_cast(const float* src, void* dst, const float* row_scale, int rows_per_sample,
+                    int64_t rows, int cols, void* stream);
+
+/* ---------------------------------------------------------------- LayerNorm (K3) ------ */
+/* nn.LayerNorm(eps=1e-6): attention.py:501,531; video_model_builder.py:69,233. */
+int svit_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16,
+                       float* y_f32, float* mean, float* rstd, int64_t rows, int C, float eps,
+                       void* stream);
+/* dx = [dres +] LN'(dy); dgamma/dbeta atomically accumulated. dy is f32. */
+int svit_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                       const float* rstd, const float* dres, float* dx, float* dgamma,
+                       float* dbeta, int64_t rows, int C, void* stream);
+
+/* ------------------------------------------------------------ patch embedding (K1/K2) - */
+/* im2col for Conv3d(3->96, k(3,7,7), s(2,4,4), p(1,3,3)) (stem_helper.py:309-320):
+ * video f32 [B,3,T,H,W] -> cols bf16 [B*T'*H'*W', 448] (441 taps, zero-padded to 448). */
+int svit_im2col_patch(const float* video, void* cols, int B, int T, int H, int W, void* stream);
+/* cls / object token rows of the block-0 input (video_model_builder.py:326-363). */
+int svit_fill_special_tokens(float* x, const float* cls, const float* objq, const float* pos_t,
+                             int B, int N, int L, int Tx, int O, int C, int add_pos, void* stream);
+
+/* ------------------------------------------------- pooled q/k/v (K5, K6, K3 fused) ---- */
+/* attention_pool with depthwise Conv3d(96,96,3^3,stride (1,s,s),pad 1) + object gain +
+ * LayerNorm(96) on every token (attention.py:13-65, 263-304).
+ * in : qkv bf16 [B, N, 3, h, 96]  (which = 0/1/2 selects q/k/v)
+ * out: bf16 [B, h, Nout, ld_out] columns 0..95 = LN(pooled); pre: bf16 [B,h,Nout,96]
+ *      pre-LN pooled values (saved for backward); mean/rstd f32 [B*h*Nout].
+ * mode 1 (keys) additionally writes the one-hot key coordinates at columns
+ *      96 + [y | kh + x | kh + kw + t] used by the in-MFMA relative-position bias. */
+typedef struct {
+  const void* qkv; int32_t which;
+  const float* conv_w;            /* f32 [96, 27]                                      */
+  const float* gamma; const float* beta;
+  void* out; int32_t ld_out;
+  void* pre; float* mean; float* rstd;
+  int32_t B, heads, T, H, W, n_obj; /* input tokens N = 1 + T*H*W + n_obj               */
+  int32_t stride_hw;               /* spatial stride s (temporal stride is 1)          */
+  int32_t mode;                    /* 0 = plain (q, v), 1 = keys (+one-hot)            */
+  float eps;
+} svit_pool_args;
+int svit_pool_ln_fwd(const svit_pool_args* a, void* stream);
+
+/* backward, step 1: LayerNorm(96) backward per pooled token.
+ * dout: up to three addends: d_main (bf16 or f32, row stride ld_main), d_res (bf16 ctx grad for
+ * the residual-pooling path, rows [B, Nout, h*96], skipped for cls), d_extra (f32 [..,96]).
+ * writes dpre bf16 [B,h,Nout,96]; dgamma/dbeta accumulated atomically. */
+typedef struct {
+  const void* d_main; int32_t main_is_f32; int32_t ld_main;
+  const void* d_res; const float* d_extra;
+  const void* pre; const float* mean; const float* rstd; const float* gamma;
+  void* dpre; float* dgamma; float* dbeta;
+  int32_t B, heads, Nout;
+} svit_pool_ln_bwd_args;
+int svit_pool_ln_bwd(const svit_pool_ln_bwd_args* a, void* stream);
+/* backward, step 2: depthwise-conv dgrad (gather form) + cls/object rows ->
+ * dqkv bf16 [B,N,3,h,96] slice `which`. */
+typedef struct {
+  const void* dpre; const float* conv_w; void* dqkv; int32_t which;
+  int32_t B, heads, T, H, W, n_obj, stride_hw;
+} svit_pool_dgrad_args;
+int svit_pool_conv_dgrad(const svit_pool_dgrad_args* a, void* stream);
+/* backward, step 3: depthwise-conv wgrad incl. the object-gain path; dw f32 [96,27] accumulated. */
+typedef struct {
+  const void* dpre; const void* qkv; int32_t which; float* dw;
+  int32_t B, heads, T, H, W, n_obj, stride_hw;
+} svit_pool_wgrad_args;
+int svit_pool_conv_wgrad(const svit_pool_wgrad_args* a, void* stream);
+
+/* ------------------------------------------- decomposed rel-pos bias, query side (K9/K10) */
+/* cal_rel_pos_spatial / cal_rel_pos_temporal (attention.py:84-183) restated as
+ * relq[q, j] = q . R_j(q) with j over [k_h | k_w | k_t]; stored (divided by the softmax
+ * scale) in columns 96.. of the augmented query so that the bias is added by the QK^T MFMA
+ * against the one-hot key columns.  tables are f32 [rows,96] already resized to
+ * 2*max(q,k)-1 rows; idx_* are int32 [q_n, k_n] row tables (dist.long()). */
+typedef struct {
+  void* qa; int32_t ld;           /* bf16 [B,h,Nq,ld]: reads cols 0..95, writes 96..96+J-1 */
+  const float* rel_h; const float* rel_w; const float* rel_t;
+  const int32_t* idx_h; const int32_t* idx_w; const int32_t* idx_t;
+  int32_t B, heads, qt, qh, qw, kt, kh, kw, n_obj;
+  float inv_scale;
+} svit_relq_args;
+int svit_relpos_q_fwd(const svit_relq_args* a, void* stream);
+typedef struct {
+  const void* qa; const void* dqa; int32_t ld;   /* bf16; dqa cols 96.. hold d(relq/scale)   */
+  const float* rel_h; const float* rel_w; const float* rel_t;
+  const int32_t* idx_h; const int32_t* idx_w; const int32_t* idx_t;
+  float* dq_extra;                /* f32 [B,h,Nq,96] written (0 for cls/objects)          */
+  float* drel_h; float* drel_w; float* drel_t; /* accumulated                           */
+  int32_t rows_h, rows_w, rows_t;
+  int32_t B, heads, qt, qh, qw, kt, kh, kw, n_obj;
+  float inv_scale;
+} svit_relq_bwd_args;
+int svit_relpos_q_bwd(const svit_relq_bwd_args* a, void* stream);
+
+/* ------------------------------------------------ fused pooled attention (K8-K12) ------ */
+/* (q*scale)@k^T + rel-pos bias -> softmax -> @v -> + pooled q (all tokens but cls) ->
+ * merge heads (attention.py:429-461).
+ * qa bf16 [B,h,Nq,DA], ka bf16 [B,h,Nk,DA] (DA = 128 or 160), v bf16 [B,h,Nk,96],
+ * ctx bf16 [B,Nq,h*96], lse2 f32 [B,h,Nq] (log2-domain log-sum-exp, saved for backward). */
+typedef struct {
+  const void* qa; const void* ka; const void* v; void* ctx; float* lse2;
+  int32_t B, heads, Nq, Nk, DA; float scale;
+} svit_attn_fwd_args;
+int svit_attn_fwd(const svit_attn_fwd_args* a, void* stream);
+typedef struct {
+  const void* qa; const void* ka; const void* v; const void* ctx; const void* dctx;
+  const float* lse2; float* delta;  /* delta f32 [B,h,Nq] scratch                        */
+  void* dqa;                        /* bf16 [B,h,Nq,DA]                                  */
+  float* dk; float* dv;             /* f32 [B,h,Nk,96], accumulated atomically (pre-zeroed) */
+  int32_t B, heads, Nq, Nk, DA, q_splits; float scale;
+} svit_attn_bwd_args;
+int svit_attn_bwd(const svit_attn_bwd_args* a, void* stream);
+
+/* ---------------------------------------------------------- max-pool skip path (K7) ---- */
+/* MaxPool3d((1,3,3),(1,2,2),(0,1,1)) on patch tokens, cls/objects copied
+ * (attention.py:549-555,562-564). x f32 [B,N,C] -> y f32 [B,Nout,C]; idx uint8 (tap 0..8). */
+int svit_maxpool_fwd(const float* x, float* y, uint8_t* idx, int B, int T, int H, int W,
+                     int n_obj, int C, void* stream);
+int svit_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int T, int H, int W,
+                     int n_obj, int C, void* stream);
+
+/* ------------------------------------------------------------- optimiser tail (K17) ---- */
+/* clip_grad_norm_(1.0) + AdamW (tools/train_net.py:144-151, models/optimizer.py:102-108)
+ * on flat f32 buffers.  sumsq is a device scalar (pre-zeroed). */
+int svit_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
+int svit_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
+                    float max_norm, float lr, float beta1, float beta2, float eps, float wd,
+                    int step, float grad_scale, void* stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,324 @@
+// Fused pooled attention, backward (flash-style recompute) -- gfx950.
+//
+// Three launches (all on the caller's stream):
+//   1. delta[q]  = sum_c dctx[q,c] * (ctx[q,c] - q_pooled[q,c])        (rowsum(dO * O))
+//   2. dq kernel : per 32-query wave, sweep K/V tiles: S^T, P^T = exp2(c*S - lse2),
+//                  dP^T = V dO^T, dS^T = P^T (dP^T - delta) * scale, dQa^T += Ka^T dS^T.
+//                  Query on the lane => P/dS reach the next MFMA as B operands in registers.
+//   3. dkv kernel: per 32-key wave (128 keys per block), sweep 32-query tiles of a query
+//                  chunk: S, P, dP, dS with the KEY on the lane; dV^T += dO^T P, dK^T += Q^T dS
+//                  accumulate in registers over the whole sweep; chunks of the query range run
+//                  in different blocks and meet in fp32 atomics shaped as whole 384-byte rows
+//                  (transposed through LDS first -- row-per-lane atomics are ~17x slower).
+// No N x N matrix is ever stored.  The residual-pooling path (ctx += q) contributes dctx to dq
+// outside these kernels (svit_pool_ln_bwd's d_res input).
+#include "attn_common.h"
+#include "../../include/svit_hip.h"
+
+namespace {
+using namespace attn;
+constexpr int KT = 64;   // keys per tile (dq kernel)
+constexpr int QT = 32;   // queries per tile (dkv kernel)
+
+__device__ __forceinline__ float quad_sum4(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ ctx,
+                                                         const bf16_t* __restrict__ dctx,
+                                                         const bf16_t* __restrict__ qa, int ldq,
+                                                         float* __restrict__ delta, int B,
+                                                         int heads, int Nq) {
+  const int64_t total = (int64_t)B * heads * Nq;
+  const int64_t row = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int sub = threadIdx.x & 3, c0 = sub * 24;
+  float acc = 0.f;
+  if (row < total) {
+    const int tok = (int)(row % Nq);
+    const int bh = (int)(row / Nq), b = bh / heads, head = bh % heads;
+    const size_t off = ((size_t)b * Nq + tok) * heads * HD + head * HD + c0;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const uint4 o = *(const uint4*)(ctx + off + v * 8);
+      const uint4 d = *(const uint4*)(dctx + off + v * 8);
+      uint4 q = make_uint4(0, 0, 0, 0);
+      if (tok > 0) q = *(const uint4*)(qa + row * ldq + c0 + v * 8);
+      acc += lo_bf16(d.x) * (lo_bf16(o.x) - lo_bf16(q.x)) + hi_bf16(d.x) * (hi_bf16(o.x) - hi_bf16(q.x));
+      acc += lo_bf16(d.y) * (lo_bf16(o.y) - lo_bf16(q.y)) + hi_bf16(d.y) * (hi_bf16(o.y) - hi_bf16(q.y));
+      acc += lo_bf16(d.z) * (lo_bf16(o.z) - lo_bf16(q.z)) + hi_bf16(d.z) * (hi_bf16(o.z) - hi_bf16(q.z));
+      acc += lo_bf16(d.w) * (lo_bf16(o.w) - lo_bf16(q.w)) + hi_bf16(d.w) * (hi_bf16(o.w) - hi_bf16(q.w));
+    }
+  }
+  acc = quad_sum4(acc);
+  if (row < total && sub == 0) delta[row] = acc;
+}
+
+// ---------------------------------------------------------------------------------------
+template <int DA>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(svit_attn_bwd_args a) {
+  constexpr int KS = DA / 16, NP = DA / 32;
+  constexpr int K_BYTES = KT * DA * 2, V_BYTES = KT * HD * 2, STAGE = K_BYTES + V_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int bh = blockIdx.y, b = bh / a.heads, head = bh % a.heads;
+  const int qi = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int qc = min(qi, a.Nq - 1);
+  const bf16_t* qa = (const bf16_t*)a.qa + ((size_t)bh * a.Nq) * DA;
+  const bf16_t* ka = (const bf16_t*)a.ka + ((size_t)bh * a.Nk) * DA;
+  const bf16_t* vv = (const bf16_t*)a.v + ((size_t)bh * a.Nk) * HD;
+  const bf16_t* dor = (const bf16_t*)a.dctx + ((size_t)b * a.Nq + qc) * a.heads * HD + head * HD;
+  const float c = a.scale * 1.4426950408889634f;
+  const float lse = a.lse2[(size_t)bh * a.Nq + qc];
+  const float dlt = a.delta[(size_t)bh * a.Nq + qc];
+
+  bf16x8_t qf[KS], dof[6];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(qa + (size_t)qc * DA + ks * 16 + hh * 8);
+#pragma unroll
+  for (int ks = 0; ks < 6; ++ks) dof[ks] = *(const bf16x8_t*)(dor + ks * 16 + hh * 8);
+
+  f32x16_t dq[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[j][r] = 0.f;
+
+  TileStager<KT, DA, 256> ks_stage;
+  TileStager<KT, HD, 256> vs_stage;
+  const int nt = (a.Nk + KT - 1) / KT;
+  ks_stage.load(ka, DA, a.Nk, tid);
+  vs_stage.load(vv, HD, a.Nk, tid);
+  ks_stage.store(smem, tid);
+  vs_stage.store(smem + K_BYTES, tid);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const unsigned char* k_cur = smem + (t & 1) * STAGE;
+    const unsigned char* v_cur = k_cur + K_BYTES;
+    unsigned char* k_nxt = smem + ((t + 1) & 1) * STAGE;
+    if (t + 1 < nt) {
+      const int k0 = (t + 1) * KT;
+      ks_stage.load(ka + (size_t)k0 * DA, DA, a.Nk - k0, tid);
+      vs_stage.load(vv + (size_t)k0 * HD, HD, a.Nk - k0, tid);
+    }
+    const int kbase = t * KT;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16_t s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s = mfma32(row_frag<KT>(k_cur, kb * 32, ks, lane), qf[ks], s);
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) dp = mfma32(row_frag<KT>(v_cur, kb * 32, ks, lane), dof[ks], dp);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float p = exp2f(s[r] * c - lse);
+        if (kbase + kb * 32 + acc_row(r, lane) >= a.Nk) p = 0.f;
+        s[r] = p * (dp[r] - dlt) * a.scale;
+      }
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp) {
+        const bf16x8_t dsf = acc_to_frag(s, sp);
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+          dq[j] = mfma32(tr_frag<KT>(k_cur, kb * 32 + sp * 16, j, lane), dsf, dq[j]);
+      }
+    }
+    if (t + 1 < nt) {
+      ks_stage.store(k_nxt, tid);
+      vs_stage.store(k_nxt + K_BYTES, tid);
+    }
+    __syncthreads();
+  }
+  if (qi < a.Nq) {
+    bf16_t* out = (bf16_t*)a.dqa + ((size_t)bh * a.Nq + qi) * DA;
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 pk;
+        pk.x = pack_bf16x2(dq[j][4 * g], dq[j][4 * g + 1]);
+        pk.y = pack_bf16x2(dq[j][4 * g + 2], dq[j][4 * g + 3]);
+        *(uint2*)(out + j * 32 + 8 * g + 4 * hh) = pk;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+template <int DA>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(svit_attn_bwd_args a,
+                                                              int tiles_per_split) {
+  constexpr int KS = DA / 16;
+  constexpr int Q_BYTES = QT * DA * 2, O_BYTES = QT * HD * 2;
+  constexpr int STAGE = Q_BYTES + O_BYTES + 2 * QT * 4;   // [Q | dO | lse2 | delta]
+  constexpr int OUT_LD = HD + 1;                          // padded fp32 transpose buffer
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int bh = blockIdx.z, b = bh / a.heads, head = bh % a.heads;
+  const int key0 = blockIdx.x * 128;
+  const int ki = key0 + wave * 32 + (lane & 31);
+  const int kc = min(ki, a.Nk - 1);
+  const bf16_t* qa = (const bf16_t*)a.qa + ((size_t)bh * a.Nq) * DA;
+  const bf16_t* ka = (const bf16_t*)a.ka + ((size_t)bh * a.Nk) * DA;
+  const bf16_t* vv = (const bf16_t*)a.v + ((size_t)bh * a.Nk) * HD;
+  const bf16_t* dob = (const bf16_t*)a.dctx + ((size_t)b * a.Nq) * a.heads * HD + head * HD;
+  const float* lse_g = a.lse2 + (size_t)bh * a.Nq;
+  const float* dlt_g = a.delta + (size_t)bh * a.Nq;
+  const float c = a.scale * 1.4426950408889634f;
+
+  bf16x8_t kf[KS], vf[6];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8_t*)(ka + (size_t)kc * DA + ks * 16 + hh * 8);
+#pragma unroll
+  for (int ks = 0; ks < 6; ++ks) vf[ks] = *(const bf16x8_t*)(vv + (size_t)kc * HD + ks * 16 + hh * 8);
+
+  f32x16_t dk[3], dv[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[j][r] = 0.f; dv[j][r] = 0.f; }
+
+  const int nqt = (a.Nq + QT - 1) / QT;
+  const int t_begin = blockIdx.y * tiles_per_split;
+  const int t_end = min(nqt, t_begin + tiles_per_split);
+
+  TileStager<QT, DA, 256> q_stage;
+  TileStager<QT, HD, 256> o_stage;
+  float st_lse = 0.f, st_dlt = 0.f;
+  auto load_tile = [&](int t) {
+    const int q0 = t * QT;
+    q_stage.load(qa + (size_t)q0 * DA, DA, a.Nq - q0, tid);
+    o_stage.load(dob + (size_t)q0 * a.heads * HD, (size_t)a.heads * HD, a.Nq - q0, tid);
+    if (tid < QT) {
+      const bool ok = q0 + tid < a.Nq;
+      st_lse = ok ? lse_g[q0 + tid] : INFINITY;  // +inf => P = 0 for rows that do not exist
+      st_dlt = ok ? dlt_g[q0 + tid] : 0.f;
+    }
+  };
+  auto store_tile = [&](unsigned char* stage) {
+    q_stage.store(stage, tid);
+    o_stage.store(stage + Q_BYTES, tid);
+    if (tid < QT) {
+      ((float*)(stage + Q_BYTES + O_BYTES))[tid] = st_lse;
+      ((float*)(stage + Q_BYTES + O_BYTES))[QT + tid] = st_dlt;
+    }
+  };
+  if (t_begin < t_end) {
+    load_tile(t_begin);
+    store_tile(smem);
+  }
+  __syncthreads();
+  for (int t = t_begin; t < t_end; ++t) {
+    const int par = (t - t_begin) & 1;
+    const unsigned char* q_cur = smem + par * STAGE;
+    const unsigned char* o_cur = q_cur + Q_BYTES;
+    const float* lse_s = (const float*)(o_cur + O_BYTES);
+    const float* dlt_s = lse_s + QT;
+    if (t + 1 < t_end) load_tile(t + 1);
+
+    f32x16_t s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) s = mfma32(row_frag<QT>(q_cur, 0, ks, lane), kf[ks], s);
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) dp = mfma32(row_frag<QT>(o_cur, 0, ks, lane), vf[ks], dp);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 l4 = *(const float4*)(lse_s + 8 * g + 4 * hh);
+      const float4 d4 = *(const float4*)(dlt_s + 8 * g + 4 * hh);
+      const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p = exp2f(s[4 * g + e] * c - lv[e]);
+        s[4 * g + e] = p;
+        dp[4 * g + e] = p * (dp[4 * g + e] - dl[e]) * a.scale;
+      }
+    }
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      const bf16x8_t pf = acc_to_frag(s, sp);
+      const bf16x8_t dsf = acc_to_frag(dp, sp);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        dv[j] = mfma32(tr_frag<QT>(o_cur, sp * 16, j, lane), pf, dv[j]);
+        dk[j] = mfma32(tr_frag<QT>(q_cur, sp * 16, j, lane), dsf, dk[j]);
+      }
+    }
+    if (t + 1 < t_end) store_tile(smem + (par ^ 1) * STAGE);
+    __syncthreads();
+  }
+  // ---- transpose through LDS so that every atomic wave-instruction adds whole rows ----------
+  float* obuf = (float*)smem;  // [128 keys][OUT_LD]
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        obuf[(wave * 32 + (lane & 31)) * OUT_LD + j * 32 + acc_row(r, lane)] =
+            pass == 0 ? dk[j][r] : dv[j][r];
+    __syncthreads();
+    float* dst = (pass == 0 ? a.dk : a.dv) + ((size_t)bh * a.Nk) * HD;
+    for (int i = tid; i < 128 * HD; i += 256) {
+      const int kr = i / HD, d = i % HD;
+      if (key0 + kr < a.Nk) atomicAdd(dst + (size_t)(key0 + kr) * HD + d, obuf[kr * OUT_LD + d]);
+    }
+  }
+}
+
+template <int DA>
+int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
+  static bool configured = false;
+  const size_t lds_dq = 2 * (size_t)(KT * DA * 2 + KT * HD * 2);
+  size_t lds_kv = 2 * (size_t)(QT * DA * 2 + QT * HD * 2 + 2 * QT * 4);
+  const size_t lds_out = (size_t)128 * (HD + 1) * 4;
+  if (lds_kv < lds_out) lds_kv = lds_out;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DA>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DA>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  const int64_t rows = (int64_t)a.B * a.heads * a.Nq;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, st,
+                     (const bf16_t*)a.ctx, (const bf16_t*)a.dctx, (const bf16_t*)a.qa, DA, a.delta,
+                     a.B, a.heads, a.Nq);
+  SVIT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<DA>, dim3((a.Nq + 127) / 128, a.B * a.heads), dim3(256),
+                     lds_dq, st, a);
+  SVIT_LAUNCH_CHECK();
+  const int nqt = (a.Nq + QT - 1) / QT;
+  const int key_blocks = (a.Nk + 127) / 128;
+  int splits = a.q_splits;
+  if (splits <= 0) {  // aim at >= ~768 blocks
+    splits = (768 + key_blocks * a.B * a.heads - 1) / (key_blocks * a.B * a.heads);
+  }
+  if (splits > nqt) splits = nqt;
+  if (splits < 1) splits = 1;
+  int tiles_per_split = (nqt + splits - 1) / splits;
+  splits = (nqt + tiles_per_split - 1) / tiles_per_split;
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<DA>, dim3(key_blocks, splits, a.B * a.heads), dim3(256),
+                     lds_kv, st, a, tiles_per_split);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+}  // namespace
+
+extern "C" int svit_attn_bwd(const svit_attn_bwd_args* a, void* stream) {
+  if (!a || !a->qa || !a->ka || !a->v || !a->ctx || !a->dctx || !a->lse2 || !a->delta || !a->dqa ||
+      !a->dk || !a->dv)
+    return SVIT_ERR_ARG;
+  if (a->B <= 0 || a->heads <= 0 || a->Nq <= 0 || a->Nk <= 0) return SVIT_ERR_SHAPE;
+  if (a->B * a->heads > 65535) return SVIT_ERR_SHAPE;
+  if (a->DA == 128) return launch_bwd<128>(*a, (hipStream_t)stream);
+  if (a->DA == 160) return launch_bwd<160>(*a, (hipStream_t)stream);
+  return SVIT_ERR_SHAPE;
+}

@@ -1,0 +1,80 @@
+// Shared device helpers for the SViT HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits in HBM
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+#define SVIT_OK 0
+#define SVIT_ERR_SHAPE (-2)
+#define SVIT_ERR_ALIGN (-3)
+#define SVIT_ERR_ARG (-4)
+
+#define SVIT_LAUNCH_CHECK()                       \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((uint32_t)v) << 16);
+}
+// round-to-nearest-even via the hardware convert (keeps NaN a NaN; see MI355X guide)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float lo_bf16(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hi_bf16(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// 32x32x16 bf16 MFMA: D = A(32x16) * B(16x32) + C.  Lane l: A[row l&31][k 8*(l>>5)+j],
+// B[k 8*(l>>5)+j][col l&31]; C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
+__device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc_row(int r, int lane) {
+  return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-col block of 16-bit elements is
+// delivered column-major; lane 4q+p supplies the address of row q, cols 4p..4p+3 and lane i
+// receives column i (rows 0..3 in elements 0..3).  All 64 lanes must be active.
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+__device__ __forceinline__ s16x4_t lds_read_tr16(const void* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (lds_s16x4_t*)(__attribute__((address_space(3))) void*)p);
+}
+
+__device__ __forceinline__ bf16x8_t make_bf16x8(s16x4_t lo, s16x4_t hi) {
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}

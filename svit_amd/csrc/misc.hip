@@ -1,0 +1,353 @@
+// Memory-bound helpers: casts / transposes of the weight copies, DropPath backward scaling,
+// im2col for the patch-embedding conv, special-token rows, max-pool skip path, and the
+// optimiser tail (global grad norm + clip + AdamW) -- gfx950 only.
+#include "common.h"
+#include "../../include/svit_hip.h"
+
+namespace {
+
+__global__ void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      const float4 a = *(const float4*)(src + i), b = *(const float4*)(src + i + 4);
+      uint4 o;
+      o.x = pack_bf16x2(a.x, a.y); o.y = pack_bf16x2(a.z, a.w);
+      o.z = pack_bf16x2(b.x, b.y); o.w = pack_bf16x2(b.z, b.w);
+      *(uint4*)(dst + i) = o;
+    } else {
+      for (int64_t j = i; j < n; ++j) dst[j] = f32_to_bf16(src[j]);
+    }
+  }
+}
+
+// one 32x32 tile per block-iteration; table rows: {src_off, dst_off, R, C}
+__global__ void transpose_cast_kernel(const float* __restrict__ src_base,
+                                      bf16_t* __restrict__ dst_base,
+                                      const int64_t* __restrict__ table, int n_mats) {
+  __shared__ float tile[32][33];
+  const int mat = blockIdx.y;
+  if (mat >= n_mats) return;
+  const int64_t so = table[mat * 4 + 0], dof = table[mat * 4 + 1];
+  const int R = (int)table[mat * 4 + 2], C = (int)table[mat * 4 + 3];
+  const int tr = (R + 31) / 32, tc = (C + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+    const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+    for (int i = ty; i < 32; i += 8) {
+      const int r = r0 + i, c = c0 + tx;
+      tile[i][tx] = (r < R && c < C) ? src_base[so + (int64_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+      const int c = c0 + i, r = r0 + tx;  // dst[c][r]
+      if (r < R && c < C) dst_base[dof + (int64_t)c * R + r] = f32_to_bf16(tile[tx][i]);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void scale_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                  const float* __restrict__ row_scale, int rows_per_sample,
+                                  int64_t rows, int cols) {
+  const int cpr = cols >> 2;  // float4 chunks per row
+  const int64_t total = rows * cpr;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / cpr;
+    const float s = row_scale ? row_scale[r / rows_per_sample] : 1.f;
+    const float4 v = ((const float4*)src)[i];
+    uint2 o;
+    o.x = pack_bf16x2(v.x * s, v.y * s);
+    o.y = pack_bf16x2(v.z * s, v.w * s);
+    ((uint2*)dst)[i] = o;
+  }
+}
+
+// ---- patch embedding im2col: Conv3d(3->96, k(3,7,7), s(2,4,4), p(1,3,3)) -----------------
+__global__ void im2col_patch_kernel(const float* __restrict__ video, bf16_t* __restrict__ cols,
+                                    int B, int T, int H, int W, int To, int Ho, int Wo) {
+  const int64_t total = (int64_t)B * To * Ho * Wo * 56;  // 56 chunks of 8 columns per row
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int chunk = (int)(i % 56);
+    int64_t m = i / 56;
+    const int xo = (int)(m % Wo); m /= Wo;
+    const int yo = (int)(m % Ho); m /= Ho;
+    const int to = (int)(m % To);
+    const int b = (int)(m / To);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int col = chunk * 8 + e;
+      v[e] = 0.f;
+      if (col < 441) {
+        const int kx = col % 7, ky = (col / 7) % 7, kt = (col / 49) % 3, c = col / 147;
+        const int t = to * 2 - 1 + kt, y = yo * 4 - 3 + ky, x = xo * 4 - 3 + kx;
+        if (t >= 0 && t < T && y >= 0 && y < H && x >= 0 && x < W)
+          v[e] = video[(((int64_t)b * 3 + c) * T + t) * H * W + (int64_t)y * W + x];
+      }
+    }
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    ((uint4*)cols)[i] = o;
+  }
+}
+
+// x[b,0,:] = cls ; x[b,1+L+t*O+o,:] = objq[o] + (add_pos ? pos_t[t] : 0)
+__global__ void fill_special_kernel(float* __restrict__ x, const float* __restrict__ cls,
+                                    const float* __restrict__ objq,
+                                    const float* __restrict__ pos_t, int B, int N, int L, int Tx,
+                                    int O, int C, int add_pos) {
+  const int per = (1 + Tx * O) * C;
+  const int64_t total = (int64_t)B * per;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per), r = (int)(i % per);
+    const int tok = r / C, c = r % C;
+    if (tok == 0) {
+      x[((int64_t)b * N) * C + c] = cls[c];
+    } else {
+      const int t = (tok - 1) / O, o = (tok - 1) % O;
+      x[((int64_t)b * N + 1 + L + (tok - 1)) * C + c] =
+          objq[o * C + c] + (add_pos ? pos_t[t * C + c] : 0.f);
+    }
+  }
+}
+
+// ---- max-pool skip: kernel (1,3,3), stride (1,2,2), pad (0,1,1) on patch tokens -----------
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                   uint8_t* __restrict__ idx, int B, int T, int H, int W, int Ho,
+                                   int Wo, int n_obj, int C) {
+  const int c4 = C >> 2;
+  const int Nin = 1 + T * H * W + n_obj, Nout = 1 + T * Ho * Wo + n_obj;
+  const int64_t total = (int64_t)B * Nout * c4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c4);
+    const int tok = (int)((i / c4) % Nout);
+    const int b = (int)(i / ((int64_t)c4 * Nout));
+    const float4* xb = (const float4*)(x + (int64_t)b * Nin * C);
+    float4 best;
+    uchar4 bi = make_uchar4(255, 255, 255, 255);
+    if (tok == 0) {
+      best = xb[cc];
+    } else if (tok > T * Ho * Wo) {
+      best = xb[(int64_t)(1 + T * H * W + (tok - 1 - T * Ho * Wo)) * c4 + cc];
+    } else {
+      const int p = tok - 1, xo = p % Wo, yo = (p / Wo) % Ho, t = p / (Wo * Ho);
+      best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = yo * 2 - 1 + ky;
+        if (yy < 0 || yy >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xx = xo * 2 - 1 + kx;
+          if (xx < 0 || xx >= W) continue;
+          const float4 v = xb[(int64_t)(1 + (t * H + yy) * W + xx) * c4 + cc];
+          const unsigned char tap = (unsigned char)(ky * 3 + kx);
+          if (v.x > best.x) { best.x = v.x; bi.x = tap; }
+          if (v.y > best.y) { best.y = v.y; bi.y = tap; }
+          if (v.z > best.z) { best.z = v.z; bi.z = tap; }
+          if (v.w > best.w) { best.w = v.w; bi.w = tap; }
+        }
+      }
+    }
+    ((float4*)y)[i] = best;
+    ((uchar4*)idx)[i] = bi;
+  }
+}
+
+// gather form: each input position sums the grads of the (<= 2x2) windows that selected it
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                   float* __restrict__ dx, int B, int T, int H, int W, int Ho,
+                                   int Wo, int n_obj, int C) {
+  const int c4 = C >> 2;
+  const int Nin = 1 + T * H * W + n_obj, Nout = 1 + T * Ho * Wo + n_obj;
+  const int64_t total = (int64_t)B * Nin * c4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c4);
+    const int tok = (int)((i / c4) % Nin);
+    const int b = (int)(i / ((int64_t)c4 * Nin));
+    const float4* db = (const float4*)(dy + (int64_t)b * Nout * C);
+    const uchar4* ib = (const uchar4*)(idx + (int64_t)b * Nout * C);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tok == 0) {
+      g = db[cc];
+    } else if (tok > T * H * W) {
+      g = db[(int64_t)(1 + T * Ho * Wo + (tok - 1 - T * H * W)) * c4 + cc];
+    } else {
+      const int p = tok - 1, xx = p % W, yy = (p / W) % H, t = p / (W * H);
+      for (int yo = (yy >> 1); yo <= (yy >> 1) + 1; ++yo) {
+        if (yo < 0 || yo >= Ho) continue;
+        const int ky = yy - (yo * 2 - 1);
+        if (ky < 0 || ky > 2) continue;
+        for (int xo = (xx >> 1); xo <= (xx >> 1) + 1; ++xo) {
+          if (xo < 0 || xo >= Wo) continue;
+          const int kx = xx - (xo * 2 - 1);
+          if (kx < 0 || kx > 2) continue;
+          const unsigned char tap = (unsigned char)(ky * 3 + kx);
+          const int64_t o = (int64_t)(1 + (t * Ho + yo) * Wo + xo) * c4 + cc;
+          const float4 d = db[o];
+          const uchar4 s = ib[o];
+          if (s.x == tap) g.x += d.x;
+          if (s.y == tap) g.y += d.y;
+          if (s.z == tap) g.z += d.z;
+          if (s.w == tap) g.w += d.w;
+        }
+      }
+    }
+    ((float4*)dx)[i] = g;
+  }
+}
+
+// ---- optimiser tail ---------------------------------------------------------------------
+__global__ void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+  float s = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      const float4 v = *(const float4*)(g + i);
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    } else {
+      for (int64_t j = i; j < n; ++j) s += g[j] * g[j];
+    }
+  }
+  s = wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                             float* __restrict__ m, float* __restrict__ v, int64_t n,
+                             const float* __restrict__ sumsq, float max_norm, float lr, float b1,
+                             float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                             float grad_scale) {
+  float coef = grad_scale;
+  if (sumsq && max_norm > 0.f) {
+    const float total = sqrtf(*sumsq) * grad_scale;
+    coef *= fminf(max_norm / (total + 1e-6f), 1.0f);
+  }
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gi = g[i] * coef;
+    float w = p[i] * (1.f - lr * wd);
+    const float mi = m[i] * b1 + gi * (1.f - b1);
+    const float vi = v[i] * b2 + gi * gi * (1.f - b2);
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    w -= (lr / bc1) * (mi / denom);
+    p[i] = w; m[i] = mi; v[i] = vi;
+  }
+}
+
+inline unsigned grid_for(int64_t work_items, int block, unsigned cap = 8192) {
+  int64_t b = (work_items + block - 1) / block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}
+}  // namespace
+
+extern "C" int svit_version(void) { return 1; }
+extern "C" const char* svit_arch(void) { return "gfx950"; }
+
+extern "C" int svit_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  if (!src || !dst || n <= 0) return SVIT_ERR_ARG;
+  if (((uintptr_t)src | (uintptr_t)dst) & 15) return SVIT_ERR_ALIGN;
+  hipLaunchKernelGGL(cast_kernel, dim3(grid_for((n + 7) / 8, 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, (bf16_t*)dst, n);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_transpose_cast_batched(const float* src_base, void* dst_base,
+                                           const int64_t* table, int n_mats, int max_tiles,
+                                           void* stream) {
+  if (!src_base || !dst_base || !table || n_mats <= 0) return SVIT_ERR_ARG;
+  int gx = max_tiles < 1 ? 1 : (max_tiles > 256 ? 256 : max_tiles);
+  hipLaunchKernelGGL(transpose_cast_kernel, dim3(gx, n_mats), dim3(256), 0, (hipStream_t)stream,
+                     src_base, (bf16_t*)dst_base, table, n_mats);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_scale_cast(const float* src, void* dst, const float* row_scale,
+                               int rows_per_sample, int64_t rows, int cols, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || cols % 4 != 0) return SVIT_ERR_ARG;
+  if (row_scale && rows_per_sample <= 0) return SVIT_ERR_ARG;
+  hipLaunchKernelGGL(scale_cast_kernel, dim3(grid_for(rows * (cols / 4), 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, (bf16_t*)dst, row_scale, rows_per_sample, rows,
+                     cols);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_im2col_patch(const float* video, void* cols, int B, int T, int H, int W,
+                                 void* stream) {
+  if (!video || !cols || B <= 0 || T <= 0 || H <= 0 || W <= 0) return SVIT_ERR_ARG;
+  const int To = (T + 2 - 3) / 2 + 1, Ho = (H + 6 - 7) / 4 + 1, Wo = (W + 6 - 7) / 4 + 1;
+  const int64_t total = (int64_t)B * To * Ho * Wo * 56;
+  hipLaunchKernelGGL(im2col_patch_kernel, dim3(grid_for(total, 256, 65535)), dim3(256), 0,
+                     (hipStream_t)stream, video, (bf16_t*)cols, B, T, H, W, To, Ho, Wo);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_fill_special_tokens(float* x, const float* cls, const float* objq,
+                                        const float* pos_t, int B, int N, int L, int Tx, int O,
+                                        int C, int add_pos, void* stream) {
+  if (!x || !cls || !objq || (add_pos && !pos_t)) return SVIT_ERR_ARG;
+  if (N != 1 + L + Tx * O) return SVIT_ERR_SHAPE;
+  const int64_t total = (int64_t)B * (1 + Tx * O) * C;
+  hipLaunchKernelGGL(fill_special_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, cls, objq, pos_t, B, N, L, Tx, O, C, add_pos);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_maxpool_fwd(const float* x, float* y, uint8_t* idx, int B, int T, int H, int W,
+                                int n_obj, int C, void* stream) {
+  if (!x || !y || !idx || C % 4 != 0) return SVIT_ERR_ARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int64_t total = (int64_t)B * (1 + T * Ho * Wo + n_obj) * (C / 4);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, idx, B, T, H, W, Ho, Wo, n_obj, C);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int T, int H,
+                                int W, int n_obj, int C, void* stream) {
+  if (!dy || !dx || !idx || C % 4 != 0) return SVIT_ERR_ARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int64_t total = (int64_t)B * (1 + T * H * W + n_obj) * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dy, idx, dx, B, T, H, W, Ho, Wo, n_obj, C);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_sumsq(const float* g, int64_t n, float* sumsq, void* stream) {
+  if (!g || !sumsq || n <= 0) return SVIT_ERR_ARG;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for((n + 3) / 4, 256, 1024)), dim3(256), 0,
+                     (hipStream_t)stream, g, n, sumsq);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_adamw_step(float* p, const float* g, float* m, float* v, int64_t n,
+                               const float* sumsq, float max_norm, float lr, float beta1,
+                               float beta2, float eps, float wd, int step, float grad_scale,
+                               void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step < 1) return SVIT_ERR_ARG;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     p, g, m, v, n, sumsq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2s,
+                     grad_scale);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}

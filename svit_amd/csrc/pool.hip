@@ -1,0 +1,596 @@
+// Pooled q/k/v path of MultiScaleAttention (SURVEY.md K5/K6/K3, K9/K10 query side) -- gfx950.
+//
+// The reference reshapes to channels-first [B*h,96,T,H,W], runs a depthwise Conv3d and
+// permutes back (two full copies, attention.py:35-43).  Here everything stays token-major /
+// channels-last: 4 lanes own one output token (24 channels each, 16-byte bf16 vector loads),
+// the 27-tap stencil reads the qkv GEMM output in place, the object-token branch is the closed
+// form obj*g(w), and LayerNorm(96) is fused (4-lane shuffle reduce).
+#include "common.h"
+#include "../../include/svit_hip.h"
+
+namespace {
+constexpr int HD = 96;
+
+__device__ __forceinline__ int pooled(int n, int s) { return (n - 1) / s + 1; }
+
+// per-axis tap counts of the object branch: how many output positions of a zero-padded 3-cube
+// see tap i in range, and the number of output positions (attention.py:45-53)
+__device__ __forceinline__ void obj_counts(int s, float n[3], float* inv_p) {
+  const int n_out = (3 - 1) / s + 1;
+  n[0] = n[1] = n[2] = 0.f;
+  for (int o = 0; o < n_out; ++o)
+    for (int tap = 0; tap < 3; ++tap) {
+      const int i = o * s - 1 + tap;
+      if (i >= 0 && i < 3) n[tap] += 1.f;
+    }
+  *inv_p = 1.f / (float)n_out;
+}
+
+__device__ __forceinline__ void unpack8(const uint4 v, float f[8]) {
+  f[0] = lo_bf16(v.x); f[1] = hi_bf16(v.x); f[2] = lo_bf16(v.y); f[3] = hi_bf16(v.y);
+  f[4] = lo_bf16(v.z); f[5] = hi_bf16(v.z); f[6] = lo_bf16(v.w); f[7] = hi_bf16(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float f[8]) {
+  uint4 o;
+  o.x = pack_bf16x2(f[0], f[1]); o.y = pack_bf16x2(f[2], f[3]);
+  o.z = pack_bf16x2(f[4], f[5]); o.w = pack_bf16x2(f[6], f[7]);
+  return o;
+}
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  return v;
+}
+
+// LDS image of the conv weights, tap-major so one lane reads its 24 channels contiguously
+__device__ __forceinline__ void load_weights(const float* __restrict__ conv_w, float* w_lds,
+                                             float* g_lds, int stride_hw) {
+  for (int i = threadIdx.x; i < 27 * HD; i += blockDim.x) {
+    const int c = i / 27, tap = i % 27;
+    w_lds[tap * HD + c] = conv_w[i];
+  }
+  __syncthreads();
+  if (g_lds) {
+    float nt[3], nh[3], ipt, iph;
+    obj_counts(1, nt, &ipt);
+    obj_counts(stride_hw, nh, &iph);
+    for (int c = threadIdx.x; c < HD; c += blockDim.x) {
+      float g = 0.f;
+      for (int kt = 0; kt < 3; ++kt)
+        for (int ky = 0; ky < 3; ++ky)
+          for (int kx = 0; kx < 3; ++kx)
+            g += w_lds[((kt * 3 + ky) * 3 + kx) * HD + c] * nt[kt] * nh[ky] * nh[kx];
+      g_lds[c] = g * ipt * iph * iph;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_ln_fwd_kernel(svit_pool_args a) {
+  __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];
+  __shared__ __attribute__((aligned(16))) float g_lds[HD];
+  load_weights(a.conv_w, w_lds, g_lds, a.stride_hw);
+  const int s = a.stride_hw;
+  const int Ho = pooled(a.H, s), Wo = pooled(a.W, s);
+  const int L = a.T * a.H * a.W, Lo = a.T * Ho * Wo;
+  const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
+  const int bh = blockIdx.y, b = bh / a.heads, head = bh % a.heads;
+  const int tok = blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int sub = threadIdx.x & 3, c0 = sub * 24;
+  const bool live = tok < Nout;
+  const bf16_t* qkv = (const bf16_t*)a.qkv;
+  const size_t tok_stride = (size_t)3 * a.heads * HD;
+  const bf16_t* base = qkv + (size_t)b * N * tok_stride + ((size_t)a.which * a.heads + head) * HD + c0;
+
+  float acc[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) acc[i] = 0.f;
+  int py = 0, px = 0, pt = 0;
+  bool is_patch = false;
+  if (live) {
+    if (tok == 0 || tok > Lo) {
+      const int src = (tok == 0) ? 0 : (1 + L + (tok - 1 - Lo));
+      const bf16_t* p = base + (size_t)src * tok_stride;
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        float f[8];
+        unpack8(*(const uint4*)(p + v * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          acc[v * 8 + e] = (tok == 0) ? f[e] : f[e] * g_lds[c0 + v * 8 + e];
+      }
+    } else {
+      is_patch = true;
+      const int p = tok - 1;
+      px = p % Wo; py = (p / Wo) % Ho; pt = p / (Wo * Ho);
+      for (int kt = 0; kt < 3; ++kt) {
+        const int t = pt - 1 + kt;
+        if (t < 0 || t >= a.T) continue;
+        for (int ky = 0; ky < 3; ++ky) {
+          const int y = py * s - 1 + ky;
+          if (y < 0 || y >= a.H) continue;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int x = px * s - 1 + kx;
+            if (x < 0 || x >= a.W) continue;
+            const bf16_t* src = base + (size_t)(1 + (t * a.H + y) * a.W + x) * tok_stride;
+            const float* w = w_lds + ((kt * 3 + ky) * 3 + kx) * HD + c0;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+              float f[8];
+              unpack8(*(const uint4*)(src + v * 8), f);
+              const float4 w0 = *(const float4*)(w + v * 8), w1 = *(const float4*)(w + v * 8 + 4);
+              acc[v * 8 + 0] += f[0] * w0.x; acc[v * 8 + 1] += f[1] * w0.y;
+              acc[v * 8 + 2] += f[2] * w0.z; acc[v * 8 + 3] += f[3] * w0.w;
+              acc[v * 8 + 4] += f[4] * w1.x; acc[v * 8 + 5] += f[5] * w1.y;
+              acc[v * 8 + 6] += f[6] * w1.z; acc[v * 8 + 7] += f[7] * w1.w;
+            }
+          }
+        }
+      }
+    }
+  }
+  // the saved pre-LN value is the bf16-rounded one: normalise exactly what backward will see
+#pragma unroll
+  for (int i = 0; i < 24; ++i) acc[i] = bf16_to_f32(f32_to_bf16(acc[i]));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 24; ++i) sum += acc[i];
+  const float mean = quad_sum(sum) * (1.f / HD);
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 24; ++i) sq += (acc[i] - mean) * (acc[i] - mean);
+  const float rstd = rsqrtf(quad_sum(sq) * (1.f / HD) + a.eps);
+  if (!live) return;
+  const size_t orow = (size_t)bh * Nout + tok;
+  if (sub == 0) { a.mean[orow] = mean; a.rstd[orow] = rstd; }
+  bf16_t* outp = (bf16_t*)a.out + orow * a.ld_out + c0;
+  bf16_t* prep = (bf16_t*)a.pre + orow * HD + c0;
+#pragma unroll
+  for (int v = 0; v < 3; ++v) {
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      o[e] = (acc[v * 8 + e] - mean) * rstd * a.gamma[c0 + v * 8 + e] + a.beta[c0 + v * 8 + e];
+    *(uint4*)(outp + v * 8) = pack8(o);
+    *(uint4*)(prep + v * 8) = pack8(&acc[v * 8]);
+  }
+  if (a.mode == 1) {  // one-hot key coordinates [y | kh+x | kh+kw+t], zeros elsewhere
+    const int extra = a.ld_out - HD, per = extra / 4;
+    bf16_t* ex = (bf16_t*)a.out + orow * a.ld_out + HD + sub * per;
+    for (int v = 0; v < per; v += 8) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = sub * per + v + e;
+        o[e] = (is_patch && (j == py || j == Ho + px || j == Ho + Wo + pt)) ? 1.f : 0.f;
+      }
+      *(uint4*)(ex + v) = pack8(o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_ln_bwd_kernel(svit_pool_ln_bwd_args a) {
+  __shared__ float red[2][HD];
+  for (int i = threadIdx.x; i < 2 * HD; i += blockDim.x) (&red[0][0])[i] = 0.f;
+  __syncthreads();
+  const int sub = threadIdx.x & 3, c0 = sub * 24;
+  const int64_t total = (int64_t)a.B * a.heads * a.Nout;
+  float gam[24], dg[24], db[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) { gam[i] = a.gamma[c0 + i]; dg[i] = 0.f; db[i] = 0.f; }
+  const int64_t iters = (total + (int64_t)gridDim.x * 64 - 1) / ((int64_t)gridDim.x * 64);
+  for (int64_t it = 0; it < iters; ++it) {
+    const int64_t row = (it * gridDim.x + blockIdx.x) * 64 + (threadIdx.x >> 2);
+    const bool live = row < total;
+    float d[24], xh[24];
+    float mean = 0.f, rstd = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { d[i] = 0.f; xh[i] = 0.f; }
+    if (live) {
+      const int tok = (int)(row % a.Nout);
+      const int bh = (int)(row / a.Nout), b = bh / a.heads, head = bh % a.heads;
+      mean = a.mean[row]; rstd = a.rstd[row];
+      if (a.d_main) {
+        if (a.main_is_f32) {
+          const float* p = (const float*)a.d_main + row * a.ld_main + c0;
+#pragma unroll
+          for (int v = 0; v < 6; ++v) {
+            const float4 f = *(const float4*)(p + v * 4);
+            d[v * 4] += f.x; d[v * 4 + 1] += f.y; d[v * 4 + 2] += f.z; d[v * 4 + 3] += f.w;
+          }
+        } else {
+          const bf16_t* p = (const bf16_t*)a.d_main + row * a.ld_main + c0;
+#pragma unroll
+          for (int v = 0; v < 3; ++v) {
+            float f[8];
+            unpack8(*(const uint4*)(p + v * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[v * 8 + e] += f[e];
+          }
+        }
+      }
+      if (a.d_res && tok > 0) {
+        const bf16_t* p = (const bf16_t*)a.d_res + ((size_t)b * a.Nout + tok) * a.heads * HD + head * HD + c0;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+          float f[8];
+          unpack8(*(const uint4*)(p + v * 8), f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d[v * 8 + e] += f[e];
+        }
+      }
+      if (a.d_extra) {
+        const float* p = a.d_extra + row * HD + c0;
+#pragma unroll
+        for (int v = 0; v < 6; ++v) {
+          const float4 f = *(const float4*)(p + v * 4);
+          d[v * 4] += f.x; d[v * 4 + 1] += f.y; d[v * 4 + 2] += f.z; d[v * 4 + 3] += f.w;
+        }
+      }
+      const bf16_t* pp = (const bf16_t*)a.pre + row * HD + c0;
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        float f[8];
+        unpack8(*(const uint4*)(pp + v * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xh[v * 8 + e] = (f[e] - mean) * rstd;
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+      dg[i] += d[i] * xh[i];
+      db[i] += d[i];
+      d[i] *= gam[i];
+      s1 += d[i];
+      s2 += d[i] * xh[i];
+    }
+    s1 = quad_sum(s1) * (1.f / HD);
+    s2 = quad_sum(s2) * (1.f / HD);
+    if (live) {
+      bf16_t* o = (bf16_t*)a.dpre + row * HD + c0;
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = rstd * (d[v * 8 + e] - s1 - xh[v * 8 + e] * s2);
+        *(uint4*)(o + v * 8) = pack8(f);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 24; ++i) {
+    atomicAdd(&red[0][c0 + i], dg[i]);
+    atomicAdd(&red[1][c0 + i], db[i]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < HD; c += blockDim.x) {
+    atomicAdd(a.dgamma + c, red[0][c]);
+    atomicAdd(a.dbeta + c, red[1][c]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_dgrad_kernel(svit_pool_dgrad_args a) {
+  __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];
+  __shared__ __attribute__((aligned(16))) float g_lds[HD];
+  load_weights(a.conv_w, w_lds, g_lds, a.stride_hw);
+  const int s = a.stride_hw;
+  const int Ho = pooled(a.H, s), Wo = pooled(a.W, s);
+  const int L = a.T * a.H * a.W, Lo = a.T * Ho * Wo;
+  const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
+  const int bh = blockIdx.y, b = bh / a.heads, head = bh % a.heads;
+  const int tok = blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int sub = threadIdx.x & 3, c0 = sub * 24;
+  if (tok >= N) return;
+  const bf16_t* dp = (const bf16_t*)a.dpre + (size_t)bh * Nout * HD + c0;
+  float acc[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) acc[i] = 0.f;
+  if (tok == 0 || tok > L) {
+    const int src = (tok == 0) ? 0 : (1 + Lo + (tok - 1 - L));
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      float f[8];
+      unpack8(*(const uint4*)(dp + (size_t)src * HD + v * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[v * 8 + e] = (tok == 0) ? f[e] : f[e] * g_lds[c0 + v * 8 + e];
+    }
+  } else {
+    const int p = tok - 1, x = p % a.W, y = (p / a.W) % a.H, t = p / (a.W * a.H);
+    for (int kt = 0; kt < 3; ++kt) {
+      const int to = t + 1 - kt;
+      if (to < 0 || to >= a.T) continue;
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yn = y + 1 - ky;
+        if (yn < 0 || yn % s != 0) continue;
+        const int yo = yn / s;
+        if (yo >= Ho) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xn = x + 1 - kx;
+          if (xn < 0 || xn % s != 0) continue;
+          const int xo = xn / s;
+          if (xo >= Wo) continue;
+          const bf16_t* src = dp + (size_t)(1 + (to * Ho + yo) * Wo + xo) * HD;
+          const float* w = w_lds + ((kt * 3 + ky) * 3 + kx) * HD + c0;
+#pragma unroll
+          for (int v = 0; v < 3; ++v) {
+            float f[8];
+            unpack8(*(const uint4*)(src + v * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[v * 8 + e] += f[e] * w[v * 8 + e];
+          }
+        }
+      }
+    }
+  }
+  const size_t tok_stride = (size_t)3 * a.heads * HD;
+  bf16_t* o = (bf16_t*)a.dqkv + ((size_t)b * N + tok) * tok_stride + ((size_t)a.which * a.heads + head) * HD + c0;
+#pragma unroll
+  for (int v = 0; v < 3; ++v) *(uint4*)(o + v * 8) = pack8(&acc[v * 8]);
+}
+
+// ---------------------------------------------------------------------------------------
+// wgrad: 24 lanes per output token (4 channels each), 8 tokens per 192-thread block,
+// 27x4 register accumulators per lane over a grid-stride loop, LDS then global atomics.
+__global__ __launch_bounds__(192) void pool_wgrad_kernel(svit_pool_wgrad_args a) {
+  __shared__ float acc_lds[27 * HD];
+  for (int i = threadIdx.x; i < 27 * HD; i += blockDim.x) acc_lds[i] = 0.f;
+  __syncthreads();
+  const int s = a.stride_hw;
+  const int Ho = pooled(a.H, s), Wo = pooled(a.W, s);
+  const int L = a.T * a.H * a.W, Lo = a.T * Ho * Wo;
+  const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
+  const int sub = threadIdx.x % 24, slot = threadIdx.x / 24, c0 = sub * 4;
+  const size_t tok_stride = (size_t)3 * a.heads * HD;
+  float nt[3], nh[3], ipt, iph;
+  obj_counts(1, nt, &ipt);
+  obj_counts(s, nh, &iph);
+  const float inv_p = ipt * iph * iph;
+  float acc[27][4];
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[k][e] = 0.f;
+  const int64_t total = (int64_t)a.B * a.heads * Nout;
+  for (int64_t row = (int64_t)blockIdx.x * 8 + slot; row < total; row += (int64_t)gridDim.x * 8) {
+    const int tok = (int)(row % Nout);
+    if (tok == 0) continue;
+    const int bh = (int)(row / Nout), b = bh / a.heads, head = bh % a.heads;
+    const uint2 dv = *(const uint2*)((const bf16_t*)a.dpre + row * HD + c0);
+    const float d0 = lo_bf16(dv.x), d1 = hi_bf16(dv.x), d2 = lo_bf16(dv.y), d3 = hi_bf16(dv.y);
+    const bf16_t* base = (const bf16_t*)a.qkv + (size_t)b * N * tok_stride +
+                         ((size_t)a.which * a.heads + head) * HD + c0;
+    if (tok > Lo) {
+      const uint2 xv = *(const uint2*)(base + (size_t)(1 + L + (tok - 1 - Lo)) * tok_stride);
+      const float x0 = lo_bf16(xv.x) * d0 * inv_p, x1 = hi_bf16(xv.x) * d1 * inv_p;
+      const float x2 = lo_bf16(xv.y) * d2 * inv_p, x3 = hi_bf16(xv.y) * d3 * inv_p;
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        const float n = nt[k / 9] * nh[(k / 3) % 3] * nh[k % 3];
+        acc[k][0] += x0 * n; acc[k][1] += x1 * n; acc[k][2] += x2 * n; acc[k][3] += x3 * n;
+      }
+    } else {
+      const int p = tok - 1, px = p % Wo, py = (p / Wo) % Ho, pt = p / (Wo * Ho);
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        const int t = pt - 1 + k / 9, y = py * s - 1 + (k / 3) % 3, x = px * s - 1 + k % 3;
+        if (t < 0 || t >= a.T || y < 0 || y >= a.H || x < 0 || x >= a.W) continue;
+        const uint2 xv = *(const uint2*)(base + (size_t)(1 + (t * a.H + y) * a.W + x) * tok_stride);
+        acc[k][0] += lo_bf16(xv.x) * d0; acc[k][1] += hi_bf16(xv.x) * d1;
+        acc[k][2] += lo_bf16(xv.y) * d2; acc[k][3] += hi_bf16(xv.y) * d3;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(&acc_lds[k * HD + c0 + e], acc[k][e]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 27 * HD; i += blockDim.x) {
+    const int k = i / HD, c = i % HD;
+    atomicAdd(a.dw + c * 27 + k, acc_lds[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// query side of the decomposed relative-position bias
+__global__ __launch_bounds__(256) void relq_fwd_kernel(svit_relq_args a) {
+  const int extra = a.ld - HD;               // 32 or 64 columns
+  const int Lq = a.qt * a.qh * a.qw, Nq = 1 + Lq + a.n_obj;
+  const int J = a.kh + a.kw + a.kt;
+  const int tok_per_block = 256 / extra;
+  const int64_t total = (int64_t)a.B * a.heads * Nq;
+  const int64_t row = (int64_t)blockIdx.x * tok_per_block + threadIdx.x / extra;
+  const int j = threadIdx.x % extra;
+  if (row >= total) return;
+  bf16_t* qrow = (bf16_t*)a.qa + row * a.ld;
+  const int tok = (int)(row % Nq);
+  float val = 0.f;
+  if (tok >= 1 && tok <= Lq && j < J) {
+    const int p = tok - 1, x = p % a.qw, y = (p / a.qw) % a.qh, t = p / (a.qw * a.qh);
+    const float* R;
+    if (j < a.kh) R = a.rel_h + (size_t)a.idx_h[y * a.kh + j] * HD;
+    else if (j < a.kh + a.kw) R = a.rel_w + (size_t)a.idx_w[x * a.kw + (j - a.kh)] * HD;
+    else R = a.rel_t + (size_t)a.idx_t[t * a.kt + (j - a.kh - a.kw)] * HD;
+#pragma unroll
+    for (int v = 0; v < 12; ++v) {
+      float f[8];
+      unpack8(*(const uint4*)(qrow + v * 8), f);
+      const float4 r0 = *(const float4*)(R + v * 8), r1 = *(const float4*)(R + v * 8 + 4);
+      val += f[0] * r0.x + f[1] * r0.y + f[2] * r0.z + f[3] * r0.w + f[4] * r1.x + f[5] * r1.y +
+             f[6] * r1.z + f[7] * r1.w;
+    }
+    val *= a.inv_scale;
+  }
+  qrow[HD + j] = f32_to_bf16(val);
+}
+
+__global__ __launch_bounds__(256) void relq_bwd_kernel(svit_relq_bwd_args a) {
+  extern __shared__ __attribute__((aligned(16))) float tabs[];  // dRh | dRw | dRt
+  float* th = tabs;
+  float* tw = th + a.rows_h * HD;
+  float* tt = tw + a.rows_w * HD;
+  const int tab_n = (a.rows_h + a.rows_w + a.rows_t) * HD;
+  for (int i = threadIdx.x; i < tab_n; i += blockDim.x) tabs[i] = 0.f;
+  __syncthreads();
+  const int Lq = a.qt * a.qh * a.qw, Nq = 1 + Lq + a.n_obj;
+  const int l32 = threadIdx.x & 31, slot = threadIdx.x >> 5;  // 8 tokens per block
+  const int64_t total = (int64_t)a.B * a.heads * Nq;
+  for (int64_t row = (int64_t)blockIdx.x * 8 + slot; row < total; row += (int64_t)gridDim.x * 8) {
+    const int tok = (int)(row % Nq);
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (tok >= 1 && tok <= Lq) {
+      const int p = tok - 1, x = p % a.qw, y = (p / a.qw) % a.qh, t = p / (a.qw * a.qh);
+      const bf16_t* qrow = (const bf16_t*)a.qa + row * a.ld;
+      const bf16_t* drow = (const bf16_t*)a.dqa + row * a.ld + HD;
+      const float q0 = bf16_to_f32(qrow[l32]), q1 = bf16_to_f32(qrow[l32 + 32]),
+                  q2 = bf16_to_f32(qrow[l32 + 64]);
+      for (int j = 0; j < a.kh; ++j) {
+        const float d = bf16_to_f32(drow[j]) * a.inv_scale;
+        const int r = a.idx_h[y * a.kh + j];
+        const float* R = a.rel_h + (size_t)r * HD;
+        o0 += d * R[l32]; o1 += d * R[l32 + 32]; o2 += d * R[l32 + 64];
+        atomicAdd(&th[r * HD + l32], d * q0);
+        atomicAdd(&th[r * HD + l32 + 32], d * q1);
+        atomicAdd(&th[r * HD + l32 + 64], d * q2);
+      }
+      for (int j = 0; j < a.kw; ++j) {
+        const float d = bf16_to_f32(drow[a.kh + j]) * a.inv_scale;
+        const int r = a.idx_w[x * a.kw + j];
+        const float* R = a.rel_w + (size_t)r * HD;
+        o0 += d * R[l32]; o1 += d * R[l32 + 32]; o2 += d * R[l32 + 64];
+        atomicAdd(&tw[r * HD + l32], d * q0);
+        atomicAdd(&tw[r * HD + l32 + 32], d * q1);
+        atomicAdd(&tw[r * HD + l32 + 64], d * q2);
+      }
+      for (int j = 0; j < a.kt; ++j) {
+        const float d = bf16_to_f32(drow[a.kh + a.kw + j]) * a.inv_scale;
+        const int r = a.idx_t[t * a.kt + j];
+        const float* R = a.rel_t + (size_t)r * HD;
+        o0 += d * R[l32]; o1 += d * R[l32 + 32]; o2 += d * R[l32 + 64];
+        atomicAdd(&tt[r * HD + l32], d * q0);
+        atomicAdd(&tt[r * HD + l32 + 32], d * q1);
+        atomicAdd(&tt[r * HD + l32 + 64], d * q2);
+      }
+    }
+    float* o = a.dq_extra + row * HD;
+    o[l32] = o0; o[l32 + 32] = o1; o[l32 + 64] = o2;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < tab_n; i += blockDim.x) {
+    const float v = tabs[i];
+    if (v == 0.f) continue;
+    if (i < a.rows_h * HD) atomicAdd(a.drel_h + i, v);
+    else if (i < (a.rows_h + a.rows_w) * HD) atomicAdd(a.drel_w + (i - a.rows_h * HD), v);
+    else atomicAdd(a.drel_t + (i - (a.rows_h + a.rows_w) * HD), v);
+  }
+}
+}  // namespace
+
+static int check_pool_dims(int B, int heads, int T, int H, int W, int n_obj, int s) {
+  if (B <= 0 || heads <= 0 || T <= 0 || H <= 0 || W <= 0 || n_obj < 0 || s < 1) return SVIT_ERR_SHAPE;
+  return SVIT_OK;
+}
+
+extern "C" int svit_pool_ln_fwd(const svit_pool_args* a, void* stream) {
+  if (!a || !a->qkv || !a->conv_w || !a->gamma || !a->beta || !a->out || !a->pre || !a->mean || !a->rstd)
+    return SVIT_ERR_ARG;
+  int rc = check_pool_dims(a->B, a->heads, a->T, a->H, a->W, a->n_obj, a->stride_hw);
+  if (rc) return rc;
+  if (a->which < 0 || a->which > 2 || a->ld_out < HD || a->ld_out % 8 != 0) return SVIT_ERR_ARG;
+  const int Ho = (a->H - 1) / a->stride_hw + 1, Wo = (a->W - 1) / a->stride_hw + 1;
+  if (a->mode == 1) {
+    const int extra = a->ld_out - HD;
+    if (extra % 32 != 0 || extra < Ho + Wo + a->T) return SVIT_ERR_SHAPE;
+  }
+  const int Nout = 1 + a->T * Ho * Wo + a->n_obj;
+  hipLaunchKernelGGL(pool_ln_fwd_kernel, dim3((Nout + 63) / 64, a->B * a->heads), dim3(256), 0,
+                     (hipStream_t)stream, *a);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_pool_ln_bwd(const svit_pool_ln_bwd_args* a, void* stream) {
+  if (!a || !a->pre || !a->mean || !a->rstd || !a->gamma || !a->dpre || !a->dgamma || !a->dbeta)
+    return SVIT_ERR_ARG;
+  if (a->B <= 0 || a->heads <= 0 || a->Nout <= 0) return SVIT_ERR_SHAPE;
+  if (a->d_main && (a->ld_main < HD || a->ld_main % 8 != 0)) return SVIT_ERR_ALIGN;
+  const int64_t total = (int64_t)a->B * a->heads * a->Nout;
+  int64_t blocks = (total + 63) / 64;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(pool_ln_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_pool_conv_dgrad(const svit_pool_dgrad_args* a, void* stream) {
+  if (!a || !a->dpre || !a->conv_w || !a->dqkv || a->which < 0 || a->which > 2) return SVIT_ERR_ARG;
+  int rc = check_pool_dims(a->B, a->heads, a->T, a->H, a->W, a->n_obj, a->stride_hw);
+  if (rc) return rc;
+  const int N = 1 + a->T * a->H * a->W + a->n_obj;
+  hipLaunchKernelGGL(pool_dgrad_kernel, dim3((N + 63) / 64, a->B * a->heads), dim3(256), 0,
+                     (hipStream_t)stream, *a);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_pool_conv_wgrad(const svit_pool_wgrad_args* a, void* stream) {
+  if (!a || !a->dpre || !a->qkv || !a->dw || a->which < 0 || a->which > 2) return SVIT_ERR_ARG;
+  int rc = check_pool_dims(a->B, a->heads, a->T, a->H, a->W, a->n_obj, a->stride_hw);
+  if (rc) return rc;
+  const int Ho = (a->H - 1) / a->stride_hw + 1, Wo = (a->W - 1) / a->stride_hw + 1;
+  const int64_t total = (int64_t)a->B * a->heads * (1 + a->T * Ho * Wo + a->n_obj);
+  int64_t blocks = (total + 7) / 8;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(pool_wgrad_kernel, dim3((unsigned)blocks), dim3(192), 0, (hipStream_t)stream, *a);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+static int check_relq(int ld, int kh, int kw, int kt) {
+  const int extra = ld - HD;
+  if (extra != 32 && extra != 64) return SVIT_ERR_SHAPE;
+  if (kh + kw + kt > extra) return SVIT_ERR_SHAPE;
+  return SVIT_OK;
+}
+
+extern "C" int svit_relpos_q_fwd(const svit_relq_args* a, void* stream) {
+  if (!a || !a->qa || !a->rel_h || !a->rel_w || !a->rel_t || !a->idx_h || !a->idx_w || !a->idx_t)
+    return SVIT_ERR_ARG;
+  int rc = check_relq(a->ld, a->kh, a->kw, a->kt);
+  if (rc) return rc;
+  const int extra = a->ld - HD;
+  const int64_t total = (int64_t)a->B * a->heads * (1 + a->qt * a->qh * a->qw + a->n_obj);
+  const int tpb = 256 / extra;
+  hipLaunchKernelGGL(relq_fwd_kernel, dim3((unsigned)((total + tpb - 1) / tpb)), dim3(256), 0,
+                     (hipStream_t)stream, *a);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_relpos_q_bwd(const svit_relq_bwd_args* a, void* stream) {
+  if (!a || !a->qa || !a->dqa || !a->dq_extra || !a->drel_h || !a->drel_w || !a->drel_t)
+    return SVIT_ERR_ARG;
+  int rc = check_relq(a->ld, a->kh, a->kw, a->kt);
+  if (rc) return rc;
+  const size_t lds = (size_t)(a->rows_h + a->rows_w + a->rows_t) * HD * sizeof(float);
+  if (lds > 150 * 1024) return SVIT_ERR_SHAPE;
+  static size_t configured = 0;
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)relq_bwd_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    configured = lds;
+  }
+  const int64_t total = (int64_t)a->B * a->heads * (1 + a->qt * a->qh * a->qw + a->n_obj);
+  int64_t blocks = (total + 7) / 8;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(relq_bwd_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, *a);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}

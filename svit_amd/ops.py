@@ -1,0 +1,270 @@
+"""Thin tensor-level wrappers over the C ABI (svit_amd/hip.py).
+
+Every function enqueues HIP kernels on torch's current stream and returns torch tensors that
+merely *own the memory*; no arithmetic here is done by PyTorch.
+"""
+import ctypes as C
+
+import torch
+
+from . import hip
+from .hip import ptr
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+HD = 96
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise hip.SvitHipError("svit_amd ops need device tensors (got %s)" % t.device)
+        if t is not None and not t.is_contiguous():
+            raise hip.SvitHipError("svit_amd ops need contiguous tensors")
+
+
+def gemm_nt(a, w, bias=None, epilogue=hip.EPI_BF16, out=None, out2=None, aux=None,
+            row_scale=None, rows_per_sample=0, accumulate=False, remap=None):
+    """C = A[M,K] @ W[N,K]^T with a fused epilogue (see include/svit_hip.h)."""
+    _chk_dev(a, w, bias, out, out2, aux, row_scale)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and a.dtype == BF16 and w.dtype == BF16
+    if out is None:
+        dt = F32 if epilogue in (hip.EPI_RESID, hip.EPI_F32) else BF16
+        out = torch.empty((M, N), device=a.device, dtype=dt)
+    if epilogue == hip.EPI_GELU and out2 is None:
+        out2 = torch.empty((M, N), device=a.device, dtype=BF16)
+    g = hip.GemmArgs()
+    g.A, g.lda, g.W, g.ldw = ptr(a), a.stride(0), ptr(w), w.stride(0)
+    g.bias = ptr(bias)
+    g.out, g.ldo = ptr(out), out.stride(-2)
+    g.out2, g.ldo2 = ptr(out2), (out2.stride(-2) if out2 is not None else 0)
+    g.aux, g.ldaux = ptr(aux), (aux.stride(-2) if aux is not None else 0)
+    g.row_scale, g.rows_per_sample = ptr(row_scale), rows_per_sample
+    g.M, g.N, g.K = M, N, K
+    g.epilogue, g.accumulate = epilogue, int(accumulate)
+    if remap is not None:
+        g.remap_L, g.remap_N, g.remap_off = remap
+    hip.call("svit_gemm_nt", C.byref(g))
+    return (out, out2) if epilogue == hip.EPI_GELU else out
+
+
+def gemm_tn(a, b, dw, splits=0):
+    """dw[N,K] (f32) += a[M,N]^T @ b[M,K]."""
+    _chk_dev(a, b, dw)
+    M, N = a.shape
+    K = b.shape[1]
+    assert b.shape[0] == M and tuple(dw.shape[-2:]) == (N, K) and dw.dtype == F32
+    hip.call("svit_gemm_tn", ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(dw), dw.stride(-2),
+             M, N, K, splits)
+    return dw
+
+
+def colsum(a, out):
+    _chk_dev(a, out)
+    hip.call("svit_colsum_bf16", ptr(a), a.stride(0), ptr(out), a.shape[0], a.shape[1])
+    return out
+
+
+def cast_bf16(src, dst=None):
+    _chk_dev(src, dst)
+    if dst is None:
+        dst = torch.empty(src.shape, device=src.device, dtype=BF16)
+    hip.call("svit_cast_f32_bf16", ptr(src), ptr(dst), src.numel())
+    return dst
+
+
+def transpose_cast_batched(src_flat, dst_flat, table, n_mats, max_tiles):
+    hip.call("svit_transpose_cast_batched", ptr(src_flat), ptr(dst_flat), ptr(table), n_mats,
+             max_tiles)
+
+
+def scale_cast(src, row_scale=None, rows_per_sample=0, dst=None):
+    _chk_dev(src, row_scale, dst)
+    rows, cols = src.shape[:-1].numel(), src.shape[-1]
+    if dst is None:
+        dst = torch.empty(src.shape, device=src.device, dtype=BF16)
+    hip.call("svit_scale_cast", ptr(src), ptr(dst), ptr(row_scale), rows_per_sample, rows, cols)
+    return dst
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-6, want_f32=False, want_bf16=True, save_stats=True):
+    _chk_dev(x, gamma, beta)
+    C_ = x.shape[-1]
+    rows = x.numel() // C_
+    y16 = torch.empty(x.shape, device=x.device, dtype=BF16) if want_bf16 else None
+    y32 = torch.empty(x.shape, device=x.device, dtype=F32) if want_f32 else None
+    mean = torch.empty(rows, device=x.device, dtype=F32) if save_stats else None
+    rstd = torch.empty(rows, device=x.device, dtype=F32) if save_stats else None
+    hip.call("svit_layernorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y16), ptr(y32), ptr(mean),
+             ptr(rstd), rows, C_, eps)
+    return y16, y32, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, dx=None):
+    _chk_dev(dy, x, gamma, mean, rstd, dgamma, dbeta, dres, dx)
+    C_ = x.shape[-1]
+    rows = x.numel() // C_
+    if dx is None:
+        dx = torch.empty(x.shape, device=x.device, dtype=F32)
+    hip.call("svit_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres),
+             ptr(dx), ptr(dgamma), ptr(dbeta), rows, C_)
+    return dx
+
+
+def im2col_patch(video):
+    _chk_dev(video)
+    B, Cin, T, H, W = video.shape
+    assert Cin == 3 and video.dtype == F32
+    To, Ho, Wo = (T - 1) // 2 + 1, (H - 1) // 4 + 1, (W - 1) // 4 + 1
+    cols = torch.empty((B * To * Ho * Wo, 448), device=video.device, dtype=BF16)
+    hip.call("svit_im2col_patch", ptr(video), ptr(cols), B, T, H, W)
+    return cols, (To, Ho, Wo)
+
+
+def fill_special_tokens(x, cls, objq, pos_t, L, Tx, O, add_pos):
+    B, N, C_ = x.shape
+    hip.call("svit_fill_special_tokens", ptr(x), ptr(cls), ptr(objq), ptr(pos_t), B, N, L, Tx, O,
+             C_, int(add_pos))
+
+
+def pooled(n, s):
+    return (n - 1) // s + 1
+
+
+def pool_ln_fwd(qkv, which, conv_w, gamma, beta, B, heads, thw, n_obj, stride_hw, ld_out=HD,
+                mode=0, eps=1e-6):
+    """-> out bf16 [B,h,Nout,ld_out], pre bf16 [B,h,Nout,96], mean, rstd f32 [B*h*Nout]."""
+    _chk_dev(qkv, conv_w, gamma, beta)
+    T, H, W = thw
+    Nout = 1 + T * pooled(H, stride_hw) * pooled(W, stride_hw) + n_obj
+    dev = qkv.device
+    out = torch.empty((B, heads, Nout, ld_out), device=dev, dtype=BF16)
+    pre = torch.empty((B, heads, Nout, HD), device=dev, dtype=BF16)
+    mean = torch.empty(B * heads * Nout, device=dev, dtype=F32)
+    rstd = torch.empty(B * heads * Nout, device=dev, dtype=F32)
+    a = hip.PoolArgs()
+    a.qkv, a.which, a.conv_w, a.gamma, a.beta = ptr(qkv), which, ptr(conv_w), ptr(gamma), ptr(beta)
+    a.out, a.ld_out, a.pre, a.mean, a.rstd = ptr(out), ld_out, ptr(pre), ptr(mean), ptr(rstd)
+    a.B, a.heads, a.T, a.H, a.W, a.n_obj = B, heads, T, H, W, n_obj
+    a.stride_hw, a.mode, a.eps = stride_hw, mode, eps
+    hip.call("svit_pool_ln_fwd", C.byref(a))
+    return out, pre, mean, rstd
+
+
+def pool_ln_bwd(pre, mean, rstd, gamma, dgamma, dbeta, B, heads, Nout, d_main=None, ld_main=HD,
+                d_res=None, d_extra=None):
+    dpre = torch.empty((B, heads, Nout, HD), device=pre.device, dtype=BF16)
+    a = hip.PoolLnBwdArgs()
+    a.d_main = ptr(d_main)
+    a.main_is_f32 = int(d_main is not None and d_main.dtype == F32)
+    a.ld_main = ld_main
+    a.d_res, a.d_extra = ptr(d_res), ptr(d_extra)
+    a.pre, a.mean, a.rstd, a.gamma = ptr(pre), ptr(mean), ptr(rstd), ptr(gamma)
+    a.dpre, a.dgamma, a.dbeta = ptr(dpre), ptr(dgamma), ptr(dbeta)
+    a.B, a.heads, a.Nout = B, heads, Nout
+    hip.call("svit_pool_ln_bwd", C.byref(a))
+    return dpre
+
+
+def pool_conv_dgrad(dpre, conv_w, dqkv, which, B, heads, thw, n_obj, stride_hw):
+    a = hip.PoolDgradArgs()
+    a.dpre, a.conv_w, a.dqkv, a.which = ptr(dpre), ptr(conv_w), ptr(dqkv), which
+    a.B, a.heads, (a.T, a.H, a.W), a.n_obj, a.stride_hw = B, heads, thw, n_obj, stride_hw
+    hip.call("svit_pool_conv_dgrad", C.byref(a))
+
+
+def pool_conv_wgrad(dpre, qkv, which, dw, B, heads, thw, n_obj, stride_hw):
+    a = hip.PoolWgradArgs()
+    a.dpre, a.qkv, a.which, a.dw = ptr(dpre), ptr(qkv), which, ptr(dw)
+    a.B, a.heads, (a.T, a.H, a.W), a.n_obj, a.stride_hw = B, heads, thw, n_obj, stride_hw
+    hip.call("svit_pool_conv_wgrad", C.byref(a))
+
+
+def relpos_q_fwd(qa, tabs, idx, B, heads, q_thw, k_thw, n_obj, inv_scale):
+    a = hip.RelqArgs()
+    a.qa, a.ld = ptr(qa), qa.shape[-1]
+    a.rel_h, a.rel_w, a.rel_t = (ptr(t) for t in tabs)
+    a.idx_h, a.idx_w, a.idx_t = (ptr(t) for t in idx)
+    a.B, a.heads = B, heads
+    a.qt, a.qh, a.qw = q_thw
+    a.kt, a.kh, a.kw = k_thw
+    a.n_obj, a.inv_scale = n_obj, inv_scale
+    hip.call("svit_relpos_q_fwd", C.byref(a))
+
+
+def relpos_q_bwd(qa, dqa, tabs, idx, dtabs, B, heads, q_thw, k_thw, n_obj, inv_scale):
+    Nq = qa.shape[2]
+    dq_extra = torch.empty((B, heads, Nq, HD), device=qa.device, dtype=F32)
+    a = hip.RelqBwdArgs()
+    a.qa, a.dqa, a.ld = ptr(qa), ptr(dqa), qa.shape[-1]
+    a.rel_h, a.rel_w, a.rel_t = (ptr(t) for t in tabs)
+    a.idx_h, a.idx_w, a.idx_t = (ptr(t) for t in idx)
+    a.dq_extra = ptr(dq_extra)
+    a.drel_h, a.drel_w, a.drel_t = (ptr(t) for t in dtabs)
+    a.rows_h, a.rows_w, a.rows_t = (t.shape[0] for t in tabs)
+    a.B, a.heads = B, heads
+    a.qt, a.qh, a.qw = q_thw
+    a.kt, a.kh, a.kw = k_thw
+    a.n_obj, a.inv_scale = n_obj, inv_scale
+    hip.call("svit_relpos_q_bwd", C.byref(a))
+    return dq_extra
+
+
+def attn_fwd(qa, ka, v, scale):
+    """qa [B,h,Nq,DA], ka [B,h,Nk,DA], v [B,h,Nk,96] -> ctx bf16 [B,Nq,h*96], lse2 [B,h,Nq]."""
+    _chk_dev(qa, ka, v)
+    B, heads, Nq, DA = qa.shape
+    Nk = ka.shape[2]
+    ctx = torch.empty((B, Nq, heads * HD), device=qa.device, dtype=BF16)
+    lse2 = torch.empty((B, heads, Nq), device=qa.device, dtype=F32)
+    a = hip.AttnFwdArgs()
+    a.qa, a.ka, a.v, a.ctx, a.lse2 = ptr(qa), ptr(ka), ptr(v), ptr(ctx), ptr(lse2)
+    a.B, a.heads, a.Nq, a.Nk, a.DA, a.scale = B, heads, Nq, Nk, DA, scale
+    hip.call("svit_attn_fwd", C.byref(a))
+    return ctx, lse2
+
+
+def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0):
+    """-> dqa bf16 [B,h,Nq,DA], dk f32 [B,h,Nk,96], dv f32 [B,h,Nk,96]."""
+    _chk_dev(qa, ka, v, ctx, dctx, lse2)
+    B, heads, Nq, DA = qa.shape
+    Nk = ka.shape[2]
+    dev = qa.device
+    dqa = torch.empty((B, heads, Nq, DA), device=dev, dtype=BF16)
+    dkv = torch.zeros((2, B, heads, Nk, HD), device=dev, dtype=F32)
+    delta = torch.empty((B, heads, Nq), device=dev, dtype=F32)
+    a = hip.AttnBwdArgs()
+    a.qa, a.ka, a.v, a.ctx, a.dctx, a.lse2 = (ptr(t) for t in (qa, ka, v, ctx, dctx, lse2))
+    a.delta, a.dqa, a.dk, a.dv = ptr(delta), ptr(dqa), ptr(dkv[0]), ptr(dkv[1])
+    a.B, a.heads, a.Nq, a.Nk, a.DA, a.q_splits, a.scale = B, heads, Nq, Nk, DA, q_splits, scale
+    hip.call("svit_attn_bwd", C.byref(a))
+    return dqa, dkv[0], dkv[1]
+
+
+def maxpool_fwd(x, thw, n_obj):
+    B, N, C_ = x.shape
+    T, H, W = thw
+    Nout = 1 + T * pooled(H, 2) * pooled(W, 2) + n_obj
+    y = torch.empty((B, Nout, C_), device=x.device, dtype=F32)
+    idx = torch.empty((B, Nout, C_), device=x.device, dtype=torch.uint8)
+    hip.call("svit_maxpool_fwd", ptr(x), ptr(y), ptr(idx), B, T, H, W, n_obj, C_)
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, thw, n_obj):
+    B, Nout, C_ = dy.shape
+    T, H, W = thw
+    dx = torch.empty((B, 1 + T * H * W + n_obj, C_), device=dy.device, dtype=F32)
+    hip.call("svit_maxpool_bwd", ptr(dy), ptr(idx), ptr(dx), B, T, H, W, n_obj, C_)
+    return dx
+
+
+def sumsq(g, out):
+    hip.call("svit_sumsq", ptr(g), g.numel(), ptr(out))
+
+
+def adamw_step(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    hip.call("svit_adamw_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(sumsq_t), max_norm,
+             lr, beta1, beta2, eps, wd, step, grad_scale)

@@ -1,0 +1,386 @@
+"""Per-kernel parity: every C-ABI entry point of libsvit_hip.so against fp32 math on the same
+inputs (the CPU oracle's functions where the op is SViT-specific).  Needs a real MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import procedural as P
+from oracle import svit_ref as R
+
+DEV = "cuda"
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from svit_amd import ops as o
+    from svit_amd import hip
+    hip.load()
+    return o
+
+
+def rnd(name, shape, amp=1.0, dtype=F32):
+    return P.tensor("kt:" + name, shape, amp).to(DEV).to(dtype)
+
+
+def rel_err(got, ref):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
+
+
+def cos(got, ref):
+    got, ref = got.float().cpu().flatten(), ref.float().cpu().flatten()
+    return float(torch.dot(got, ref) / (got.norm() * ref.norm() + 1e-30))
+
+
+# ------------------------------------------------------------------------------ GEMMs ----
+@pytest.mark.parametrize("M,K,N", [(300, 96, 96), (9000, 96, 96), (500, 384, 192), (257, 448, 96),
+                                   (1000, 192, 576), (130, 768, 3072), (8200, 96, 288)])
+def test_gemm_nt_epilogues(ops, M, K, N):
+    from svit_amd import hip
+    a = rnd("a%d" % M, (M, K), 1.0, BF16)
+    w = rnd("w%d" % N, (N, K), 0.2, BF16)
+    bias = rnd("b%d" % N, (N,), 0.5)
+    ref = a.float() @ w.float().t() + bias
+    out = ops.gemm_nt(a, w, bias, hip.EPI_BF16)
+    assert rel_err(out, ref) < 1.5e-2
+    act, pre = ops.gemm_nt(a, w, bias, hip.EPI_GELU)
+    assert rel_err(pre, ref) < 1.5e-2 and rel_err(act, F.gelu(ref)) < 1.5e-2
+    rows_per = (M + 2) // 3
+    scale = torch.tensor([1.0, 0.0, 1.6667], device=DEV)
+    resid = rnd("r%d" % M, (M, N), 1.0)
+    out = ops.gemm_nt(a, w, bias, hip.EPI_RESID, aux=resid, row_scale=scale, rows_per_sample=rows_per)
+    rs = scale[torch.arange(M, device=DEV) // rows_per][:, None]
+    assert rel_err(out, resid + rs * ref) < 1e-3
+    x = resid.clone()  # in place on the residual stream
+    ops.gemm_nt(a, w, bias, hip.EPI_RESID, out=x, aux=x, row_scale=scale, rows_per_sample=rows_per)
+    assert rel_err(x, resid + rs * ref) < 1e-3
+    out = ops.gemm_nt(a, w, bias, hip.EPI_F32)
+    assert rel_err(out, ref) < 1e-3
+    ops.gemm_nt(a, w, None, hip.EPI_F32, out=out, accumulate=True)
+    assert rel_err(out, 2 * ref - bias) < 1e-3
+    hpre = rnd("h%d" % M, (M, N), 2.0, BF16)
+    hp = hpre.float().requires_grad_(True)
+    F.gelu(hp).backward(torch.ones_like(hp))
+    out = ops.gemm_nt(a, w, None, hip.EPI_DGELU, aux=hpre)
+    assert rel_err(out, (ref - bias) * hp.grad) < 1.5e-2
+
+
+def test_gemm_nt_row_remap(ops):
+    from svit_amd import hip
+    B, L, N, K = 3, 50, 96, 448
+    a = rnd("ra", (B * L, K), 1.0, BF16)
+    w = rnd("rw", (N, K), 0.1, BF16)
+    bias = rnd("rb", (N,), 0.5)
+    Ntok = 1 + L + 4
+    x = torch.full((B, Ntok, N), 7.0, device=DEV)
+    ops.gemm_nt(a, w, bias, hip.EPI_F32, out=x, remap=(L, Ntok, 1))
+    ref = (a.float() @ w.float().t() + bias).reshape(B, L, N)
+    assert rel_err(x[:, 1:1 + L], ref) < 1e-3
+    assert float((x[:, 0] - 7).abs().max()) == 0 and float((x[:, 1 + L:] - 7).abs().max()) == 0
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(1000, 288, 96, 0), (70, 96, 448, 1), (4100, 384, 1536, 0),
+                                          (333, 96, 96, 3), (64, 3072, 768, 0)])
+def test_gemm_tn(ops, M, N, K, splits):
+    a = rnd("ta%d" % M, (M, N), 1.0, BF16)
+    b = rnd("tb%d" % M, (M, K), 1.0, BF16)
+    dw = torch.ones((N, K), device=DEV)
+    ops.gemm_tn(a, b, dw, splits)
+    ref = a.float().t() @ b.float() + 1.0
+    assert rel_err(dw, ref) < 2e-4
+
+
+def test_colsum_cast_scale(ops):
+    a = rnd("cs", (1234, 288), 1.0, BF16)
+    out = torch.zeros(288, device=DEV)
+    ops.colsum(a, out)
+    assert rel_err(out, a.float().sum(0)) < 1e-4
+    src = rnd("cast", (1000003,), 3.0)
+    assert torch.equal(ops.cast_bf16(src), src.to(BF16))
+    x = rnd("sc", (6, 50, 96), 1.0)
+    s = torch.tensor([1.0, 0.0, 2.5], device=DEV)
+    got = ops.scale_cast(x.reshape(300, 96), s, 100)
+    ref = (x.reshape(3, 100, 96) * s[:, None, None]).to(BF16).reshape(300, 96)
+    assert torch.equal(got, ref)
+    assert torch.equal(ops.scale_cast(x.reshape(300, 96)), x.reshape(300, 96).to(BF16))
+
+
+def test_transpose_cast_batched(ops):
+    mats = [(96, 288), (100, 37), (768, 3072)]
+    total = sum(r * c for r, c in mats)
+    src = rnd("tp", (total,), 1.0)
+    dst = torch.zeros(total, device=DEV, dtype=BF16)
+    table, off = [], 0
+    for r, c in mats:
+        table += [off, off, r, c]
+        off += r * c
+    tab = torch.tensor(table, dtype=torch.int64, device=DEV)
+    ops.transpose_cast_batched(src, dst, tab, len(mats), 256)
+    off = 0
+    for r, c in mats:
+        ref = src[off:off + r * c].reshape(r, c).t().contiguous().to(BF16)
+        assert torch.equal(dst[off:off + r * c].reshape(c, r), ref)
+        off += r * c
+
+
+# -------------------------------------------------------------------------- LayerNorm ----
+@pytest.mark.parametrize("C", [96, 192, 384, 768])
+def test_layernorm(ops, C):
+    rows = 1037
+    x = rnd("lnx%d" % C, (rows, C), 2.0) + 0.3
+    g = rnd("lng%d" % C, (C,), 0.2) + 1.0
+    b = rnd("lnb%d" % C, (C,), 0.1)
+    y16, y32, mean, rstd = ops.layernorm_fwd(x, g, b, want_f32=True)
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-6)
+    assert rel_err(y32, ref) < 1e-5 and rel_err(y16, ref) < 1e-2
+    dy = rnd("lnd%d" % C, (rows, C), 1.0)
+    dres = rnd("lnr%d" % C, (rows, C), 1.0)
+    ref.backward(dy)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = ops.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dres=dres)
+    assert rel_err(dx, xr.grad + dres) < 1e-4
+    assert rel_err(dg, gr.grad) < 1e-4 and rel_err(db, br.grad) < 1e-4
+
+
+# -------------------------------------------------------------------- patch embedding ----
+def test_patch_embed(ops):
+    from svit_amd import hip
+    B, T, S = 2, 4, 36
+    video = rnd("vid", (B, 3, T, S, S), 1.7)
+    w = rnd("pw", (96, 3, 3, 7, 7), 0.08)
+    bias = rnd("pb", (96,), 0.05)
+    cols, (To, Ho, Wo) = ops.im2col_patch(video)
+    ref_cols = F.conv3d  # silence linters
+    wk = torch.zeros((96, 448), device=DEV)
+    wk[:, :441] = w.reshape(96, 441)
+    out = ops.gemm_nt(cols, wk.to(BF16), bias, hip.EPI_F32)
+    ref = F.conv3d(video, w, bias, stride=(2, 4, 4), padding=(1, 3, 3))
+    assert ref.shape[2:] == (To, Ho, Wo)
+    ref = ref.flatten(2).transpose(1, 2).reshape(-1, 96)
+    assert rel_err(out, ref) < 1.5e-2 and cos(out, ref) > 0.9999
+
+
+def test_special_tokens(ops):
+    B, L, Tx, O, C = 2, 10, 4, 4, 96
+    N = 1 + L + Tx * O
+    x = torch.zeros((B, N, C), device=DEV)
+    cls, objq, pos = rnd("cls", (C,)), rnd("oq", (O, C)), rnd("pt", (Tx, C))
+    ops.fill_special_tokens(x, cls, objq, pos, L, Tx, O, True)
+    assert torch.equal(x[:, 0], cls.expand(B, C))
+    ref = (objq[None, :, :] + pos[:, None, :]).reshape(Tx * O, C)
+    assert torch.equal(x[:, 1 + L:], ref.expand(B, -1, -1))
+    assert float(x[:, 1:1 + L].abs().max()) == 0
+
+
+# ------------------------------------------------------------------ pooled q/k/v path ----
+def _qkv(B, h, thw, O, tag):
+    N = 1 + thw[0] * thw[1] * thw[2] + O
+    return rnd("qkv:" + tag, (B, N, 3, h, 96), 1.0, BF16)
+
+
+@pytest.mark.parametrize("stride,thw", [(1, (2, 8, 8)), (2, (2, 8, 8)), (2, (2, 7, 7)), (4, (2, 8, 8)),
+                                        (8, (3, 16, 16)), (2, (1, 9, 9))])
+def test_pool_ln_fwd_bwd(ops, stride, thw):
+    B, h, O = 2, 2, 3
+    qkv = _qkv(B, h, thw, O, "p%d" % stride)
+    w = rnd("pcw%d" % stride, (96, 1, 3, 3, 3), 0.3)
+    g = rnd("pg", (96,), 0.2) + 1.0
+    b = rnd("pb2", (96,), 0.1)
+    which = 1
+    Ho, Wo = ops.pooled(thw[1], stride), ops.pooled(thw[2], stride)
+    ld = 128 if (Ho + Wo + thw[0]) <= 32 else 160
+    out, pre, mean, rstd = ops.pool_ln_fwd(qkv, which, w.reshape(96, 27).contiguous(), g, b, B, h,
+                                           thw, O, stride, ld_out=ld, mode=1)
+    x = qkv[:, :, which].permute(0, 2, 1, 3).float().cpu().requires_grad_(True)   # [B,h,N,96]
+    wc = w.cpu().requires_grad_(True)
+    gc, bc = g.cpu().requires_grad_(True), b.cpu().requires_grad_(True)
+    ref, thw_o = R.pool_tokens(x, thw, (1, stride, stride), wc, gc, bc, O)
+    assert thw_o == (thw[0], Ho, Wo)
+    assert rel_err(out[..., :96], ref) < 2e-2 and cos(out[..., :96], ref) > 0.9999
+    # one-hot key coordinates
+    oh = out[..., 96:].float().cpu()
+    Lo = thw[0] * Ho * Wo
+    assert float(oh[:, :, 0].abs().max()) == 0 and float(oh[:, :, 1 + Lo:].abs().max()) == 0
+    p = torch.arange(Lo)
+    exp = torch.zeros(Lo, ld - 96)
+    exp[p, (p // Wo) % Ho] = 1
+    exp[p, Ho + p % Wo] = 1
+    exp[p, Ho + Wo + p // (Wo * Ho)] = 1
+    assert torch.equal(oh[0, 0, 1:1 + Lo], exp) and torch.equal(oh[1, 1, 1:1 + Lo], exp)
+    # backward: LN bwd + conv dgrad + conv wgrad (+ object gain) against autograd of the oracle
+    Nout = ref.shape[2]
+    dout = rnd("pd%d" % stride, (B, h, Nout, 96), 1.0, BF16)
+    ref.backward(dout.float().cpu())
+    dgam, dbet = torch.zeros(96, device=DEV), torch.zeros(96, device=DEV)
+    dpre = ops.pool_ln_bwd(pre, mean, rstd, g, dgam, dbet, B, h, Nout, d_main=dout, ld_main=96)
+    assert rel_err(dgam, gc.grad) < 2e-2 and rel_err(dbet, bc.grad) < 2e-2
+    dqkv = torch.zeros_like(qkv)
+    ops.pool_conv_dgrad(dpre, w.reshape(96, 27).contiguous(), dqkv, which, B, h, thw, O, stride)
+    got = dqkv[:, :, which].permute(0, 2, 1, 3)
+    assert cos(got, x.grad) > 0.9995 and rel_err(got, x.grad) < 3e-2
+    assert float(dqkv[:, :, 0].float().abs().max()) == 0
+    dw = torch.zeros((96, 27), device=DEV)
+    ops.pool_conv_wgrad(dpre, qkv, which, dw, B, h, thw, O, stride)
+    assert cos(dw, wc.grad.reshape(96, 27)) > 0.9995 and rel_err(dw, wc.grad.reshape(96, 27)) < 3e-2
+
+
+def test_pool_ln_bwd_three_inputs(ops):
+    B, h, Nout = 2, 2, 37
+    pre = rnd("pre3", (B, h, Nout, 96), 1.0, BF16)
+    g = rnd("g3", (96,), 0.2) + 1.0
+    x = pre.float()
+    mean = x.mean(-1).flatten().contiguous()
+    rstd = (1.0 / torch.sqrt(x.var(-1, unbiased=False) + 1e-6)).flatten().contiguous()
+    d_main = rnd("dm3", (B, h, Nout, 128), 1.0, BF16)
+    d_res = rnd("dr3", (B, Nout, h * 96), 1.0, BF16)
+    d_extra = rnd("de3", (B, h, Nout, 96), 1.0)
+    dg, db = torch.zeros(96, device=DEV), torch.zeros(96, device=DEV)
+    dpre = ops.pool_ln_bwd(pre, mean, rstd, g, dg, db, B, h, Nout, d_main=d_main, ld_main=128,
+                           d_res=d_res, d_extra=d_extra)
+    res = d_res.float().reshape(B, Nout, h, 96).permute(0, 2, 1, 3).clone()
+    res[:, :, 0] = 0  # the residual-pooling path skips cls
+    dsum = d_main[..., :96].float() + res + d_extra
+    xr = x.clone().requires_grad_(True)
+    F.layer_norm(xr, (96,), g, torch.zeros_like(g), 1e-6).backward(dsum)
+    assert rel_err(dpre, xr.grad) < 2e-2 and cos(dpre, xr.grad) > 0.9999
+
+
+@pytest.mark.parametrize("q_thw,k_thw", [((2, 8, 8), (2, 2, 2)), ((2, 4, 4), (2, 4, 4)),
+                                         ((3, 5, 5), (3, 3, 3)), ((1, 4, 4), (1, 2, 2)),
+                                         ((2, 14, 14), (2, 14, 14))])
+def test_relpos_q(ops, q_thw, k_thw):
+    B, h, O = 2, 2, 3
+    Lq = q_thw[0] * q_thw[1] * q_thw[2]
+    J = sum(k_thw)
+    ld = 128 if J <= 32 else 160
+    qa = torch.zeros((B, h, 1 + Lq + O, ld), device=DEV, dtype=BF16)
+    qa[..., :96] = rnd("rq%d" % Lq, (B, h, 1 + Lq + O, 96), 1.0, BF16)
+    qa[..., 96:] = 5.0  # must be overwritten
+    rows = [2 * max(q_thw[i], k_thw[i]) - 1 for i in (1, 2, 0)]
+    tabs = [rnd("rt%d%d" % (i, Lq), (rows[i], 96), 0.3) for i in range(3)]
+    idx = [R.rel_index(q_thw[1], k_thw[1]), R.rel_index(q_thw[2], k_thw[2]),
+           R.rel_index(q_thw[0], k_thw[0])]
+    idx_d = [t.to(torch.int32).to(DEV).contiguous() for t in idx]
+    scale = 96 ** -0.5
+    ops.relpos_q_fwd(qa, tabs, idx_d, B, h, q_thw, k_thw, O, 1.0 / scale)
+    q = qa[..., :96].float().cpu().requires_grad_(True)
+    tc = [t.cpu().requires_grad_(True) for t in tabs]
+    bias = R.rel_pos_bias(q, q_thw, k_thw, tc[0], tc[1], tc[2])        # [B,h,Lq,Lk]
+    # rebuild the bias from the stored per-query vectors and the key coordinates
+    rel = qa[..., 96:].float().cpu() * scale
+    kt, kh, kw = k_thw
+    p = torch.arange(kt * kh * kw)
+    got = (rel[:, :, 1:1 + Lq][..., (p // kw) % kh] + rel[:, :, 1:1 + Lq][..., kh + p % kw] +
+           rel[:, :, 1:1 + Lq][..., kh + kw + p // (kw * kh)])
+    assert rel_err(got, bias) < 2e-2 and cos(got, bias) > 0.9999
+    assert float(rel[:, :, 0].abs().max()) == 0 and float(rel[:, :, 1 + Lq:].abs().max()) == 0
+    assert float(rel[..., J:].abs().max()) == 0
+    # backward
+    dqa = torch.zeros_like(qa)
+    dqa[..., 96:96 + J] = rnd("rdq%d" % Lq, (B, h, 1 + Lq + O, J), 1.0, BF16)
+    dtabs = [torch.zeros_like(t) for t in tabs]
+    dq_extra = ops.relpos_q_bwd(qa, dqa, tabs, idx_d, dtabs, B, h, q_thw, k_thw, O, 1.0 / scale)
+    # reference: stored value s_j = relq_j/scale  =>  loss = sum_j d_j * relq_j / scale
+    d = dqa[..., 96:96 + J].float().cpu()[:, :, 1:1 + Lq] / scale
+    qp = q[:, :, 1:1 + Lq].reshape(B, h, q_thw[0], q_thw[1], q_thw[2], 96)
+    Rh, Rw, Rt = tc[0][idx[0]], tc[1][idx[1]], tc[2][idx[2]]
+    relq = torch.cat([torch.einsum("bntyxc,ykc->bntyxk", qp, Rh),
+                      torch.einsum("bntyxc,xkc->bntyxk", qp, Rw),
+                      torch.einsum("bntyxc,tkc->bntyxk", qp, Rt)], dim=-1).reshape(B, h, Lq, J)
+    (relq * d).sum().backward()
+    assert rel_err(dq_extra, q.grad) < 2e-3
+    for i in range(3):
+        assert rel_err(dtabs[i], tc[i].grad) < 2e-3
+
+
+# -------------------------------------------------------------------- fused attention ----
+def _attn_ref(qa, ka, v, scale):
+    s = (qa.float() @ ka.float().transpose(-1, -2)) * scale
+    p = s.softmax(-1)
+    o = p @ v.float()
+    o = torch.cat([o[:, :, :1], o[:, :, 1:] + qa[:, :, 1:, :96].float()], dim=2)
+    B, h, Nq, _ = o.shape
+    return o.transpose(1, 2).reshape(B, Nq, h * 96), s
+
+
+@pytest.mark.parametrize("Nq,Nk,DA,h", [(200, 70, 128, 2), (457, 457, 128, 1), (130, 300, 160, 2),
+                                        (33, 64, 128, 1), (700, 129, 160, 1)])
+def test_attention_fwd_bwd(ops, Nq, Nk, DA, h):
+    B = 2
+    scale = 96 ** -0.5
+    qa = rnd("aq%d" % Nq, (B, h, Nq, DA), 1.0, BF16)
+    ka = rnd("ak%d" % Nk, (B, h, Nk, DA), 1.0, BF16)
+    v = rnd("av%d" % Nk, (B, h, Nk, 96), 1.0, BF16)
+    ctx, lse2 = ops.attn_fwd(qa, ka, v, scale)
+    qr = qa.float().cpu().requires_grad_(True)
+    kr = ka.float().cpu().requires_grad_(True)
+    vr = v.float().cpu().requires_grad_(True)
+    ref, s = _attn_ref(qr, kr, vr, scale)
+    assert rel_err(ctx, ref) < 2e-2 and cos(ctx, ref) > 0.9999
+    lse_ref = torch.logsumexp(s, dim=-1) * math.log2(math.e)
+    assert rel_err(lse2, lse_ref) < 1e-3
+    dctx = rnd("ad%d" % Nq, (B, Nq, h * 96), 1.0, BF16)
+    # the kernels do not include the residual-pooling path in dq (it is fed to pool_ln_bwd)
+    o_only = ref - torch.cat([torch.zeros(B, 1, h * 96),
+                              qr[:, :, 1:, :96].transpose(1, 2).reshape(B, Nq - 1, h * 96)], 1)
+    o_only.backward(dctx.float().cpu())
+    for splits in (0, 1, 3):
+        dqa, dk, dv = ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=splits)
+        assert cos(dqa, qr.grad) > 0.999 and rel_err(dqa, qr.grad) < 4e-2
+        assert cos(dk, kr.grad[..., :96]) > 0.999 and rel_err(dk, kr.grad[..., :96]) < 4e-2
+        assert cos(dv, vr.grad) > 0.999 and rel_err(dv, vr.grad) < 4e-2
+
+
+def test_attention_large_scores(ops):
+    """Online-softmax rescale path: one key dominates late in the sweep (forces max jumps)."""
+    B, h, Nq, Nk, DA = 1, 1, 64, 200, 128
+    scale = 96 ** -0.5
+    qa = rnd("lq", (B, h, Nq, DA), 1.0, BF16)
+    ka = rnd("lk", (B, h, Nk, DA), 1.0, BF16)
+    ka[:, :, 150] = qa[:, :, 5] * 6
+    ka[:, :, 199] = qa[:, :, 9] * 9
+    v = rnd("lv", (B, h, Nk, 96), 1.0, BF16)
+    ctx, _ = ops.attn_fwd(qa, ka, v, scale)
+    ref, _ = _attn_ref(qa.cpu(), ka.cpu(), v.cpu(), scale)
+    assert rel_err(ctx, ref) < 2e-2
+
+
+# ------------------------------------------------------------------- max-pool skip ------
+@pytest.mark.parametrize("thw", [(2, 8, 8), (2, 7, 7), (1, 5, 6)])
+def test_maxpool(ops, thw):
+    B, O, C = 2, 3, 192
+    N = 1 + thw[0] * thw[1] * thw[2] + O
+    x = rnd("mp%d" % thw[1], (B, N, C), 1.0)
+    y, idx = ops.maxpool_fwd(x, thw, O)
+    xr = x.cpu().requires_grad_(True)
+    ref = R.maxpool_skip(xr, thw, (1, 2, 2), O)
+    assert torch.equal(y.cpu(), ref)
+    dy = rnd("mpd%d" % thw[1], tuple(ref.shape), 1.0)
+    ref.backward(dy.cpu())
+    dx = ops.maxpool_bwd(dy, idx, thw, O)
+    assert rel_err(dx, xr.grad) < 1e-6
+
+
+# ------------------------------------------------------------------ optimiser tail ------
+def test_clip_adamw(ops):
+    n = 100003
+    p = rnd("op", (n,), 1.0)
+    g = rnd("og", (n,), 0.05)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pw = {"w": p.cpu().clone()}
+    st = {"w": (torch.zeros(n), torch.zeros(n))}
+    for step in (1, 2):
+        ss = torch.zeros(1, device=DEV)
+        ops.sumsq(g, ss)
+        assert abs(float(ss) - float((g.double() ** 2).sum())) / float(ss) < 1e-5
+        ops.adamw_step(p, g, m, v, ss, 1.0, 1e-3, 0.9, 0.999, 1e-8, 1e-4, step)
+        R.clip_and_adamw_step(pw, {"w": g.cpu()}, st, 1e-3, step, 1.0, lambda n_, s_: 1e-4)
+        assert float((p.cpu() - pw["w"]).abs().max()) < 2e-6
