@@ -50,7 +50,8 @@ typedef struct {
 } svit_gemm_args;
 /* C[M,N] = A[M,K] * W[N,K]^T with fused epilogue (forward Linear; dgrad with W^T copy). */
 int svit_gemm_nt(const svit_gemm_args* args, void* stream);
-/* dW[N,K] (f32, atomically accumulated) += A[M,N]^T * B[M,K]  (Linear wgrad; split over M). */
+/* dW[N,K] (f32, atomically accumulated) += A[M,N]^T * B[M,K]  (Linear wgrad; split over M).
+ * lda/ldb multiples of 8; K need not be (patch-embed wgrad: K = 441 inside ldb = 448). */
 int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, float* dW, int lddw,
                  int M, int N, int K, int splits, void* stream);
 /* dbias[N] (f32, atomically accumulated) += column sums of bf16 A[M,N]. */
@@ -62,6 +63,8 @@ int svit_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
  * {src_off, dst_off, R, C} int64 quadruples (the W^T copies used by dgrad). */
 int svit_transpose_cast_batched(const float* src_base, void* dst_base, const int64_t* table,
                                 int n_mats, int max_tiles, void* stream);
+/* dst(bf16)[R,ldd] = [src(f32)[R,C] | 0]: row-padded bf16 copy (patch-embed weight 441 -> 448). */
+int svit_pad_cast_rows(const float* src, void* dst, int R, int C, int ldd, void* stream);
 /* dst(bf16)[r,:] = scale[r/rows_per_sample] * src(f32)[r,:]   (DropPath backward). */
 int svit_scale_cast(const float* src, void* dst, const float* row_scale, int rows_per_sample,
                     int64_t rows, int cols, void* stream);

@@ -316,7 +316,7 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
 extern "C" int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, float* dW, int lddw,
                             int M, int N, int K, int splits, void* stream) {
   if (!A || !B || !dW) return SVIT_ERR_ARG;
-  if (M <= 0 || N <= 0 || K <= 0 || N % 8 != 0 || K % 8 != 0) return SVIT_ERR_SHAPE;
+  if (M <= 0 || N <= 0 || K <= 0) return SVIT_ERR_SHAPE;
   if (lda % 8 != 0 || ldb % 8 != 0 || lda < N || ldb < K || lddw < K) return SVIT_ERR_ALIGN;
   if (((uintptr_t)A | (uintptr_t)B) & 15) return SVIT_ERR_ALIGN;
   const int tiles = ((N + TN_TN - 1) / TN_TN) * ((K + TN_TK - 1) / TN_TK);

@@ -64,6 +64,17 @@ __global__ void scale_cast_kernel(const float* __restrict__ src, bf16_t* __restr
   }
 }
 
+// dst(bf16)[r, 0..ldd) = [src(f32)[r, 0..C) | zeros]   (row-padded weight copies)
+__global__ void pad_cast_rows_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int R,
+                                     int C, int ldd) {
+  const int64_t total = (int64_t)R * ldd;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ldd), c = (int)(i % ldd);
+    dst[i] = f32_to_bf16(c < C ? src[(int64_t)r * C + c] : 0.f);
+  }
+}
+
 // ---- patch embedding im2col: Conv3d(3->96, k(3,7,7), s(2,4,4), p(1,3,3)) -----------------
 __global__ void im2col_patch_kernel(const float* __restrict__ video, bf16_t* __restrict__ cols,
                                     int B, int T, int H, int W, int To, int Ho, int Wo) {
@@ -281,6 +292,14 @@ extern "C" int svit_scale_cast(const float* src, void* dst, const float* row_sca
   hipLaunchKernelGGL(scale_cast_kernel, dim3(grid_for(rows * (cols / 4), 256)), dim3(256), 0,
                      (hipStream_t)stream, src, (bf16_t*)dst, row_scale, rows_per_sample, rows,
                      cols);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_pad_cast_rows(const float* src, void* dst, int R, int C, int ldd, void* stream) {
+  if (!src || !dst || R <= 0 || C <= 0 || ldd < C) return SVIT_ERR_ARG;
+  hipLaunchKernelGGL(pad_cast_rows_kernel, dim3(grid_for((int64_t)R * ldd, 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, (bf16_t*)dst, R, C, ldd);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }

@@ -1,0 +1,334 @@
+"""Forward / backward schedule of the SViT backbone over the HIP kernels.
+
+This is the MI355X-first replacement for what the reference leaves to autograd over ~60 ATen
+ops per block (slowfast/models/attention.py:331-466,557-571; video_model_builder.py:315-375):
+an explicit, fixed launch schedule -- every launch is a C-ABI call into libsvit_hip.so on
+torch's current stream, activations live in the fp32 residual stream / bf16 GEMM operands laid
+out token-major, and parameter gradients are accumulated straight into one flat fp32 buffer
+(which is what the optimiser and the data-parallel all-reduce consume).  torch is used for
+memory, streams and a handful of O(B*65*C) index/reduction ops on the special tokens.
+"""
+import math
+
+import torch
+
+from . import arch, hip, ops
+
+HD = arch.HEAD_DIM
+F32, BF16 = torch.float32, torch.bfloat16
+SCALE = HD ** -0.5
+
+
+def _align(n, a=8):
+    return (n + a - 1) // a * a
+
+
+class FlatParams:
+    """One fp32 buffer for all parameters ([decayed | not decayed]), one for their grads, a bf16
+    mirror for GEMM operands and a bf16 buffer of transposed Linear weights for dgrad."""
+
+    def __init__(self, shapes, decay_of, device, rank_of):
+        names = list(shapes)
+        depth = 1 + max([int(n.split(".")[1]) for n in names if n.startswith("blocks.")] or [0])
+        ranks = {n: rank_of(n, depth) for n in names}
+        # [decayed | not decayed]; inside each group in gradient-readiness order
+        order = sorted(names, key=lambda n: (not decay_of(n, shapes[n]), ranks[n]))
+        self.slots, off = {}, 0
+        self.n_decay = 0
+        self.n_ranks = depth + 2
+        # ready_ranges[r] = list of (begin, end) slices of the flat buffer final after rank r
+        self.ready_ranges = [[] for _ in range(self.n_ranks)]
+        for n in order:
+            numel = int(math.prod(shapes[n]))
+            self.slots[n] = (off, numel, tuple(shapes[n]))
+            rr = self.ready_ranges[ranks[n]]
+            if rr and rr[-1][1] == off:
+                rr[-1] = (rr[-1][0], off + _align(numel))
+            else:
+                rr.append((off, off + _align(numel)))
+            off += _align(numel)
+            if decay_of(n, shapes[n]):
+                self.n_decay = off
+        self.total = off
+        self.data = torch.zeros(off, device=device, dtype=F32)
+        self.grad = torch.zeros(off, device=device, dtype=F32)
+        self.w16 = torch.zeros(off, device=device, dtype=BF16)
+        # transposed copies of every 2-D Linear weight in the blocks
+        self.t_slots, toff, table = {}, 0, []
+        for n in order:
+            if n.startswith("blocks.") and n.endswith(".weight") and len(shapes[n]) == 2:
+                r, c = shapes[n]
+                self.t_slots[n] = (toff, (c, r))
+                table += [self.slots[n][0], toff, r, c]
+                toff += _align(r * c)
+        self.wT16 = torch.zeros(max(toff, 8), device=device, dtype=BF16)
+        self.t_table = torch.tensor(table, dtype=torch.int64, device=device)
+        self.n_t = len(table) // 4
+
+    def view(self, buf, name):
+        off, numel, shape = self.slots[name]
+        return buf[off:off + numel].view(shape)
+
+    def p(self, name):
+        return self.view(self.data, name)
+
+    def g(self, name):
+        return self.view(self.grad, name)
+
+    def w(self, name):
+        """bf16 copy [out,in] of a weight."""
+        off, numel, shape = self.slots[name]
+        return self.w16[off:off + numel].view(shape)
+
+    def wt(self, name):
+        """bf16 transposed copy [in,out] of a 2-D weight."""
+        off, shape = self.t_slots[name]
+        return self.wT16[off:off + shape[0] * shape[1]].view(shape)
+
+    def refresh_low_precision(self):
+        ops.cast_bf16(self.data, self.w16)
+        if self.n_t:
+            ops.transpose_cast_batched(self.data, self.wT16, self.t_table, self.n_t, 256)
+
+
+def _rel_index(q_n, k_n):
+    """dist.long() table of cal_rel_pos_* (attention.py:100-119,156-163), float32 arithmetic as
+    in the reference so that truncation agrees for non-integer ratios."""
+    q_ratio = max(k_n / q_n, 1.0)
+    k_ratio = max(q_n / k_n, 1.0)
+    d = torch.arange(q_n)[:, None] * q_ratio - torch.arange(k_n)[None, :] * k_ratio
+    d = d + (k_n - 1) * k_ratio
+    return d.long().to(torch.int32)
+
+
+def _resize_matrix(rows_have, rows_need):
+    """Dense [rows_need, rows_have] matrix of F.interpolate(mode='linear', align_corners=False)
+    used by get_rel_pos (attention.py:68-81) when a table's length differs from 2*max(q,k)-1."""
+    m = torch.zeros(rows_need, rows_have)
+    scale = rows_have / rows_need
+    for i in range(rows_need):
+        pos = max((i + 0.5) * scale - 0.5, 0.0)
+        i0 = min(int(math.floor(pos)), rows_have - 1)
+        i1 = min(i0 + 1, rows_have - 1)
+        lam = pos - i0
+        m[i, i0] += 1.0 - lam
+        m[i, i1] += lam
+    return m
+
+
+class Engine:
+    def __init__(self, plan: arch.Plan, flat: FlatParams):
+        self.plan, self.flat = plan, flat
+        self.dev = flat.data.device
+        self._rel_cache = {}
+        self.patch_w16 = torch.zeros((plan.embed_dim, 448), device=self.dev, dtype=BF16)
+
+    # ------------------------------------------------------------------ helpers ----------
+    def refresh_weights(self):
+        self.flat.refresh_low_precision()
+        ops.pad_cast_rows(self.flat.p("patch_embed.proj.weight").view(self.plan.embed_dim, 441),
+                          self.patch_w16)
+
+    def _rel(self, blk, q_thw, k_thw):
+        """index tables (+ resize matrices when needed) for a block at this resolution."""
+        key = (blk.index, q_thw, k_thw)
+        ent = self._rel_cache.get(key)
+        if ent is None:
+            idx = [_rel_index(q_thw[1], k_thw[1]), _rel_index(q_thw[2], k_thw[2]),
+                   _rel_index(q_thw[0], k_thw[0])]
+            need = [2 * max(q_thw[i], k_thw[i]) - 1 for i in (1, 2, 0)]
+            have = [blk.rel_sp_rows, blk.rel_sp_rows, blk.rel_t_rows]
+            mats = [None if n == h else _resize_matrix(h, n).to(self.dev) for n, h in zip(need, have)]
+            ent = ([t.contiguous().to(self.dev) for t in idx], mats)
+            self._rel_cache[key] = ent
+        return ent
+
+    def _tables(self, pre, mats):
+        names = (pre + "attn.rel_pos_h", pre + "attn.rel_pos_w", pre + "attn.rel_pos_t")
+        out = []
+        for n, m in zip(names, mats):
+            t = self.flat.p(n)
+            out.append(t if m is None else (m @ t).contiguous())
+        return out
+
+    # ------------------------------------------------------------------ forward ----------
+    def forward(self, video, drop_scales=None, save=True):
+        """video f32 [B,3,Tx,S,S] -> (normed tokens f32 [B,N_last,C_last], saved-state dict)."""
+        plan, f = self.plan, self.flat
+        if video.dim() == 4:
+            video = video.unsqueeze(2)
+        video = video.contiguous().to(F32)
+        B, _, Tx = video.shape[:3]
+        cols, (To, Ho, Wo) = ops.im2col_patch(video)
+        T = plan.num_frames // plan.patch_stride[0] if Tx > 1 else Tx  # from cfg, builder:322
+        if To != T:
+            raise hip.SvitHipError("clip has %d frames but cfg.DATA.NUM_FRAMES=%d" % (Tx, plan.num_frames))
+        L, n_obj, C = To * Ho * Wo, Tx * plan.objects, plan.embed_dim
+        N = 1 + L + n_obj
+        x = torch.empty((B, N, C), device=self.dev, dtype=F32)
+        ops.gemm_nt(cols, self.patch_w16, f.p("patch_embed.proj.bias"), hip.EPI_F32,
+                    out=x.view(B * N, C), remap=(L, N, 1))
+        ops.fill_special_tokens(x, f.p("cls_token"), f.p("object_queries"),
+                                f.p("pos_embed_temporal"), L, Tx, plan.objects, Tx > 1)
+        st = {"B": B, "Tx": Tx, "n_obj": n_obj, "L0": L, "cols": cols if save else None,
+              "blocks": []}
+        thw = (T, Ho, Wo)
+        for blk in plan.blocks:
+            ds = drop_scales[blk.index] if drop_scales is not None else None
+            x, thw, sv = self._block_fwd(blk, x, thw, n_obj, ds, save)
+            st["blocks"].append(sv)
+        y16, y32, mean, rstd = ops.layernorm_fwd(x, f.p("norm.weight"), f.p("norm.bias"),
+                                                 want_f32=True, want_bf16=False, save_stats=save)
+        st.update(x_last=x if save else None, mean=mean, rstd=rstd, thw=thw)
+        return y32, st
+
+    def _block_fwd(self, blk, x, thw, n_obj, ds, save):
+        f = self.flat
+        pre = "blocks.%d." % blk.index
+        B, N, C = x.shape
+        Co, h = blk.dim_out, blk.heads
+        sq, skv = blk.stride_q[1], blk.stride_kv[1]
+        q_thw = (thw[0], arch.pooled(thw[1], sq), arch.pooled(thw[2], sq))
+        k_thw = (thw[0], arch.pooled(thw[1], skv), arch.pooled(thw[2], skv))
+        Nq = 1 + q_thw[0] * q_thw[1] * q_thw[2] + n_obj
+        J = k_thw[0] + k_thw[1] + k_thw[2]
+        DA = HD + 32 if J <= 32 else HD + 64
+        if J > 64:
+            raise hip.SvitHipError("key grid %s too large for the in-MFMA rel-pos bias" % (k_thw,))
+        xn, _, mean1, rstd1 = ops.layernorm_fwd(x, f.p(pre + "norm1.weight"), f.p(pre + "norm1.bias"))
+        xn2d = xn.view(B * N, C)
+        qkv = ops.gemm_nt(xn2d, f.w(pre + "attn.qkv.weight"), f.p(pre + "attn.qkv.bias"), hip.EPI_BF16)
+        pools = []
+        for which, r, stride, ld, mode in ((0, "q", sq, DA, 0), (1, "k", skv, DA, 1), (2, "v", skv, HD, 0)):
+            pools.append(ops.pool_ln_fwd(
+                qkv, which, f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27),
+                f.p(pre + "attn.norm_%s.weight" % r), f.p(pre + "attn.norm_%s.bias" % r),
+                B, h, thw, n_obj, stride, ld_out=ld, mode=mode))
+        qa, ka, v = pools[0][0], pools[1][0], pools[2][0]
+        idx, mats = self._rel(blk, q_thw, k_thw)
+        tabs = self._tables(pre, mats)
+        ops.relpos_q_fwd(qa, tabs, idx, B, h, q_thw, k_thw, n_obj, 1.0 / SCALE)
+        ctx, lse2 = ops.attn_fwd(qa, ka, v, SCALE)
+        pool_idx = None
+        if blk.has_proj:
+            skip = ops.gemm_nt(xn2d, f.w(pre + "proj.weight"), f.p(pre + "proj.bias"), hip.EPI_F32)
+            skip = skip.view(B, N, Co)
+        else:
+            skip = x
+        if blk.pools_q:
+            skip, pool_idx = ops.maxpool_fwd(skip, thw, n_obj)
+        dpa, dpm = ds if ds is not None else (None, None)
+        x1 = ops.gemm_nt(ctx.view(B * Nq, Co), f.w(pre + "attn.proj.weight"), f.p(pre + "attn.proj.bias"),
+                         hip.EPI_RESID, aux=skip.view(B * Nq, Co), row_scale=dpa, rows_per_sample=Nq)
+        x1 = x1.view(B, Nq, Co)
+        xn2, _, mean2, rstd2 = ops.layernorm_fwd(x1, f.p(pre + "norm2.weight"), f.p(pre + "norm2.bias"))
+        act, hpre = ops.gemm_nt(xn2.view(B * Nq, Co), f.w(pre + "mlp.fc1.weight"),
+                                f.p(pre + "mlp.fc1.bias"), hip.EPI_GELU)
+        x2 = ops.gemm_nt(act, f.w(pre + "mlp.fc2.weight"), f.p(pre + "mlp.fc2.bias"), hip.EPI_RESID,
+                         aux=x1.view(B * Nq, Co), row_scale=dpm, rows_per_sample=Nq).view(B, Nq, Co)
+        sv = None
+        if save:
+            sv = dict(x=x, thw=thw, q_thw=q_thw, k_thw=k_thw, mean1=mean1, rstd1=rstd1, xn=xn2d,
+                      qkv=qkv, pools=pools, tabs=tabs, idx=idx, mats=mats, ctx=ctx, lse2=lse2,
+                      pool_idx=pool_idx, x1=x1, mean2=mean2, rstd2=rstd2, xn2=xn2, act=act,
+                      hpre=hpre, dpa=dpa, dpm=dpm, Nq=Nq)
+        return x2, q_thw, sv
+
+    # ------------------------------------------------------------------ backward ---------
+    def backward(self, st, dy, on_ready=None):
+        """dy: grad of the normed tokens f32 [B,N_last,C_last]; accumulates every parameter
+        gradient into flat.grad.  on_ready(rank) is called when the gradients of readiness rank
+        `rank` (arch.readiness_rank) are final -- the data-parallel wrapper launches the
+        all-reduce of that slice there, overlapping it with the remaining backward."""
+        plan, f = self.plan, self.flat
+        depth = len(plan.blocks)
+        dx = ops.layernorm_bwd(dy.contiguous(), st["x_last"], f.p("norm.weight"), st["mean"],
+                               st["rstd"], f.g("norm.weight"), f.g("norm.bias"))
+        if on_ready is not None:
+            on_ready(0)
+        for blk in reversed(plan.blocks):
+            dx = self._block_bwd(blk, st["blocks"][blk.index], dx, st["n_obj"])
+            if on_ready is not None:
+                on_ready(1 + (depth - 1 - blk.index))
+        # block-0 input: [cls | patches | objects]
+        B, Tx, L, O, C = st["B"], st["Tx"], st["L0"], plan.objects, plan.embed_dim
+        f.g("cls_token").add_(dx[:, 0].sum(0).view(1, 1, C))
+        dobj = dx[:, 1 + L:].reshape(B, Tx, O, C)
+        f.g("object_queries").add_(dobj.sum((0, 1)).view(1, O, C))
+        if Tx > 1:
+            f.g("pos_embed_temporal").add_(dobj.sum((0, 2)).view(1, Tx, C))
+        dtok = torch.empty((B * L, C), device=self.dev, dtype=BF16)
+        for b in range(B):
+            ops.scale_cast(dx[b, 1:1 + L], dst=dtok[b * L:(b + 1) * L])
+        ops.gemm_tn(dtok, st["cols"], f.g("patch_embed.proj.weight").view(C, 441))
+        ops.colsum(dtok, f.g("patch_embed.proj.bias"))
+        if on_ready is not None:
+            on_ready(depth + 1)
+
+    def _linear_bwd(self, dy16, x16, wname, bname, need_dx, out=None, accumulate=False,
+                    epilogue=hip.EPI_F32, aux=None):
+        f = self.flat
+        ops.gemm_tn(dy16, x16, f.g(wname))
+        ops.colsum(dy16, f.g(bname))
+        if not need_dx:
+            return None
+        return ops.gemm_nt(dy16, f.wt(wname), None, epilogue, out=out, aux=aux, accumulate=accumulate)
+
+    def _block_bwd(self, blk, sv, dx2, n_obj):
+        f = self.flat
+        pre = "blocks.%d." % blk.index
+        B, Nq, Co = dx2.shape
+        x = sv["x"]
+        N, C, h = x.shape[1], x.shape[2], blk.heads
+        M, Mq = B * N, B * Nq
+        sq, skv = blk.stride_q[1], blk.stride_kv[1]
+        thw, q_thw, k_thw = sv["thw"], sv["q_thw"], sv["k_thw"]
+        # ---- MLP branch: x2 = x1 + dp * fc2(gelu(fc1(LN2(x1)))) ------------------------------
+        dy = ops.scale_cast(dx2.view(Mq, Co), sv["dpm"], Nq)
+        dh = self._linear_bwd(dy, sv["act"], pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", True,
+                              epilogue=hip.EPI_DGELU, aux=sv["hpre"])
+        dxn2 = self._linear_bwd(dh, sv["xn2"].view(Mq, Co), pre + "mlp.fc1.weight",
+                                pre + "mlp.fc1.bias", True)
+        dx1 = ops.layernorm_bwd(dxn2, sv["x1"], f.p(pre + "norm2.weight"), sv["mean2"], sv["rstd2"],
+                                f.g(pre + "norm2.weight"), f.g(pre + "norm2.bias"), dres=dx2)
+        # ---- attention branch: x1 = skip + dp * proj(ctx) ------------------------------------
+        dy = ops.scale_cast(dx1.view(Mq, Co), sv["dpa"], Nq)
+        dctx = self._linear_bwd(dy, sv["ctx"].view(Mq, Co), pre + "attn.proj.weight",
+                                pre + "attn.proj.bias", True, epilogue=hip.EPI_BF16)
+        (qa, preq, mq, rq), (ka, prek, mk, rk), (v, prev, mv, rv) = sv["pools"]
+        dqa, dk, dv = ops.attn_bwd(qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE)
+        tabs, mats = sv["tabs"], sv["mats"]
+        names = (pre + "attn.rel_pos_h", pre + "attn.rel_pos_w", pre + "attn.rel_pos_t")
+        dtabs = [f.g(n) if m is None else torch.zeros_like(t) for n, m, t in zip(names, mats, tabs)]
+        dq_extra = ops.relpos_q_bwd(qa, dqa, tabs, sv["idx"], dtabs, B, h, q_thw, k_thw, n_obj,
+                                    1.0 / SCALE)
+        for n, m, d in zip(names, mats, dtabs):
+            if m is not None:
+                f.g(n).add_(m.t() @ d)
+        Nk = ka.shape[2]
+        dqkv = torch.empty_like(sv["qkv"])
+        for which, r, stride, pre_t, mean, rstd, nout, kw in (
+                (0, "q", sq, preq, mq, rq, Nq, dict(d_main=dqa, ld_main=qa.shape[-1],
+                                                     d_res=dctx, d_extra=dq_extra)),
+                (1, "k", skv, prek, mk, rk, Nk, dict(d_main=dk, ld_main=HD)),
+                (2, "v", skv, prev, mv, rv, Nk, dict(d_main=dv, ld_main=HD))):
+            dpre = ops.pool_ln_bwd(pre_t, mean, rstd, f.p(pre + "attn.norm_%s.weight" % r),
+                                   f.g(pre + "attn.norm_%s.weight" % r),
+                                   f.g(pre + "attn.norm_%s.bias" % r), B, h, nout, **kw)
+            wconv = f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27)
+            ops.pool_conv_dgrad(dpre, wconv, dqkv, which, B, h, thw, n_obj, stride)
+            ops.pool_conv_wgrad(dpre, sv["qkv"], which, f.g(pre + "attn.pool_%s.weight" % r).view(HD, 27),
+                                B, h, thw, n_obj, stride)
+        dxn = self._linear_bwd(dqkv, sv["xn"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", True)
+        # ---- skip path ------------------------------------------------------------------------
+        dskip = dx1
+        if blk.pools_q:
+            dskip = ops.maxpool_bwd(dskip, sv["pool_idx"], thw, n_obj)
+        if blk.has_proj:
+            ds16 = ops.scale_cast(dskip.view(M, Co))
+            self._linear_bwd(ds16, sv["xn"], pre + "proj.weight", pre + "proj.bias", True, out=dxn,
+                             accumulate=True)
+            dskip = None
+        return ops.layernorm_bwd(dxn, x, f.p(pre + "norm1.weight"), sv["mean1"], sv["rstd1"],
+                                 f.g(pre + "norm1.weight"), f.g(pre + "norm1.bias"),
+                                 dres=dskip).view(B, N, C)

@@ -1,0 +1,282 @@
+"""Host-side mirror of the reference's model interface for the SViT hot path.
+
+    MODEL_REGISTRY.get("SViT")(cfg)  /  build_model(cfg, gpu_id=None)
+    model(inputs: List[Tensor], metadata=None, bboxes=None) -> (preds, extra_preds)
+
+Same names, argument meaning, outputs, state_dict layout and error behaviour as
+slowfast/models/build.py:20-75 and slowfast/models/video_model_builder.py:24-551 (SURVEY.md
+8(b), Appendix D), but the backbone is ONE autograd node whose forward/backward are the HIP
+launch schedules of svit_amd/engine.py.  There is no PyTorch fallback for the backbone: without
+a GPU or without libsvit_hip.so the forward raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import arch, hip
+from .engine import Engine, FlatParams
+
+
+class Registry:
+    """fvcore-style registry (slowfast/models/build.py:9)."""
+
+    def __init__(self, name):
+        self._name, self._map = name, {}
+
+    def register(self, obj=None):
+        def deco(o):
+            self._map[o.__name__] = o
+            return o
+        return deco if obj is None else deco(obj)
+
+    def get(self, name):
+        if name not in self._map:
+            raise KeyError("No object named '%s' found in '%s' registry!" % (name, self._name))
+        return self._map[name]
+
+
+MODEL_REGISTRY = Registry("MODEL")
+
+
+def _weight_decayed(name, shape):
+    """slowfast/models/optimizer.py:39-60 with ZERO_WD_1D_PARAM: 1-D tensors and biases are not
+    decayed; everything else (incl. cls_token, object_queries, rel_pos_*) is."""
+    return not (len(shape) == 1 or name.endswith(".bias"))
+
+
+def _trunc_normal_(t, std=0.02):
+    return nn.init.trunc_normal_(t, std=std)
+
+
+class _Backbone(torch.autograd.Function):
+    """video -> LayerNorm-ed tokens.  Parameter gradients are accumulated by the engine straight
+    into the flat grad buffer that every `param.grad` is a view of."""
+
+    @staticmethod
+    def forward(ctx, model, video, drop_scales, need_grad, anchor):
+        with torch.no_grad():
+            y, st = model.engine.forward(video, drop_scales, save=need_grad)
+        ctx.model, ctx.st = model, (st if need_grad else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        model = ctx.model
+        if ctx.st is None:
+            raise RuntimeError("backward through an SViT forward that was run without grad")
+        model._attach_grads()
+        with torch.no_grad():
+            model.engine.backward(ctx.st, dy, on_ready=model._grad_ready_hook)
+        ctx.st = None
+        return None, None, None, None, None
+
+
+class SViTHead(nn.Module):
+    """slowfast/models/video_model_builder.py:408-551 -- tiny ([B,65,768]) fp32 torch ops."""
+
+    def __init__(self, cfg, dim_in, num_classes, dropout_rate=0.0, act_func="softmax"):
+        super().__init__()
+        self.T = cfg.DATA.NUM_FRAMES
+        self.dropout_rate = dropout_rate
+        if act_func not in ("softmax", "sigmoid"):
+            raise NotImplementedError("{} is not supported as an activationfunction.".format(act_func))
+        self.act_func = act_func
+        self.projection = nn.Linear(dim_in, num_classes, bias=True)
+        self.boxes_mlp = nn.Sequential(nn.Linear(dim_in, 4, bias=True), nn.Sigmoid())
+        self.boxes_bce_mlp = nn.Linear(dim_in, 1, bias=True)
+        self.contact_mlp = nn.Linear(dim_in, 5, bias=True)
+
+    def forward(self, x, T=None, dropout_keep=None):
+        T = self.T if T is None else T
+        if self.dropout_rate > 0.0 and self.training:
+            x = x * dropout_keep if dropout_keep is not None else F.dropout(x, self.dropout_rate, True)
+        B = x.size(0)
+        # the reference touches every head parameter so that DDP sees a grad on every rank
+        # (video_model_builder.py:514); same here: image-only heads get exact zeros on video steps
+        x = x + sum(p.sum() for p in self.parameters()) * 0
+        cls, xobj = x[:, 0], x[:, 1:]
+        extra = {"obj_desc": xobj.reshape(B, T, -1, xobj.size(-1))}
+        logits = self.projection(cls)
+        if not self.training:
+            logits = logits.softmax(dim=1) if self.act_func == "softmax" else logits.sigmoid()
+        xobj = xobj.reshape(B, T, -1, xobj.size(-1))
+        boxes = self.boxes_mlp(xobj)
+        boxes_bce = self.boxes_bce_mlp(xobj)
+        contact = self.contact_mlp(xobj[:, :, :2])
+        if not self.training:
+            boxes_bce = boxes_bce.sigmoid()
+            contact = contact.softmax(dim=-1)
+        extra["pred_bboxes"] = torch.cat((boxes_bce, boxes), dim=-1)
+        extra["pred_contact_state"] = contact
+        return logits, extra
+
+
+@MODEL_REGISTRY.register()
+class SViT(nn.Module):
+    """MI355X-native SViT (reference: slowfast/models/video_model_builder.py:24-398)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.plan = arch.build_plan(cfg)
+        self.O = cfg.SVIT.O
+        shapes = arch.param_shapes(self.plan)
+        self._shapes = shapes
+        # parameters first live as ordinary CPU tensors with the reference's init
+        # (video_model_builder.py:244-265, attention.py:317-327); finalize() moves them into the
+        # flat device buffers.
+        self._names = []
+        for name, shape in shapes.items():
+            if name.startswith("head."):
+                continue
+            t = torch.zeros(shape)
+            leaf = name.split(".")[-1]
+            if name in ("cls_token", "pos_embed_temporal", "object_queries") or leaf.startswith("rel_pos_"):
+                _trunc_normal_(t)
+            elif "pool_" in name or name == "patch_embed.proj.weight":
+                fan_in = int(math.prod(shape[1:]))
+                nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+            elif name == "patch_embed.proj.bias":
+                bound = 1.0 / math.sqrt(3 * 3 * 7 * 7)
+                nn.init.uniform_(t, -bound, bound)
+            elif leaf == "weight" and len(shape) == 2:
+                _trunc_normal_(t)
+            elif leaf == "weight":          # LayerNorm gains
+                t.fill_(1.0)
+            self._register(name, t)
+        self.head = SViTHead(cfg, self.plan.final_dim, self.plan.num_classes,
+                             dropout_rate=cfg.MODEL.DROPOUT_RATE, act_func=cfg.MODEL.HEAD_ACT)
+        for m in self.head.modules():
+            if isinstance(m, nn.Linear):
+                _trunc_normal_(m.weight)
+                nn.init.constant_(m.bias, 0)
+        self.engine = None
+        self.flat = None
+        self._grad_ready_hook = None   # set by the data-parallel wrapper (svit_amd/dp.py)
+        self._anchor = None
+
+    # -- parameters are registered under the reference's dotted names ---------------------------
+    def _register(self, name, tensor):
+        parts = name.split(".")
+        mod = self
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, nn.Module())
+            mod = getattr(mod, p)
+        mod.register_parameter(parts[-1], nn.Parameter(tensor))
+        self._names.append(name)
+
+    def _param(self, name):
+        mod = self
+        for p in name.split("."):
+            mod = getattr(mod, p)
+        return mod
+
+    def no_weight_decay(self):
+        """video_model_builder.py:267-289."""
+        names = []
+        if self.cfg.MVIT.ZERO_DECAY_POS_CLS:
+            names.extend(["rel_pos_h", "rel_pos_w", "rel_pos_hw", "rel_pos_t", "cls_token",
+                          "object_queries", "pos_embed_temporal"])
+        return names
+
+    # -- device placement ------------------------------------------------------------------------
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        p0 = self.cls_token
+        if p0.is_cuda and (self.flat is None or self.flat.data.device != p0.device):
+            self.finalize()
+        return out
+
+    def finalize(self):
+        """Move every parameter (head included) into the flat fp32 buffer on the current device
+        and make `param.data` / `param.grad` views of the flat data / grad buffers."""
+        named = dict(self.named_parameters())
+        dev = self.cls_token.device
+        if dev.type != "cuda":
+            raise hip.SvitHipError("SViT (svit_amd) runs on an MI355X only: move the model to a "
+                                   "GPU (build_model with cfg.NUM_GPUS >= 1); no CPU fallback")
+        hip.load()
+        shapes = {n: tuple(p.shape) for n, p in named.items()}
+        flat = FlatParams(shapes, _weight_decayed, dev, arch.readiness_rank)
+        for n, p in named.items():
+            flat.p(n).copy_(p.data)
+            p.data = flat.p(n)
+            p.grad = None
+        self.flat = flat
+        self.engine = Engine(self.plan, flat)
+        self._grads_attached = False
+        self._anchor = torch.zeros((), device=dev, requires_grad=True)
+        return self
+
+    def _attach_grads(self):
+        """Make every `.grad` a view of the flat grad buffer before the engine accumulates into
+        it.  Called at the start of the backbone's backward, i.e. after the (tiny) head has
+        already back-propagated through ordinary autograd: grads it produced into fresh tensors
+        (after `optimizer.zero_grad()` dropped ours, tools/train_net.py:133) are adopted."""
+        flat = self.flat
+        first = self.cls_token
+        fresh = first.grad is None or first.grad.data_ptr() != flat.g("cls_token").data_ptr()
+        if fresh:
+            flat.grad.zero_()
+        for n, p in self.named_parameters():
+            v = flat.g(n)
+            if p.grad is None:
+                p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():
+                if fresh:
+                    v.copy_(p.grad)
+                else:
+                    v.add_(p.grad)
+                p.grad = v
+
+    # -- forward ---------------------------------------------------------------------------------
+    def sample_drop_scales(self, batch, device):
+        """Per-sample stochastic-depth factors floor(keep + U[0,1)) / keep (common.py:46-59)."""
+        out = []
+        for blk in self.plan.blocks:
+            if blk.drop_path <= 0.0 or not self.training:
+                out.append(None)
+                continue
+            keep = 1.0 - blk.drop_path
+            r = torch.rand((2, batch), device=device)
+            m = torch.floor(keep + r) / keep
+            out.append((m[0].contiguous(), m[1].contiguous()))
+        return out
+
+    def forward(self, x, metadata=None, bboxes=None, drop_scales=None, dropout_keep=None):
+        if self.engine is None:
+            raise hip.SvitHipError("SViT (svit_amd) has no CPU path: build it with "
+                                   "build_model(cfg) / call .cuda() on an MI355X first")
+        x = x[0]
+        if x.dim() == 4:  # image
+            x = x.unsqueeze(2)
+        Tx = x.shape[2]
+        self.engine.refresh_weights()
+        if drop_scales is None:
+            drop_scales = self.sample_drop_scales(x.shape[0], x.device)
+        need_grad = torch.is_grad_enabled()
+        tokens = _Backbone.apply(self, x, drop_scales, need_grad, self._anchor)
+        n_obj = Tx * self.O
+        feat = torch.cat((tokens[:, :1], tokens[:, -n_obj:]), dim=1)
+        return self.head(feat, T=Tx, dropout_keep=dropout_keep)
+
+
+def build_model(cfg, gpu_id=None):
+    """slowfast/models/build.py:20-75: same contract (GPU-count asserts, registry lookup,
+    `.cuda(device)`, data-parallel wrap when NUM_GPUS > 1)."""
+    if torch.cuda.is_available():
+        assert cfg.NUM_GPUS <= torch.cuda.device_count(), "Cannot use more GPU devices than available"
+    else:
+        assert cfg.NUM_GPUS == 0, "Cuda is not available. Please set `NUM_GPUS: 0 for running on CPUs."
+    model = MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg)
+    if cfg.NUM_GPUS:
+        cur_device = torch.cuda.current_device() if gpu_id is None else gpu_id
+        model = model.cuda(device=cur_device)
+    if cfg.NUM_GPUS > 1:
+        from .dp import DataParallel
+        model = DataParallel(model, device_ids=[cur_device], output_device=cur_device,
+                             find_unused_parameters=cfg.DDP_FIND_UNUSED_PARAMETERS)
+    return model

@@ -54,8 +54,8 @@ def gemm_tn(a, b, dw, splits=0):
     """dw[N,K] (f32) += a[M,N]^T @ b[M,K]."""
     _chk_dev(a, b, dw)
     M, N = a.shape
-    K = b.shape[1]
-    assert b.shape[0] == M and tuple(dw.shape[-2:]) == (N, K) and dw.dtype == F32
+    K = dw.shape[-1]  # may be smaller than b's padded width (patch-embed wgrad)
+    assert b.shape[0] == M and b.shape[1] >= K and dw.shape[-2] == N and dw.dtype == F32
     hip.call("svit_gemm_tn", ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(dw), dw.stride(-2),
              M, N, K, splits)
     return dw
@@ -78,6 +78,13 @@ def cast_bf16(src, dst=None):
 def transpose_cast_batched(src_flat, dst_flat, table, n_mats, max_tiles):
     hip.call("svit_transpose_cast_batched", ptr(src_flat), ptr(dst_flat), ptr(table), n_mats,
              max_tiles)
+
+
+def pad_cast_rows(src, dst):
+    """dst bf16 [R,ldd] = [src f32 [R,C] | 0]."""
+    _chk_dev(src, dst)
+    hip.call("svit_pad_cast_rows", ptr(src), ptr(dst), src.shape[0], src.shape[1], dst.shape[1])
+    return dst
 
 
 def scale_cast(src, row_scale=None, rows_per_sample=0, dst=None):

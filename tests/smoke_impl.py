@@ -1,0 +1,89 @@
+"""One tiny SViT forward+backward through the HIP path on cuda:0, checked against the CPU
+oracle (used by __graft_entry__.smoke() and by tests/test_model_gpu.py)."""
+import torch
+
+from oracle import procedural as P
+from oracle import svit_ref as R
+
+
+def build_hip_model(num_frames, crop, drop=False, train=True):
+    from svit_amd import config
+    from svit_amd.model import build_model
+    cfg = config.ssv2_cfg(num_frames=num_frames, crop=crop)
+    if not drop:
+        cfg.MVIT.DROPPATH_RATE = 0.0
+        cfg.MODEL.DROPOUT_RATE = 0.0
+    model = build_model(cfg)
+    spec = R.make_spec(num_frames=num_frames, crop=crop,
+                       drop_path_rate=cfg.MVIT.DROPPATH_RATE, dropout_rate=cfg.MODEL.DROPOUT_RATE)
+    sd = P.state_dict(R.param_shapes(spec))
+    model.load_state_dict(sd, strict=True)
+    model.train(train)
+    return cfg, model, spec, sd
+
+
+def cosine(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+
+
+def compare_step(num_frames=4, crop=64, batch=2, frames_path=False, verbose=False):
+    """-> dict of parity numbers (HIP bf16 path vs fp32 oracle) for one video CE step."""
+    cfg, model, spec, sd = build_hip_model(num_frames, crop)
+    x = P.frames(batch, 1 if frames_path else num_frames, crop)
+    y = P.labels(batch)
+    logits, extra = model([x.cuda()], {})
+    loss = torch.nn.functional.cross_entropy(logits, y.cuda())
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lg, ex = R.forward(p, spec, x, training=True)
+    ls = R.video_loss(lg, y)
+    ls.backward()
+    out = {"logits_maxabs": float((logits.detach().cpu() - lg.detach()).abs().max()),
+           "logits_cos": cosine(logits.detach(), lg.detach()),
+           "loss_abs": abs(float(loss.detach()) - float(ls.detach())),
+           "obj_desc_cos": cosine(extra["obj_desc"].detach(), ex["obj_desc"].detach()),
+           "obj_desc_maxabs": float((extra["obj_desc"].detach().cpu() - ex["obj_desc"].detach()).abs().max())}
+    named = dict(model.named_parameters())
+    gmax = max(float(v.grad.abs().max()) for v in p.values() if v.grad is not None)
+    worst, worst_name = 1.0, ""
+    num = den_a = den_b = 0.0
+    for k, v in p.items():
+        ref = v.grad if v.grad is not None else torch.zeros_like(v)
+        got = named[k].grad.detach().cpu()
+        num += float((got.double() * ref.double()).sum())
+        den_a += float((got.double() ** 2).sum())
+        den_b += float((ref.double() ** 2).sum())
+        if float(ref.abs().max()) < 1e-4 * gmax:   # mathematically ~zero (e.g. norm_k.bias)
+            assert float(got.abs().max()) < 2e-2 * gmax, (k, float(got.abs().max()), gmax)
+            continue
+        c = cosine(got, ref)
+        if c < worst:
+            worst, worst_name = c, k
+        if verbose:
+            print("%-40s cos %.5f  |ref| %.3e |got| %.3e" % (k, c, float(ref.norm()), float(got.norm())))
+    out["grad_cos_worst"] = worst
+    out["grad_cos_worst_name"] = worst_name
+    out["grad_cos_global"] = num / ((den_a ** 0.5) * (den_b ** 0.5) + 1e-30)
+    return out
+
+
+# stated tolerance of the bf16 HIP path against the fp32 oracle (BASELINE.json north_star;
+# SURVEY.md 8(c)): logits max-abs <= 0.05 and cosine >= 0.999; per-tensor grad cosine >= 0.99.
+TOL = {"logits_maxabs": 0.05, "logits_cos": 0.999, "grad_cos": 0.99, "obj_desc_cos": 0.999}
+
+
+def check(res):
+    assert res["logits_maxabs"] <= TOL["logits_maxabs"], res
+    assert res["logits_cos"] >= TOL["logits_cos"], res
+    assert res["obj_desc_cos"] >= TOL["obj_desc_cos"], res
+    assert res["grad_cos_worst"] >= TOL["grad_cos"], res
+    assert res["grad_cos_global"] >= 0.995, res
+
+
+def run():
+    res = compare_step(4, 64, 2)
+    print("smoke:", res)
+    check(res)
