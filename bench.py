@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""SViT 16x224^2 bf16 training-step benchmark on MI355X (BASELINE.json metric: clips/sec,
+fwd+bwd, B=8 clips per GPU, synthetic SSv2-shaped input + 4 object tokens per frame).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = forward (DropPath + dropout on, as in training) + CE loss + backward through every
+HIP kernel + (N>1: RCCL gradient all-reduce overlapped with backward) + global-norm clip +
+AdamW.  Prints ONE JSON line on rank 0.  `--frames-pass` adds the reference's as-released
+no-grad B*T single-frame pass (tools/train_net.py:105-110); it is off for the headline metric.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+FWD_GFLOP_PER_CLIP = 138.16    # SURVEY.md 8(d), 16x224^2, 2*MAC, reference flop counter
+STEP_GFLOP_PER_CLIP = 412.4    # fwd+bwd: 3x GEMM/bmm/depthwise + 2x patch-embed
+
+
+def synth_batch(cfg, batch, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(batch, 3, cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE,
+                    cfg.DATA.TRAIN_CROP_SIZE, generator=g)
+    y = torch.randint(0, cfg.MODEL.NUM_CLASSES, (batch,), generator=g)
+    return x.to(device), y.to(device)
+
+
+def cpu_baseline(frames, crop, timed_steps=2):
+    """fp32 CPU oracle (oracle/svit_ref.py, pinned against the reference) fwd+bwd at B=1."""
+    from oracle import svit_ref as R
+    threads = torch.get_num_threads()
+    spec = R.make_spec(num_frames=frames, crop=crop)
+    torch.manual_seed(0)
+    p = {k: (torch.randn(s) * 0.02).requires_grad_(True) for k, s in R.param_shapes(spec).items()}
+    for k in p:
+        if k.endswith("norm.weight") or ".norm" in k and k.endswith("weight"):
+            p[k].data.fill_(1.0)
+    x = torch.randn(1, 3, frames, crop, crop)
+    y = torch.randint(0, 174, (1,))
+    times = []
+    for i in range(1 + timed_steps):
+        t0 = time.perf_counter()
+        ds = R.sample_drop_scales(spec, 1)
+        keep = (torch.rand(1, 1 + frames * 4, spec.final_dim) > 0.5).float() * 2.0
+        logits, _ = R.forward(p, spec, x, training=True, drop_scales=ds, dropout_keep=keep)
+        R.video_loss(logits, y).backward()
+        for v in p.values():
+            v.grad = None
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {"value": round(1.0 / best, 4), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": "fp32 CPU oracle (oracle/svit_ref.py), %dx%d^2, B=1, 1 warm-up + %d timed "
+                      "fwd+bwd steps, best step %.2f s" % (frames, crop, timed_steps, best)}
+
+
+def kernel_report(trace, batch):
+    """Aggregate the HIP-event trace of one profiled step per C-ABI entry point."""
+    torch.cuda.synchronize()
+    agg = {}
+    for name, e0, e1, meta in trace:
+        ms = e0.elapsed_time(e1)
+        a = agg.setdefault(name, {"ms": 0.0, "calls": 0, "flop": 0.0})
+        a["ms"] += ms
+        a["calls"] += 1
+        if meta and meta[0] == "mnk":
+            a["flop"] += 2.0 * meta[1] * meta[2] * meta[3]
+        elif meta and meta[0] == "attn":
+            _, B, h, Nq, Nk, DA = meta
+            alg = 2.0 * B * h * Nq * Nk * (96 + 96)        # QK^T + AV at head_dim 96
+            a["flop"] += alg * (2.0 if name.endswith("bwd") else 1.0)
+    total = sum(a["ms"] for a in agg.values())
+    rows = []
+    for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        r = {"kernel": name, "ms": round(a["ms"], 3), "calls": a["calls"],
+             "share": round(a["ms"] / total, 4)}
+        if a["flop"] > 0:
+            r["tflops"] = round(a["flop"] / (a["ms"] * 1e-3) / 1e12, 2)
+        rows.append(r)
+    return rows, total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--crop", type=int, default=224)
+    ap.add_argument("--frames-pass", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-trace", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from svit_amd import config, optim
+    from svit_amd.model import build_model
+    cfg = config.ssv2_cfg(num_frames=args.frames, crop=args.crop, num_gpus=world)
+    torch.manual_seed(cfg.RNG_SEED)
+    model = build_model(cfg, gpu_id=local_rank)
+    model.train()
+    opt = optim.construct_optimizer(model, cfg)
+    x, y = synth_batch(cfg, args.batch, dev, seed=cfg.RNG_SEED + rank)
+    core = model.module if hasattr(model, "module") else model
+
+    def step(it):
+        optim.set_lr(opt, optim.get_lr_at_epoch(cfg, it / 1000.0))
+        logits, extra = model([x], {})
+        if args.frames_pass:
+            with torch.no_grad():
+                model([x.transpose(1, 2).flatten(0, 1).unsqueeze(2)], {})
+        loss = torch.nn.functional.cross_entropy(logits, y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for it in range(args.warmup):
+        loss = step(it)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        loss = step(args.warmup + it)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    loss_val = float(loss)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms_per_step = dt / args.steps * 1e3
+    clips_per_s = args.batch * world * args.steps / dt
+
+    out = {
+        "metric": "clips/sec (fwd+bwd) SViT %dx%d^2 bf16" % (args.frames, args.crop),
+        "value": round(clips_per_s, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "SViT %dx%d^2, %d clips/GPU, 4 object tokens/frame, fwd+CE+bwd+"
+                               "clip+AdamW%s" % (args.frames, args.crop, args.batch,
+                                                 " + no-grad frames pass" if args.frames_pass else ""),
+                   "global_batch": args.batch * world, "seq_len": None,
+                   "parallelism": "dp%d" % world},
+        "loss": round(loss_val, 4),
+        "step_mfma_frac": round(clips_per_s / world * STEP_GFLOP_PER_CLIP * 1e9 /
+                                (MFMA_PEAK_TFLOPS * 1e12), 4),
+    }
+    if rank == 0 and not args.no_kernel_trace:
+        from svit_amd import hip
+        hip.start_trace()
+        step(args.warmup + args.steps)
+        rows, total = kernel_report(hip.stop_trace(), args.batch)
+        out["kernels"] = rows[:12]
+        out["kernel_ms_total"] = round(total, 3)
+        top = rows[0]
+        # the north-star kernel is the fused attention; report the dominant kernel's roofline and
+        # always the attention forward's
+        attn = next(r for r in rows if r["kernel"] == "svit_attn_fwd")
+        dom = top if "tflops" in top else attn
+        out["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"],
+                           "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "avg_launch_ms": round(dom["ms"] / dom["calls"], 4)}
+        out["roofline_attn_fwd"] = {"bound": "mfma", "achieved": attn["tflops"],
+                                    "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(attn["tflops"] / MFMA_PEAK_TFLOPS, 4),
+                                    "avg_launch_ms": round(attn["ms"] / attn["calls"], 4)}
+    elif world > 1 and not args.no_kernel_trace:
+        step(args.warmup + args.steps)      # keep ranks in lock-step with rank 0's traced step
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.frames, args.crop)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

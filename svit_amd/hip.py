@@ -145,6 +145,29 @@ def check(rc, what):
         raise SvitHipError("%s failed: %s" % (what, kind))
 
 
-def call(name, *args):
+_trace = None  # list of (name, start_event, end_event, meta) while bench.py profiles a step
+
+
+def start_trace():
+    global _trace
+    _trace = []
+
+
+def stop_trace():
+    global _trace
+    t, _trace = _trace, None
+    return t
+
+
+def call(name, *args, meta=None):
+    if _trace is None:
+        rc = getattr(load(), name)(*args, stream())
+        check(rc, name)
+        return
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
     rc = getattr(load(), name)(*args, stream())
+    e1.record()
     check(rc, name)
+    _trace.append((name, e0, e1, meta))

@@ -46,7 +46,7 @@ def gemm_nt(a, w, bias=None, epilogue=hip.EPI_BF16, out=None, out2=None, aux=Non
     g.epilogue, g.accumulate = epilogue, int(accumulate)
     if remap is not None:
         g.remap_L, g.remap_N, g.remap_off = remap
-    hip.call("svit_gemm_nt", C.byref(g))
+    hip.call("svit_gemm_nt", C.byref(g), meta=("mnk", M, N, K))
     return (out, out2) if epilogue == hip.EPI_GELU else out
 
 
@@ -57,7 +57,7 @@ def gemm_tn(a, b, dw, splits=0):
     K = dw.shape[-1]  # may be smaller than b's padded width (patch-embed wgrad)
     assert b.shape[0] == M and b.shape[1] >= K and dw.shape[-2] == N and dw.dtype == F32
     hip.call("svit_gemm_tn", ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(dw), dw.stride(-2),
-             M, N, K, splits)
+             M, N, K, splits, meta=("mnk", M, N, K))
     return dw
 
 
@@ -229,7 +229,7 @@ def attn_fwd(qa, ka, v, scale):
     a = hip.AttnFwdArgs()
     a.qa, a.ka, a.v, a.ctx, a.lse2 = ptr(qa), ptr(ka), ptr(v), ptr(ctx), ptr(lse2)
     a.B, a.heads, a.Nq, a.Nk, a.DA, a.scale = B, heads, Nq, Nk, DA, scale
-    hip.call("svit_attn_fwd", C.byref(a))
+    hip.call("svit_attn_fwd", C.byref(a), meta=("attn", B, heads, Nq, Nk, DA))
     return ctx, lse2
 
 
@@ -246,7 +246,7 @@ def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0):
     a.qa, a.ka, a.v, a.ctx, a.dctx, a.lse2 = (ptr(t) for t in (qa, ka, v, ctx, dctx, lse2))
     a.delta, a.dqa, a.dk, a.dv = ptr(delta), ptr(dqa), ptr(dkv[0]), ptr(dkv[1])
     a.B, a.heads, a.Nq, a.Nk, a.DA, a.q_splits, a.scale = B, heads, Nq, Nk, DA, q_splits, scale
-    hip.call("svit_attn_bwd", C.byref(a))
+    hip.call("svit_attn_bwd", C.byref(a), meta=("attn", B, heads, Nq, Nk, DA))
     return dqa, dkv[0], dkv[1]
 
 
