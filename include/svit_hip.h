@@ -60,7 +60,8 @@ int svit_colsum_bf16(const void* A, int lda, float* out, int M, int N, void* str
 /* ------------------------------------------------------------- elementwise / casts ---- */
 int svit_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* batched fp32 [R,C] -> bf16 [C,R] transposes described by a device table of
- * {src_off, dst_off, R, C} int64 quadruples (the W^T copies used by dgrad). */
+ * {src_off, dst_off, R, C, ldd} int64 quintuples: dst[c*ldd + r] (the W^T copies used by
+ * dgrad; ldd > R places a table inside a wider row, e.g. the concatenated rel-pos tables). */
 int svit_transpose_cast_batched(const float* src_base, void* dst_base, const int64_t* table,
                                 int n_mats, int max_tiles, void* stream);
 /* dst(bf16)[R,ldd] = [src(f32)[R,C] | 0]: row-padded bf16 copy (patch-embed weight 441 -> 448). */
@@ -74,10 +75,12 @@ int svit_scale_cast(const float* src, void* dst, const float* row_scale, int row
 int svit_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16,
                        float* y_f32, float* mean, float* rstd, int64_t rows, int C, float eps,
                        void* stream);
-/* dx = [dres +] LN'(dy); dgamma/dbeta atomically accumulated. dy is f32. */
+/* dx = [dres +] LN'(dy); dgamma/dbeta += column sums (two-stage: per-block partial rows in
+ * `workspace`, then one reduce launch -- no same-address atomics). dy is f32. */
 int svit_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, const float* dres, float* dx, float* dgamma,
-                       float* dbeta, int64_t rows, int C, void* stream);
+                       float* dbeta, int64_t rows, int C, float* workspace,
+                       int64_t workspace_floats, void* stream);
 
 /* ------------------------------------------------------------ patch embedding (K1/K2) - */
 /* im2col for Conv3d(3->96, k(3,7,7), s(2,4,4), p(1,3,3)) (stem_helper.py:309-320):
@@ -111,13 +114,14 @@ int svit_pool_ln_fwd(const svit_pool_args* a, void* stream);
 /* backward, step 1: LayerNorm(96) backward per pooled token.
  * dout: up to three addends: d_main (bf16 or f32, row stride ld_main), d_res (bf16 ctx grad for
  * the residual-pooling path, rows [B, Nout, h*96], skipped for cls), d_extra (f32 [..,96]).
- * writes dpre bf16 [B,h,Nout,96]; dgamma/dbeta accumulated atomically. */
+ * writes dpre bf16 [B,h,Nout,96]; dgamma/dbeta accumulated (two-stage via workspace). */
 typedef struct {
   const void* d_main; int32_t main_is_f32; int32_t ld_main;
   const void* d_res; const float* d_extra;
   const void* pre; const float* mean; const float* rstd; const float* gamma;
   void* dpre; float* dgamma; float* dbeta;
   int32_t B, heads, Nout;
+  float* workspace; int64_t workspace_floats;   /* scratch for the two-stage dgamma/dbeta sum */
 } svit_pool_ln_bwd_args;
 int svit_pool_ln_bwd(const svit_pool_ln_bwd_args* a, void* stream);
 /* backward, step 2: depthwise-conv dgrad (gather form) + cls/object rows ->
@@ -131,6 +135,7 @@ int svit_pool_conv_dgrad(const svit_pool_dgrad_args* a, void* stream);
 typedef struct {
   const void* dpre; const void* qkv; int32_t which; float* dw;
   int32_t B, heads, T, H, W, n_obj, stride_hw;
+  float* workspace; int64_t workspace_floats;
 } svit_pool_wgrad_args;
 int svit_pool_conv_wgrad(const svit_pool_wgrad_args* a, void* stream);
 
@@ -157,8 +162,20 @@ typedef struct {
   int32_t rows_h, rows_w, rows_t;
   int32_t B, heads, qt, qh, qw, kt, kh, kw, n_obj;
   float inv_scale;
+  float* workspace; int64_t workspace_floats;
 } svit_relq_bwd_args;
 int svit_relpos_q_bwd(const svit_relq_bwd_args* a, void* stream);
+/* GEMM formulation of the same backward (the one the engine uses): D[tokens, ldd] (bf16,
+ * zero-filled here) receives d(relq) at column off_{h,w,t} + idx; then
+ * drel_x += D[:, sec_x]^T q (svit_gemm_tn) and dq_extra = D Rcat (svit_gemm_nt). */
+typedef struct {
+  const void* dqa; int32_t ld; void* D; int32_t ldd;
+  const int32_t* idx_h; const int32_t* idx_w; const int32_t* idx_t;
+  int32_t off_h, off_w, off_t;
+  int32_t B, heads, qt, qh, qw, kt, kh, kw, n_obj;
+  float inv_scale;
+} svit_relq_scatter_args;
+int svit_relpos_scatter(const svit_relq_scatter_args* a, void* stream);
 
 /* ------------------------------------------------ fused pooled attention (K8-K12) ------ */
 /* (q*scale)@k^T + rel-pos bias -> softmax -> @v -> + pooled q (all tokens but cls) ->

@@ -78,3 +78,45 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+
+// Second stage of the two-stage parameter-gradient reductions: every block of the producing
+// kernel stores its partial sums as one row of `partial` [nblocks][n] with plain stores, then
+// this kernel adds the column sums into up to three destination vectors (segments of n).
+// (Thousands of blocks atomically adding to the same few hundred addresses serialise at the
+// memory side: MI355X guide, "Global float atomics", contention row.)
+struct SvitReduceDst {
+  float* ptr[3];
+  int end[3];  // exclusive end of each segment within [0, n)
+};
+static __global__ void svit_reduce_partials_kernel(const float* __restrict__ partial, int nblocks,
+                                                   int n, SvitReduceDst dst) {
+  // block (32 columns x 8 row lanes): coalesced 128-byte row segments, 8x4 rows in flight
+  __shared__ float red[8][33];
+  const int i = blockIdx.x * 32 + threadIdx.x;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int b = threadIdx.y;
+    for (; b + 24 < nblocks; b += 32) {
+      s0 += partial[(size_t)b * n + i];
+      s1 += partial[(size_t)(b + 8) * n + i];
+      s2 += partial[(size_t)(b + 16) * n + i];
+      s3 += partial[(size_t)(b + 24) * n + i];
+    }
+    for (; b < nblocks; b += 8) s0 += partial[(size_t)b * n + i];
+  }
+  red[threadIdx.y][threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (threadIdx.y == 0 && i < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
+    if (i < dst.end[0]) dst.ptr[0][i] += s;
+    else if (i < dst.end[1]) dst.ptr[1][i - dst.end[0]] += s;
+    else dst.ptr[2][i - dst.end[1]] += s;
+  }
+}
+static inline void svit_launch_reduce(const float* partial, int nblocks, int n, SvitReduceDst dst,
+                                      hipStream_t st) {
+  hipLaunchKernelGGL(svit_reduce_partials_kernel, dim3((n + 31) / 32), dim3(32, 8), 0, st, partial,
+                     nblocks, n, dst);
+}

@@ -21,15 +21,16 @@ __global__ void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ 
   }
 }
 
-// one 32x32 tile per block-iteration; table rows: {src_off, dst_off, R, C}
+// one 32x32 tile per block-iteration; table rows: {src_off, dst_off, R, C, ldd}: dst[c*ldd + r]
 __global__ void transpose_cast_kernel(const float* __restrict__ src_base,
                                       bf16_t* __restrict__ dst_base,
                                       const int64_t* __restrict__ table, int n_mats) {
   __shared__ float tile[32][33];
   const int mat = blockIdx.y;
   if (mat >= n_mats) return;
-  const int64_t so = table[mat * 4 + 0], dof = table[mat * 4 + 1];
-  const int R = (int)table[mat * 4 + 2], C = (int)table[mat * 4 + 3];
+  const int64_t so = table[mat * 5 + 0], dof = table[mat * 5 + 1];
+  const int R = (int)table[mat * 5 + 2], C = (int)table[mat * 5 + 3];
+  const int64_t ldd = table[mat * 5 + 4];
   const int tr = (R + 31) / 32, tc = (C + 31) / 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
@@ -41,7 +42,7 @@ __global__ void transpose_cast_kernel(const float* __restrict__ src_base,
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
       const int c = c0 + i, r = r0 + tx;  // dst[c][r]
-      if (r < R && c < C) dst_base[dof + (int64_t)c * R + r] = f32_to_bf16(tile[tx][i]);
+      if (r < R && c < C) dst_base[dof + (int64_t)c * ldd + r] = f32_to_bf16(tile[tx][i]);
     }
     __syncthreads();
   }

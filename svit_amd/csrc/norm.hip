@@ -73,9 +73,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ rstd_in,
                                                      const float* __restrict__ dres,
                                                      float* __restrict__ dx,
-                                                     float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int64_t rows,
-                                                     int C) {
+                                                     float* __restrict__ partial,
+                                                     int64_t rows, int C) {
   __shared__ float red[4][2][768];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = C >> 2;
@@ -140,11 +139,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
   }
   __syncthreads();
+  float* prow = partial + (size_t)blockIdx.x * 2 * C;   // [dgamma | dbeta] row of this block
   for (int c = threadIdx.x; c < C; c += 256) {
-    const float a = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
-    const float b = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
-    atomicAdd(dgamma + c, a);
-    atomicAdd(dbeta + c, b);
+    prow[c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
+    prow[C + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
   }
 }
 }  // namespace
@@ -165,13 +163,19 @@ extern "C" int svit_layernorm_fwd(const float* x, const float* gamma, const floa
 extern "C" int svit_layernorm_bwd(const float* dy, const float* x, const float* gamma,
                                   const float* mean, const float* rstd, const float* dres,
                                   float* dx, float* dgamma, float* dbeta, int64_t rows, int C,
-                                  void* stream) {
-  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta) return SVIT_ERR_ARG;
+                                  float* workspace, int64_t workspace_floats, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace)
+    return SVIT_ERR_ARG;
   if (rows <= 0 || C <= 0 || C % 4 != 0 || C > 768) return SVIT_ERR_SHAPE;
   int64_t blocks = (rows + 3) / 4;
   if (blocks > 2048) blocks = 2048;
+  if (blocks > workspace_floats / (2 * C)) blocks = workspace_floats / (2 * C);
+  if (blocks < 1) return SVIT_ERR_ARG;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy,
-                     x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, C);
+                     x, gamma, mean, rstd, dres, dx, workspace, rows, C);
+  SVIT_LAUNCH_CHECK();
+  SvitReduceDst dst = {{dgamma, dbeta, dbeta}, {C, 2 * C, 2 * C}};
+  svit_launch_reduce(workspace, (int)blocks, 2 * C, dst, (hipStream_t)stream);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }

@@ -267,10 +267,8 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(svit_pool_ln_bwd_args 
     atomicAdd(&red[1][c0 + i], db[i]);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < HD; c += blockDim.x) {
-    atomicAdd(a.dgamma + c, red[0][c]);
-    atomicAdd(a.dbeta + c, red[1][c]);
-  }
+  float* prow = a.workspace + (size_t)blockIdx.x * 2 * HD;
+  for (int c = threadIdx.x; c < 2 * HD; c += blockDim.x) prow[c] = (&red[0][0])[c];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -335,66 +333,72 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(svit_pool_dgrad_args a)
 }
 
 // ---------------------------------------------------------------------------------------
-// wgrad: 24 lanes per output token (4 channels each), 8 tokens per 192-thread block,
-// 27x4 register accumulators per lane over a grid-stride loop, LDS then global atomics.
-__global__ __launch_bounds__(192) void pool_wgrad_kernel(svit_pool_wgrad_args a) {
-  __shared__ float acc_lds[27 * HD];
-  for (int i = threadIdx.x; i < 27 * HD; i += blockDim.x) acc_lds[i] = 0.f;
-  __syncthreads();
+// wgrad: one thread per (tap, 4-channel group): block = 24 x 27 threads, 4 register
+// accumulators each, tokens streamed 4 at a time (8 independent 8-byte loads in flight per
+// lane); every block stores its [c][tap] partial row, summed by the reduce launch.
+__global__ __launch_bounds__(648) void pool_wgrad_kernel(svit_pool_wgrad_args a, int toks_per_block) {
   const int s = a.stride_hw;
   const int Ho = pooled(a.H, s), Wo = pooled(a.W, s);
   const int L = a.T * a.H * a.W, Lo = a.T * Ho * Wo;
   const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
-  const int sub = threadIdx.x % 24, slot = threadIdx.x / 24, c0 = sub * 4;
+  const int c0 = threadIdx.x * 4, tap = threadIdx.y;
+  const int kt = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
   const size_t tok_stride = (size_t)3 * a.heads * HD;
   float nt[3], nh[3], ipt, iph;
   obj_counts(1, nt, &ipt);
   obj_counts(s, nh, &iph);
-  const float inv_p = ipt * iph * iph;
-  float acc[27][4];
-#pragma unroll
-  for (int k = 0; k < 27; ++k)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[k][e] = 0.f;
+  const float obj_coef = nt[kt] * nh[ky] * nh[kx] * ipt * iph * iph;
+  const bf16_t* qkv = (const bf16_t*)a.qkv + (size_t)a.which * a.heads * HD + c0;
+  const bf16_t* dpre = (const bf16_t*)a.dpre + c0;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
   const int64_t total = (int64_t)a.B * a.heads * Nout;
-  for (int64_t row = (int64_t)blockIdx.x * 8 + slot; row < total; row += (int64_t)gridDim.x * 8) {
-    const int tok = (int)(row % Nout);
-    if (tok == 0) continue;
-    const int bh = (int)(row / Nout), b = bh / a.heads, head = bh % a.heads;
-    const uint2 dv = *(const uint2*)((const bf16_t*)a.dpre + row * HD + c0);
-    const float d0 = lo_bf16(dv.x), d1 = hi_bf16(dv.x), d2 = lo_bf16(dv.y), d3 = hi_bf16(dv.y);
-    const bf16_t* base = (const bf16_t*)a.qkv + (size_t)b * N * tok_stride +
-                         ((size_t)a.which * a.heads + head) * HD + c0;
-    if (tok > Lo) {
-      const uint2 xv = *(const uint2*)(base + (size_t)(1 + L + (tok - 1 - Lo)) * tok_stride);
-      const float x0 = lo_bf16(xv.x) * d0 * inv_p, x1 = hi_bf16(xv.x) * d1 * inv_p;
-      const float x2 = lo_bf16(xv.y) * d2 * inv_p, x3 = hi_bf16(xv.y) * d3 * inv_p;
+  const int64_t r_begin = (int64_t)blockIdx.x * toks_per_block;
+  const int64_t r_end = min(total, r_begin + toks_per_block);
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += 4) {
+    uint2 dv[4], xv[4];
+    float coef[4];
 #pragma unroll
-      for (int k = 0; k < 27; ++k) {
-        const float n = nt[k / 9] * nh[(k / 3) % 3] * nh[k % 3];
-        acc[k][0] += x0 * n; acc[k][1] += x1 * n; acc[k][2] += x2 * n; acc[k][3] += x3 * n;
+    for (int u = 0; u < 4; ++u) {
+      const int64_t row = r0 + u;
+      coef[u] = 0.f;
+      dv[u] = make_uint2(0, 0);
+      xv[u] = make_uint2(0, 0);
+      if (row >= r_end) continue;
+      const int tok = (int)(row % Nout);
+      if (tok == 0) continue;
+      const int bh = (int)(row / Nout), b = bh / a.heads, head = bh % a.heads;
+      const bf16_t* base = qkv + (size_t)b * N * tok_stride + (size_t)head * HD;
+      int src = -1;
+      if (tok > Lo) {
+        src = 1 + L + (tok - 1 - Lo);
+        coef[u] = obj_coef;
+      } else {
+        const int p = tok - 1, px = p % Wo, py = (p / Wo) % Ho, pt = p / (Wo * Ho);
+        const int t = pt - 1 + kt, y = py * s - 1 + ky, x = px * s - 1 + kx;
+        if (t >= 0 && t < a.T && y >= 0 && y < a.H && x >= 0 && x < a.W) {
+          src = 1 + (t * a.H + y) * a.W + x;
+          coef[u] = 1.f;
+        }
       }
-    } else {
-      const int p = tok - 1, px = p % Wo, py = (p / Wo) % Ho, pt = p / (Wo * Ho);
-#pragma unroll
-      for (int k = 0; k < 27; ++k) {
-        const int t = pt - 1 + k / 9, y = py * s - 1 + (k / 3) % 3, x = px * s - 1 + k % 3;
-        if (t < 0 || t >= a.T || y < 0 || y >= a.H || x < 0 || x >= a.W) continue;
-        const uint2 xv = *(const uint2*)(base + (size_t)(1 + (t * a.H + y) * a.W + x) * tok_stride);
-        acc[k][0] += lo_bf16(xv.x) * d0; acc[k][1] += hi_bf16(xv.x) * d1;
-        acc[k][2] += lo_bf16(xv.y) * d2; acc[k][3] += hi_bf16(xv.y) * d3;
+      if (src >= 0) {
+        dv[u] = *(const uint2*)(dpre + row * HD);
+        xv[u] = *(const uint2*)(base + (size_t)src * tok_stride);
       }
     }
-  }
 #pragma unroll
-  for (int k = 0; k < 27; ++k)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(&acc_lds[k * HD + c0 + e], acc[k][e]);
-  __syncthreads();
-  for (int i = threadIdx.x; i < 27 * HD; i += blockDim.x) {
-    const int k = i / HD, c = i % HD;
-    atomicAdd(a.dw + c * 27 + k, acc_lds[i]);
+    for (int u = 0; u < 4; ++u) {
+      acc0 += coef[u] * lo_bf16(dv[u].x) * lo_bf16(xv[u].x);
+      acc1 += coef[u] * hi_bf16(dv[u].x) * hi_bf16(xv[u].x);
+      acc2 += coef[u] * lo_bf16(dv[u].y) * lo_bf16(xv[u].y);
+      acc3 += coef[u] * hi_bf16(dv[u].y) * hi_bf16(xv[u].y);
+    }
   }
+  // partial row in the dw layout [c][tap]
+  float* prow = a.workspace + (size_t)blockIdx.x * 27 * HD;
+  prow[(c0 + 0) * 27 + tap] = acc0;
+  prow[(c0 + 1) * 27 + tap] = acc1;
+  prow[(c0 + 2) * 27 + tap] = acc2;
+  prow[(c0 + 3) * 27 + tap] = acc3;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -428,6 +432,29 @@ __global__ __launch_bounds__(256) void relq_fwd_kernel(svit_relq_args a) {
     val *= a.inv_scale;
   }
   qrow[HD + j] = f32_to_bf16(val);
+}
+
+// backward as GEMMs: scatter d(relq) into the dense-but-sparse matrix D [tokens, Lpad] whose
+// column sections are the rows of the h / w / t tables; then dR = D^T q (svit_gemm_tn) and
+// dq = D R (svit_gemm_nt).  D is zero-filled by the launcher.
+__global__ __launch_bounds__(256) void relq_scatter_kernel(svit_relq_scatter_args a) {
+  const int extra = a.ld - HD;
+  const int Lq = a.qt * a.qh * a.qw, Nq = 1 + Lq + a.n_obj;
+  const int J = a.kh + a.kw + a.kt;
+  const int tok_per_block = 256 / extra;
+  const int64_t total = (int64_t)a.B * a.heads * Nq;
+  const int64_t row = (int64_t)blockIdx.x * tok_per_block + threadIdx.x / extra;
+  const int j = threadIdx.x % extra;
+  if (row >= total || j >= J) return;
+  const int tok = (int)(row % Nq);
+  if (tok < 1 || tok > Lq) return;
+  const int p = tok - 1, x = p % a.qw, y = (p / a.qw) % a.qh, t = p / (a.qw * a.qh);
+  int col;
+  if (j < a.kh) col = a.off_h + a.idx_h[y * a.kh + j];
+  else if (j < a.kh + a.kw) col = a.off_w + a.idx_w[x * a.kw + (j - a.kh)];
+  else col = a.off_t + a.idx_t[t * a.kt + (j - a.kh - a.kw)];
+  const float d = bf16_to_f32(((const bf16_t*)a.dqa)[row * a.ld + HD + j]) * a.inv_scale;
+  ((bf16_t*)a.D)[row * a.ldd + col] = f32_to_bf16(d);
 }
 
 __global__ __launch_bounds__(256) void relq_bwd_kernel(svit_relq_bwd_args a) {
@@ -482,13 +509,8 @@ __global__ __launch_bounds__(256) void relq_bwd_kernel(svit_relq_bwd_args a) {
     o[l32] = o0; o[l32 + 32] = o1; o[l32 + 64] = o2;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < tab_n; i += blockDim.x) {
-    const float v = tabs[i];
-    if (v == 0.f) continue;
-    if (i < a.rows_h * HD) atomicAdd(a.drel_h + i, v);
-    else if (i < (a.rows_h + a.rows_w) * HD) atomicAdd(a.drel_w + (i - a.rows_h * HD), v);
-    else atomicAdd(a.drel_t + (i - (a.rows_h + a.rows_w) * HD), v);
-  }
+  float* prow = a.workspace + (size_t)blockIdx.x * tab_n;
+  for (int i = threadIdx.x; i < tab_n; i += blockDim.x) prow[i] = tabs[i];
 }
 }  // namespace
 
@@ -520,10 +542,16 @@ extern "C" int svit_pool_ln_bwd(const svit_pool_ln_bwd_args* a, void* stream) {
     return SVIT_ERR_ARG;
   if (a->B <= 0 || a->heads <= 0 || a->Nout <= 0) return SVIT_ERR_SHAPE;
   if (a->d_main && (a->ld_main < HD || a->ld_main % 8 != 0)) return SVIT_ERR_ALIGN;
+  if (!a->workspace) return SVIT_ERR_ARG;
   const int64_t total = (int64_t)a->B * a->heads * a->Nout;
   int64_t blocks = (total + 63) / 64;
   if (blocks > 1024) blocks = 1024;
+  if (blocks > a->workspace_floats / (2 * HD)) blocks = a->workspace_floats / (2 * HD);
+  if (blocks < 1) return SVIT_ERR_ARG;
   hipLaunchKernelGGL(pool_ln_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+  SVIT_LAUNCH_CHECK();
+  SvitReduceDst dst = {{a->dgamma, a->dbeta, a->dbeta}, {HD, 2 * HD, 2 * HD}};
+  svit_launch_reduce(a->workspace, (int)blocks, 2 * HD, dst, (hipStream_t)stream);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }
@@ -545,9 +573,19 @@ extern "C" int svit_pool_conv_wgrad(const svit_pool_wgrad_args* a, void* stream)
   if (rc) return rc;
   const int Ho = (a->H - 1) / a->stride_hw + 1, Wo = (a->W - 1) / a->stride_hw + 1;
   const int64_t total = (int64_t)a->B * a->heads * (1 + a->T * Ho * Wo + a->n_obj);
-  int64_t blocks = (total + 7) / 8;
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(pool_wgrad_kernel, dim3((unsigned)blocks), dim3(192), 0, (hipStream_t)stream, *a);
+  if (!a->workspace) return SVIT_ERR_ARG;
+  int64_t blocks = (total + 63) / 64;          // >= 64 tokens per block
+  if (blocks > 2048) blocks = 2048;
+  if (blocks > a->workspace_floats / (27 * HD)) blocks = a->workspace_floats / (27 * HD);
+  if (blocks < 1) return SVIT_ERR_ARG;
+  int toks_per_block = (int)((total + blocks - 1) / blocks);
+  toks_per_block = (toks_per_block + 3) / 4 * 4;
+  blocks = (total + toks_per_block - 1) / toks_per_block;
+  hipLaunchKernelGGL(pool_wgrad_kernel, dim3((unsigned)blocks), dim3(24, 27), 0, (hipStream_t)stream,
+                     *a, toks_per_block);
+  SVIT_LAUNCH_CHECK();
+  SvitReduceDst dst = {{a->dw, a->dw, a->dw}, {27 * HD, 27 * HD, 27 * HD}};
+  svit_launch_reduce(a->workspace, (int)blocks, 27 * HD, dst, (hipStream_t)stream);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }
@@ -573,6 +611,22 @@ extern "C" int svit_relpos_q_fwd(const svit_relq_args* a, void* stream) {
   return SVIT_OK;
 }
 
+extern "C" int svit_relpos_scatter(const svit_relq_scatter_args* a, void* stream) {
+  if (!a || !a->dqa || !a->D || !a->idx_h || !a->idx_w || !a->idx_t) return SVIT_ERR_ARG;
+  int rc = check_relq(a->ld, a->kh, a->kw, a->kt);
+  if (rc) return rc;
+  if (a->ldd % 8 != 0 || a->off_h < 0 || a->off_w < a->off_h || a->off_t < a->off_w) return SVIT_ERR_ARG;
+  const int extra = a->ld - HD;
+  const int64_t total = (int64_t)a->B * a->heads * (1 + a->qt * a->qh * a->qw + a->n_obj);
+  hipError_t e = hipMemsetAsync(a->D, 0, (size_t)total * a->ldd * 2, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  const int tpb = 256 / extra;
+  hipLaunchKernelGGL(relq_scatter_kernel, dim3((unsigned)((total + tpb - 1) / tpb)), dim3(256), 0,
+                     (hipStream_t)stream, *a);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
 extern "C" int svit_relpos_q_bwd(const svit_relq_bwd_args* a, void* stream) {
   if (!a || !a->qa || !a->dqa || !a->dq_extra || !a->drel_h || !a->drel_w || !a->drel_t)
     return SVIT_ERR_ARG;
@@ -588,9 +642,17 @@ extern "C" int svit_relpos_q_bwd(const svit_relq_bwd_args* a, void* stream) {
     configured = lds;
   }
   const int64_t total = (int64_t)a->B * a->heads * (1 + a->qt * a->qh * a->qw + a->n_obj);
+  if (!a->workspace) return SVIT_ERR_ARG;
+  const int tab_n = (a->rows_h + a->rows_w + a->rows_t) * HD;
   int64_t blocks = (total + 7) / 8;
   if (blocks > 512) blocks = 512;
+  if (blocks > a->workspace_floats / tab_n) blocks = a->workspace_floats / tab_n;
+  if (blocks < 1) return SVIT_ERR_ARG;
   hipLaunchKernelGGL(relq_bwd_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, *a);
+  SVIT_LAUNCH_CHECK();
+  SvitReduceDst dst = {{a->drel_h, a->drel_w, a->drel_t},
+                       {a->rows_h * HD, (a->rows_h + a->rows_w) * HD, tab_n}};
+  svit_launch_reduce(a->workspace, (int)blocks, tab_n, dst, (hipStream_t)stream);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }

@@ -59,11 +59,23 @@ class FlatParams:
             if n.startswith("blocks.") and n.endswith(".weight") and len(shapes[n]) == 2:
                 r, c = shapes[n]
                 self.t_slots[n] = (toff, (c, r))
-                table += [self.slots[n][0], toff, r, c]
+                table += [self.slots[n][0], toff, r, c, r]
                 toff += _align(r * c)
+        # per block: the three rel-pos tables transposed side by side, [96, Lpad] with 8-aligned
+        # column sections (h | w | t) -- the B operand of the rel-pos backward GEMMs
+        self.rel_slots = {}
+        for n in order:
+            if n.endswith("attn.rel_pos_h"):
+                pre = n[:-len("attn.rel_pos_h")]
+                rows = [shapes[pre + "attn.rel_pos_" + a][0] for a in "hwt"]
+                offs, lpad = rel_sections(rows)
+                self.rel_slots[pre] = (toff, lpad, offs)
+                for a, o, r in zip("hwt", offs, rows):
+                    table += [self.slots[pre + "attn.rel_pos_" + a][0], toff + o, r, HD, lpad]
+                toff += _align(HD * lpad)
         self.wT16 = torch.zeros(max(toff, 8), device=device, dtype=BF16)
         self.t_table = torch.tensor(table, dtype=torch.int64, device=device)
-        self.n_t = len(table) // 4
+        self.n_t = len(table) // 5
 
     def view(self, buf, name):
         off, numel, shape = self.slots[name]
@@ -85,10 +97,22 @@ class FlatParams:
         off, shape = self.t_slots[name]
         return self.wT16[off:off + shape[0] * shape[1]].view(shape)
 
+    def rel_cat_t(self, pre):
+        """-> (bf16 [96, Lpad] transposed concatenation of the block's tables, Lpad, offsets)."""
+        off, lpad, offs = self.rel_slots[pre]
+        return self.wT16[off:off + HD * lpad].view(HD, lpad), lpad, offs
+
     def refresh_low_precision(self):
         ops.cast_bf16(self.data, self.w16)
         if self.n_t:
             ops.transpose_cast_batched(self.data, self.wT16, self.t_table, self.n_t, 256)
+
+
+def rel_sections(rows):
+    """column offsets (8-aligned) of the h / w / t sections and the 32-aligned total width."""
+    off_w = _align(rows[0])
+    off_t = off_w + _align(rows[1])
+    return (0, off_w, off_t), _align(off_t + rows[2], 32)
 
 
 def _rel_index(q_n, k_n):
@@ -297,14 +321,28 @@ class Engine:
                                 pre + "attn.proj.bias", True, epilogue=hip.EPI_BF16)
         (qa, preq, mq, rq), (ka, prek, mk, rk), (v, prev, mv, rv) = sv["pools"]
         dqa, dk, dv = ops.attn_bwd(qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE)
+        # rel-pos backward as GEMMs over the scattered matrix D [tokens, Lpad]
         tabs, mats = sv["tabs"], sv["mats"]
         names = (pre + "attn.rel_pos_h", pre + "attn.rel_pos_w", pre + "attn.rel_pos_t")
-        dtabs = [f.g(n) if m is None else torch.zeros_like(t) for n, m, t in zip(names, mats, tabs)]
-        dq_extra = ops.relpos_q_bwd(qa, dqa, tabs, sv["idx"], dtabs, B, h, q_thw, k_thw, n_obj,
-                                    1.0 / SCALE)
-        for n, m, d in zip(names, mats, dtabs):
-            if m is not None:
+        if all(m is None for m in mats):
+            rcat_t, lpad, offs = f.rel_cat_t(pre)
+        else:   # interpolated tables (odd crops, T=1 frames pass): tiny torch plumbing
+            offs, lpad = rel_sections([t.shape[0] for t in tabs])
+            rcat = torch.zeros((lpad, HD), device=self.dev, dtype=F32)
+            for o, t in zip(offs, tabs):
+                rcat[o:o + t.shape[0]] = t
+            rcat_t = rcat.t().contiguous().to(BF16)
+        D = ops.relpos_scatter(dqa, sv["idx"], offs, lpad, B, h, q_thw, k_thw, n_obj, 1.0 / SCALE)
+        qa2 = qa.view(B * h * Nq, qa.shape[-1])
+        for n, m, t, o in zip(names, mats, tabs, offs):
+            rows = t.shape[0]
+            if m is None:
+                ops.gemm_tn(D[:, o:o + rows], qa2[:, :HD], f.g(n))
+            else:
+                d = torch.zeros_like(t)
+                ops.gemm_tn(D[:, o:o + rows], qa2[:, :HD], d)
                 f.g(n).add_(m.t() @ d)
+        dq_extra = ops.gemm_nt(D, rcat_t, None, hip.EPI_F32)
         Nk = ka.shape[2]
         dqkv = torch.empty_like(sv["qkv"])
         for which, r, stride, pre_t, mean, rstd, nout, kw in (

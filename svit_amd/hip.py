@@ -38,7 +38,7 @@ class PoolLnBwdArgs(C.Structure):
     _fields_ = [("d_main", vp), ("main_is_f32", i32), ("ld_main", i32), ("d_res", vp),
                 ("d_extra", vp), ("pre", vp), ("mean", vp), ("rstd", vp), ("gamma", vp),
                 ("dpre", vp), ("dgamma", vp), ("dbeta", vp), ("B", i32), ("heads", i32),
-                ("Nout", i32)]
+                ("Nout", i32), ("workspace", vp), ("workspace_floats", i64)]
 
 
 class PoolDgradArgs(C.Structure):
@@ -49,7 +49,8 @@ class PoolDgradArgs(C.Structure):
 
 class PoolWgradArgs(C.Structure):
     _fields_ = [("dpre", vp), ("qkv", vp), ("which", i32), ("dw", vp), ("B", i32), ("heads", i32),
-                ("T", i32), ("H", i32), ("W", i32), ("n_obj", i32), ("stride_hw", i32)]
+                ("T", i32), ("H", i32), ("W", i32), ("n_obj", i32), ("stride_hw", i32),
+                ("workspace", vp), ("workspace_floats", i64)]
 
 
 class RelqArgs(C.Structure):
@@ -64,7 +65,15 @@ class RelqBwdArgs(C.Structure):
                 ("idx_h", vp), ("idx_w", vp), ("idx_t", vp), ("dq_extra", vp), ("drel_h", vp),
                 ("drel_w", vp), ("drel_t", vp), ("rows_h", i32), ("rows_w", i32), ("rows_t", i32),
                 ("B", i32), ("heads", i32), ("qt", i32), ("qh", i32), ("qw", i32), ("kt", i32),
-                ("kh", i32), ("kw", i32), ("n_obj", i32), ("inv_scale", f32)]
+                ("kh", i32), ("kw", i32), ("n_obj", i32), ("inv_scale", f32),
+                ("workspace", vp), ("workspace_floats", i64)]
+
+
+class RelqScatterArgs(C.Structure):
+    _fields_ = [("dqa", vp), ("ld", i32), ("D", vp), ("ldd", i32), ("idx_h", vp), ("idx_w", vp),
+                ("idx_t", vp), ("off_h", i32), ("off_w", i32), ("off_t", i32), ("B", i32),
+                ("heads", i32), ("qt", i32), ("qh", i32), ("qw", i32), ("kt", i32), ("kh", i32),
+                ("kw", i32), ("n_obj", i32), ("inv_scale", f32)]
 
 
 class AttnFwdArgs(C.Structure):
@@ -89,7 +98,7 @@ _SIGS = {
     "svit_scale_cast": (i32, [vp, vp, vp, i32, i64, i32, vp]),
     "svit_pad_cast_rows": (i32, [vp, vp, i32, i32, i32, vp]),
     "svit_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp]),
-    "svit_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]),
+    "svit_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, i64, vp]),
     "svit_im2col_patch": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "svit_fill_special_tokens": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "svit_pool_ln_fwd": (i32, [C.POINTER(PoolArgs), vp]),
@@ -98,6 +107,7 @@ _SIGS = {
     "svit_pool_conv_wgrad": (i32, [C.POINTER(PoolWgradArgs), vp]),
     "svit_relpos_q_fwd": (i32, [C.POINTER(RelqArgs), vp]),
     "svit_relpos_q_bwd": (i32, [C.POINTER(RelqBwdArgs), vp]),
+    "svit_relpos_scatter": (i32, [C.POINTER(RelqScatterArgs), vp]),
     "svit_attn_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),
     "svit_attn_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),
     "svit_maxpool_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

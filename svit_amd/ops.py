@@ -13,6 +13,24 @@ from .hip import ptr
 BF16 = torch.bfloat16
 F32 = torch.float32
 HD = 96
+_scratch = {}
+
+
+def scratch(device, floats=8 * 1024 * 1024):
+    """Per-device fp32 scratch for the two-stage parameter-gradient reductions (32 MB)."""
+    key = (device.index, floats)
+    buf = _scratch.get(key)
+    if buf is None:
+        buf = torch.empty(floats, device=device, dtype=F32)
+        _scratch[key] = buf
+    return buf
+
+
+def _chk_rows(*ts):
+    """2-D operands that may be column slices of a wider matrix (unit inner stride)."""
+    for t in ts:
+        if not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+            raise hip.SvitHipError("svit_amd GEMM operands must be 2-D device tensors with unit inner stride")
 
 
 def _chk_dev(*ts):
@@ -51,8 +69,9 @@ def gemm_nt(a, w, bias=None, epilogue=hip.EPI_BF16, out=None, out2=None, aux=Non
 
 
 def gemm_tn(a, b, dw, splits=0):
-    """dw[N,K] (f32) += a[M,N]^T @ b[M,K]."""
-    _chk_dev(a, b, dw)
+    """dw[N,K] (f32) += a[M,N]^T @ b[M,K].  a / b may be column slices (row-strided views)."""
+    _chk_rows(a, b)
+    _chk_dev(dw)
     M, N = a.shape
     K = dw.shape[-1]  # may be smaller than b's padded width (patch-embed wgrad)
     assert b.shape[0] == M and b.shape[1] >= K and dw.shape[-2] == N and dw.dtype == F32
@@ -115,8 +134,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, dx=None):
     rows = x.numel() // C_
     if dx is None:
         dx = torch.empty(x.shape, device=x.device, dtype=F32)
+    ws = scratch(x.device)
     hip.call("svit_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres),
-             ptr(dx), ptr(dgamma), ptr(dbeta), rows, C_)
+             ptr(dx), ptr(dgamma), ptr(dbeta), rows, C_, ptr(ws), ws.numel())
     return dx
 
 
@@ -171,6 +191,8 @@ def pool_ln_bwd(pre, mean, rstd, gamma, dgamma, dbeta, B, heads, Nout, d_main=No
     a.pre, a.mean, a.rstd, a.gamma = ptr(pre), ptr(mean), ptr(rstd), ptr(gamma)
     a.dpre, a.dgamma, a.dbeta = ptr(dpre), ptr(dgamma), ptr(dbeta)
     a.B, a.heads, a.Nout = B, heads, Nout
+    ws = scratch(pre.device)
+    a.workspace, a.workspace_floats = ptr(ws), ws.numel()
     hip.call("svit_pool_ln_bwd", C.byref(a))
     return dpre
 
@@ -186,6 +208,8 @@ def pool_conv_wgrad(dpre, qkv, which, dw, B, heads, thw, n_obj, stride_hw):
     a = hip.PoolWgradArgs()
     a.dpre, a.qkv, a.which, a.dw = ptr(dpre), ptr(qkv), which, ptr(dw)
     a.B, a.heads, (a.T, a.H, a.W), a.n_obj, a.stride_hw = B, heads, thw, n_obj, stride_hw
+    ws = scratch(dpre.device)
+    a.workspace, a.workspace_floats = ptr(ws), ws.numel()
     hip.call("svit_pool_conv_wgrad", C.byref(a))
 
 
@@ -215,8 +239,26 @@ def relpos_q_bwd(qa, dqa, tabs, idx, dtabs, B, heads, q_thw, k_thw, n_obj, inv_s
     a.qt, a.qh, a.qw = q_thw
     a.kt, a.kh, a.kw = k_thw
     a.n_obj, a.inv_scale = n_obj, inv_scale
+    ws = scratch(qa.device)
+    a.workspace, a.workspace_floats = ptr(ws), ws.numel()
     hip.call("svit_relpos_q_bwd", C.byref(a))
     return dq_extra
+
+
+def relpos_scatter(dqa, idx, offs, ldd, B, heads, q_thw, k_thw, n_obj, inv_scale):
+    """-> D bf16 [B*h*Nq, ldd] with d(relq)*inv_scale scattered to table-row columns."""
+    Nq = dqa.shape[2]
+    D = torch.empty((B * heads * Nq, ldd), device=dqa.device, dtype=BF16)
+    a = hip.RelqScatterArgs()
+    a.dqa, a.ld, a.D, a.ldd = ptr(dqa), dqa.shape[-1], ptr(D), ldd
+    a.idx_h, a.idx_w, a.idx_t = (ptr(t) for t in idx)
+    a.off_h, a.off_w, a.off_t = offs
+    a.B, a.heads = B, heads
+    a.qt, a.qh, a.qw = q_thw
+    a.kt, a.kh, a.kw = k_thw
+    a.n_obj, a.inv_scale = n_obj, inv_scale
+    hip.call("svit_relpos_scatter", C.byref(a))
+    return D
 
 
 def attn_fwd(qa, ka, v, scale):

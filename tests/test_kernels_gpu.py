@@ -118,7 +118,7 @@ def test_transpose_cast_batched(ops):
     dst = torch.zeros(total, device=DEV, dtype=BF16)
     table, off = [], 0
     for r, c in mats:
-        table += [off, off, r, c]
+        table += [off, off, r, c, r]
         off += r * c
     tab = torch.tensor(table, dtype=torch.int64, device=DEV)
     ops.transpose_cast_batched(src, dst, tab, len(mats), 256)
@@ -299,6 +299,21 @@ def test_relpos_q(ops, q_thw, k_thw):
     assert rel_err(dq_extra, q.grad) < 2e-3
     for i in range(3):
         assert rel_err(dtabs[i], tc[i].grad) < 2e-3
+    # the GEMM formulation the engine uses: scatter -> D, dR = D^T q, dq = D Rcat
+    from svit_amd import hip
+    from svit_amd.engine import rel_sections
+    offs, lpad = rel_sections(rows)
+    D = ops.relpos_scatter(dqa, idx_d, offs, lpad, B, h, q_thw, k_thw, O, 1.0 / scale)
+    qa2 = qa.view(-1, ld)
+    rcat = torch.zeros((lpad, 96), device=DEV)
+    for o, tb in zip(offs, tabs):
+        rcat[o:o + tb.shape[0]] = tb
+    for i in range(3):
+        d = torch.zeros_like(tabs[i])
+        ops.gemm_tn(D[:, offs[i]:offs[i] + rows[i]], qa2[:, :96], d)
+        assert rel_err(d, tc[i].grad) < 1e-2 and cos(d, tc[i].grad) > 0.9999
+    dq2 = ops.gemm_nt(D, rcat.t().contiguous().to(BF16), None, hip.EPI_F32)
+    assert rel_err(dq2.view(B, h, -1, 96), q.grad) < 1e-2 and cos(dq2.view(B, h, -1, 96), q.grad) > 0.9999
 
 
 # -------------------------------------------------------------------- fused attention ----
