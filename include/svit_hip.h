@@ -53,7 +53,8 @@ int svit_gemm_nt(const svit_gemm_args* args, void* stream);
 /* dW[N,K] (f32, atomically accumulated) += A[M,N]^T * B[M,K]  (Linear wgrad; split over M).
  * lda/ldb multiples of 8; K need not be (patch-embed wgrad: K = 441 inside ldb = 448). */
 int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, float* dW, int lddw,
-                 int M, int N, int K, int splits, void* stream);
+                 int M, int N, int K, int splits, float* dbias /* f32 [N] += colsum(A), or NULL */,
+                 void* stream);
 /* dbias[N] (f32, atomically accumulated) += column sums of bf16 A[M,N]. */
 int svit_colsum_bf16(const void* A, int lda, float* out, int M, int N, void* stream);
 

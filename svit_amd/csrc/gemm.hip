@@ -12,6 +12,7 @@
 namespace {
 
 template <int BK> struct LdsRow { static constexpr int kBytes = BK * 2 + 16; };
+constexpr int EP_LD = 100;   // fp32 row stride of the per-wave epilogue staging block (32 x 96)
 
 // ---------------------------------------------------------------------------------------
 // NT kernel.  Block = WAVES_M x WAVES_N waves; wave tile = (32*RB) x 96.
@@ -104,40 +105,66 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(svit_gem
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns column (lane&31) of each 32x32 block, 16 rows in registers ----
+  // ---- epilogue: each wave transposes its 32x96 accumulator blocks through a private LDS
+  // region so that global traffic is row-contiguous and vectorised (16 B fp32 / 8 B bf16 per
+  // lane, 24 lanes per 96-column row) instead of 2-byte column-strided accesses ----------------
+  float* stg = (float*)smem + wave * (32 * EP_LD);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int col = n0 + wn * 96 + j * 32 + (lane & 31);
-    if (col >= p.N) continue;
-    const float bias = p.bias ? p.bias[col] : 0.f;
+  for (int i = 0; i < RB; ++i) {
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
+    for (int j = 0; j < 3; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 32 * RB + i * 32 + acc_row(r, lane);
-        if (row >= p.M) continue;
-        float v = acc[i][j][r] + bias;
-        if constexpr (EPI == SVIT_EPI_BF16) {
-          ((bf16_t*)p.out)[(size_t)row * p.ldo + col] = f32_to_bf16(v);
-        } else if constexpr (EPI == SVIT_EPI_GELU) {
-          ((bf16_t*)p.out2)[(size_t)row * p.ldo2 + col] = f32_to_bf16(v);
-          ((bf16_t*)p.out)[(size_t)row * p.ldo + col] = f32_to_bf16(gelu_erf(v));
-        } else if constexpr (EPI == SVIT_EPI_RESID) {
-          const float s = p.row_scale ? p.row_scale[row / p.rows_per_sample] : 1.f;
-          const float res = ((const float*)p.aux)[(size_t)row * p.ldaux + col];
-          ((float*)p.out)[(size_t)row * p.ldo + col] = res + s * v;
-        } else if constexpr (EPI == SVIT_EPI_F32) {
-          size_t orow = row;
-          if (p.remap_L > 0)
-            orow = (size_t)(row / p.remap_L) * p.remap_N + p.remap_off + (row % p.remap_L);
-          float* o = (float*)p.out + orow * p.ldo + col;
-          *o = p.accumulate ? (*o + v) : v;
-        } else if constexpr (EPI == SVIT_EPI_DGELU) {
-          const float h = bf16_to_f32(((const bf16_t*)p.aux)[(size_t)row * p.ldaux + col]);
-          ((bf16_t*)p.out)[(size_t)row * p.ldo + col] = f32_to_bf16(v * gelu_erf_grad(h));
+      for (int r = 0; r < 16; ++r)
+        stg[acc_row(r, lane) * EP_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+      const int idx = lane + 64 * it;
+      const int rl = idx / 24, c4 = idx % 24;
+      const int row = m0 + wm * 32 * RB + i * 32 + rl;
+      const int col = n0 + wn * 96 + c4 * 4;
+      if (row >= p.M || col >= p.N) continue;
+      float4 v = *(const float4*)(stg + rl * EP_LD + c4 * 4);
+      if (p.bias) {
+        const float4 b = *(const float4*)(p.bias + col);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      if constexpr (EPI == SVIT_EPI_BF16) {
+        uint2 o;
+        o.x = pack_bf16x2(v.x, v.y); o.y = pack_bf16x2(v.z, v.w);
+        *(uint2*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = o;
+      } else if constexpr (EPI == SVIT_EPI_GELU) {
+        uint2 o;
+        o.x = pack_bf16x2(v.x, v.y); o.y = pack_bf16x2(v.z, v.w);
+        *(uint2*)((bf16_t*)p.out2 + (size_t)row * p.ldo2 + col) = o;
+        o.x = pack_bf16x2(gelu_erf(v.x), gelu_erf(v.y));
+        o.y = pack_bf16x2(gelu_erf(v.z), gelu_erf(v.w));
+        *(uint2*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = o;
+      } else if constexpr (EPI == SVIT_EPI_RESID) {
+        const float s = p.row_scale ? p.row_scale[row / p.rows_per_sample] : 1.f;
+        const float4 res = *(const float4*)((const float*)p.aux + (size_t)row * p.ldaux + col);
+        float4 o;
+        o.x = res.x + s * v.x; o.y = res.y + s * v.y; o.z = res.z + s * v.z; o.w = res.w + s * v.w;
+        *(float4*)((float*)p.out + (size_t)row * p.ldo + col) = o;
+      } else if constexpr (EPI == SVIT_EPI_F32) {
+        size_t orow = row;
+        if (p.remap_L > 0)
+          orow = (size_t)(row / p.remap_L) * p.remap_N + p.remap_off + (row % p.remap_L);
+        float4* o = (float4*)((float*)p.out + orow * p.ldo + col);
+        if (p.accumulate) {
+          const float4 old = *o;
+          v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
         }
+        *o = v;
+      } else if constexpr (EPI == SVIT_EPI_DGELU) {
+        const uint2 h = *(const uint2*)((const bf16_t*)p.aux + (size_t)row * p.ldaux + col);
+        uint2 o;
+        o.x = pack_bf16x2(v.x * gelu_erf_grad(lo_bf16(h.x)), v.y * gelu_erf_grad(hi_bf16(h.x)));
+        o.y = pack_bf16x2(v.z * gelu_erf_grad(lo_bf16(h.y)), v.w * gelu_erf_grad(hi_bf16(h.y)));
+        *(uint2*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = o;
       }
     }
+    if (i + 1 < RB) __syncthreads();
   }
 }
 
@@ -145,7 +172,9 @@ template <int RB, int WAVES_M, int WAVES_N, int BK>
 int launch_nt(const svit_gemm_args& a, hipStream_t st) {
   constexpr int BM = 32 * RB * WAVES_M, BN = 96 * WAVES_N;
   constexpr int NT = WAVES_M * WAVES_N * 64;
-  const size_t lds = 2 * (size_t)(BM + BN) * LdsRow<BK>::kBytes;
+  size_t lds = 2 * (size_t)(BM + BN) * LdsRow<BK>::kBytes;
+  const size_t lds_epi = (size_t)WAVES_M * WAVES_N * 32 * EP_LD * sizeof(float);
+  if (lds < lds_epi) lds = lds_epi;
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM);
 #define SVIT_NT_CASE(E)                                                                  \
   case E:                                                                                \
@@ -177,7 +206,8 @@ constexpr int TN_ROWB = TN_TK * 2;       // 192 B: conflict-free as is
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ A, int lda,
                                                       const bf16_t* __restrict__ B, int ldb,
                                                       float* __restrict__ dW, int lddw, int M,
-                                                      int N, int K, int rows_per_split) {
+                                                      int N, int K, int rows_per_split,
+                                                      float* __restrict__ dbias) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][TN_BM * (TN_ROWA + TN_ROWB)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * TN_TN, k0 = blockIdx.y * TN_TK;
@@ -204,6 +234,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
       if (gm < m_end && gk < K) rb[i] = *(const uint4*)(B + (size_t)gm * ldb + gk);
     }
   };
+  // fused bias gradient: column sums of A (= dY) ride along on the k-tile-0 blocks; a thread
+  // always stages the same 8-column chunk (tid % 16), so it keeps 8 running sums
+  const bool do_bias = (dbias != nullptr) && (blockIdx.y == 0);
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto store_tiles = [&](int buf) {
     unsigned char* la = lds[buf];
     unsigned char* lb = lds[buf] + TN_BM * TN_ROWA;
@@ -211,6 +245,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
     for (int i = 0; i < A_PER; ++i) {
       const int c = tid + i * 256;
       *(uint4*)(la + (c / A_CH) * TN_ROWA + (c % A_CH) * 16) = ra[i];
+      if (do_bias) {
+        bsum[0] += lo_bf16(ra[i].x); bsum[1] += hi_bf16(ra[i].x);
+        bsum[2] += lo_bf16(ra[i].y); bsum[3] += hi_bf16(ra[i].y);
+        bsum[4] += lo_bf16(ra[i].z); bsum[5] += hi_bf16(ra[i].z);
+        bsum[6] += lo_bf16(ra[i].w); bsum[7] += hi_bf16(ra[i].w);
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
@@ -263,6 +303,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
       if (row < N) atomicAdd(dW + (size_t)row * lddw + col, acc[j][r]);
     }
   }
+  if (do_bias) {  // 16 threads share a column chunk: reduce through LDS, one atomic per column
+    float* red = (float*)&lds[0][0];  // [16][128]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(tid / A_CH) * TN_TN + (tid % A_CH) * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < TN_TN && n0 + tid < N) {
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) sum += red[g * TN_TN + tid];
+      atomicAdd(dbias + n0 + tid, sum);
+    }
+  }
 }
 
 __global__ void colsum_kernel(const bf16_t* __restrict__ A, int lda, float* __restrict__ out,
@@ -303,6 +355,10 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
   if (a.lda % 8 != 0 || a.ldw % 8 != 0 || a.lda < a.K || a.ldw < a.K || a.ldo < a.N)
     return SVIT_ERR_ALIGN;
   if (((uintptr_t)a.A | (uintptr_t)a.W) & 15) return SVIT_ERR_ALIGN;
+  if (a.ldo % 4 != 0 || ((uintptr_t)a.out & 15)) return SVIT_ERR_ALIGN;
+  if (a.bias && ((uintptr_t)a.bias & 15)) return SVIT_ERR_ALIGN;
+  if (a.aux && (a.ldaux % 4 != 0 || ((uintptr_t)a.aux & 15))) return SVIT_ERR_ALIGN;
+  if (a.out2 && (a.ldo2 % 4 != 0 || ((uintptr_t)a.out2 & 15))) return SVIT_ERR_ALIGN;
   if (a.epilogue == SVIT_EPI_GELU && !a.out2) return SVIT_ERR_ARG;
   if ((a.epilogue == SVIT_EPI_RESID || a.epilogue == SVIT_EPI_DGELU) && !a.aux) return SVIT_ERR_ARG;
   if (a.epilogue == SVIT_EPI_RESID && a.row_scale && a.rows_per_sample <= 0) return SVIT_ERR_ARG;
@@ -314,7 +370,7 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
 }
 
 extern "C" int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, float* dW, int lddw,
-                            int M, int N, int K, int splits, void* stream) {
+                            int M, int N, int K, int splits, float* dbias, void* stream) {
   if (!A || !B || !dW) return SVIT_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0) return SVIT_ERR_SHAPE;
   if (lda % 8 != 0 || ldb % 8 != 0 || lda < N || ldb < K || lddw < K) return SVIT_ERR_ALIGN;
@@ -328,7 +384,7 @@ extern "C" int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, floa
   splits = (M + rows_per_split - 1) / rows_per_split;
   dim3 grid((N + TN_TN - 1) / TN_TN, (K + TN_TK - 1) / TN_TK, splits);
   hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)A,
-                     lda, (const bf16_t*)B, ldb, dW, lddw, M, N, K, rows_per_split);
+                     lda, (const bf16_t*)B, ldb, dW, lddw, M, N, K, rows_per_split, dbias);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }

@@ -261,11 +261,27 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(svit_pool_ln_bwd_args 
       }
     }
   }
+  // reduce the 16 tokens of each wave with shuffles (lanes l, l+4, ... share a channel group),
+  // then the 4 waves through LDS
+  __shared__ float wred[4][2][HD];
 #pragma unroll
   for (int i = 0; i < 24; ++i) {
-    atomicAdd(&red[0][c0 + i], dg[i]);
-    atomicAdd(&red[1][c0 + i], db[i]);
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) {
+      dg[i] += __shfl_xor(dg[i], o, 64);
+      db[i] += __shfl_xor(db[i], o, 64);
+    }
   }
+  if ((threadIdx.x & 63) < 4) {
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+      wred[threadIdx.x >> 6][0][c0 + i] = dg[i];
+      wred[threadIdx.x >> 6][1][c0 + i] = db[i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * HD; c += blockDim.x)
+    (&red[0][0])[c] = (&wred[0][0][0])[c] + (&wred[1][0][0])[c] + (&wred[2][0][0])[c] + (&wred[3][0][0])[c];
   __syncthreads();
   float* prow = a.workspace + (size_t)blockIdx.x * 2 * HD;
   for (int c = threadIdx.x; c < 2 * HD; c += blockDim.x) prow[c] = (&red[0][0])[c];

@@ -284,16 +284,15 @@ class Engine:
         dtok = torch.empty((B * L, C), device=self.dev, dtype=BF16)
         for b in range(B):
             ops.scale_cast(dx[b, 1:1 + L], dst=dtok[b * L:(b + 1) * L])
-        ops.gemm_tn(dtok, st["cols"], f.g("patch_embed.proj.weight").view(C, 441))
-        ops.colsum(dtok, f.g("patch_embed.proj.bias"))
+        ops.gemm_tn(dtok, st["cols"], f.g("patch_embed.proj.weight").view(C, 441),
+                    dbias=f.g("patch_embed.proj.bias"))
         if on_ready is not None:
             on_ready(depth + 1)
 
     def _linear_bwd(self, dy16, x16, wname, bname, need_dx, out=None, accumulate=False,
                     epilogue=hip.EPI_F32, aux=None):
         f = self.flat
-        ops.gemm_tn(dy16, x16, f.g(wname))
-        ops.colsum(dy16, f.g(bname))
+        ops.gemm_tn(dy16, x16, f.g(wname), dbias=f.g(bname))
         if not need_dx:
             return None
         return ops.gemm_nt(dy16, f.wt(wname), None, epilogue, out=out, aux=aux, accumulate=accumulate)

@@ -68,7 +68,7 @@ def gemm_nt(a, w, bias=None, epilogue=hip.EPI_BF16, out=None, out2=None, aux=Non
     return (out, out2) if epilogue == hip.EPI_GELU else out
 
 
-def gemm_tn(a, b, dw, splits=0):
+def gemm_tn(a, b, dw, splits=0, dbias=None):
     """dw[N,K] (f32) += a[M,N]^T @ b[M,K].  a / b may be column slices (row-strided views)."""
     _chk_rows(a, b)
     _chk_dev(dw)
@@ -76,7 +76,7 @@ def gemm_tn(a, b, dw, splits=0):
     K = dw.shape[-1]  # may be smaller than b's padded width (patch-embed wgrad)
     assert b.shape[0] == M and b.shape[1] >= K and dw.shape[-2] == N and dw.dtype == F32
     hip.call("svit_gemm_tn", ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(dw), dw.stride(-2),
-             M, N, K, splits, meta=("mnk", M, N, K))
+             M, N, K, splits, ptr(dbias), meta=("mnk", M, N, K))
     return dw
 
 

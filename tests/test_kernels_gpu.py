@@ -91,9 +91,11 @@ def test_gemm_tn(ops, M, N, K, splits):
     a = rnd("ta%d" % M, (M, N), 1.0, BF16)
     b = rnd("tb%d" % M, (M, K), 1.0, BF16)
     dw = torch.ones((N, K), device=DEV)
-    ops.gemm_tn(a, b, dw, splits)
+    db = torch.ones(N, device=DEV)
+    ops.gemm_tn(a, b, dw, splits, dbias=db)
     ref = a.float().t() @ b.float() + 1.0
     assert rel_err(dw, ref) < 2e-4
+    assert rel_err(db, a.float().sum(0) + 1.0) < 2e-4
 
 
 def test_colsum_cast_scale(ops):
