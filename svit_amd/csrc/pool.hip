@@ -349,72 +349,89 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(svit_pool_dgrad_args a)
 }
 
 // ---------------------------------------------------------------------------------------
-// wgrad: one thread per (tap, 4-channel group): block = 24 x 27 threads, 4 register
-// accumulators each, tokens streamed 4 at a time (8 independent 8-byte loads in flight per
-// lane); every block stores its [c][tap] partial row, summed by the reduce launch.
-__global__ __launch_bounds__(648) void pool_wgrad_kernel(svit_pool_wgrad_args a, int toks_per_block) {
+// wgrad: one lane per channel walks an output row (b, head, t, yo) along x with a sliding
+// 9-row x 3-column register window of the input, so each input element is fetched ~9/s times
+// instead of 27 (2-byte coalesced 192-byte row loads); 27 register accumulators per lane.
+// Block = 2 row streams x 96 channels; every block stores one [c][tap] partial row.
+template <int S>
+__global__ __launch_bounds__(192) void pool_wgrad_kernel(svit_pool_wgrad_args a, int n_streams) {
+  __shared__ float comb[27 * HD];
   const int s = a.stride_hw;
   const int Ho = pooled(a.H, s), Wo = pooled(a.W, s);
   const int L = a.T * a.H * a.W, Lo = a.T * Ho * Wo;
   const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
-  const int c0 = threadIdx.x * 4, tap = threadIdx.y;
-  const int kt = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+  const int c = threadIdx.x % HD, slot = threadIdx.x / HD;
   const size_t tok_stride = (size_t)3 * a.heads * HD;
-  float nt[3], nh[3], ipt, iph;
-  obj_counts(1, nt, &ipt);
-  obj_counts(s, nh, &iph);
-  const float obj_coef = nt[kt] * nh[ky] * nh[kx] * ipt * iph * iph;
-  const bf16_t* qkv = (const bf16_t*)a.qkv + (size_t)a.which * a.heads * HD + c0;
-  const bf16_t* dpre = (const bf16_t*)a.dpre + c0;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-  const int64_t total = (int64_t)a.B * a.heads * Nout;
-  const int64_t r_begin = (int64_t)blockIdx.x * toks_per_block;
-  const int64_t r_end = min(total, r_begin + toks_per_block);
-  for (int64_t r0 = r_begin; r0 < r_end; r0 += 4) {
-    uint2 dv[4], xv[4];
-    float coef[4];
+  const bf16_t* qkv = (const bf16_t*)a.qkv + (size_t)a.which * a.heads * HD + c;
+  const bf16_t* dpre = (const bf16_t*)a.dpre + c;
+  float acc[27];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t row = r0 + u;
-      coef[u] = 0.f;
-      dv[u] = make_uint2(0, 0);
-      xv[u] = make_uint2(0, 0);
-      if (row >= r_end) continue;
-      const int tok = (int)(row % Nout);
-      if (tok == 0) continue;
-      const int bh = (int)(row / Nout), b = bh / a.heads, head = bh % a.heads;
-      const bf16_t* base = qkv + (size_t)b * N * tok_stride + (size_t)head * HD;
-      int src = -1;
-      if (tok > Lo) {
-        src = 1 + L + (tok - 1 - Lo);
-        coef[u] = obj_coef;
-      } else {
-        const int p = tok - 1, px = p % Wo, py = (p / Wo) % Ho, pt = p / (Wo * Ho);
-        const int t = pt - 1 + kt, y = py * s - 1 + ky, x = px * s - 1 + kx;
-        if (t >= 0 && t < a.T && y >= 0 && y < a.H && x >= 0 && x < a.W) {
-          src = 1 + (t * a.H + y) * a.W + x;
-          coef[u] = 1.f;
-        }
-      }
-      if (src >= 0) {
-        dv[u] = *(const uint2*)(dpre + row * HD);
-        xv[u] = *(const uint2*)(base + (size_t)src * tok_stride);
-      }
+  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+  for (int stream = blockIdx.x * 2 + slot; stream < n_streams; stream += gridDim.x * 2) {
+    const int yo = stream % Ho, t = (stream / Ho) % a.T, bh = stream / (Ho * a.T);
+    const int b = bh / a.heads, head = bh % a.heads;
+    const bf16_t* xin = qkv + (size_t)b * N * tok_stride + (size_t)head * HD;
+    const bf16_t* dyr = dpre + ((size_t)bh * Nout + 1 + (size_t)(t * Ho + yo) * Wo) * HD;
+    const bf16_t* rows[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const int tt = t - 1 + r / 3, yy = yo * s - 1 + r % 3;
+      rows[r] = (tt >= 0 && tt < a.T && yy >= 0 && yy < a.H)
+                    ? xin + (size_t)(1 + (tt * a.H + yy) * a.W) * tok_stride : nullptr;
     }
+    float win[9][3];
+    for (int xo = 0; xo < Wo; ++xo) {
+      constexpr int KEEP = (S >= 3) ? 0 : 3 - S;   // columns shared with the previous window
+      const int first_new = (xo == 0) ? 0 : KEEP;
+      if (xo > 0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc0 += coef[u] * lo_bf16(dv[u].x) * lo_bf16(xv[u].x);
-      acc1 += coef[u] * hi_bf16(dv[u].x) * hi_bf16(xv[u].x);
-      acc2 += coef[u] * lo_bf16(dv[u].y) * lo_bf16(xv[u].y);
-      acc3 += coef[u] * hi_bf16(dv[u].y) * hi_bf16(xv[u].y);
+        for (int r = 0; r < 9; ++r)
+#pragma unroll
+          for (int kx = 0; kx < KEEP; ++kx) win[r][kx] = win[r][kx + S];
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        if (kx < first_new) continue;
+        const int xx = xo * s - 1 + kx;
+        const bool okx = xx >= 0 && xx < a.W;
+#pragma unroll
+        for (int r = 0; r < 9; ++r)
+          win[r][kx] = (okx && rows[r]) ? bf16_to_f32(rows[r][(size_t)xx * tok_stride]) : 0.f;
+      }
+      const float d = bf16_to_f32(dyr[(size_t)xo * HD]);
+#pragma unroll
+      for (int r = 0; r < 9; ++r)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc[r * 3 + kx] += d * win[r][kx];
     }
   }
-  // partial row in the dw layout [c][tap]
-  float* prow = a.workspace + (size_t)blockIdx.x * 27 * HD;
-  prow[(c0 + 0) * 27 + tap] = acc0;
-  prow[(c0 + 1) * 27 + tap] = acc1;
-  prow[(c0 + 2) * 27 + tap] = acc2;
-  prow[(c0 + 3) * 27 + tap] = acc3;
+  // object tokens: dw[c][tap] += ncoef[tap] * sum_obj dy*x  (closed form of the cube branch)
+  if (a.n_obj > 0) {
+    float g = 0.f;
+    const int n_obj_rows = a.B * a.heads * a.n_obj;
+    for (int i = blockIdx.x * 2 + slot; i < n_obj_rows; i += gridDim.x * 2) {
+      const int o = i % a.n_obj, bh = i / a.n_obj, b = bh / a.heads, head = bh % a.heads;
+      const float d = bf16_to_f32(dpre[((size_t)bh * Nout + 1 + Lo + o) * HD]);
+      const float x = bf16_to_f32(qkv[((size_t)b * N + 1 + L + o) * tok_stride + (size_t)head * HD]);
+      g += d * x;
+    }
+    float nt[3], nh[3], ipt, iph;
+    obj_counts(1, nt, &ipt);
+    obj_counts(s, nh, &iph);
+    g *= ipt * iph * iph;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] += g * nt[k / 9] * nh[(k / 3) % 3] * nh[k % 3];
+  }
+  if (slot == 1) {
+#pragma unroll
+    for (int k = 0; k < 27; ++k) comb[k * HD + c] = acc[k];
+  }
+  __syncthreads();
+  if (slot == 0) {
+    float* prow = a.workspace + (size_t)blockIdx.x * 27 * HD + c * 27;   // [c][tap]
+#pragma unroll
+    for (int k = 0; k < 27; ++k) prow[k] = acc[k] + comb[k * HD + c];
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -590,15 +607,18 @@ extern "C" int svit_pool_conv_wgrad(const svit_pool_wgrad_args* a, void* stream)
   const int Ho = (a->H - 1) / a->stride_hw + 1, Wo = (a->W - 1) / a->stride_hw + 1;
   const int64_t total = (int64_t)a->B * a->heads * (1 + a->T * Ho * Wo + a->n_obj);
   if (!a->workspace) return SVIT_ERR_ARG;
-  int64_t blocks = (total + 63) / 64;          // >= 64 tokens per block
-  if (blocks > 2048) blocks = 2048;
+  (void)total;
+  const int n_streams = a->B * a->heads * a->T * Ho;
+  int64_t blocks = (n_streams + 1) / 2;
+  if (blocks > 1024) blocks = 1024;
   if (blocks > a->workspace_floats / (27 * HD)) blocks = a->workspace_floats / (27 * HD);
   if (blocks < 1) return SVIT_ERR_ARG;
-  int toks_per_block = (int)((total + blocks - 1) / blocks);
-  toks_per_block = (toks_per_block + 3) / 4 * 4;
-  blocks = (total + toks_per_block - 1) / toks_per_block;
-  hipLaunchKernelGGL(pool_wgrad_kernel, dim3((unsigned)blocks), dim3(24, 27), 0, (hipStream_t)stream,
-                     *a, toks_per_block);
+  if (a->stride_hw == 1)
+    hipLaunchKernelGGL(pool_wgrad_kernel<1>, dim3((unsigned)blocks), dim3(192), 0, (hipStream_t)stream, *a, n_streams);
+  else if (a->stride_hw == 2)
+    hipLaunchKernelGGL(pool_wgrad_kernel<2>, dim3((unsigned)blocks), dim3(192), 0, (hipStream_t)stream, *a, n_streams);
+  else
+    hipLaunchKernelGGL(pool_wgrad_kernel<3>, dim3((unsigned)blocks), dim3(192), 0, (hipStream_t)stream, *a, n_streams);
   SVIT_LAUNCH_CHECK();
   SvitReduceDst dst = {{a->dw, a->dw, a->dw}, {27 * HD, 27 * HD, 27 * HD}};
   svit_launch_reduce(a->workspace, (int)blocks, 27 * HD, dst, (hipStream_t)stream);

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Per-shape micro-benchmarks of the hot kernels at the BASELINE C2 shapes (B=8, 16x224^2).
+Usage (GPU box): python tools/bench_kernels.py [gemm|tn|attn|pool|all]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from svit_amd import hip, ops
+
+DEV = "cuda"
+BF16 = torch.bfloat16
+B = 8
+# (blk, N_in, Nq, Nk, C_in, C_out, heads, DA)
+BLOCKS = [(0, 25153, 25153, 457, 96, 96, 1, 128), (1, 25153, 6337, 1633, 96, 192, 2, 160),
+          (2, 6337, 6337, 457, 192, 192, 2, 128), (3, 6337, 1633, 1633, 192, 384, 4, 160),
+          (4, 1633, 1633, 457, 384, 384, 4, 128), (14, 1633, 457, 1633, 384, 768, 8, 160),
+          (15, 457, 457, 457, 768, 768, 8, 128)]
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def rnd(*shape, dtype=BF16):
+    return (torch.randn(*shape, device=DEV) * 0.5).to(dtype)
+
+
+def bench_gemm():
+    print("== gemm_nt (M, N, K, epilogue) ==")
+    seen = set()
+    for blk, Nin, Nq, Nk, Ci, Co, h, DA in BLOCKS:
+        for (M, N, K, epi, tag) in [(B * Nin, 3 * Co, Ci, hip.EPI_BF16, "qkv"),
+                                    (B * Nq, Co, Co, hip.EPI_RESID, "proj"),
+                                    (B * Nq, 4 * Co, Co, hip.EPI_GELU, "fc1"),
+                                    (B * Nq, Co, 4 * Co, hip.EPI_RESID, "fc2"),
+                                    (B * Nq, 4 * Co, Co, hip.EPI_DGELU, "fc2-dgrad"),
+                                    (B * Nq, Co, 4 * Co, hip.EPI_F32, "fc1-dgrad"),
+                                    (B * Nin, Ci, 3 * Co, hip.EPI_F32, "qkv-dgrad")]:
+            if (M, N, K, epi) in seen:
+                continue
+            seen.add((M, N, K, epi))
+            a, w = rnd(M, K), rnd(N, K)
+            bias = torch.zeros(N, device=DEV)
+            aux = None
+            if epi == hip.EPI_RESID:
+                aux = torch.zeros(M, N, device=DEV)
+            if epi == hip.EPI_DGELU:
+                aux = rnd(M, N)
+            out = torch.empty(M, N, device=DEV, dtype=torch.float32 if epi in (hip.EPI_RESID, hip.EPI_F32) else BF16)
+            out2 = torch.empty(M, N, device=DEV, dtype=BF16) if epi == hip.EPI_GELU else None
+            us = timeit(lambda: ops.gemm_nt(a, w, bias, epi, out=out, out2=out2, aux=aux))
+            flop = 2.0 * M * N * K
+            osz = out.element_size() * M * N * (2 if epi == hip.EPI_GELU else 1)
+            byts = 2 * M * K + 2 * N * K + osz + (aux.element_size() * M * N if aux is not None else 0)
+            print("blk%-2d %-10s M=%6d N=%4d K=%4d  %8.1f us  %7.1f TFLOP/s  %6.2f TB/s" %
+                  (blk, tag, M, N, K, us, flop / us / 1e6, byts / us / 1e6))
+
+
+def bench_tn():
+    print("== gemm_tn (M, N, K) ==")
+    seen = set()
+    for blk, Nin, Nq, Nk, Ci, Co, h, DA in BLOCKS:
+        for (M, N, K, tag) in [(B * Nin, 3 * Co, Ci, "qkv-w"), (B * Nq, Co, Co, "proj-w"),
+                               (B * Nq, 4 * Co, Co, "fc1-w"), (B * Nq, Co, 4 * Co, "fc2-w")]:
+            if (M, N, K) in seen:
+                continue
+            seen.add((M, N, K))
+            a, b = rnd(M, N), rnd(M, K)
+            dw = torch.zeros(N, K, device=DEV)
+            db = torch.zeros(N, device=DEV)
+            us = timeit(lambda: ops.gemm_tn(a, b, dw, dbias=db))
+            flop = 2.0 * M * N * K
+            byts = 2 * M * (N + K)
+            print("blk%-2d %-8s M=%6d N=%4d K=%4d  %8.1f us  %7.1f TFLOP/s  %6.2f TB/s" %
+                  (blk, tag, M, N, K, us, flop / us / 1e6, byts / us / 1e6))
+
+
+def bench_attn():
+    print("== attention (fwd / bwd) ==")
+    for blk, Nin, Nq, Nk, Ci, Co, h, DA in BLOCKS:
+        qa, ka, v = rnd(B, h, Nq, DA), rnd(B, h, Nk, DA), rnd(B, h, Nk, 96)
+        scale = 96 ** -0.5
+        us = timeit(lambda: ops.attn_fwd(qa, ka, v, scale))
+        alg = 2.0 * B * h * Nq * Nk * 192
+        ctx, lse2 = ops.attn_fwd(qa, ka, v, scale)
+        dctx = rnd(B, Nq, h * 96)
+        usb = timeit(lambda: ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, scale), iters=10)
+        print("blk%-2d h=%d Nq=%6d Nk=%5d DA=%d  fwd %8.1f us %7.1f TF | bwd %8.1f us %7.1f TF" %
+              (blk, h, Nq, Nk, DA, us, alg / us / 1e6, usb, 2 * alg / usb / 1e6))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    hip.load()
+    print(torch.cuda.get_device_name(0))
+    if what in ("gemm", "all"):
+        bench_gemm()
+    if what in ("tn", "all"):
+        bench_tn()
+    if what in ("attn", "all"):
+        bench_attn()
