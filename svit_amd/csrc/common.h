@@ -70,12 +70,29 @@ __device__ __forceinline__ bf16x8_t make_bf16x8(s16x4_t lo, s16x4_t hi) {
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// exact-erf GELU (nn.GELU() default, attention.py:481 / common.py:13) with erf evaluated by the
+// Abramowitz-Stegun 7.1.26 rational (|abs err| <= 1.5e-7, far below bf16 resolution): one exp
+// and one reciprocal instead of libm's branchy erff -- the fc1 / fc2-dgrad epilogues evaluate
+// it 77M times per call in block 0.  exp(-x^2/2) is shared between the cdf and the pdf.
+__device__ __forceinline__ void gelu_parts(float x, float* cdf, float* pdf_scaled) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float e = __expf(-ax * ax);                       // exp(-x^2/2)
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f +
+                     t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * e;                  // erf(|x|/sqrt2)
+  const float erfv = x < 0.f ? -erf_abs : erf_abs;
+  *cdf = 0.5f * (1.0f + erfv);
+  *pdf_scaled = 0.39894228040143268f * e;                 // standard normal pdf(x)
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+  float cdf, pdf;
+  gelu_parts(x, &cdf, &pdf);
+  return x * cdf;
 }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  float cdf, pdf;
+  gelu_parts(x, &cdf, &pdf);
   return cdf + x * pdf;
 }
 

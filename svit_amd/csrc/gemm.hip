@@ -12,16 +12,17 @@
 namespace {
 
 template <int BK> struct LdsRow { static constexpr int kBytes = BK * 2 + 16; };
-constexpr int EP_LD = 100;   // fp32 row stride of the per-wave epilogue staging block (32 x 96)
 
 // ---------------------------------------------------------------------------------------
 // NT kernel.  Block = WAVES_M x WAVES_N waves; wave tile = (32*RB) x 96.
 // ---------------------------------------------------------------------------------------
-template <int RB, int WAVES_M, int WAVES_N, int BK, int EPI>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(svit_gemm_args p) {
+template <int RB, int NB, int WAVES_M, int WAVES_N, int BK, int EPI>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_nt_kernel(svit_gemm_args p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = 32 * RB * WAVES_M;
-  constexpr int BN = 96 * WAVES_N;
+  constexpr int WN = 32 * NB;               // columns per wave
+  constexpr int BN = WN * WAVES_N;
+  constexpr int EP_LD = WN + 4;             // fp32 row stride of the epilogue staging block
   constexpr int ROWB = LdsRow<BK>::kBytes;
   constexpr int CH = BK / 8;                 // 16-byte chunks per tile row
   constexpr int A_CHUNKS = BM * CH, W_CHUNKS = BN * CH;
@@ -31,8 +32,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(svit_gem
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  // grid: x = N tiles (fast, so neighbouring blocks share the A panel in L2), y = M tiles
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // Tile order: N tiles fastest, so consecutive tiles share the A row panel.  The dispatcher
+  // deals consecutive workgroups round-robin over the 8 XCDs (private L2 each), so remap the
+  // linear id to give every XCD a CONTIGUOUS run of tiles (bijective for any grid size).
+  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+  const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  const int m0 = (wgid / gridDim.x) * BM, n0 = (wgid % gridDim.x) * BN;
   const bf16_t* A = (const bf16_t*)p.A;
   const bf16_t* W = (const bf16_t*)p.W;
 
@@ -71,11 +77,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(svit_gem
     }
   };
 
-  f32x16_t acc[RB][3];
+  f32x16_t acc[RB][NB];
 #pragma unroll
   for (int i = 0; i < RB; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -88,41 +94,44 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(svit_gem
     const int cur = kt & 1;
     if (kt + 1 < nk) load_tiles((kt + 1) * BK);
     const unsigned char* la = smem + cur * STAGE + (wm * 32 * RB) * ROWB + frag_off;
-    const unsigned char* lw = smem + cur * STAGE + BM * ROWB + (wn * 96) * ROWB + frag_off;
+    const unsigned char* lw = smem + cur * STAGE + BM * ROWB + (wn * WN) * ROWB + frag_off;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8_t af[RB], wf[3];
+      bf16x8_t af[RB], wf[NB];
 #pragma unroll
       for (int i = 0; i < RB; ++i) af[i] = *(const bf16x8_t*)(la + i * 32 * ROWB + ks * 32);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) wf[j] = *(const bf16x8_t*)(lw + j * 32 * ROWB + ks * 32);
+      for (int j = 0; j < NB; ++j) wf[j] = *(const bf16x8_t*)(lw + j * 32 * ROWB + ks * 32);
 #pragma unroll
       for (int i = 0; i < RB; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = mfma32(af[i], wf[j], acc[i][j]);
+        for (int j = 0; j < NB; ++j) acc[i][j] = mfma32(af[i], wf[j], acc[i][j]);
     }
     if (kt + 1 < nk) store_tiles(cur ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue: each wave transposes its 32x96 accumulator blocks through a private LDS
-  // region so that global traffic is row-contiguous and vectorised (16 B fp32 / 8 B bf16 per
-  // lane, 24 lanes per 96-column row) instead of 2-byte column-strided accesses ----------------
-  float* stg = (float*)smem + wave * (32 * EP_LD);
+  // ---- epilogue: each wave transposes its accumulators, 16 rows x 96 columns at a time,
+  // through a private LDS region so that global traffic is row-contiguous and vectorised
+  // (16 B fp32 / 8 B bf16 per lane, 24 lanes per 96-column row) instead of 2-byte
+  // column-strided accesses ------------------------------------------------------------------
+  float* stg = (float*)smem + wave * (16 * EP_LD);
 #pragma unroll
-  for (int i = 0; i < RB; ++i) {
+  for (int ih = 0; ih < 2 * RB; ++ih) {
+    const int i = ih >> 1, half = ih & 1;
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        stg[acc_row(r, lane) * EP_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+      for (int rr = 0; rr < 8; ++rr)
+        stg[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] =
+            acc[i][j][half * 8 + rr];
     __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 12; ++it) {
+#pragma unroll 1
+    for (int it = 0; it < 2 * NB; ++it) {
       const int idx = lane + 64 * it;
-      const int rl = idx / 24, c4 = idx % 24;
-      const int row = m0 + wm * 32 * RB + i * 32 + rl;
-      const int col = n0 + wn * 96 + c4 * 4;
+      const int rl = idx / (8 * NB), c4 = idx % (8 * NB);
+      const int row = m0 + wm * 32 * RB + i * 32 + half * 16 + rl;
+      const int col = n0 + wn * WN + c4 * 4;
       if (row >= p.M || col >= p.N) continue;
       float4 v = *(const float4*)(stg + rl * EP_LD + c4 * 4);
       if (p.bias) {
@@ -164,21 +173,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_kernel(svit_gem
         *(uint2*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = o;
       }
     }
-    if (i + 1 < RB) __syncthreads();
+    if (ih + 1 < 2 * RB) __syncthreads();
   }
 }
 
-template <int RB, int WAVES_M, int WAVES_N, int BK>
+template <int RB, int NB, int WAVES_M, int WAVES_N, int BK>
 int launch_nt(const svit_gemm_args& a, hipStream_t st) {
-  constexpr int BM = 32 * RB * WAVES_M, BN = 96 * WAVES_N;
+  constexpr int BM = 32 * RB * WAVES_M, BN = 32 * NB * WAVES_N;
   constexpr int NT = WAVES_M * WAVES_N * 64;
   size_t lds = 2 * (size_t)(BM + BN) * LdsRow<BK>::kBytes;
-  const size_t lds_epi = (size_t)WAVES_M * WAVES_N * 32 * EP_LD * sizeof(float);
+  const size_t lds_epi = (size_t)WAVES_M * WAVES_N * 16 * (32 * NB + 4) * sizeof(float);
   if (lds < lds_epi) lds = lds_epi;
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM);
 #define SVIT_NT_CASE(E)                                                                  \
   case E:                                                                                \
-    hipLaunchKernelGGL((gemm_nt_kernel<RB, WAVES_M, WAVES_N, BK, E>), grid, dim3(NT), lds, st, a); \
+    hipLaunchKernelGGL((gemm_nt_kernel<RB, NB, WAVES_M, WAVES_N, BK, E>), grid, dim3(NT), lds, st, a); \
     break;
   switch (a.epilogue) {
     SVIT_NT_CASE(SVIT_EPI_BF16)
@@ -363,10 +372,25 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
   if ((a.epilogue == SVIT_EPI_RESID || a.epilogue == SVIT_EPI_DGELU) && !a.aux) return SVIT_ERR_ARG;
   if (a.epilogue == SVIT_EPI_RESID && a.row_scale && a.rows_per_sample <= 0) return SVIT_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  // wide-N problems: 128x192 block tiles (64x96 per wave); N == 96 (mod 192): 256x96 / 128x96
-  if (a.N % 192 == 0) return launch_nt<2, 2, 2, 32>(a, st);
-  if (a.M >= 8192) return launch_nt<2, 4, 1, 32>(a, st);
-  return launch_nt<1, 4, 1, 32>(a, st);
+  // Tile choice: arithmetic intensity (FLOP per L2 byte) grows with the tile, so take the
+  // 256x192 tile (4 waves x (64 x 192)) whenever it still yields >= ~1.5 tiles per CU;
+  // otherwise 128x192.  N == 96 (mod 192): 256x96 for tall problems, 128x96 for the rest.
+  static bool configured = false;
+  if (!configured) {   // the 256x192 pipeline needs > 64 KB of dynamic LDS
+#define SVIT_SET_LDS(E) hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 6, 4, 1, 32, E>, \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)
+    SVIT_SET_LDS(SVIT_EPI_BF16); SVIT_SET_LDS(SVIT_EPI_GELU); SVIT_SET_LDS(SVIT_EPI_RESID);
+    SVIT_SET_LDS(SVIT_EPI_F32); SVIT_SET_LDS(SVIT_EPI_DGELU);
+#undef SVIT_SET_LDS
+    configured = true;
+  }
+  if (a.N % 192 == 0) {
+    const long tiles_big = (long)((a.M + 255) / 256) * (a.N / 192);
+    if (tiles_big >= 384) return launch_nt<2, 6, 4, 1, 32>(a, st);
+    return launch_nt<2, 3, 2, 2, 32>(a, st);
+  }
+  if (a.M >= 8192) return launch_nt<2, 3, 4, 1, 32>(a, st);
+  return launch_nt<1, 3, 4, 1, 32>(a, st);
 }
 
 extern "C" int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, float* dW, int lddw,
@@ -376,8 +400,13 @@ extern "C" int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, floa
   if (lda % 8 != 0 || ldb % 8 != 0 || lda < N || ldb < K || lddw < K) return SVIT_ERR_ALIGN;
   if (((uintptr_t)A | (uintptr_t)B) & 15) return SVIT_ERR_ALIGN;
   const int tiles = ((N + TN_TN - 1) / TN_TN) * ((K + TN_TK - 1) / TN_TK);
-  if (splits <= 0) {  // aim at ~4 blocks per CU
-    splits = (1024 + tiles - 1) / tiles;
+  if (splits <= 0) {
+    // every split adds the whole [N,K] tile set with fp32 atomics (~1.3 TB/s chip-wide): take
+    // just enough splits to fill the chip (~2 blocks per CU), at least 4 reduction steps each
+    splits = (512 + tiles - 1) / tiles;
+    const int max_by_rows = (M + 4 * TN_BM - 1) / (4 * TN_BM);
+    if (splits > max_by_rows) splits = max_by_rows;
+    if (splits < 1) splits = 1;
   }
   int rows_per_split = (M + splits - 1) / splits;
   rows_per_split = ((rows_per_split + TN_BM - 1) / TN_BM) * TN_BM;
