@@ -1,0 +1,163 @@
+// NT GEMM, multi-stage direct-to-LDS pipeline (gfx950).
+//
+// Same math and epilogues as gemm.hip's register-staged kernel, different main loop: A/W tiles
+// go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write), STAGES tiles of
+// BK=32 are kept in flight behind a COUNTED s_waitcnt vmcnt(N) and ONE raw s_barrier per
+// K-step, so the prefetch distance (STAGES-1 tiles) covers L2/HBM latency instead of the single
+// tile a register-staged double buffer can hide (cdna guide: "Pipelining across barriers").
+//
+// LDS image of a stage: rows of 64 B (32 bf16), lane-linear as global_load_lds requires
+// (wave-uniform base + lane*16); the four 16-B chunks of a row are XOR-swizzled with
+// ((row>>2)&3) on the per-lane SOURCE address, and the same XOR is applied on the fragment
+// reads -> ds_read_b128 of 16 consecutive rows hits 16 distinct slots of the 256-B bank row.
+#include "gemm_epilogue.h"
+
+namespace {
+
+constexpr int BK2 = 32;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int RB, int NB, int WAVES_M, int WAVES_N, int STAGES, int EPI>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_nt_v2_kernel(svit_gemm_args p) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int BM = 32 * RB * WAVES_M, WN = 32 * NB, BN = WN * WAVES_N;
+  // rows per stage, padded so that every wave issues the same number of loads per stage (the
+  // counted vmcnt must be the same immediate for all waves); pad rows re-read a valid W row
+  constexpr int ROWS = (BM + BN + NT / 4 - 1) / (NT / 4) * (NT / 4);
+  constexpr int STAGE_BYTES = ROWS * 64;
+  constexpr int PER = ROWS * 4 / NT;         // global_load_lds per thread per stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+  const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  const int m0 = (wgid / gridDim.x) * BM, n0 = (wgid % gridDim.x) * BN;
+
+  // per-lane source pointers of this thread's PER chunks (k offset added per tile)
+  const bf16_t* src[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int q = tid + i * NT;              // LDS position q*16 bytes within a stage
+    const int row = q >> 2, slot = q & 3;
+    const int ch = slot ^ ((row >> 2) & 3);
+    if (row < BM) {
+      const int gr = min(m0 + row, p.M - 1);
+      src[i] = (const bf16_t*)p.A + (size_t)gr * p.lda + ch * 8;
+    } else {
+      const int gr = min(n0 + row - BM, p.N - 1);
+      src[i] = (const bf16_t*)p.W + (size_t)gr * p.ldw + ch * 8;
+    }
+  }
+  auto issue = [&](int kt, int stage) {
+    unsigned char* base = smem + stage * STAGE_BYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src[i] + kt * BK2),
+          (__attribute__((address_space(3))) void*)(base + i * (NT * 16)), 16, 0, 0);
+  };
+
+  f32x16_t acc[RB][NB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK2;
+  // prologue: STAGES-1 tiles in flight
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue(s, s);
+
+  const int a_row = wm * 32 * RB + (lane & 31);
+  const int w_row = BM + wn * WN + (lane & 31);
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed once at most the (STAGES-2) younger tiles' loads are outstanding
+    if (kt + STAGES - 2 < nk) wait_vmcnt<(STAGES - 2) * PER>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // (a) everyone's part of tile kt is in LDS
+                                    // (b) everyone finished reading tile kt-1's buffer
+    if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+    const unsigned char* st = smem + (kt % STAGES) * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK2 / 16; ++ks) {
+      const int ch = 2 * ks + (lane >> 5);
+      bf16x8_t af[RB], wf[NB];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int r = a_row + i * 32;
+        af[i] = *(const bf16x8_t*)(st + r * 64 + 16 * (ch ^ ((r >> 2) & 3)));
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int r = w_row + j * 32;
+        wf[j] = *(const bf16x8_t*)(st + r * 64 + 16 * (ch ^ ((r >> 2) & 3)));
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = mfma32(af[i], wf[j], acc[i][j]);
+    }
+  }
+  __syncthreads();   // all LDS reads of the last tiles done before the epilogue reuses LDS
+  nt_epilogue<RB, NB, EPI>(p, acc, smem, m0, n0, wm, wn, lane, wave);
+}
+
+template <int RB, int NB, int WAVES_M, int WAVES_N, int STAGES>
+int launch_v2(const svit_gemm_args& a, hipStream_t st) {
+  constexpr int BM = 32 * RB * WAVES_M, BN = 32 * NB * WAVES_N;
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  size_t lds = (size_t)STAGES * ((BM + BN + NT / 4 - 1) / (NT / 4) * (NT / 4)) * 64;
+  const size_t lds_epi = (size_t)WAVES_M * WAVES_N * 16 * (32 * NB + 4) * sizeof(float);
+  if (lds < lds_epi) lds = lds_epi;
+  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM);
+  static bool configured = false;
+  if (!configured) {
+#define SVIT_V2_ATTR(E)                                                                      \
+  hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<RB, NB, WAVES_M, WAVES_N, STAGES, E>,   \
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+    SVIT_V2_ATTR(SVIT_EPI_BF16); SVIT_V2_ATTR(SVIT_EPI_GELU); SVIT_V2_ATTR(SVIT_EPI_RESID);
+    SVIT_V2_ATTR(SVIT_EPI_F32); SVIT_V2_ATTR(SVIT_EPI_DGELU);
+#undef SVIT_V2_ATTR
+    configured = true;
+  }
+#define SVIT_V2_CASE(E)                                                                       \
+  case E:                                                                                     \
+    hipLaunchKernelGGL((gemm_nt_v2_kernel<RB, NB, WAVES_M, WAVES_N, STAGES, E>), grid, dim3(NT), \
+                       lds, st, a);                                                           \
+    break;
+  switch (a.epilogue) {
+    SVIT_V2_CASE(SVIT_EPI_BF16)
+    SVIT_V2_CASE(SVIT_EPI_GELU)
+    SVIT_V2_CASE(SVIT_EPI_RESID)
+    SVIT_V2_CASE(SVIT_EPI_F32)
+    SVIT_V2_CASE(SVIT_EPI_DGELU)
+    default:
+      return SVIT_ERR_ARG;
+  }
+#undef SVIT_V2_CASE
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+}  // namespace
+
+// config: 0 = 128x192 (2x2 waves of 64x96), 1 = 256x96 (4x1 waves of 64x96),
+//         2 = 128x96 (4x1 waves of 32x96), 3 = 256x192 (4x1 waves of 64x192)
+extern "C" int svit_gemm_nt_v2_launch(const svit_gemm_args* a, int config, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  switch (config) {
+    case 0: return launch_v2<2, 3, 2, 2, 4>(*a, st);
+    case 1: return launch_v2<2, 3, 4, 1, 4>(*a, st);
+    case 2: return launch_v2<1, 3, 4, 1, 4>(*a, st);
+    case 3: return launch_v2<2, 6, 4, 1, 3>(*a, st);
+    default: return SVIT_ERR_ARG;
+  }
+}
