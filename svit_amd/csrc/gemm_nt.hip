@@ -1,10 +1,14 @@
-// NT GEMM, multi-stage direct-to-LDS pipeline (gfx950).
+// bf16 MFMA GEMM for the nn.Linear family, forward and dgrad -- gfx950.
+//   svit_gemm_nt : C[M,N] = A[M,K] * W[N,K]^T with fused epilogues (bias / GELU / residual +
+//                  DropPath / fp32 accumulate + row remap / GELU-backward), gemm_epilogue.h
 //
-// Same math and epilogues as gemm.hip's register-staged kernel, different main loop: A/W tiles
-// go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write), STAGES tiles of
-// BK=32 are kept in flight behind a COUNTED s_waitcnt vmcnt(N) and ONE raw s_barrier per
-// K-step, so the prefetch distance (STAGES-1 tiles) covers L2/HBM latency instead of the single
-// tile a register-staged double buffer can hide (cdna guide: "Pipelining across barriers").
+// Main loop: multi-stage direct-to-LDS pipeline.  A/W tiles go HBM/L2 -> LDS with
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write), STAGES tiles of BK=32 are kept in
+// flight behind a COUNTED s_waitcnt vmcnt(N) and ONE raw s_barrier per K-step, so the prefetch
+// distance (STAGES-1 tiles) covers L2/HBM latency instead of the single tile a register-staged
+// double buffer can hide (cdna guide: "Pipelining across barriers").  Every wave owns a
+// (32*RB) x 96 output tile as 32x32x16 MFMA accumulators; tiles are walked in an XCD-aware
+// order (N tiles of one A row panel stay on one XCD's L2).
 //
 // LDS image of a stage: rows of 64 B (32 bf16), lane-linear as global_load_lds requires
 // (wave-uniform base + lane*16); the four 16-B chunks of a row are XOR-swizzled with
@@ -149,15 +153,25 @@ int launch_v2(const svit_gemm_args& a, hipStream_t st) {
 }
 }  // namespace
 
-// config: 0 = 128x192 (2x2 waves of 64x96), 1 = 256x96 (4x1 waves of 64x96),
-//         2 = 128x96 (4x1 waves of 32x96), 3 = 256x192 (4x1 waves of 64x192)
-extern "C" int svit_gemm_nt_v2_launch(const svit_gemm_args* a, int config, void* stream) {
+extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
+  if (!args || !args->A || !args->W || !args->out) return SVIT_ERR_ARG;
+  const svit_gemm_args& a = *args;
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % 32 != 0 || a.N % 96 != 0) return SVIT_ERR_SHAPE;
+  if (a.lda % 8 != 0 || a.ldw % 8 != 0 || a.lda < a.K || a.ldw < a.K || a.ldo < a.N)
+    return SVIT_ERR_ALIGN;
+  if (((uintptr_t)a.A | (uintptr_t)a.W) & 15) return SVIT_ERR_ALIGN;
+  if (a.ldo % 4 != 0 || ((uintptr_t)a.out & 15)) return SVIT_ERR_ALIGN;
+  if (a.bias && ((uintptr_t)a.bias & 15)) return SVIT_ERR_ALIGN;
+  if (a.aux && (a.ldaux % 4 != 0 || ((uintptr_t)a.aux & 15))) return SVIT_ERR_ALIGN;
+  if (a.out2 && (a.ldo2 % 4 != 0 || ((uintptr_t)a.out2 & 15))) return SVIT_ERR_ALIGN;
+  if (a.epilogue == SVIT_EPI_GELU && !a.out2) return SVIT_ERR_ARG;
+  if ((a.epilogue == SVIT_EPI_RESID || a.epilogue == SVIT_EPI_DGELU) && !a.aux) return SVIT_ERR_ARG;
+  if (a.epilogue == SVIT_EPI_RESID && a.row_scale && a.rows_per_sample <= 0) return SVIT_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  switch (config) {
-    case 0: return launch_v2<2, 3, 2, 2, 4>(*a, st);
-    case 1: return launch_v2<2, 3, 4, 1, 4>(*a, st);
-    case 2: return launch_v2<1, 3, 4, 1, 4>(*a, st);
-    case 3: return launch_v2<2, 6, 4, 1, 3>(*a, st);
-    default: return SVIT_ERR_ARG;
-  }
+  // Tile choice (measured on MI355X, tools/bench_kernels.py gemm2): 128x192 blocks (2x2 waves
+  // of 64x96) win whenever they still give >= 1 tile per CU; otherwise, and for N = 96 (mod
+  // 192), 128x96 blocks (4 waves of 32x96) double the number of workgroups.
+  if (a.N % 192 == 0 && (long)((a.M + 127) / 128) * (a.N / 192) >= 256)
+    return launch_v2<2, 3, 2, 2, 4>(a, st);
+  return launch_v2<1, 3, 4, 1, 4>(a, st);
 }

@@ -1,143 +1,11 @@
-// bf16 MFMA GEMMs for the nn.Linear family -- gfx950 only.
-//   svit_gemm_nt : C[M,N] = A[M,K] * W[N,K]^T, fused epilogues (bias / GELU / residual +
-//                  DropPath / fp32 accumulate / GELU-backward)
-//   svit_gemm_tn : dW[N,K] += A[M,N]^T * B[M,K]  (weight gradients, reduction over rows,
-//                  operands consumed through ds_read_b64_tr_b16 transposed LDS reads)
-// Tiling is wave64-native: every wave owns (WM x 96) of the output as 32x32x16 MFMA
-// accumulators; A/W tiles are register-staged into padded (bank-conflict-free) LDS rows,
-// double-buffered, one barrier per K-step.
-#include "gemm_epilogue.h"
+// bf16 MFMA weight-gradient GEMM for the nn.Linear family -- gfx950 only.
+//   svit_gemm_tn : dW[N,K] += A[M,N]^T * B[M,K]  (reduction over rows, operands consumed
+//                  through ds_read_b64_tr_b16 transposed LDS reads; fused bias gradient)
+// (the forward / dgrad kernel svit_gemm_nt lives in gemm_nt.hip)
+#include "common.h"
+#include "../../include/svit_hip.h"
 
 namespace {
-
-template <int BK> struct LdsRow { static constexpr int kBytes = BK * 2 + 16; };
-
-// ---------------------------------------------------------------------------------------
-// NT kernel.  Block = WAVES_M x WAVES_N waves; wave tile = (32*RB) x 96.
-// ---------------------------------------------------------------------------------------
-template <int RB, int NB, int WAVES_M, int WAVES_N, int BK, int EPI>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_nt_kernel(svit_gemm_args p) {
-  constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr int BM = 32 * RB * WAVES_M;
-  constexpr int WN = 32 * NB;               // columns per wave
-  constexpr int BN = WN * WAVES_N;
-  constexpr int EP_LD = WN + 4;             // fp32 row stride of the epilogue staging block
-  constexpr int ROWB = LdsRow<BK>::kBytes;
-  constexpr int CH = BK / 8;                 // 16-byte chunks per tile row
-  constexpr int A_CHUNKS = BM * CH, W_CHUNKS = BN * CH;
-  constexpr int A_PER = (A_CHUNKS + NT - 1) / NT, W_PER = (W_CHUNKS + NT - 1) / NT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int STAGE = (BM + BN) * ROWB;   // [A tile | W tile] per pipeline stage
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  // Tile order: N tiles fastest, so consecutive tiles share the A row panel.  The dispatcher
-  // deals consecutive workgroups round-robin over the 8 XCDs (private L2 each), so remap the
-  // linear id to give every XCD a CONTIGUOUS run of tiles (bijective for any grid size).
-  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
-  const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
-  const int m0 = (wgid / gridDim.x) * BM, n0 = (wgid % gridDim.x) * BN;
-  const bf16_t* A = (const bf16_t*)p.A;
-  const bf16_t* W = (const bf16_t*)p.W;
-
-  uint4 ra[A_PER], rw[W_PER];
-  auto load_tiles = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
-      const int c = tid + i * NT;
-      const int r = c / CH, cc = c % CH;
-      const int gr = m0 + r;
-      ra[i] = make_uint4(0, 0, 0, 0);
-      if (c < A_CHUNKS && gr < p.M)
-        ra[i] = *(const uint4*)(A + (size_t)gr * p.lda + k0 + cc * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < W_PER; ++i) {
-      const int c = tid + i * NT;
-      const int r = c / CH, cc = c % CH;
-      const int gr = n0 + r;
-      rw[i] = make_uint4(0, 0, 0, 0);
-      if (c < W_CHUNKS && gr < p.N)
-        rw[i] = *(const uint4*)(W + (size_t)gr * p.ldw + k0 + cc * 8);
-    }
-  };
-  auto store_tiles = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
-      const int c = tid + i * NT;
-      if (c < A_CHUNKS) *(uint4*)(smem + buf * STAGE + (c / CH) * ROWB + (c % CH) * 16) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < W_PER; ++i) {
-      const int c = tid + i * NT;
-      if (c < W_CHUNKS)
-        *(uint4*)(smem + buf * STAGE + BM * ROWB + (c / CH) * ROWB + (c % CH) * 16) = rw[i];
-    }
-  };
-
-  f32x16_t acc[RB][NB];
-#pragma unroll
-  for (int i = 0; i < RB; ++i)
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = p.K / BK;
-  load_tiles(0);
-  store_tiles(0);
-  __syncthreads();
-  const int frag_off = (lane & 31) * ROWB + (lane >> 5) * 16;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tiles((kt + 1) * BK);
-    const unsigned char* la = smem + cur * STAGE + (wm * 32 * RB) * ROWB + frag_off;
-    const unsigned char* lw = smem + cur * STAGE + BM * ROWB + (wn * WN) * ROWB + frag_off;
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8_t af[RB], wf[NB];
-#pragma unroll
-      for (int i = 0; i < RB; ++i) af[i] = *(const bf16x8_t*)(la + i * 32 * ROWB + ks * 32);
-#pragma unroll
-      for (int j = 0; j < NB; ++j) wf[j] = *(const bf16x8_t*)(lw + j * 32 * ROWB + ks * 32);
-#pragma unroll
-      for (int i = 0; i < RB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) acc[i][j] = mfma32(af[i], wf[j], acc[i][j]);
-    }
-    if (kt + 1 < nk) store_tiles(cur ^ 1);
-    __syncthreads();
-  }
-
-  nt_epilogue<RB, NB, EPI>(p, acc, smem, m0, n0, wm, wn, lane, wave);
-}
-
-template <int RB, int NB, int WAVES_M, int WAVES_N, int BK>
-int launch_nt(const svit_gemm_args& a, hipStream_t st) {
-  constexpr int BM = 32 * RB * WAVES_M, BN = 32 * NB * WAVES_N;
-  constexpr int NT = WAVES_M * WAVES_N * 64;
-  size_t lds = 2 * (size_t)(BM + BN) * LdsRow<BK>::kBytes;
-  const size_t lds_epi = (size_t)WAVES_M * WAVES_N * 16 * (32 * NB + 4) * sizeof(float);
-  if (lds < lds_epi) lds = lds_epi;
-  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM);
-#define SVIT_NT_CASE(E)                                                                  \
-  case E:                                                                                \
-    hipLaunchKernelGGL((gemm_nt_kernel<RB, NB, WAVES_M, WAVES_N, BK, E>), grid, dim3(NT), lds, st, a); \
-    break;
-  switch (a.epilogue) {
-    SVIT_NT_CASE(SVIT_EPI_BF16)
-    SVIT_NT_CASE(SVIT_EPI_GELU)
-    SVIT_NT_CASE(SVIT_EPI_RESID)
-    SVIT_NT_CASE(SVIT_EPI_F32)
-    SVIT_NT_CASE(SVIT_EPI_DGELU)
-    default:
-      return SVIT_ERR_ARG;
-  }
-#undef SVIT_NT_CASE
-  SVIT_LAUNCH_CHECK();
-  return SVIT_OK;
-}
 
 // ---------------------------------------------------------------------------------------
 // TN kernel: out tile 128(n) x 96(k), 4 waves, each wave one 32-row n-block x 96 k columns.
@@ -292,42 +160,6 @@ __global__ void colsum_kernel(const bf16_t* __restrict__ A, int lda, float* __re
 }
 
 }  // namespace
-
-extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
-  if (!args || !args->A || !args->W || !args->out) return SVIT_ERR_ARG;
-  const svit_gemm_args& a = *args;
-  if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % 32 != 0 || a.N % 96 != 0) return SVIT_ERR_SHAPE;
-  if (a.lda % 8 != 0 || a.ldw % 8 != 0 || a.lda < a.K || a.ldw < a.K || a.ldo < a.N)
-    return SVIT_ERR_ALIGN;
-  if (((uintptr_t)a.A | (uintptr_t)a.W) & 15) return SVIT_ERR_ALIGN;
-  if (a.ldo % 4 != 0 || ((uintptr_t)a.out & 15)) return SVIT_ERR_ALIGN;
-  if (a.bias && ((uintptr_t)a.bias & 15)) return SVIT_ERR_ALIGN;
-  if (a.aux && (a.ldaux % 4 != 0 || ((uintptr_t)a.aux & 15))) return SVIT_ERR_ALIGN;
-  if (a.out2 && (a.ldo2 % 4 != 0 || ((uintptr_t)a.out2 & 15))) return SVIT_ERR_ALIGN;
-  if (a.epilogue == SVIT_EPI_GELU && !a.out2) return SVIT_ERR_ARG;
-  if ((a.epilogue == SVIT_EPI_RESID || a.epilogue == SVIT_EPI_DGELU) && !a.aux) return SVIT_ERR_ARG;
-  if (a.epilogue == SVIT_EPI_RESID && a.row_scale && a.rows_per_sample <= 0) return SVIT_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  // Tile choice: arithmetic intensity (FLOP per L2 byte) grows with the tile, so take the
-  // 256x192 tile (4 waves x (64 x 192)) whenever it still yields >= ~1.5 tiles per CU;
-  // otherwise 128x192.  N == 96 (mod 192): 256x96 for tall problems, 128x96 for the rest.
-  static bool configured = false;
-  if (!configured) {   // the 256x192 pipeline needs > 64 KB of dynamic LDS
-#define SVIT_SET_LDS(E) hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 6, 4, 1, 32, E>, \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)
-    SVIT_SET_LDS(SVIT_EPI_BF16); SVIT_SET_LDS(SVIT_EPI_GELU); SVIT_SET_LDS(SVIT_EPI_RESID);
-    SVIT_SET_LDS(SVIT_EPI_F32); SVIT_SET_LDS(SVIT_EPI_DGELU);
-#undef SVIT_SET_LDS
-    configured = true;
-  }
-  if (a.N % 192 == 0) {
-    const long tiles_big = (long)((a.M + 255) / 256) * (a.N / 192);
-    if (tiles_big >= 384) return launch_nt<2, 6, 4, 1, 32>(a, st);
-    return launch_nt<2, 3, 2, 2, 32>(a, st);
-  }
-  if (a.M >= 8192) return launch_nt<2, 3, 4, 1, 32>(a, st);
-  return launch_nt<1, 3, 4, 1, 32>(a, st);
-}
 
 extern "C" int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, float* dW, int lddw,
                             int M, int N, int K, int splits, float* dbias, void* stream) {

@@ -113,47 +113,3 @@ if __name__ == "__main__":
     if what in ("attn", "all"):
         bench_attn()
 
-
-def bench_gemm_v2():
-    """A/B of the multi-stage direct-to-LDS NT kernel (gemm_v2.hip) against the shipping one."""
-    import ctypes as C
-    lib = hip.load()
-    fn = lib.svit_gemm_nt_v2_launch
-    fn.restype, fn.argtypes = C.c_int32, [C.POINTER(hip.GemmArgs), C.c_int32, C.c_void_p]
-    print("== gemm_nt v1 vs v2 configs (us) ==")
-    seen = set()
-    for blk, Nin, Nq, Nk, Ci, Co, h, DA in BLOCKS:
-        for (M, N, K, tag) in [(B * Nin, 3 * Co, Ci, "qkv"), (B * Nq, Co, Co, "proj"),
-                               (B * Nq, 4 * Co, Co, "fc1"), (B * Nq, Co, 4 * Co, "fc2"),
-                               (B * Nin, Ci, 3 * Co, "qkv-dgrad")]:
-            if (M, N, K) in seen:
-                continue
-            seen.add((M, N, K))
-            a, w = rnd(M, K), rnd(N, K)
-            bias = torch.randn(N, device=DEV)
-            out1 = torch.empty(M, N, device=DEV, dtype=BF16)
-            out2 = torch.empty(M, N, device=DEV, dtype=BF16)
-            us1 = timeit(lambda: ops.gemm_nt(a, w, bias, hip.EPI_BF16, out=out1))
-            g = hip.GemmArgs()
-            g.A, g.lda, g.W, g.ldw, g.bias = a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr()
-            g.out, g.ldo, g.M, g.N, g.K, g.epilogue = out2.data_ptr(), N, M, N, K, hip.EPI_BF16
-            res = []
-            for cfg in (0, 1, 2, 3):
-                if cfg in (0, 3) and N % 192 != 0:
-                    res.append("   -  ")
-                    continue
-                out2.zero_()
-
-                def run():
-                    rc = fn(C.byref(g), cfg, hip.stream())
-                    assert rc == 0, rc
-                us = timeit(run)
-                err = float((out2.float() - out1.float()).abs().max())
-                res.append("%6.1f%s" % (us, "" if err < 0.1 else "(ERR %.2g)" % err))
-            flop = 2.0 * M * N * K
-            print("blk%-2d %-10s M=%6d N=%4d K=%4d  v1 %7.1f (%5.0f TF) | v2 %s" %
-                  (blk, tag, M, N, K, us1, flop / us1 / 1e6, " ".join(res)))
-
-
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "gemm2":
-    bench_gemm_v2()
