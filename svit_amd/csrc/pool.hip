@@ -379,30 +379,44 @@ __global__ __launch_bounds__(192) void pool_wgrad_kernel(svit_pool_wgrad_args a,
       rows[r] = (tt >= 0 && tt < a.T && yy >= 0 && yy < a.H)
                     ? xin + (size_t)(1 + (tt * a.H + yy) * a.W) * tok_stride : nullptr;
     }
-    float win[9][3];
-    for (int xo = 0; xo < Wo; ++xo) {
-      constexpr int KEEP = (S >= 3) ? 0 : 3 - S;   // columns shared with the previous window
-      const int first_new = (xo == 0) ? 0 : KEEP;
-      if (xo > 0) {
+    // XU outputs per step: all their input columns (XU*S + 2 - carried) and dy values are
+    // requested up front, so ~9*XU*S independent 2-byte loads are in flight per lane instead
+    // of 9 (the walk is latency-bound otherwise)
+    constexpr int XU = 4;
+    // S = 1, 2: contiguous input columns, KEEP of them carried over from the previous step;
+    // S = 3 stands for "any stride >= 3": windows do not overlap, 3 columns per output
+    constexpr bool SPARSE = (S >= 3);
+    constexpr int CS = SPARSE ? 3 : S;            // column-slot stride between outputs
+    constexpr int NC = (XU - 1) * CS + 3;         // column slots touched by XU outputs
+    constexpr int KEEP = SPARSE ? 0 : 3 - S;      // columns shared with the previous step
+    float col[9][NC];
+    for (int xo0 = 0; xo0 < Wo; xo0 += XU) {
+      const int first_new = (xo0 == 0) ? 0 : KEEP;
+      if (xo0 > 0) {
 #pragma unroll
         for (int r = 0; r < 9; ++r)
 #pragma unroll
-          for (int kx = 0; kx < KEEP; ++kx) win[r][kx] = win[r][kx + S];
+          for (int k = 0; k < KEEP; ++k) col[r][k] = col[r][XU * CS + k];
       }
+      float d[XU];
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        if (kx < first_new) continue;
-        const int xx = xo * s - 1 + kx;
-        const bool okx = xx >= 0 && xx < a.W;
+      for (int u = 0; u < XU; ++u)
+        d[u] = (xo0 + u < Wo) ? bf16_to_f32(dyr[(size_t)(xo0 + u) * HD]) : 0.f;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        if (k < first_new) continue;
+        const int xx = SPARSE ? (xo0 + k / 3) * s - 1 + k % 3 : xo0 * s - 1 + k;
+        const bool okx = xx >= 0 && xx < a.W && (!SPARSE || xo0 + k / 3 < Wo);
 #pragma unroll
         for (int r = 0; r < 9; ++r)
-          win[r][kx] = (okx && rows[r]) ? bf16_to_f32(rows[r][(size_t)xx * tok_stride]) : 0.f;
+          col[r][k] = (okx && rows[r]) ? bf16_to_f32(rows[r][(size_t)xx * tok_stride]) : 0.f;
       }
-      const float d = bf16_to_f32(dyr[(size_t)xo * HD]);
 #pragma unroll
-      for (int r = 0; r < 9; ++r)
+      for (int u = 0; u < XU; ++u)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) acc[r * 3 + kx] += d * win[r][kx];
+        for (int r = 0; r < 9; ++r)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) acc[r * 3 + kx] += d[u] * col[r][u * CS + kx];
     }
   }
   // object tokens: dw[c][tap] += ncoef[tap] * sum_obj dy*x  (closed form of the cube branch)

@@ -113,3 +113,36 @@ if __name__ == "__main__":
     if what in ("attn", "all"):
         bench_attn()
 
+
+
+def bench_pool():
+    """pooled q/k/v kernels per block shape: fwd, ln_bwd, dgrad, wgrad (us)."""
+    print("== pool kernels (which, stride) fwd / ln_bwd / dgrad / wgrad us ==")
+    # (blk, heads, thw_in, stride_q, stride_kv)
+    cfgs = [(0, 1, (8, 56, 56), 1, 8), (1, 2, (8, 56, 56), 2, 4), (2, 2, (8, 28, 28), 1, 4),
+            (3, 4, (8, 28, 28), 2, 2), (4, 4, (8, 14, 14), 1, 2), (14, 8, (8, 14, 14), 2, 1),
+            (15, 8, (8, 7, 7), 1, 1)]
+    n_obj = 64
+    for blk, h, thw, sq, skv in cfgs:
+        N = 1 + thw[0] * thw[1] * thw[2] + n_obj
+        qkv = rnd(B, N, 3, h, 96)
+        w = torch.randn(96, 27, device=DEV) * 0.2
+        g, b = torch.ones(96, device=DEV), torch.zeros(96, device=DEV)
+        for which, s in ((0, sq), (1, skv)):
+            out, pre, mean, rstd = ops.pool_ln_fwd(qkv, which, w, g, b, B, h, thw, n_obj, s)
+            Nout = out.shape[2]
+            t_f = timeit(lambda: ops.pool_ln_fwd(qkv, which, w, g, b, B, h, thw, n_obj, s))
+            dout = rnd(B, h, Nout, 96)
+            dg, db = torch.zeros(96, device=DEV), torch.zeros(96, device=DEV)
+            t_l = timeit(lambda: ops.pool_ln_bwd(pre, mean, rstd, g, dg, db, B, h, Nout, d_main=dout, ld_main=96))
+            dpre = ops.pool_ln_bwd(pre, mean, rstd, g, dg, db, B, h, Nout, d_main=dout, ld_main=96)
+            dqkv = torch.empty_like(qkv)
+            t_d = timeit(lambda: ops.pool_conv_dgrad(dpre, w, dqkv, which, B, h, thw, n_obj, s))
+            dw = torch.zeros(96, 27, device=DEV)
+            t_w = timeit(lambda: ops.pool_conv_wgrad(dpre, qkv, which, dw, B, h, thw, n_obj, s))
+            print("blk%-2d h=%d in=%6d out=%6d which=%d s=%d  fwd %7.1f  ln_bwd %7.1f  dgrad %7.1f  wgrad %7.1f" %
+                  (blk, h, N, Nout, which, s, t_f, t_l, t_d, t_w))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pool":
+    bench_pool()
