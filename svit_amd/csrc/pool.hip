@@ -349,84 +349,103 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(svit_pool_dgrad_args a)
 }
 
 // ---------------------------------------------------------------------------------------
-// wgrad: one lane per channel walks an output row (b, head, t, yo) along x with a sliding
-// 9-row x 3-column register window of the input, so each input element is fetched ~9/s times
-// instead of 27 (2-byte coalesced 192-byte row loads); 27 register accumulators per lane.
-// Block = 2 row streams x 96 channels; every block stores one [c][tap] partial row.
+// wgrad, LDS-tiled: a block owns an (R x TX) patch of output positions of one (b, head) and
+// walks t; the input halo of three consecutive planes lives in an LDS ring (one new plane slab
+// per step, fetched with coalesced 16-byte loads, zero-filled outside the volume), so every
+// input element is fetched ~2x instead of 27x, and the 27 taps are read from LDS by one lane
+// per channel (2-byte conflict-free reads) into 27 register accumulators.
+// Block = R(2) x 96 threads.  S = 1 / 2: dense halo; S = 3 stands for any stride >= 3 (only the
+// 3 rows/columns each output touches are staged).  Each block stores one [c][tap] partial row.
 template <int S>
-__global__ __launch_bounds__(192) void pool_wgrad_kernel(svit_pool_wgrad_args a, int n_streams) {
-  __shared__ float comb[27 * HD];
+struct WgradTile {
+  static constexpr int R = 2;
+  static constexpr int TX = (S == 1) ? 14 : 7;
+  static constexpr bool SPARSE = (S >= 3);
+  static constexpr int CS = SPARSE ? 3 : S;
+  static constexpr int RI = (R - 1) * CS + 3;
+  static constexpr int CI = (TX - 1) * CS + 3;
+  static constexpr int PLANE = RI * CI * HD;          // bf16 elements per plane slab
+  static constexpr int LDS_BYTES = (3 * PLANE + R * TX * HD) * 2;
+};
+
+template <int S>
+__global__ __launch_bounds__(192) void pool_wgrad_kernel(svit_pool_wgrad_args a, int n_tiles,
+                                                         int tiles_x, int tiles_y) {
+  using TL = WgradTile<S>;
+  constexpr int R = TL::R, TX = TL::TX, CS = TL::CS, RI = TL::RI, CI = TL::CI, PLANE = TL::PLANE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+  bf16_t* ring = (bf16_t*)smem_w;                 // [3][RI][CI][96]
+  bf16_t* dyt = ring + 3 * PLANE;                 // [R][TX][96]
   const int s = a.stride_hw;
   const int Ho = pooled(a.H, s), Wo = pooled(a.W, s);
   const int L = a.T * a.H * a.W, Lo = a.T * Ho * Wo;
   const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
-  const int c = threadIdx.x % HD, slot = threadIdx.x / HD;
+  const int tid = threadIdx.x, c = tid % HD, r = tid / HD;
   const size_t tok_stride = (size_t)3 * a.heads * HD;
-  const bf16_t* qkv = (const bf16_t*)a.qkv + (size_t)a.which * a.heads * HD + c;
-  const bf16_t* dpre = (const bf16_t*)a.dpre + c;
+  const bf16_t* qkv = (const bf16_t*)a.qkv + (size_t)a.which * a.heads * HD;
+  const bf16_t* dpre = (const bf16_t*)a.dpre;
   float acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.f;
-  for (int stream = blockIdx.x * 2 + slot; stream < n_streams; stream += gridDim.x * 2) {
-    const int yo = stream % Ho, t = (stream / Ho) % a.T, bh = stream / (Ho * a.T);
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int xc = tile % tiles_x, yc = (tile / tiles_x) % tiles_y, bh = tile / (tiles_x * tiles_y);
     const int b = bh / a.heads, head = bh % a.heads;
+    const int yo0 = yc * R, xo0 = xc * TX;
     const bf16_t* xin = qkv + (size_t)b * N * tok_stride + (size_t)head * HD;
-    const bf16_t* dyr = dpre + ((size_t)bh * Nout + 1 + (size_t)(t * Ho + yo) * Wo) * HD;
-    const bf16_t* rows[9];
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      const int tt = t - 1 + r / 3, yy = yo * s - 1 + r % 3;
-      rows[r] = (tt >= 0 && tt < a.T && yy >= 0 && yy < a.H)
-                    ? xin + (size_t)(1 + (tt * a.H + yy) * a.W) * tok_stride : nullptr;
-    }
-    // XU outputs per step: all their input columns (XU*S + 2 - carried) and dy values are
-    // requested up front, so ~9*XU*S independent 2-byte loads are in flight per lane instead
-    // of 9 (the walk is latency-bound otherwise)
-    constexpr int XU = 4;
-    // S = 1, 2: contiguous input columns, KEEP of them carried over from the previous step;
-    // S = 3 stands for "any stride >= 3": windows do not overlap, 3 columns per output
-    constexpr bool SPARSE = (S >= 3);
-    constexpr int CS = SPARSE ? 3 : S;            // column-slot stride between outputs
-    constexpr int NC = (XU - 1) * CS + 3;         // column slots touched by XU outputs
-    constexpr int KEEP = SPARSE ? 0 : 3 - S;      // columns shared with the previous step
-    float col[9][NC];
-    for (int xo0 = 0; xo0 < Wo; xo0 += XU) {
-      const int first_new = (xo0 == 0) ? 0 : KEEP;
-      if (xo0 > 0) {
-#pragma unroll
-        for (int r = 0; r < 9; ++r)
-#pragma unroll
-          for (int k = 0; k < KEEP; ++k) col[r][k] = col[r][XU * CS + k];
+    auto load_plane = [&](int tp) {   // stage input plane tp into ring slot (tp+1) % 3
+      bf16_t* dst = ring + ((tp + 1) % 3) * PLANE;
+      for (int q = tid; q < RI * CI * 12; q += 192) {
+        const int tok = q / 12, cc = q % 12, j = tok / CI, i = tok % CI;
+        const int y = TL::SPARSE ? (yo0 + j / 3) * s - 1 + j % 3 : yo0 * s - 1 + j;
+        const int x = TL::SPARSE ? (xo0 + i / 3) * s - 1 + i % 3 : xo0 * s - 1 + i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (tp >= 0 && tp < a.T && y >= 0 && y < a.H && x >= 0 && x < a.W)
+          v = *(const uint4*)(xin + (size_t)(1 + (tp * a.H + y) * a.W + x) * tok_stride + cc * 8);
+        *(uint4*)(dst + (size_t)tok * HD + cc * 8) = v;
       }
-      float d[XU];
-#pragma unroll
-      for (int u = 0; u < XU; ++u)
-        d[u] = (xo0 + u < Wo) ? bf16_to_f32(dyr[(size_t)(xo0 + u) * HD]) : 0.f;
-#pragma unroll
-      for (int k = 0; k < NC; ++k) {
-        if (k < first_new) continue;
-        const int xx = SPARSE ? (xo0 + k / 3) * s - 1 + k % 3 : xo0 * s - 1 + k;
-        const bool okx = xx >= 0 && xx < a.W && (!SPARSE || xo0 + k / 3 < Wo);
-#pragma unroll
-        for (int r = 0; r < 9; ++r)
-          col[r][k] = (okx && rows[r]) ? bf16_to_f32(rows[r][(size_t)xx * tok_stride]) : 0.f;
+    };
+    __syncthreads();            // previous tile's readers are done with the ring
+    load_plane(-1);
+    load_plane(0);
+    for (int t = 0; t < a.T; ++t) {
+      load_plane(t + 1);
+      for (int q = tid; q < R * TX * 12; q += 192) {
+        const int tok = q / 12, cc = q % 12, rr = tok / TX, xo = tok % TX;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (yo0 + rr < Ho && xo0 + xo < Wo)
+          v = *(const uint4*)(dpre + ((size_t)bh * Nout + 1 + (size_t)(t * Ho + yo0 + rr) * Wo +
+                                      xo0 + xo) * HD + cc * 8);
+        *(uint4*)(dyt + (size_t)tok * HD + cc * 8) = v;
       }
+      __syncthreads();
+      const bf16_t* p0 = ring + ((t + 0) % 3) * PLANE + c;   // plane t-1
+      const bf16_t* p1 = ring + ((t + 1) % 3) * PLANE + c;   // plane t
+      const bf16_t* p2 = ring + ((t + 2) % 3) * PLANE + c;   // plane t+1
+#pragma unroll 2
+      for (int xo = 0; xo < TX; ++xo) {
+        const float d = bf16_to_f32(dyt[(r * TX + xo) * HD + c]);
 #pragma unroll
-      for (int u = 0; u < XU; ++u)
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int r = 0; r < 9; ++r)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) acc[r * 3 + kx] += d[u] * col[r][u * CS + kx];
+          for (int kx = 0; kx < 3; ++kx) {
+            const int off = ((r * CS + ky) * CI + xo * CS + kx) * HD;
+            acc[0 * 9 + ky * 3 + kx] += d * bf16_to_f32(p0[off]);
+            acc[1 * 9 + ky * 3 + kx] += d * bf16_to_f32(p1[off]);
+            acc[2 * 9 + ky * 3 + kx] += d * bf16_to_f32(p2[off]);
+          }
+      }
+      __syncthreads();          // ring slot of plane t-1 is overwritten by the next step
     }
   }
   // object tokens: dw[c][tap] += ncoef[tap] * sum_obj dy*x  (closed form of the cube branch)
   if (a.n_obj > 0) {
     float g = 0.f;
     const int n_obj_rows = a.B * a.heads * a.n_obj;
-    for (int i = blockIdx.x * 2 + slot; i < n_obj_rows; i += gridDim.x * 2) {
+    for (int i = blockIdx.x * R + r; i < n_obj_rows; i += gridDim.x * R) {
       const int o = i % a.n_obj, bh = i / a.n_obj, b = bh / a.heads, head = bh % a.heads;
-      const float d = bf16_to_f32(dpre[((size_t)bh * Nout + 1 + Lo + o) * HD]);
-      const float x = bf16_to_f32(qkv[((size_t)b * N + 1 + L + o) * tok_stride + (size_t)head * HD]);
+      const float d = bf16_to_f32(dpre[((size_t)bh * Nout + 1 + Lo + o) * HD + c]);
+      const float x = bf16_to_f32(qkv[((size_t)b * N + 1 + L + o) * tok_stride + (size_t)head * HD + c]);
       g += d * x;
     }
     float nt[3], nh[3], ipt, iph;
@@ -436,16 +455,43 @@ __global__ __launch_bounds__(192) void pool_wgrad_kernel(svit_pool_wgrad_args a,
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] += g * nt[k / 9] * nh[(k / 3) % 3] * nh[k % 3];
   }
-  if (slot == 1) {
+  __syncthreads();
+  float* comb = (float*)smem_w;   // [27][96]
+  if (r == 1) {
 #pragma unroll
     for (int k = 0; k < 27; ++k) comb[k * HD + c] = acc[k];
   }
   __syncthreads();
-  if (slot == 0) {
+  if (r == 0) {
     float* prow = a.workspace + (size_t)blockIdx.x * 27 * HD + c * 27;   // [c][tap]
 #pragma unroll
     for (int k = 0; k < 27; ++k) prow[k] = acc[k] + comb[k * HD + c];
   }
+}
+
+template <int S>
+static int launch_wgrad(const svit_pool_wgrad_args& a, int Ho, int Wo, hipStream_t st) {
+  using TL = WgradTile<S>;
+  const int tiles_x = (Wo + TL::TX - 1) / TL::TX, tiles_y = (Ho + TL::R - 1) / TL::R;
+  const int n_tiles = tiles_x * tiles_y * a.B * a.heads;
+  int64_t blocks = n_tiles;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks > a.workspace_floats / (27 * HD)) blocks = a.workspace_floats / (27 * HD);
+  if (blocks < 1) return SVIT_ERR_ARG;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)pool_wgrad_kernel<S>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, TL::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  hipLaunchKernelGGL(pool_wgrad_kernel<S>, dim3((unsigned)blocks), dim3(192), TL::LDS_BYTES, st, a,
+                     n_tiles, tiles_x, tiles_y);
+  SVIT_LAUNCH_CHECK();
+  SvitReduceDst dst = {{a.dw, a.dw, a.dw}, {27 * HD, 27 * HD, 27 * HD}};
+  svit_launch_reduce(a.workspace, (int)blocks, 27 * HD, dst, st);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -622,22 +668,9 @@ extern "C" int svit_pool_conv_wgrad(const svit_pool_wgrad_args* a, void* stream)
   const int64_t total = (int64_t)a->B * a->heads * (1 + a->T * Ho * Wo + a->n_obj);
   if (!a->workspace) return SVIT_ERR_ARG;
   (void)total;
-  const int n_streams = a->B * a->heads * a->T * Ho;
-  int64_t blocks = (n_streams + 1) / 2;
-  if (blocks > 1024) blocks = 1024;
-  if (blocks > a->workspace_floats / (27 * HD)) blocks = a->workspace_floats / (27 * HD);
-  if (blocks < 1) return SVIT_ERR_ARG;
-  if (a->stride_hw == 1)
-    hipLaunchKernelGGL(pool_wgrad_kernel<1>, dim3((unsigned)blocks), dim3(192), 0, (hipStream_t)stream, *a, n_streams);
-  else if (a->stride_hw == 2)
-    hipLaunchKernelGGL(pool_wgrad_kernel<2>, dim3((unsigned)blocks), dim3(192), 0, (hipStream_t)stream, *a, n_streams);
-  else
-    hipLaunchKernelGGL(pool_wgrad_kernel<3>, dim3((unsigned)blocks), dim3(192), 0, (hipStream_t)stream, *a, n_streams);
-  SVIT_LAUNCH_CHECK();
-  SvitReduceDst dst = {{a->dw, a->dw, a->dw}, {27 * HD, 27 * HD, 27 * HD}};
-  svit_launch_reduce(a->workspace, (int)blocks, 27 * HD, dst, (hipStream_t)stream);
-  SVIT_LAUNCH_CHECK();
-  return SVIT_OK;
+  if (a->stride_hw == 1) return launch_wgrad<1>(*a, Ho, Wo, (hipStream_t)stream);
+  if (a->stride_hw == 2) return launch_wgrad<2>(*a, Ho, Wo, (hipStream_t)stream);
+  return launch_wgrad<3>(*a, Ho, Wo, (hipStream_t)stream);
 }
 
 static int check_relq(int ld, int kh, int kw, int kt) {
