@@ -370,7 +370,8 @@ struct WgradTile {
 
 template <int S>
 __global__ __launch_bounds__(192) void pool_wgrad_kernel(svit_pool_wgrad_args a, int n_tiles,
-                                                         int tiles_x, int tiles_y) {
+                                                         int tiles_x, int tiles_y, int t_chunks,
+                                                         int t_len) {
   using TL = WgradTile<S>;
   constexpr int R = TL::R, TX = TL::TX, CS = TL::CS, RI = TL::RI, CI = TL::CI, PLANE = TL::PLANE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
@@ -388,37 +389,69 @@ __global__ __launch_bounds__(192) void pool_wgrad_kernel(svit_pool_wgrad_args a,
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.f;
 
+  constexpr int SLAB_CH = RI * CI * 12;                  // 16-byte chunks per plane slab
+  constexpr int SLAB_PER = (SLAB_CH + 191) / 192;
+  constexpr int DY_CH = R * TX * 12;
+  constexpr int DY_PER = (DY_CH + 191) / 192;
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int xc = tile % tiles_x, yc = (tile / tiles_x) % tiles_y, bh = tile / (tiles_x * tiles_y);
+    const int xc = tile % tiles_x, yc = (tile / tiles_x) % tiles_y;
+    const int tc = (tile / (tiles_x * tiles_y)) % t_chunks, bh = tile / (tiles_x * tiles_y * t_chunks);
     const int b = bh / a.heads, head = bh % a.heads;
     const int yo0 = yc * R, xo0 = xc * TX;
+    const int t_begin = tc * t_len, t_end = min(a.T, t_begin + t_len);
     const bf16_t* xin = qkv + (size_t)b * N * tok_stride + (size_t)head * HD;
-    auto load_plane = [&](int tp) {   // stage input plane tp into ring slot (tp+1) % 3
-      bf16_t* dst = ring + ((tp + 1) % 3) * PLANE;
-      for (int q = tid; q < RI * CI * 12; q += 192) {
+    uint4 sreg[SLAB_PER], dreg[DY_PER];
+    auto fetch_plane = [&](int tp) {   // global -> registers (zero outside the volume)
+#pragma unroll
+      for (int u = 0; u < SLAB_PER; ++u) {
+        const int q = tid + u * 192;
         const int tok = q / 12, cc = q % 12, j = tok / CI, i = tok % CI;
         const int y = TL::SPARSE ? (yo0 + j / 3) * s - 1 + j % 3 : yo0 * s - 1 + j;
         const int x = TL::SPARSE ? (xo0 + i / 3) * s - 1 + i % 3 : xo0 * s - 1 + i;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (tp >= 0 && tp < a.T && y >= 0 && y < a.H && x >= 0 && x < a.W)
-          v = *(const uint4*)(xin + (size_t)(1 + (tp * a.H + y) * a.W + x) * tok_stride + cc * 8);
-        *(uint4*)(dst + (size_t)tok * HD + cc * 8) = v;
+        sreg[u] = make_uint4(0, 0, 0, 0);
+        if (q < SLAB_CH && tp >= 0 && tp < a.T && y >= 0 && y < a.H && x >= 0 && x < a.W)
+          sreg[u] = *(const uint4*)(xin + (size_t)(1 + (tp * a.H + y) * a.W + x) * tok_stride + cc * 8);
+      }
+    };
+    auto store_plane = [&](int tp) {   // registers -> ring slot (tp+1) % 3
+      bf16_t* dst = ring + ((tp + 1) % 3) * PLANE;
+#pragma unroll
+      for (int u = 0; u < SLAB_PER; ++u) {
+        const int q = tid + u * 192;
+        if (q < SLAB_CH) *(uint4*)(dst + (size_t)(q / 12) * HD + (q % 12) * 8) = sreg[u];
+      }
+    };
+    auto fetch_dy = [&](int t) {
+#pragma unroll
+      for (int u = 0; u < DY_PER; ++u) {
+        const int q = tid + u * 192;
+        const int tok = q / 12, cc = q % 12, rr = tok / TX, xo = tok % TX;
+        dreg[u] = make_uint4(0, 0, 0, 0);
+        if (q < DY_CH && t < t_end && yo0 + rr < Ho && xo0 + xo < Wo)
+          dreg[u] = *(const uint4*)(dpre + ((size_t)bh * Nout + 1 + (size_t)(t * Ho + yo0 + rr) * Wo +
+                                            xo0 + xo) * HD + cc * 8);
+      }
+    };
+    auto store_dy = [&]() {
+#pragma unroll
+      for (int u = 0; u < DY_PER; ++u) {
+        const int q = tid + u * 192;
+        if (q < DY_CH) *(uint4*)(dyt + (size_t)(q / 12) * HD + (q % 12) * 8) = dreg[u];
       }
     };
     __syncthreads();            // previous tile's readers are done with the ring
-    load_plane(-1);
-    load_plane(0);
-    for (int t = 0; t < a.T; ++t) {
-      load_plane(t + 1);
-      for (int q = tid; q < R * TX * 12; q += 192) {
-        const int tok = q / 12, cc = q % 12, rr = tok / TX, xo = tok % TX;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (yo0 + rr < Ho && xo0 + xo < Wo)
-          v = *(const uint4*)(dpre + ((size_t)bh * Nout + 1 + (size_t)(t * Ho + yo0 + rr) * Wo +
-                                      xo0 + xo) * HD + cc * 8);
-        *(uint4*)(dyt + (size_t)tok * HD + cc * 8) = v;
-      }
+    fetch_plane(t_begin - 1); store_plane(t_begin - 1);
+    fetch_plane(t_begin);     store_plane(t_begin);
+    fetch_plane(t_begin + 1);
+    fetch_dy(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+      store_plane(t + 1);       // slot of plane t-2: its readers passed the barrier below
+      store_dy();
       __syncthreads();
+      if (t + 1 < t_end) {      // next step's data travels while this step computes
+        fetch_plane(t + 2);
+        fetch_dy(t + 1);
+      }
       const bf16_t* p0 = ring + ((t + 0) % 3) * PLANE + c;   // plane t-1
       const bf16_t* p1 = ring + ((t + 1) % 3) * PLANE + c;   // plane t
       const bf16_t* p2 = ring + ((t + 2) % 3) * PLANE + c;   // plane t+1
@@ -435,7 +468,7 @@ __global__ __launch_bounds__(192) void pool_wgrad_kernel(svit_pool_wgrad_args a,
             acc[2 * 9 + ky * 3 + kx] += d * bf16_to_f32(p2[off]);
           }
       }
-      __syncthreads();          // ring slot of plane t-1 is overwritten by the next step
+      __syncthreads();          // ring slot of plane t-1 and dyt are overwritten next step
     }
   }
   // object tokens: dw[c][tap] += ncoef[tap] * sum_obj dy*x  (closed form of the cube branch)
@@ -473,7 +506,13 @@ template <int S>
 static int launch_wgrad(const svit_pool_wgrad_args& a, int Ho, int Wo, hipStream_t st) {
   using TL = WgradTile<S>;
   const int tiles_x = (Wo + TL::TX - 1) / TL::TX, tiles_y = (Ho + TL::R - 1) / TL::R;
-  const int n_tiles = tiles_x * tiles_y * a.B * a.heads;
+  // split the t walk when the (y, x) tiling alone gives too few workgroups
+  int t_chunks = 1;
+  while (t_chunks < a.T && (long)tiles_x * tiles_y * a.B * a.heads * t_chunks < 768 &&
+         a.T / (t_chunks * 2) >= 2)
+    t_chunks *= 2;
+  const int t_len = (a.T + t_chunks - 1) / t_chunks;
+  const int n_tiles = tiles_x * tiles_y * a.B * a.heads * t_chunks;
   int64_t blocks = n_tiles;
   if (blocks > 2048) blocks = 2048;
   if (blocks > a.workspace_floats / (27 * HD)) blocks = a.workspace_floats / (27 * HD);
@@ -486,7 +525,7 @@ static int launch_wgrad(const svit_pool_wgrad_args& a, int Ho, int Wo, hipStream
     configured = true;
   }
   hipLaunchKernelGGL(pool_wgrad_kernel<S>, dim3((unsigned)blocks), dim3(192), TL::LDS_BYTES, st, a,
-                     n_tiles, tiles_x, tiles_y);
+                     n_tiles, tiles_x, tiles_y, t_chunks, t_len);
   SVIT_LAUNCH_CHECK();
   SvitReduceDst dst = {{a.dw, a.dw, a.dw}, {27 * HD, 27 * HD, 27 * HD}};
   svit_launch_reduce(a.workspace, (int)blocks, 27 * HD, dst, st);
