@@ -1,7 +1,8 @@
 // Fused pooled attention, backward (flash-style recompute) -- gfx950.
 //
 // Three launches (all on the caller's stream):
-//   1. delta[q]  = sum_c dctx[q,c] * (ctx[q,c] - q_pooled[q,c])        (rowsum(dO * O))
+//   1. delta[q]  = sum_c dctx[q,c] * (ctx[q,c] - q_pooled[q,c])        (rowsum(dO * O)),
+//      stored as (lse2, delta) pairs in the caller's scratch
 //   2. dq kernel : per 32-query wave, sweep K/V tiles: S^T, P^T = exp2(c*S - lse2),
 //                  dP^T = V dO^T, dS^T = P^T (dP^T - delta) * scale, dQa^T += Ka^T dS^T.
 //                  Query on the lane => P/dS reach the next MFMA as B operands in registers.
@@ -30,6 +31,7 @@ __device__ __forceinline__ float quad_sum4(float v) {
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ ctx,
                                                          const bf16_t* __restrict__ dctx,
                                                          const bf16_t* __restrict__ qa, int ldq,
+                                                         const float* __restrict__ lse2,
                                                          float* __restrict__ delta, int B,
                                                          int heads, int Nq) {
   const int64_t total = (int64_t)B * heads * Nq;
@@ -53,14 +55,21 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     }
   }
   acc = quad_sum4(acc);
-  if (row < total && sub == 0) delta[row] = acc;
+  // (lse2, delta) pairs: one 8-byte record per query row for the two sweep kernels
+  if (row < total && sub == 0) ((float2*)delta)[row] = make_float2(lse2[row], acc);
 }
 
 // ---------------------------------------------------------------------------------------
+// dq kernel.  K/V tiles travel HBM -> LDS by LDS-DMA (no staging registers), two stages, one
+// raw barrier per tile behind a counted vmcnt; 2 blocks per CU (2 waves per SIMD) so one
+// wave's exp/convert VALU work overlaps the other's MFMAs.
 template <int DA>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(svit_attn_bwd_args a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args a) {
   constexpr int KS = DA / 16, NP = DA / 32;
   constexpr int K_BYTES = KT * DA * 2, V_BYTES = KT * HD * 2, STAGE = K_BYTES + V_BYTES;
+  using KLoad = GldsTile<KT, DA, 4>;
+  using VLoad = GldsTile<KT, HD, 4>;
+  constexpr int PER_TILE = KLoad::PER_WAVE + VLoad::PER_WAVE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.heads, head = bh % a.heads;
@@ -71,8 +80,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(svit_attn_bwd_args a) 
   const bf16_t* vv = (const bf16_t*)a.v + ((size_t)bh * a.Nk) * HD;
   const bf16_t* dor = (const bf16_t*)a.dctx + ((size_t)b * a.Nq + qc) * a.heads * HD + head * HD;
   const float c = a.scale * 1.4426950408889634f;
-  const float lse = a.lse2[(size_t)bh * a.Nq + qc];
-  const float dlt = a.delta[(size_t)bh * a.Nq + qc];
+  const float2 ld = ((const float2*)a.delta)[(size_t)bh * a.Nq + qc];   // (lse2, delta)
+  const float lse = ld.x, dlt = ld.y;
 
   bf16x8_t qf[KS], dof[6];
 #pragma unroll
@@ -80,29 +89,35 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(svit_attn_bwd_args a) 
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks) dof[ks] = *(const bf16x8_t*)(dor + ks * 16 + hh * 8);
 
+  // Pin the register operands NOW: their first use must not sit inside the tile loop, or the
+  // compiler's wait for them (vmcnt(0)) would drain the LDS-DMA pipeline every iteration.
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+#pragma unroll
+  for (int ks = 0; ks < 6; ++ks) asm volatile("" : "+v"(dof[ks]));
+  float lse_p = lse, dlt_p = dlt;
+  asm volatile("" : "+v"(lse_p), "+v"(dlt_p));
+
   f32x16_t dq[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[j][r] = 0.f;
 
-  TileStager<KT, DA, 256> ks_stage;
-  TileStager<KT, HD, 256> vs_stage;
   const int nt = (a.Nk + KT - 1) / KT;
-  ks_stage.load(ka, DA, a.Nk, tid);
-  vs_stage.load(vv, HD, a.Nk, tid);
-  ks_stage.store(smem, tid);
-  vs_stage.store(smem + K_BYTES, tid);
-  __syncthreads();
+  auto issue = [&](int t) {
+    unsigned char* st = smem + (t & 1) * STAGE;
+    const int k0 = t * KT;
+    KLoad::issue(ka + (size_t)k0 * DA, DA, a.Nk - k0, st, wave, lane);
+    VLoad::issue(vv + (size_t)k0 * HD, HD, a.Nk - k0, st + K_BYTES, wave, lane);
+  };
+  issue(0);
   for (int t = 0; t < nt; ++t) {
+    wait_vmcnt<0>();                 // this wave's share of tile t has landed
+    __builtin_amdgcn_s_barrier();    // everyone's share has; everyone is done with tile t-1
+    if (t + 1 < nt) issue(t + 1);    // travels while tile t is consumed
     const unsigned char* k_cur = smem + (t & 1) * STAGE;
     const unsigned char* v_cur = k_cur + K_BYTES;
-    unsigned char* k_nxt = smem + ((t + 1) & 1) * STAGE;
-    if (t + 1 < nt) {
-      const int k0 = (t + 1) * KT;
-      ks_stage.load(ka + (size_t)k0 * DA, DA, a.Nk - k0, tid);
-      vs_stage.load(vv + (size_t)k0 * HD, HD, a.Nk - k0, tid);
-    }
     const int kbase = t * KT;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -115,23 +130,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(svit_attn_bwd_args a) 
       for (int ks = 0; ks < 6; ++ks) dp = mfma32(row_frag<KT>(v_cur, kb * 32, ks, lane), dof[ks], dp);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = exp2f(s[r] * c - lse);
-        if (kbase + kb * 32 + acc_row(r, lane) >= a.Nk) p = 0.f;
-        s[r] = p * (dp[r] - dlt) * a.scale;
+        float p = exp2f(s[r] * c - lse_p);
+        if (kbase + kb * 32 + acc_row(r, lane) >= a.Nk) p = 0.f;   // rows past Nk hold re-read data
+        s[r] = p * (dp[r] - dlt_p) * a.scale;
       }
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp) {
         const bf16x8_t dsf = acc_to_frag(s, sp);
+        bf16x8_t kt[NP];
+        tr_frags_asm<KT, NP>(k_cur, kb * 32 + sp * 16, lane, kt);
 #pragma unroll
-        for (int j = 0; j < NP; ++j)
-          dq[j] = mfma32(tr_frag<KT>(k_cur, kb * 32 + sp * 16, j, lane), dsf, dq[j]);
+        for (int j = 0; j < NP; ++j) dq[j] = mfma32(kt[j], dsf, dq[j]);
       }
     }
-    if (t + 1 < nt) {
-      ks_stage.store(k_nxt, tid);
-      vs_stage.store(k_nxt + K_BYTES, tid);
-    }
-    __syncthreads();
   }
   if (qi < a.Nq) {
     bf16_t* out = (bf16_t*)a.dqa + ((size_t)bh * a.Nq + qi) * DA;
@@ -148,13 +159,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(svit_attn_bwd_args a) 
 }
 
 // ---------------------------------------------------------------------------------------
+// dkv kernel.  Q / dO tiles (32 queries) and the (lse2, delta) pairs arrive by LDS-DMA into a
+// three-stage ring; key on the lane; dK^T / dV^T accumulate in registers over the sweep.
 template <int DA>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(svit_attn_bwd_args a,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(svit_attn_bwd_args a,
                                                               int tiles_per_split) {
   constexpr int KS = DA / 16;
   constexpr int Q_BYTES = QT * DA * 2, O_BYTES = QT * HD * 2;
-  constexpr int STAGE = Q_BYTES + O_BYTES + 2 * QT * 4;   // [Q | dO | lse2 | delta]
+  constexpr int STAGE = Q_BYTES + O_BYTES + 2 * QT * 4;   // [Q | dO | (lse2, delta) pairs]
+  constexpr int NSTAGE = 3;
   constexpr int OUT_LD = HD + 1;                          // padded fp32 transpose buffer
+  using QLoad = GldsTile<QT, DA, 4>;
+  using OLoad = GldsTile<QT, HD, 4>;
+  constexpr int PER_TILE = QLoad::PER_WAVE + OLoad::PER_WAVE + 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int bh = blockIdx.z, b = bh / a.heads, head = bh % a.heads;
@@ -165,8 +182,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(svit_attn_bwd_args a,
   const bf16_t* ka = (const bf16_t*)a.ka + ((size_t)bh * a.Nk) * DA;
   const bf16_t* vv = (const bf16_t*)a.v + ((size_t)bh * a.Nk) * HD;
   const bf16_t* dob = (const bf16_t*)a.dctx + ((size_t)b * a.Nq) * a.heads * HD + head * HD;
-  const float* lse_g = a.lse2 + (size_t)bh * a.Nq;
-  const float* dlt_g = a.delta + (size_t)bh * a.Nq;
+  const float* ld_g = a.delta + (size_t)bh * a.Nq * 2;    // (lse2, delta) pairs
   const float c = a.scale * 1.4426950408889634f;
 
   bf16x8_t kf[KS], vf[6];
@@ -174,6 +190,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(svit_attn_bwd_args a,
   for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8_t*)(ka + (size_t)kc * DA + ks * 16 + hh * 8);
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks) vf[ks] = *(const bf16x8_t*)(vv + (size_t)kc * HD + ks * 16 + hh * 8);
+
+  // pin the register operands before the tile loop (see the dq kernel)
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(kf[ks]));
+#pragma unroll
+  for (int ks = 0; ks < 6; ++ks) asm volatile("" : "+v"(vf[ks]));
 
   f32x16_t dk[3], dv[3];
 #pragma unroll
@@ -184,40 +206,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(svit_attn_bwd_args a,
   const int nqt = (a.Nq + QT - 1) / QT;
   const int t_begin = blockIdx.y * tiles_per_split;
   const int t_end = min(nqt, t_begin + tiles_per_split);
-
-  TileStager<QT, DA, 256> q_stage;
-  TileStager<QT, HD, 256> o_stage;
-  float st_lse = 0.f, st_dlt = 0.f;
-  auto load_tile = [&](int t) {
+  auto issue = [&](int t) {
+    unsigned char* st = smem + ((t - t_begin) % NSTAGE) * STAGE;
     const int q0 = t * QT;
-    q_stage.load(qa + (size_t)q0 * DA, DA, a.Nq - q0, tid);
-    o_stage.load(dob + (size_t)q0 * a.heads * HD, (size_t)a.heads * HD, a.Nq - q0, tid);
-    if (tid < QT) {
-      const bool ok = q0 + tid < a.Nq;
-      st_lse = ok ? lse_g[q0 + tid] : INFINITY;  // +inf => P = 0 for rows that do not exist
-      st_dlt = ok ? dlt_g[q0 + tid] : 0.f;
-    }
+    QLoad::issue(qa + (size_t)q0 * DA, DA, a.Nq - q0, st, wave, lane);
+    OLoad::issue(dob + (size_t)q0 * a.heads * HD, (size_t)a.heads * HD, a.Nq - q0, st + Q_BYTES, wave, lane);
+    // 32 (lse2, delta) pairs = 64 floats = one dword LDS-DMA (rows past Nq re-read the last pair)
+    const int qrow = min(q0 + (lane >> 1), a.Nq - 1);
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(ld_g + (size_t)qrow * 2 + (lane & 1)),
+        (__attribute__((address_space(3))) void*)(st + Q_BYTES + O_BYTES), 4, 0, 0);
   };
-  auto store_tile = [&](unsigned char* stage) {
-    q_stage.store(stage, tid);
-    o_stage.store(stage + Q_BYTES, tid);
-    if (tid < QT) {
-      ((float*)(stage + Q_BYTES + O_BYTES))[tid] = st_lse;
-      ((float*)(stage + Q_BYTES + O_BYTES))[QT + tid] = st_dlt;
-    }
-  };
-  if (t_begin < t_end) {
-    load_tile(t_begin);
-    store_tile(smem);
-  }
-  __syncthreads();
+  if (t_begin < t_end) issue(t_begin);
+  if (t_begin + 1 < t_end) issue(t_begin + 1);
   for (int t = t_begin; t < t_end; ++t) {
-    const int par = (t - t_begin) & 1;
-    const unsigned char* q_cur = smem + par * STAGE;
+    if (t + 1 < t_end) wait_vmcnt<PER_TILE>();   // all but the youngest tile's loads are done
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < t_end) issue(t + 2);             // into the stage consumed two steps ago
+    const unsigned char* q_cur = smem + ((t - t_begin) % NSTAGE) * STAGE;
     const unsigned char* o_cur = q_cur + Q_BYTES;
-    const float* lse_s = (const float*)(o_cur + O_BYTES);
-    const float* dlt_s = lse_s + QT;
-    if (t + 1 < t_end) load_tile(t + 1);
+    const float* ld_s = (const float*)(o_cur + O_BYTES);
+    const int q0 = t * QT;
 
     f32x16_t s, dp;
 #pragma unroll
@@ -228,12 +238,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(svit_attn_bwd_args a,
     for (int ks = 0; ks < 6; ++ks) dp = mfma32(row_frag<QT>(o_cur, 0, ks, lane), vf[ks], dp);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float4 l4 = *(const float4*)(lse_s + 8 * g + 4 * hh);
-      const float4 d4 = *(const float4*)(dlt_s + 8 * g + 4 * hh);
-      const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+      // rows 8g + 4hh + e, e = 0..3: four consecutive (lse2, delta) pairs
+      const float4 p01 = *(const float4*)(ld_s + 2 * (8 * g + 4 * hh));
+      const float4 p23 = *(const float4*)(ld_s + 2 * (8 * g + 4 * hh) + 4);
+      const float lv[4] = {p01.x, p01.z, p23.x, p23.z}, dl[4] = {p01.y, p01.w, p23.y, p23.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float p = exp2f(s[4 * g + e] * c - lv[e]);
+        float p = exp2f(s[4 * g + e] * c - lv[e]);
+        if (q0 + 8 * g + 4 * hh + e >= a.Nq) p = 0.f;          // rows past Nq hold re-read data
         s[4 * g + e] = p;
         dp[4 * g + e] = p * (dp[4 * g + e] - dl[e]) * a.scale;
       }
@@ -242,14 +254,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(svit_attn_bwd_args a,
     for (int sp = 0; sp < 2; ++sp) {
       const bf16x8_t pf = acc_to_frag(s, sp);
       const bf16x8_t dsf = acc_to_frag(dp, sp);
+      bf16x8_t ot[3], qt[3];
+      tr_frags_asm<QT, 3>(o_cur, sp * 16, lane, ot);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        dv[j] = mfma32(tr_frag<QT>(o_cur, sp * 16, j, lane), pf, dv[j]);
-        dk[j] = mfma32(tr_frag<QT>(q_cur, sp * 16, j, lane), dsf, dk[j]);
-      }
+      for (int j = 0; j < 3; ++j) dv[j] = mfma32(ot[j], pf, dv[j]);
+      tr_frags_asm<QT, 3>(q_cur, sp * 16, lane, qt);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) dk[j] = mfma32(qt[j], dsf, dk[j]);
     }
-    if (t + 1 < t_end) store_tile(smem + (par ^ 1) * STAGE);
-    __syncthreads();
   }
   // ---- transpose through LDS so that every atomic wave-instruction adds whole rows ----------
   float* obuf = (float*)smem;  // [128 keys][OUT_LD]
@@ -275,7 +287,7 @@ template <int DA>
 int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
   static bool configured = false;
   const size_t lds_dq = 2 * (size_t)(KT * DA * 2 + KT * HD * 2);
-  size_t lds_kv = 2 * (size_t)(QT * DA * 2 + QT * HD * 2 + 2 * QT * 4);
+  size_t lds_kv = 3 * (size_t)(QT * DA * 2 + QT * HD * 2 + 2 * QT * 4);
   const size_t lds_out = (size_t)128 * (HD + 1) * 4;
   if (lds_kv < lds_out) lds_kv = lds_out;
   if (!configured) {
@@ -289,8 +301,8 @@ int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
   }
   const int64_t rows = (int64_t)a.B * a.heads * a.Nq;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, st,
-                     (const bf16_t*)a.ctx, (const bf16_t*)a.dctx, (const bf16_t*)a.qa, DA, a.delta,
-                     a.B, a.heads, a.Nq);
+                     (const bf16_t*)a.ctx, (const bf16_t*)a.dctx, (const bf16_t*)a.qa, DA, a.lse2,
+                     a.delta, a.B, a.heads, a.Nq);
   SVIT_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_bwd_dq_kernel<DA>, dim3((a.Nq + 127) / 128, a.B * a.heads), dim3(256),
                      lds_dq, st, a);

@@ -87,4 +87,100 @@ struct TileStager {
   }
 };
 
+// Direct-to-LDS staging of a [ROWS][COLS] bf16 tile into the panel image with
+// global_load_lds_dwordx4: one wave-instruction writes 1 KB = 16 rows of one panel, lane ->
+// (row = lane>>2, slot = lane&3); the XOR swizzle goes on the per-lane SOURCE address (the LDS
+// destination of an LDS-DMA is always wave-uniform base + lane*16).  Rows >= valid_rows re-read
+// the last valid row (callers mask those rows arithmetically).  Every wave issues exactly
+// PER_WAVE instructions (the counted s_waitcnt vmcnt needs one immediate for all waves); waves
+// past the end repeat the last instruction (same bytes to the same place).
+template <int ROWS, int COLS, int NWAVES>
+struct GldsTile {
+  static_assert(ROWS % 16 == 0 && COLS % 32 == 0, "panel image geometry");
+  static constexpr int RG = ROWS / 16;                   // 16-row groups per panel
+  static constexpr int INSTRS = RG * (COLS / 32);
+  static constexpr int PER_WAVE = (INSTRS + NWAVES - 1) / NWAVES;
+  __device__ static __forceinline__ void issue(const bf16_t* __restrict__ src, size_t ld,
+                                               int valid_rows, unsigned char* tile, int wave,
+                                               int lane) {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      int n = wave + i * NWAVES;
+      if (n >= INSTRS) n = INSTRS - 1;
+      const int panel = n / RG, rg = n % RG;
+      const int row = rg * 16 + (lane >> 2);
+      const int ch = (lane & 3) ^ ((row >> 2) & 3);
+      const int grow = min(row, valid_rows - 1);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + (size_t)grow * ld + panel * 32 + ch * 8),
+          (__attribute__((address_space(3))) void*)(tile + panel * ROWS * 64 + rg * 1024), 16, 0, 0);
+    }
+  }
+};
+
+// NP transposed fragments (panels 0..NP-1, same rows) fetched by ONE inline-asm statement that
+// also waits for them.  Needed in kernels that keep LDS-DMA in flight: hipcc puts an
+// s_waitcnt vmcnt(0) in front of every ds_read_tr *builtin* that follows a global_load_lds
+// (it cannot prove the intrinsic does not read the bytes being DMA'd), which drains the
+// pipeline each tile; an asm read is invisible to that pass.  Outputs are early-clobber and the
+// lgkmcnt wait sits inside the statement, so no register is consumed before its data landed
+// (cdna guide 5.7, form (i)).
+template <int ROWS, int NP>
+__device__ __forceinline__ void tr_frags_asm(const unsigned char* tile, int rbase, int lane,
+                                             bf16x8_t (&out)[NP]) {
+  static_assert(NP >= 3 && NP <= 5, "3..5 panels");
+  const int hh = lane >> 5, cg = (lane >> 4) & 1, i = lane & 15, q = i >> 2, pp = i & 3;
+  const int r0 = rbase + 4 * hh;
+  const int ch = 2 * cg + (pp >> 1);
+  const int sw0 = (r0 >> 2) & 3, sw1 = ((r0 + 8) >> 2) & 3;
+  const unsigned base = (unsigned)(size_t)tile + 8 * (pp & 1);
+  const unsigned a_lo = base + (r0 + q) * 64 + 16 * (ch ^ sw0);
+  const unsigned a_hi = base + (r0 + 8 + q) * 64 + 16 * (ch ^ sw1);
+  constexpr int PS = ROWS * 64;   // panel stride in bytes
+  s16x4_t l0, h0, l1, h1, l2, h2, l3, h3, l4, h4;
+  if constexpr (NP == 3) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %6\n\tds_read_b64_tr_b16 %1, %7\n\t"
+        "ds_read_b64_tr_b16 %2, %6 offset:%8\n\tds_read_b64_tr_b16 %3, %7 offset:%8\n\t"
+        "ds_read_b64_tr_b16 %4, %6 offset:%9\n\tds_read_b64_tr_b16 %5, %7 offset:%9\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2)
+        : "v"(a_lo), "v"(a_hi), "i"(PS), "i"(2 * PS)
+        : "memory");
+  } else if constexpr (NP == 4) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\t"
+        "ds_read_b64_tr_b16 %2, %8 offset:%10\n\tds_read_b64_tr_b16 %3, %9 offset:%10\n\t"
+        "ds_read_b64_tr_b16 %4, %8 offset:%11\n\tds_read_b64_tr_b16 %5, %9 offset:%11\n\t"
+        "ds_read_b64_tr_b16 %6, %8 offset:%12\n\tds_read_b64_tr_b16 %7, %9 offset:%12\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+        : "v"(a_lo), "v"(a_hi), "i"(PS), "i"(2 * PS), "i"(3 * PS)
+        : "memory");
+  } else {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %10\n\tds_read_b64_tr_b16 %1, %11\n\t"
+        "ds_read_b64_tr_b16 %2, %10 offset:%12\n\tds_read_b64_tr_b16 %3, %11 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %4, %10 offset:%13\n\tds_read_b64_tr_b16 %5, %11 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %6, %10 offset:%14\n\tds_read_b64_tr_b16 %7, %11 offset:%14\n\t"
+        "ds_read_b64_tr_b16 %8, %10 offset:%15\n\tds_read_b64_tr_b16 %9, %11 offset:%15\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3),
+          "=&v"(l4), "=&v"(h4)
+        : "v"(a_lo), "v"(a_hi), "i"(PS), "i"(2 * PS), "i"(3 * PS), "i"(4 * PS)
+        : "memory");
+  }
+  __builtin_amdgcn_sched_barrier(0);   // keep the MFMAs below the in-statement wait (guide rule 18)
+  out[0] = make_bf16x8(l0, h0);
+  out[1] = make_bf16x8(l1, h1);
+  out[2] = make_bf16x8(l2, h2);
+  if constexpr (NP >= 4) out[3] = make_bf16x8(l3, h3);
+  if constexpr (NP >= 5) out[4] = make_bf16x8(l4, h4);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 }  // namespace attn
