@@ -276,9 +276,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(svit_attn_bwd_args
             pass == 0 ? dk[j][r] : dv[j][r];
     __syncthreads();
     float* dst = (pass == 0 ? a.dk : a.dv) + ((size_t)bh * a.Nk) * HD;
-    for (int i = tid; i < 128 * HD; i += 256) {
-      const int kr = i / HD, d = i % HD;
-      if (key0 + kr < a.Nk) atomicAdd(dst + (size_t)(key0 + kr) * HD + d, obuf[kr * OUT_LD + d]);
+    if (gridDim.y == 1) {   // this block owns its keys outright: plain coalesced row stores
+      for (int i = tid; i < 128 * HD; i += 256) {
+        const int kr = i / HD, d = i % HD;
+        if (key0 + kr < a.Nk) dst[(size_t)(key0 + kr) * HD + d] += obuf[kr * OUT_LD + d];
+      }
+    } else {
+      for (int i = tid; i < 128 * HD; i += 256) {
+        const int kr = i / HD, d = i % HD;
+        if (key0 + kr < a.Nk) atomicAdd(dst + (size_t)(key0 + kr) * HD + d, obuf[kr * OUT_LD + d]);
+      }
     }
   }
 }
@@ -310,8 +317,11 @@ int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
   const int nqt = (a.Nq + QT - 1) / QT;
   const int key_blocks = (a.Nk + 127) / 128;
   int splits = a.q_splits;
-  if (splits <= 0) {  // aim at >= ~768 blocks
-    splits = (768 + key_blocks * a.B * a.heads - 1) / (key_blocks * a.B * a.heads);
+  if (splits <= 0) {
+    // every split adds a full [128 keys x 192] fp32 tile per block with atomics (~1.3 TB/s
+    // chip-wide), so split the query range only as far as needed to fill the chip
+    const int base = key_blocks * a.B * a.heads;
+    splits = base >= 192 ? 1 : (320 + base - 1) / base;
   }
   if (splits > nqt) splits = nqt;
   if (splits < 1) splits = 1;
