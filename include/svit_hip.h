@@ -166,6 +166,17 @@ typedef struct {
   float* workspace; int64_t workspace_floats;
 } svit_relq_bwd_args;
 int svit_relpos_q_bwd(const svit_relq_bwd_args* a, void* stream);
+/* GEMM formulation of the forward (the one the engine uses): P[tokens, ldp] = q . Rcat^T with
+ * svit_gemm_nt over the concatenated tables (rows row_h.., row_w.., row_t..), then this gather
+ * writes qa[:, 96 + j] = P[token, row_x + idx] * inv_scale (zeros for cls / objects / j >= J). */
+typedef struct {
+  const void* P; int32_t ldp; void* qa; int32_t ld;
+  const int32_t* idx_h; const int32_t* idx_w; const int32_t* idx_t;
+  int32_t row_h, row_w, row_t;
+  int32_t B, heads, qt, qh, qw, kt, kh, kw, n_obj;
+  float inv_scale;
+} svit_relq_gather_args;
+int svit_relpos_gather(const svit_relq_gather_args* a, void* stream);
 /* GEMM formulation of the same backward (the one the engine uses): D[tokens, ldd] (bf16,
  * zero-filled here) receives d(relq) at column off_{h,w,t} + idx; then
  * drel_x += D[:, sec_x]^T q (svit_gemm_tn) and dq_extra = D Rcat (svit_gemm_nt). */

@@ -320,8 +320,10 @@ int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
   if (splits <= 0) {
     // every split adds a full [128 keys x 192] fp32 tile per block with atomics (~1.3 TB/s
     // chip-wide), so split the query range only as far as needed to fill the chip
+    // ~2 blocks per CU, but keep >= 8 query tiles per block to amortise the epilogue
     const int base = key_blocks * a.B * a.heads;
-    splits = base >= 192 ? 1 : (320 + base - 1) / base;
+    splits = (512 + base - 1) / base;
+    if (splits > nqt / 8) splits = nqt / 8;
   }
   if (splits > nqt) splits = nqt;
   if (splits < 1) splits = 1;

@@ -167,7 +167,10 @@ extern "C" int svit_layernorm_bwd(const float* dy, const float* x, const float* 
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace)
     return SVIT_ERR_ARG;
   if (rows <= 0 || C <= 0 || C % 4 != 0 || C > 768) return SVIT_ERR_SHAPE;
-  int64_t blocks = (rows + 3) / 4;
+  // one partial row per block feeds the reduce launch: few rows for small inputs (the reduce
+  // is latency-bound on its row count), up to 2048 blocks for the big ones (bandwidth)
+  int64_t blocks = (rows + 31) / 32;
+  if (blocks < 256) blocks = (rows + 3) / 4 < 256 ? (rows + 3) / 4 : 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks > workspace_floats / (2 * C)) blocks = workspace_floats / (2 * C);
   if (blocks < 1) return SVIT_ERR_ARG;

@@ -514,7 +514,7 @@ static int launch_wgrad(const svit_pool_wgrad_args& a, int Ho, int Wo, hipStream
   const int t_len = (a.T + t_chunks - 1) / t_chunks;
   const int n_tiles = tiles_x * tiles_y * a.B * a.heads * t_chunks;
   int64_t blocks = n_tiles;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 1024) blocks = 1024;
   if (blocks > a.workspace_floats / (27 * HD)) blocks = a.workspace_floats / (27 * HD);
   if (blocks < 1) return SVIT_ERR_ARG;
   static bool configured = false;
@@ -564,6 +564,30 @@ __global__ __launch_bounds__(256) void relq_fwd_kernel(svit_relq_args a) {
     val *= a.inv_scale;
   }
   qrow[HD + j] = f32_to_bf16(val);
+}
+
+// forward as a GEMM + gather: P = q . Rcat^T (svit_gemm_nt, all table rows at once), then each
+// (query, j) picks P[query, section_row_offset + idx] -- 2 bytes read instead of a 96-long dot
+__global__ __launch_bounds__(256) void relq_gather_kernel(svit_relq_gather_args a) {
+  const int extra = a.ld - HD;
+  const int Lq = a.qt * a.qh * a.qw, Nq = 1 + Lq + a.n_obj;
+  const int J = a.kh + a.kw + a.kt;
+  const int tok_per_block = 256 / extra;
+  const int64_t total = (int64_t)a.B * a.heads * Nq;
+  const int64_t row = (int64_t)blockIdx.x * tok_per_block + threadIdx.x / extra;
+  const int j = threadIdx.x % extra;
+  if (row >= total) return;
+  const int tok = (int)(row % Nq);
+  float val = 0.f;
+  if (tok >= 1 && tok <= Lq && j < J) {
+    const int p = tok - 1, x = p % a.qw, y = (p / a.qw) % a.qh, t = p / (a.qw * a.qh);
+    int col;
+    if (j < a.kh) col = a.row_h + a.idx_h[y * a.kh + j];
+    else if (j < a.kh + a.kw) col = a.row_w + a.idx_w[x * a.kw + (j - a.kh)];
+    else col = a.row_t + a.idx_t[t * a.kt + (j - a.kh - a.kw)];
+    val = bf16_to_f32(((const bf16_t*)a.P)[row * a.ldp + col]) * a.inv_scale;
+  }
+  ((bf16_t*)a.qa)[row * a.ld + HD + j] = f32_to_bf16(val);
 }
 
 // backward as GEMMs: scatter d(relq) into the dense-but-sparse matrix D [tokens, Lpad] whose
@@ -676,7 +700,8 @@ extern "C" int svit_pool_ln_bwd(const svit_pool_ln_bwd_args* a, void* stream) {
   if (a->d_main && (a->ld_main < HD || a->ld_main % 8 != 0)) return SVIT_ERR_ALIGN;
   if (!a->workspace) return SVIT_ERR_ARG;
   const int64_t total = (int64_t)a->B * a->heads * a->Nout;
-  int64_t blocks = (total + 63) / 64;
+  int64_t blocks = (total + 255) / 256;            // >= 4 token groups per block
+  if (blocks < 128) blocks = (total + 63) / 64 < 128 ? (total + 63) / 64 : 128;
   if (blocks > 1024) blocks = 1024;
   if (blocks > a->workspace_floats / (2 * HD)) blocks = a->workspace_floats / (2 * HD);
   if (blocks < 1) return SVIT_ERR_ARG;
@@ -728,6 +753,19 @@ extern "C" int svit_relpos_q_fwd(const svit_relq_args* a, void* stream) {
   const int64_t total = (int64_t)a->B * a->heads * (1 + a->qt * a->qh * a->qw + a->n_obj);
   const int tpb = 256 / extra;
   hipLaunchKernelGGL(relq_fwd_kernel, dim3((unsigned)((total + tpb - 1) / tpb)), dim3(256), 0,
+                     (hipStream_t)stream, *a);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_relpos_gather(const svit_relq_gather_args* a, void* stream) {
+  if (!a || !a->P || !a->qa || !a->idx_h || !a->idx_w || !a->idx_t) return SVIT_ERR_ARG;
+  int rc = check_relq(a->ld, a->kh, a->kw, a->kt);
+  if (rc) return rc;
+  const int extra = a->ld - HD;
+  const int64_t total = (int64_t)a->B * a->heads * (1 + a->qt * a->qh * a->qw + a->n_obj);
+  const int tpb = 256 / extra;
+  hipLaunchKernelGGL(relq_gather_kernel, dim3((unsigned)((total + tpb - 1) / tpb)), dim3(256), 0,
                      (hipStream_t)stream, *a);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;

@@ -52,7 +52,8 @@ class FlatParams:
         self.total = off
         self.data = torch.zeros(off, device=device, dtype=F32)
         self.grad = torch.zeros(off, device=device, dtype=F32)
-        self.w16 = torch.zeros(off, device=device, dtype=BF16)
+        # bf16 mirror (+ slack so that GEMM operands padded past a slot stay inside the buffer)
+        self.w16 = torch.zeros(off + 96 * 96, device=device, dtype=BF16)
         # transposed copies of every 2-D Linear weight in the blocks
         self.t_slots, toff, table = {}, 0, []
         for n in order:
@@ -102,8 +103,20 @@ class FlatParams:
         off, lpad, offs = self.rel_slots[pre]
         return self.wT16[off:off + HD * lpad].view(HD, lpad), lpad, offs
 
+    def rel_cat(self, pre):
+        """bf16 [Lpad96, 96] view of the block's three rel-pos tables (adjacent slots of the
+        mirror; rows past h+w+t belong to other parameters and are never gathered),
+        plus the row offsets of the three sections."""
+        names = [pre + "attn.rel_pos_" + a for a in "hwt"]
+        offs = [self.slots[n][0] for n in names]
+        rows = [self.slots[n][2][0] for n in names]
+        assert offs[1] == offs[0] + rows[0] * HD and offs[2] == offs[1] + rows[1] * HD
+        total = rows[0] + rows[1] + rows[2]
+        lpad = (total + 95) // 96 * 96
+        return (self.w16[offs[0]:offs[0] + lpad * HD].view(lpad, HD), (0, rows[0], rows[0] + rows[1]))
+
     def refresh_low_precision(self):
-        ops.cast_bf16(self.data, self.w16)
+        ops.cast_bf16(self.data, self.w16[:self.total])
         if self.n_t:
             ops.transpose_cast_batched(self.data, self.wT16, self.t_table, self.n_t, 256)
 
@@ -231,7 +244,17 @@ class Engine:
         qa, ka, v = pools[0][0], pools[1][0], pools[2][0]
         idx, mats = self._rel(blk, q_thw, k_thw)
         tabs = self._tables(pre, mats)
-        ops.relpos_q_fwd(qa, tabs, idx, B, h, q_thw, k_thw, n_obj, 1.0 / SCALE)
+        # rel-pos query side: P = q . Rcat^T on the MFMA GEMM, then a 2-byte gather per (q, j)
+        if all(m is None for m in mats):
+            rcat, rows_off = f.rel_cat(pre)
+        else:   # interpolated tables (odd crops, T=1 frames pass): tiny torch plumbing
+            rows = [t.shape[0] for t in tabs]
+            lp = (sum(rows) + 95) // 96 * 96
+            rcat = torch.zeros((lp, HD), device=self.dev, dtype=BF16)
+            rcat[:sum(rows)] = torch.cat(tabs, 0).to(BF16)
+            rows_off = (0, rows[0], rows[0] + rows[1])
+        P = ops.gemm_nt(qa.view(B * h * Nq, DA)[:, :HD], rcat, None, hip.EPI_BF16)
+        ops.relpos_gather(P, qa, idx, rows_off, B, h, q_thw, k_thw, n_obj, 1.0 / SCALE)
         ctx, lse2 = ops.attn_fwd(qa, ka, v, SCALE)
         pool_idx = None
         if blk.has_proj:

@@ -69,6 +69,13 @@ class RelqBwdArgs(C.Structure):
                 ("workspace", vp), ("workspace_floats", i64)]
 
 
+class RelqGatherArgs(C.Structure):
+    _fields_ = [("P", vp), ("ldp", i32), ("qa", vp), ("ld", i32), ("idx_h", vp), ("idx_w", vp),
+                ("idx_t", vp), ("row_h", i32), ("row_w", i32), ("row_t", i32), ("B", i32),
+                ("heads", i32), ("qt", i32), ("qh", i32), ("qw", i32), ("kt", i32), ("kh", i32),
+                ("kw", i32), ("n_obj", i32), ("inv_scale", f32)]
+
+
 class RelqScatterArgs(C.Structure):
     _fields_ = [("dqa", vp), ("ld", i32), ("D", vp), ("ldd", i32), ("idx_h", vp), ("idx_w", vp),
                 ("idx_t", vp), ("off_h", i32), ("off_w", i32), ("off_t", i32), ("B", i32),
@@ -108,6 +115,7 @@ _SIGS = {
     "svit_relpos_q_fwd": (i32, [C.POINTER(RelqArgs), vp]),
     "svit_relpos_q_bwd": (i32, [C.POINTER(RelqBwdArgs), vp]),
     "svit_relpos_scatter": (i32, [C.POINTER(RelqScatterArgs), vp]),
+    "svit_relpos_gather": (i32, [C.POINTER(RelqGatherArgs), vp]),
     "svit_attn_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),
     "svit_attn_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),
     "svit_maxpool_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

@@ -43,8 +43,10 @@ def _chk_dev(*ts):
 
 def gemm_nt(a, w, bias=None, epilogue=hip.EPI_BF16, out=None, out2=None, aux=None,
             row_scale=None, rows_per_sample=0, accumulate=False, remap=None):
-    """C = A[M,K] @ W[N,K]^T with a fused epilogue (see include/svit_hip.h)."""
-    _chk_dev(a, w, bias, out, out2, aux, row_scale)
+    """C = A[M,K] @ W[N,K]^T with a fused epilogue (see include/svit_hip.h).  `a` may be a
+    column slice of a wider matrix (row-strided view)."""
+    _chk_rows(a)
+    _chk_dev(w, bias, out, out2, aux, row_scale)
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K and a.dtype == BF16 and w.dtype == BF16
@@ -243,6 +245,19 @@ def relpos_q_bwd(qa, dqa, tabs, idx, dtabs, B, heads, q_thw, k_thw, n_obj, inv_s
     a.workspace, a.workspace_floats = ptr(ws), ws.numel()
     hip.call("svit_relpos_q_bwd", C.byref(a))
     return dq_extra
+
+
+def relpos_gather(P, qa, idx, rows_off, B, heads, q_thw, k_thw, n_obj, inv_scale):
+    """qa[..., 96 + j] = P[token, rows_off[sec] + idx] * inv_scale (see svit_relpos_gather)."""
+    a = hip.RelqGatherArgs()
+    a.P, a.ldp, a.qa, a.ld = ptr(P), P.shape[-1], ptr(qa), qa.shape[-1]
+    a.idx_h, a.idx_w, a.idx_t = (ptr(t) for t in idx)
+    a.row_h, a.row_w, a.row_t = rows_off
+    a.B, a.heads = B, heads
+    a.qt, a.qh, a.qw = q_thw
+    a.kt, a.kh, a.kw = k_thw
+    a.n_obj, a.inv_scale = n_obj, inv_scale
+    hip.call("svit_relpos_gather", C.byref(a))
 
 
 def relpos_scatter(dqa, idx, offs, ldd, B, heads, q_thw, k_thw, n_obj, inv_scale):

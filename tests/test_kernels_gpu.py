@@ -301,8 +301,22 @@ def test_relpos_q(ops, q_thw, k_thw):
     assert rel_err(dq_extra, q.grad) < 2e-3
     for i in range(3):
         assert rel_err(dtabs[i], tc[i].grad) < 2e-3
-    # the GEMM formulation the engine uses: scatter -> D, dR = D^T q, dq = D Rcat
+    # forward, GEMM formulation the engine uses: P = q Rcat^T, then gather
     from svit_amd import hip
+    rows_off = (0, rows[0], rows[0] + rows[1])
+    lp96 = (sum(rows) + 95) // 96 * 96
+    rc16 = torch.zeros((lp96, 96), device=DEV, dtype=BF16)
+    rc16[:sum(rows)] = torch.cat(tabs, 0).to(BF16)
+    qb = qa.clone()
+    qb[..., 96:] = 5.0
+    Pm = ops.gemm_nt(qb.view(-1, ld)[:, :96], rc16, None, hip.EPI_BF16)
+    ops.relpos_gather(Pm, qb, idx_d, rows_off, B, h, q_thw, k_thw, O, 1.0 / scale)
+    rel2 = qb[..., 96:].float().cpu() * scale
+    got2 = (rel2[:, :, 1:1 + Lq][..., (p // kw) % kh] + rel2[:, :, 1:1 + Lq][..., kh + p % kw] +
+            rel2[:, :, 1:1 + Lq][..., kh + kw + p // (kw * kh)])
+    assert rel_err(got2, bias) < 3e-2 and cos(got2, bias) > 0.9998
+    assert float(rel2[:, :, 0].abs().max()) == 0 and float(rel2[..., J:].abs().max()) == 0
+    # the GEMM formulation the engine uses: scatter -> D, dR = D^T q, dq = D Rcat
     from svit_amd.engine import rel_sections
     offs, lpad = rel_sections(rows)
     D = ops.relpos_scatter(dqa, idx_d, offs, lpad, B, h, q_thw, k_thw, O, 1.0 / scale)
