@@ -9,116 +9,102 @@ namespace {
 
 // ---------------------------------------------------------------------------------------
 // TN kernel: out tile 128(n) x 96(k), 4 waves, each wave one 32-row n-block x 96 k columns.
-// Reduction rows arrive 32 at a time by LDS-DMA (global_load_lds_dwordx4) into a 4-stage ring
-// behind a counted vmcnt and one raw barrier per step; both operands sit [m][cols] in LDS and
-// are consumed through ds_read_b64_tr_b16 (inline asm: see attn_common.h on why not the
-// builtin while DMA is in flight).  LDS images are lane-linear as the DMA requires:
-//   A stage [32][128] bf16, 256-B rows; the four 64-B column groups of a row are XOR-swizzled
-//     with (row & 3) on the SOURCE address so the 4 rows of a transposed block hit 4 bank groups;
-//   B stage [32][96] bf16, 192-B rows: 4 consecutive rows already fall on disjoint bank groups.
-// Rows past the split's end and columns past N / K are fetched from a zero block.
-// The bias gradient (column sums of A) rides along as one extra MFMA against an all-ones
-// operand on the k-tile-0 blocks.
+// Both operands are [rows=m][cols] in LDS and read transposed (ds_read_b64_tr_b16).
 // ---------------------------------------------------------------------------------------
-constexpr int TN_BM = 32;        // reduction rows per stage
-constexpr int TN_STAGES = 4;
+constexpr int TN_BM = 64;        // reduction rows per step
 constexpr int TN_TN = 128, TN_TK = 96;
-constexpr int TN_A_BYTES = TN_BM * TN_TN * 2;   // 8 KB
-constexpr int TN_B_BYTES = TN_BM * TN_TK * 2;   // 6 KB
-constexpr int TN_STAGE_BYTES = TN_A_BYTES + TN_B_BYTES;
-constexpr int TN_PER_WAVE = 4;   // 14 KB = 14 one-KB DMA instructions -> 4 per wave (2 repeats)
+constexpr int TN_ROWA = TN_TN * 2 + 64;  // 320 B: the 4 rows of a tr block hit disjoint banks
+constexpr int TN_ROWB = TN_TK * 2;       // 192 B: conflict-free as is
 
-__device__ uint4 svit_zero16 = {0u, 0u, 0u, 0u};
-
-template <int N>
-__device__ __forceinline__ void tn_wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restrict__ A, int lda,
-                                                         const bf16_t* __restrict__ B, int ldb,
-                                                         float* __restrict__ dW, int lddw, int M,
-                                                         int N, int K, int rows_per_split,
-                                                         float* __restrict__ dbias) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[TN_STAGES * TN_STAGE_BYTES];
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ A, int lda,
+                                                      const bf16_t* __restrict__ B, int ldb,
+                                                      float* __restrict__ dW, int lddw, int M,
+                                                      int N, int K, int rows_per_split,
+                                                      float* __restrict__ dbias) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][TN_BM * (TN_ROWA + TN_ROWB)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * TN_TN, k0 = blockIdx.y * TN_TK;
   const int m_begin = blockIdx.z * rows_per_split;
   const int m_end = min(M, m_begin + rows_per_split);
   if (m_begin >= m_end) return;
-  const bf16_t* zero = (const bf16_t*)&svit_zero16;
 
-  // DMA instruction n (0..13) of a stage: n < 8 -> A rows 4n..4n+3; else B chunks (n-8)*64..
-  auto issue = [&](int step, int stage) {
-    unsigned char* st = lds + stage * TN_STAGE_BYTES;
-    const int mb = m_begin + step * TN_BM;
+  constexpr int A_CH = TN_TN / 8, B_CH = TN_TK / 8;        // 16 / 12 chunks per row
+  constexpr int A_PER = TN_BM * A_CH / 256, B_PER = TN_BM * B_CH / 256;  // 4 / 3
+  uint4 ra[A_PER], rb[B_PER];
+  auto load_tiles = [&](int mb) {
 #pragma unroll
-    for (int i = 0; i < TN_PER_WAVE; ++i) {
-      int n = wave + i * 4;
-      if (n > 13) n = 13;
-      const bf16_t* src;
-      unsigned char* dst;
-      if (n < 8) {
-        const int row = n * 4 + (lane >> 4), slot = lane & 15;
-        const int grp = (slot >> 2) ^ (row & 3);             // logical 64-B column group
-        const int col = n0 + grp * 32 + (slot & 3) * 8;
-        src = (mb + row < m_end && col < N) ? A + (size_t)(mb + row) * lda + col : zero;
-        dst = st + n * 1024;
-      } else {
-        const int q = (n - 8) * 64 + lane;                   // chunk index in the B stage
-        const int row = q / 12, col = k0 + (q % 12) * 8;
-        src = (mb + row < m_end && col < K) ? B + (size_t)(mb + row) * ldb + col : zero;
-        dst = st + TN_A_BYTES + (n - 8) * 1024;
+    for (int i = 0; i < A_PER; ++i) {
+      const int c = tid + i * 256, r = c / A_CH, cc = c % A_CH;
+      const int gm = mb + r, gn = n0 + cc * 8;
+      ra[i] = make_uint4(0, 0, 0, 0);
+      if (gm < m_end && gn < N) ra[i] = *(const uint4*)(A + (size_t)gm * lda + gn);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int c = tid + i * 256, r = c / B_CH, cc = c % B_CH;
+      const int gm = mb + r, gk = k0 + cc * 8;
+      rb[i] = make_uint4(0, 0, 0, 0);
+      if (gm < m_end && gk < K) rb[i] = *(const uint4*)(B + (size_t)gm * ldb + gk);
+    }
+  };
+  // fused bias gradient: column sums of A (= dY) ride along on the k-tile-0 blocks; a thread
+  // always stages the same 8-column chunk (tid % 16), so it keeps 8 running sums
+  const bool do_bias = (dbias != nullptr) && (blockIdx.y == 0);
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto store_tiles = [&](int buf) {
+    unsigned char* la = lds[buf];
+    unsigned char* lb = lds[buf] + TN_BM * TN_ROWA;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int c = tid + i * 256;
+      *(uint4*)(la + (c / A_CH) * TN_ROWA + (c % A_CH) * 16) = ra[i];
+      if (do_bias) {
+        bsum[0] += lo_bf16(ra[i].x); bsum[1] += hi_bf16(ra[i].x);
+        bsum[2] += lo_bf16(ra[i].y); bsum[3] += hi_bf16(ra[i].y);
+        bsum[4] += lo_bf16(ra[i].z); bsum[5] += hi_bf16(ra[i].z);
+        bsum[6] += lo_bf16(ra[i].w); bsum[7] += hi_bf16(ra[i].w);
       }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int c = tid + i * 256;
+      *(uint4*)(lb + (c / B_CH) * TN_ROWB + (c % B_CH) * 16) = rb[i];
     }
   };
 
-  f32x16_t acc[3], accb;
+  f32x16_t acc[3];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; acc[2][r] = 0.f; accb[r] = 0.f; }
-  const bool do_bias = (dbias != nullptr) && (blockIdx.y == 0);
-  bf16x8_t ones;
+  for (int j = 0; j < 3; ++j)
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  // transposed-read addresses within a stage (k-step 0); lane -> (hh, cg, q, pp)
+  // transposed-read addressing: lane -> (half hh, column group cg, in-group i -> (q,p))
   const int hh = lane >> 5, cg = (lane >> 4) & 1, ii = lane & 15, q = ii >> 2, pp = ii & 3;
-  const unsigned lds0 = (unsigned)(size_t)lds;
-  const unsigned a_off = (8 * hh + q) * 256 + ((wave ^ q) & 3) * 64 + 32 * cg + 8 * pp;
-  const unsigned b_off = TN_A_BYTES + (8 * hh + q) * 192 + 32 * cg + 8 * pp;
+  const int a_off = (8 * hh + q) * TN_ROWA + (wave * 32 + 16 * cg + 4 * pp) * 2;
+  const int b_off = (8 * hh + q) * TN_ROWB + (16 * cg + 4 * pp) * 2;
 
   const int nsteps = (m_end - m_begin + TN_BM - 1) / TN_BM;
-#pragma unroll
-  for (int s = 0; s < TN_STAGES - 1; ++s)
-    if (s < nsteps) issue(s, s);
+  load_tiles(m_begin);
+  store_tiles(0);
+  __syncthreads();
   for (int s = 0; s < nsteps; ++s) {
-    if (s + TN_STAGES - 2 < nsteps) tn_wait_vmcnt<(TN_STAGES - 2) * TN_PER_WAVE>();
-    else tn_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (s + TN_STAGES - 1 < nsteps) issue(s + TN_STAGES - 1, (s + TN_STAGES - 1) % TN_STAGES);
-    const unsigned st = lds0 + (s % TN_STAGES) * TN_STAGE_BYTES;
+    const int cur = s & 1;
+    if (s + 1 < nsteps) load_tiles(m_begin + (s + 1) * TN_BM);
+    const unsigned char* la = lds[cur] + a_off;
+    const unsigned char* lb = lds[cur] + TN_BM * TN_ROWA + b_off;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      s16x4_t al, ah, b0l, b0h, b1l, b1h, b2l, b2h;
-      const unsigned pa = st + a_off + ks * 16 * 256, pb = st + b_off + ks * 16 * 192;
-      asm volatile(
-          "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
-          "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:768\n\t"
-          "ds_read_b64_tr_b16 %4, %9 offset:64\n\tds_read_b64_tr_b16 %5, %9 offset:832\n\t"
-          "ds_read_b64_tr_b16 %6, %9 offset:128\n\tds_read_b64_tr_b16 %7, %9 offset:896\n\t"
-          "s_waitcnt lgkmcnt(0)"
-          : "=&v"(al), "=&v"(ah), "=&v"(b0l), "=&v"(b0h), "=&v"(b1l), "=&v"(b1h), "=&v"(b2l), "=&v"(b2h)
-          : "v"(pa), "v"(pb)
-          : "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      const bf16x8_t af = make_bf16x8(al, ah);
-      acc[0] = mfma32(af, make_bf16x8(b0l, b0h), acc[0]);
-      acc[1] = mfma32(af, make_bf16x8(b1l, b1h), acc[1]);
-      acc[2] = mfma32(af, make_bf16x8(b2l, b2h), acc[2]);
-      if (do_bias) accb = mfma32(af, ones, accb);
+    for (int ks = 0; ks < TN_BM / 16; ++ks) {
+      const bf16x8_t af = make_bf16x8(lds_read_tr16(la + (ks * 16) * TN_ROWA),
+                                      lds_read_tr16(la + (ks * 16 + 4) * TN_ROWA));
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const bf16x8_t bfr = make_bf16x8(lds_read_tr16(lb + (ks * 16) * TN_ROWB + j * 64),
+                                         lds_read_tr16(lb + (ks * 16 + 4) * TN_ROWB + j * 64));
+        acc[j] = mfma32(af, bfr, acc[j]);
+      }
     }
+    if (s + 1 < nsteps) store_tiles(cur ^ 1);
+    __syncthreads();
   }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -130,11 +116,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t* __restric
       if (row < N) atomicAdd(dW + (size_t)row * lddw + col, acc[j][r]);
     }
   }
-  if (do_bias && (lane & 31) == 0) {   // every column of accb holds the same column sums
+  if (do_bias) {  // 16 threads share a column chunk: reduce through LDS, one atomic per column
+    float* red = (float*)&lds[0][0];  // [16][128]
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = n0 + wave * 32 + acc_row(r, lane);
-      if (row < N) atomicAdd(dbias + row, accb[r]);
+    for (int e = 0; e < 8; ++e) red[(tid / A_CH) * TN_TN + (tid % A_CH) * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < TN_TN && n0 + tid < N) {
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) sum += red[g * TN_TN + tid];
+      atomicAdd(dbias + n0 + tid, sum);
     }
   }
 }

@@ -1,0 +1,90 @@
+"""Two data-parallel ranks sharing the one GPU of the test box (gloo transport on device
+tensors): the full training step through build_model -> DataParallel -> engine hooks ->
+bucketed async all-reduce -> fused optimiser must equal a single rank on the merged batch."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import procedural as P
+    from oracle import svit_ref as R
+    from svit_amd import config, optim
+    from svit_amd.dp import DataParallel
+    from svit_amd.model import MODEL_REGISTRY
+    cfg = config.ssv2_cfg(num_frames=4, crop=64, num_gpus=world)
+    cfg.MVIT.DROPPATH_RATE = 0.0
+    cfg.MODEL.DROPOUT_RATE = 0.0
+    model = MODEL_REGISTRY.get("SViT")(cfg).cuda()
+    spec = R.make_spec(4, 64, drop_path_rate=0.0, dropout_rate=0.0)
+    sd = P.state_dict(R.param_shapes(spec))
+    if rank == 0:
+        model.load_state_dict(sd)          # rank 1 keeps its random init: must be overwritten
+    dp = DataParallel(model, bucket_ranks=4) if world > 1 else model
+    opt = optim.construct_optimizer(dp, cfg)
+    optim.set_lr(opt, 1e-3)
+    x_all, y_all = P.frames(4, 4, 64), P.labels(4)
+    per = 4 // world
+    x = x_all[rank * per:(rank + 1) * per].cuda()
+    y = y_all[rank * per:(rank + 1) * per].cuda()
+    for _ in range(2):
+        logits, _ = dp([x], {})
+        loss = torch.nn.functional.cross_entropy(logits, y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    flat = model.flat.data.detach().cpu()
+    if world > 1:
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1]), "ranks diverged"
+    if rank == 0:
+        torch.save(flat, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, out):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return torch.load(out)
+
+
+def test_two_ranks_equal_one_rank_on_merged_batch(tmp_path):
+    one = _run(1, str(tmp_path / "w1.pt"))
+    two = _run(2, str(tmp_path / "w2.pt"))
+    # same weights after two optimiser steps (CE mean over 4 clips == mean of two 2-clip means)
+    diff = (one - two).abs().max().item()
+    scale = (one.abs().max().item())
+    assert diff < 2e-3 * scale, (diff, scale)
+    cos = torch.dot(one.double(), two.double()) / (one.double().norm() * two.double().norm())
+    assert cos > 0.999999
