@@ -219,7 +219,10 @@ int svit_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int 
 /* ------------------------------------------------------------- optimiser tail (K17) ---- */
 /* clip_grad_norm_(1.0) + AdamW (tools/train_net.py:144-151, models/optimizer.py:102-108)
  * on flat f32 buffers.  sumsq is a device scalar (pre-zeroed). */
-int svit_sumsq(const float* g, int64_t n, float* sumsq, void* stream);
+/* sumsq += sum(g^2), deterministic (two-stage through `workspace`, >= 1024 floats): replicas
+ * of a data-parallel job must derive the bit-identical clip coefficient. */
+int svit_sumsq(const float* g, int64_t n, float* sumsq, float* workspace,
+               int64_t workspace_floats, void* stream);
 int svit_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
                     float max_norm, float lr, float beta1, float beta2, float eps, float wd,
                     int step, float grad_scale, void* stream);

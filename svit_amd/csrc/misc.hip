@@ -215,7 +215,9 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
 }
 
 // ---- optimiser tail ---------------------------------------------------------------------
-__global__ void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+// Deterministic two-stage sum of squares: replicas of a data-parallel job must compute the
+// bit-identical clip coefficient from their (identical, all-reduced) gradients, so no atomics.
+__global__ void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partial) {
   float s = 0.f;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
@@ -230,7 +232,15 @@ __global__ void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __re
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void sumsq_final_kernel(const float* __restrict__ partial, int nblocks,
+                                   float* __restrict__ out) {
+  // one wave, fixed order: lane l sums partial[l], partial[l+64], ... then a butterfly
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 64) s += partial[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) *out += s;
 }
 
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -350,10 +360,16 @@ extern "C" int svit_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, 
   return SVIT_OK;
 }
 
-extern "C" int svit_sumsq(const float* g, int64_t n, float* sumsq, void* stream) {
-  if (!g || !sumsq || n <= 0) return SVIT_ERR_ARG;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for((n + 3) / 4, 256, 1024)), dim3(256), 0,
-                     (hipStream_t)stream, g, n, sumsq);
+extern "C" int svit_sumsq(const float* g, int64_t n, float* sumsq, float* workspace,
+                          int64_t workspace_floats, void* stream) {
+  if (!g || !sumsq || !workspace || n <= 0) return SVIT_ERR_ARG;
+  unsigned blocks = grid_for((n + 3) / 4, 256, 1024);
+  if ((int64_t)blocks > workspace_floats) blocks = (unsigned)workspace_floats;
+  if (blocks < 1) return SVIT_ERR_ARG;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, workspace);
+  SVIT_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace,
+                     (int)blocks, sumsq);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }

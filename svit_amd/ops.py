@@ -326,7 +326,8 @@ def maxpool_bwd(dy, idx, thw, n_obj):
 
 
 def sumsq(g, out):
-    hip.call("svit_sumsq", ptr(g), g.numel(), ptr(out))
+    ws = scratch(g.device)
+    hip.call("svit_sumsq", ptr(g), g.numel(), ptr(out), ptr(ws), ws.numel())
 
 
 def adamw_step(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):

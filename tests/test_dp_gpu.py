@@ -60,7 +60,8 @@ def _worker(rank, world, port, out):
     if world > 1:
         both = [torch.zeros_like(flat) for _ in range(world)]
         dist.all_gather(both, flat)
-        assert torch.equal(both[0], both[1]), "ranks diverged"
+        assert torch.equal(both[0], both[1]), "ranks diverged: max |diff| = %g" % float(
+            (both[0] - both[1]).abs().max())
     if rank == 0:
         torch.save(flat, out)
     dist.barrier()
