@@ -37,10 +37,23 @@ def synth_batch(cfg, batch, device, seed):
     return x.to(device), y.to(device)
 
 
+def usable_cores():
+    """CPU share of this process: affinity mask capped by the cgroup cpu quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(frames, crop, timed_steps=2):
     """fp32 CPU oracle (oracle/svit_ref.py, pinned against the reference) fwd+bwd at B=1."""
     from oracle import svit_ref as R
-    threads = torch.get_num_threads()
+    threads = min(usable_cores(), 64)
+    torch.set_num_threads(threads)
     spec = R.make_spec(num_frames=frames, crop=crop)
     torch.manual_seed(0)
     p = {k: (torch.randn(s) * 0.02).requires_grad_(True) for k, s in R.param_shapes(spec).items()}
