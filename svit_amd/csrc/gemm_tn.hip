@@ -199,12 +199,18 @@ extern "C" int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, floa
   const int TN = wide_k ? 128 : 256, TK = wide_k ? 192 : 96;
   const int tiles = ((N + TN - 1) / TN) * ((K + TK - 1) / TK);
   if (splits <= 0) {
-    // every split adds the whole [N,K] tile set with fp32 atomics (~1.3 TB/s chip-wide): take
-    // just enough splits to fill the chip (~2 blocks per CU), at least 8 reduction steps each
-    splits = (512 + tiles - 1) / tiles;
-    const int max_by_rows = (M + 8 * TN_BM - 1) / (8 * TN_BM);
-    if (splits > max_by_rows) splits = max_by_rows;
-    if (splits < 1) splits = 1;
+    // Cost model fitted on MI355X (tools/bench_kernels.py tnsplit): a block needs ~0.8 us per
+    // 32-row step, 512 blocks run concurrently, and every split adds the whole [N,K] fp32
+    // tile set with atomics at ~1.3 TB/s chip-wide.  Take the split count minimising the sum.
+    const double atom_us = (double)N * K * 4.0 / 1.3e6;
+    double best = 1e30;
+    for (int s = 1; s <= 1024; s *= 2) {
+      const long steps = ((M + s - 1) / s + TN_BM - 1) / TN_BM;
+      if (steps < 2 && s > 1) break;
+      const long rounds = ((long)tiles * s + 511) / 512;
+      const double t = (double)rounds * steps * 0.8 + s * atom_us;
+      if (t < best) { best = t; splits = s; }
+    }
   }
   int rows_per_split = (M + splits - 1) / splits;
   rows_per_split = ((rows_per_split + TN_BM - 1) / TN_BM) * TN_BM;

@@ -146,3 +146,20 @@ def bench_pool():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pool":
     bench_pool()
+
+
+def bench_tn_splits():
+    print("== gemm_tn split sweep (us) ==")
+    for (M, N, K) in [(13064, 1152, 384), (13064, 384, 384), (13064, 384, 1536), (50696, 576, 192),
+                      (201224, 288, 96), (3656, 2304, 768)]:
+        a, b = rnd(M, N), rnd(M, K)
+        dw = torch.zeros(N, K, device=DEV)
+        res = []
+        for sp in (1, 2, 4, 8, 16, 32, 64, 0):
+            us = timeit(lambda: ops.gemm_tn(a, b, dw, splits=sp), iters=10)
+            res.append("%d:%.0f" % (sp, us))
+        print("M=%6d N=%4d K=%4d  " % (M, N, K), "  ".join(res))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tnsplit":
+    bench_tn_splits()
