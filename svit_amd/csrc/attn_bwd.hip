@@ -105,11 +105,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
     for (int r = 0; r < 16; ++r) dq[j][r] = 0.f;
 
   const int nt = (a.Nk + KT - 1) / KT;
+  KLoad kload;
+  VLoad vload;
+  kload.init(DA, wave, lane);
+  vload.init(HD, wave, lane);
   auto issue = [&](int t) {
     unsigned char* st = smem + (t & 1) * STAGE;
     const int k0 = t * KT;
-    KLoad::issue(ka + (size_t)k0 * DA, DA, a.Nk - k0, st, wave, lane);
-    VLoad::issue(vv + (size_t)k0 * HD, HD, a.Nk - k0, st + K_BYTES, wave, lane);
+    kload.issue_auto(ka + (size_t)k0 * DA, DA, a.Nk - k0, st, wave, lane);
+    vload.issue_auto(vv + (size_t)k0 * HD, HD, a.Nk - k0, st + K_BYTES, wave, lane);
   };
   issue(0);
   for (int t = 0; t < nt; ++t) {
@@ -128,12 +132,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
       for (int ks = 0; ks < KS; ++ks) s = mfma32(row_frag<KT>(k_cur, kb * 32, ks, lane), qf[ks], s);
 #pragma unroll
       for (int ks = 0; ks < 6; ++ks) dp = mfma32(row_frag<KT>(v_cur, kb * 32, ks, lane), dof[ks], dp);
+      if (kbase + KT > a.Nk) {   // ragged last tile: rows past Nk hold re-read data
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float p = exp2f(s[r] * c - lse_p);
-        if (kbase + kb * 32 + acc_row(r, lane) >= a.Nk) p = 0.f;   // rows past Nk hold re-read data
-        s[r] = p * (dp[r] - dlt_p) * a.scale;
+        for (int r = 0; r < 16; ++r)
+          if (kbase + kb * 32 + acc_row(r, lane) >= a.Nk) s[r] = -INFINITY;
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r] * c - lse_p) * (dp[r] - dlt_p) * a.scale;
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp) {
         const bf16x8_t dsf = acc_to_frag(s, sp);
@@ -206,11 +211,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(svit_attn_bwd_args
   const int nqt = (a.Nq + QT - 1) / QT;
   const int t_begin = blockIdx.y * tiles_per_split;
   const int t_end = min(nqt, t_begin + tiles_per_split);
+  QLoad qload;
+  OLoad oload;
+  qload.init(DA, wave, lane);
+  oload.init((size_t)a.heads * HD, wave, lane);
   auto issue = [&](int t) {
     unsigned char* st = smem + ((t - t_begin) % NSTAGE) * STAGE;
     const int q0 = t * QT;
-    QLoad::issue(qa + (size_t)q0 * DA, DA, a.Nq - q0, st, wave, lane);
-    OLoad::issue(dob + (size_t)q0 * a.heads * HD, (size_t)a.heads * HD, a.Nq - q0, st + Q_BYTES, wave, lane);
+    qload.issue_auto(qa + (size_t)q0 * DA, DA, a.Nq - q0, st, wave, lane);
+    oload.issue_auto(dob + (size_t)q0 * a.heads * HD, (size_t)a.heads * HD, a.Nq - q0, st + Q_BYTES, wave, lane);
     // 32 (lse2, delta) pairs = 64 floats = one dword LDS-DMA (rows past Nq re-read the last pair)
     const int qrow = min(q0 + (lane >> 1), a.Nq - 1);
     __builtin_amdgcn_global_load_lds(
@@ -244,8 +253,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(svit_attn_bwd_args
       const float lv[4] = {p01.x, p01.z, p23.x, p23.z}, dl[4] = {p01.y, p01.w, p23.y, p23.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float p = exp2f(s[4 * g + e] * c - lv[e]);
-        if (q0 + 8 * g + 4 * hh + e >= a.Nq) p = 0.f;          // rows past Nq hold re-read data
+        float p = fast_exp2(s[4 * g + e] * c - lv[e]);
+        if (q0 + QT > a.Nq && q0 + 8 * g + 4 * hh + e >= a.Nq) p = 0.f;   // re-read rows past Nq
         s[4 * g + e] = p;
         dp[4 * g + e] = p * (dp[4 * g + e] - dl[e]) * a.scale;
       }

@@ -100,6 +100,35 @@ struct GldsTile {
   static constexpr int RG = ROWS / 16;                   // 16-row groups per panel
   static constexpr int INSTRS = RG * (COLS / 32);
   static constexpr int PER_WAVE = (INSTRS + NWAVES - 1) / NWAVES;
+  // per-lane element offsets inside a tile are tile-invariant: computed once, so a full tile
+  // costs one 64-bit add per DMA instruction instead of ~10 VALU of address arithmetic
+  unsigned off[PER_WAVE];
+  __device__ __forceinline__ void init(size_t ld, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      int n = wave + i * NWAVES;
+      if (n >= INSTRS) n = INSTRS - 1;
+      const int panel = n / RG, rg = n % RG;
+      const int row = rg * 16 + (lane >> 2);
+      const int ch = (lane & 3) ^ ((row >> 2) & 3);
+      off[i] = (unsigned)(row * ld + panel * 32 + ch * 8);
+    }
+  }
+  __device__ static __forceinline__ unsigned char* dst_of(unsigned char* tile, int wave, int i) {
+    int n = wave + i * NWAVES;
+    if (n >= INSTRS) n = INSTRS - 1;
+    return tile + (n / RG) * ROWS * 64 + (n % RG) * 1024;
+  }
+  // all ROWS rows exist
+  __device__ __forceinline__ void issue_full(const bf16_t* __restrict__ src, unsigned char* tile,
+                                             int wave) const {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + off[i]),
+          (__attribute__((address_space(3))) void*)dst_of(tile, wave, i), 16, 0, 0);
+  }
+  // ragged tile: rows >= valid_rows re-read the last valid row
   __device__ static __forceinline__ void issue(const bf16_t* __restrict__ src, size_t ld,
                                                int valid_rows, unsigned char* tile, int wave,
                                                int lane) {
@@ -113,10 +142,23 @@ struct GldsTile {
       const int grow = min(row, valid_rows - 1);
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(src + (size_t)grow * ld + panel * 32 + ch * 8),
-          (__attribute__((address_space(3))) void*)(tile + panel * ROWS * 64 + rg * 1024), 16, 0, 0);
+          (__attribute__((address_space(3))) void*)dst_of(tile, wave, i), 16, 0, 0);
     }
   }
+  __device__ __forceinline__ void issue_auto(const bf16_t* __restrict__ src, size_t ld,
+                                             int valid_rows, unsigned char* tile, int wave,
+                                             int lane) const {
+    if (valid_rows >= ROWS) issue_full(src, tile, wave);
+    else issue(src, ld, valid_rows, tile, wave, lane);
+  }
 };
+
+// max of three in one VALU op (fmaxf() compiles to canonicalise + v_max pairs on MFMA outputs)
+__device__ __forceinline__ float max3(float a, float b, float c3) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c3));
+  return r;
+}
 
 // NP transposed fragments (panels 0..NP-1, same rows) fetched by ONE inline-asm statement that
 // also waits for them.  Needed in kernels that keep LDS-DMA in flight: hipcc puts an

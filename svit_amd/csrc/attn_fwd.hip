@@ -7,8 +7,9 @@
 // qa.ka^T * scale = scale*q.k + rel_h[y] + rel_w[x] + rel_t[t]; cls/object rows/cols carry
 // zeros there.  Head dim of the contraction DA = 128 or 160, value dim 96.
 //
-// Work split: block = 4 waves x 32 queries; K/V tiles of 64 keys are register-staged into a
-// double-buffered, swizzled LDS panel image (attn_common.h), one barrier per tile.  Scores are
+// Work split: block = 4 waves x 32 queries; K/V tiles of 64 keys arrive by LDS-DMA
+// (global_load_lds) in a two-stage, swizzled LDS panel image (attn_common.h), one raw barrier
+// per tile behind the wave's own vmcnt wait.  Scores are
 // computed "swapped" (S^T = ka qa^T): every lane owns ONE query column and 16 key rows per
 // 32x32 block, so the online-softmax row reduction is in-register plus one lane<->lane+32
 // exchange, and the exponentiated tile feeds the PV MFMA as its B operand without leaving
@@ -24,8 +25,10 @@ template <int DA>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(svit_attn_fwd_args a) {
   constexpr int KS = DA / 16;                 // k-steps of the QK^T contraction
   constexpr int K_BYTES = KT * DA * 2, V_BYTES = KT * HD * 2;
+  constexpr int STAGE = K_BYTES + V_BYTES;    // [K tile | V tile] per pipeline stage
+  using KLoad = GldsTile<KT, DA, 4>;
+  using VLoad = GldsTile<KT, HD, 4>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int STAGE = K_BYTES + V_BYTES;   // [K tile | V tile] per pipeline stage
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int bh = blockIdx.y, b = bh / a.heads, head = bh % a.heads;
@@ -41,32 +44,37 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(svit_attn_fwd_args a) 
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
     qf[ks] = *(const bf16x8_t*)(qa + (size_t)qc * DA + ks * 16 + hh * 8);
+  // pin the register operands before the tile loop: their first use must not sit inside it,
+  // or the compiler's wait for them (vmcnt(0)) would drain the LDS-DMA pipeline every tile
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
 
   f32x16_t o[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+  // running max kept in the exp2 domain (already multiplied by c); l = partial row sum
   float m_run = -INFINITY, l_run = 0.f;
 
-  TileStager<KT, DA, 256> ks_stage;
-  TileStager<KT, HD, 256> vs_stage;
   const int nt = (a.Nk + KT - 1) / KT;
-  ks_stage.load(ka, DA, a.Nk, tid);
-  vs_stage.load(vv, HD, a.Nk, tid);
-  ks_stage.store(smem, tid);
-  vs_stage.store(smem + K_BYTES, tid);
-  __syncthreads();
-
+  KLoad kload;
+  VLoad vload;
+  kload.init(DA, wave, lane);
+  vload.init(HD, wave, lane);
+  auto issue = [&](int t) {
+    unsigned char* st = smem + (t & 1) * STAGE;
+    const int k0 = t * KT;
+    kload.issue_auto(ka + (size_t)k0 * DA, DA, a.Nk - k0, st, wave, lane);
+    vload.issue_auto(vv + (size_t)k0 * HD, HD, a.Nk - k0, st + K_BYTES, wave, lane);
+  };
+  issue(0);
   for (int t = 0; t < nt; ++t) {
+    wait_vmcnt<0>();                 // this wave's share of tile t has landed
+    __builtin_amdgcn_s_barrier();    // everyone's share has; everyone is done with tile t-1
+    if (t + 1 < nt) issue(t + 1);    // travels while tile t is consumed
     const unsigned char* k_cur = smem + (t & 1) * STAGE;
     const unsigned char* v_cur = k_cur + K_BYTES;
-    unsigned char* k_nxt = smem + ((t + 1) & 1) * STAGE;
-    if (t + 1 < nt) {
-      const int k0 = (t + 1) * KT;
-      ks_stage.load(ka + (size_t)k0 * DA, DA, a.Nk - k0, tid);
-      vs_stage.load(vv + (size_t)k0 * HD, HD, a.Nk - k0, tid);
-    }
     // ---- S^T = ka . qa^T for the two 32-key blocks of the tile --------------------------
     f32x16_t s[2];
 #pragma unroll
@@ -78,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(svit_attn_fwd_args a) 
         s[kb] = mfma32(row_frag<KT>(k_cur, kb * 32, ks, lane), qf[ks], s[kb]);
     }
     const int kbase = t * KT;
-    if (kbase + KT > a.Nk) {  // ragged last tile: keys >= Nk do not exist
+    if (kbase + KT > a.Nk) {  // ragged last tile: rows >= Nk hold re-read data
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -86,52 +94,53 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(svit_attn_fwd_args a) 
           if (kbase + kb * 32 + acc_row(r, lane) >= a.Nk) s[kb][r] = -INFINITY;
     }
     // ---- online softmax: lane = one query, its two halves hold disjoint key rows ---------
-    float mx = s[0][0];
+    float mx = max3(s[0][0], s[1][0], s[0][1]);
+    mx = max3(mx, s[1][1], s[0][2]);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int r = 2; r < 15; ++r) mx = max3(mx, s[1][r], s[0][r + 1]);
+    mx = max3(mx, s[1][15], __shfl_xor(max3(mx, s[1][15], mx), 32, 64)) * c;
+    // defer-max: only re-base when the max grew by more than 2^RESCALE_THR; until then P is
+    // bounded by 2^THR instead of 1, which fp32 accumulation absorbs (cdna guide T13).  The
+    // previous tile's P.V is complete at this point, so O and l carry exactly one scale.
+    constexpr float RESCALE_THR = 6.0f;
+    if (!__all(mx - m_run <= RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = fast_exp2(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f((m_run - m_new) * c);
-    const float mc = m_new * c;
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[j][r] *= alpha;
+    }
     float rs = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(s[kb][r] * c - mc);
+        const float p = fast_exp2(s[kb][r] * c - m_run);
         s[kb][r] = p;
         rs += p;
       }
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[j][r] *= alpha;
+    l_run += rs;
     // ---- O^T += V^T . P^T -------------------------------------------------------------
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp) {
         const bf16x8_t pf = acc_to_frag(s[kb], sp);
+        bf16x8_t vt[3];
+        tr_frags_asm<KT, 3>(v_cur, kb * 32 + sp * 16, lane, vt);
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-          o[j] = mfma32(tr_frag<KT>(v_cur, kb * 32 + sp * 16, j, lane), pf, o[j]);
+        for (int j = 0; j < 3; ++j) o[j] = mfma32(vt[j], pf, o[j]);
       }
-    if (t + 1 < nt) {
-      ks_stage.store(k_nxt, tid);
-      vs_stage.store(k_nxt + K_BYTES, tid);
-    }
-    __syncthreads();
   }
 
   // ---- epilogue: normalise, add the pooled query (residual pooling), merge heads ----------
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
   if (qi < a.Nq) {
-    if (hh == 0) a.lse2[(size_t)bh * a.Nq + qi] = m_run * c + log2f(l_tot);
+    if (hh == 0) a.lse2[(size_t)bh * a.Nq + qi] = m_run + log2f(l_tot);
     bf16_t* out = (bf16_t*)a.ctx + ((size_t)b * a.Nq + qi) * a.heads * HD + head * HD;
     const bf16_t* qres = qa + (size_t)qi * DA;
 #pragma unroll

@@ -47,6 +47,11 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// raw v_exp_f32 (2^x; -inf -> 0).  exp2f() under hipcc expands to a ~5-instruction
+// denormal-safe sequence per element, which made the attention kernels VALU-bound
+// (16 VALU per MFMA measured); probabilities below 2^-126 may flush to 0, which is harmless.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // 32x32x16 bf16 MFMA: D = A(32x16) * B(16x32) + C.  Lane l: A[row l&31][k 8*(l>>5)+j],
 // B[k 8*(l>>5)+j][col l&31]; C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
 __device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
