@@ -169,12 +169,20 @@ extern "C" int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, floa
   if (((uintptr_t)A | (uintptr_t)B) & 15) return SVIT_ERR_ALIGN;
   const int tiles = ((N + TN_TN - 1) / TN_TN) * ((K + TN_TK - 1) / TN_TK);
   if (splits <= 0) {
-    // every split adds the whole [N,K] tile set with fp32 atomics (~1.3 TB/s chip-wide): take
-    // just enough splits to fill the chip (~2 blocks per CU), at least 4 reduction steps each
-    splits = (512 + tiles - 1) / tiles;
-    const int max_by_rows = (M + 4 * TN_BM - 1) / (4 * TN_BM);
-    if (splits > max_by_rows) splits = max_by_rows;
-    if (splits < 1) splits = 1;
+    // Cost model fitted on MI355X (tools/bench_kernels.py tnsplit): a block needs ~0.85 us per
+    // 64-row step, 512 blocks run concurrently, and every split adds the whole [N,K] fp32 tile
+    // set with atomics at ~0.75 TB/s effective.  Take the split count minimising the sum.
+    const double atom_us = (double)N * K * 4.0 / 0.75e6;
+    double best = 1e30;
+    static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512};
+    for (int ci = 0; ci < (int)(sizeof(cand) / sizeof(cand[0])); ++ci) {
+      const int s = cand[ci];
+      const long steps = ((M + s - 1) / s + TN_BM - 1) / TN_BM;
+      if (steps < 2 && s > 1) break;
+      const long rounds = ((long)tiles * s + 511) / 512;
+      const double t = (double)rounds * steps * 0.85 + s * atom_us;
+      if (t < best) { best = t; splits = s; }
+    }
   }
   int rows_per_split = (M + splits - 1) / splits;
   rows_per_split = ((rows_per_split + TN_BM - 1) / TN_BM) * TN_BM;
