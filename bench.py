@@ -82,7 +82,15 @@ def kernel_report(trace, batch):
     """Aggregate the HIP-event trace of one profiled step per C-ABI entry point."""
     torch.cuda.synchronize()
     agg = {}
+    phases, last = [], None
     for name, e0, e1, meta in trace:
+        if name.startswith("mark:"):
+            if last is not None:
+                phases.append((name[5:], round(last.elapsed_time(e0), 3)))
+            last = e0
+            continue
+        if last is None:
+            last = e0
         ms = e0.elapsed_time(e1)
         a = agg.setdefault(name, {"ms": 0.0, "calls": 0, "flop": 0.0})
         a["ms"] += ms
@@ -101,6 +109,7 @@ def kernel_report(trace, batch):
         if a["flop"] > 0:
             r["tflops"] = round(a["flop"] / (a["ms"] * 1e-3) / 1e12, 2)
         rows.append(r)
+    kernel_report.phases = phases
     return rows, total
 
 
@@ -191,6 +200,7 @@ def main():
         step(args.warmup + args.steps)
         rows, total = kernel_report(hip.stop_trace(), args.batch)
         out["kernels"] = rows[:12]
+        out["phases_ms"] = dict(kernel_report.phases)
         out["kernel_ms_total"] = round(total, 3)
         top = rows[0]
         # the north-star kernel is the fused attention; report the dominant kernel's roofline and

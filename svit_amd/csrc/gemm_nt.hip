@@ -153,6 +153,15 @@ int launch_v2(const svit_gemm_args& a, hipStream_t st) {
 }
 }  // namespace
 
+static int g_nt_stages = 0;     // tuning knob (svit_debug_set(0, n)); 2..4, 0 = heuristic
+static int g_nt_force_cfg = -1; // tuning knob (svit_debug_set(1, c)); -1 = heuristic
+extern "C" int svit_debug_set(int key, int val) {
+  if (key == 0) g_nt_stages = val;
+  else if (key == 1) g_nt_force_cfg = val;
+  else return SVIT_ERR_ARG;
+  return SVIT_OK;
+}
+
 extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
   if (!args || !args->A || !args->W || !args->out) return SVIT_ERR_ARG;
   const svit_gemm_args& a = *args;
@@ -171,7 +180,18 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
   // Tile choice (measured on MI355X, tools/bench_kernels.py gemm2): 128x192 blocks (2x2 waves
   // of 64x96) win whenever they still give >= 1 tile per CU; otherwise, and for N = 96 (mod
   // 192), 128x96 blocks (4 waves of 32x96) double the number of workgroups.
-  if (a.N % 192 == 0 && (long)((a.M + 127) / 128) * (a.N / 192) >= 256)
+  bool big = a.N % 192 == 0 && (long)((a.M + 127) / 128) * (a.N / 192) >= 256;
+  if (g_nt_force_cfg == 0 && a.N % 192 == 0) big = true;
+  if (g_nt_force_cfg == 2) big = false;
+  // pipeline depth (measured, tools/bench_kernels.py ntstages): short K loops prefer 2 stages
+  // (less LDS -> more resident workgroups), K >= 2048 wants the 4-deep prefetch
+  const int stages = g_nt_stages ? g_nt_stages : (a.K >= 2048 ? 4 : 2);
+  if (big) {
+    if (stages == 2) return launch_v2<2, 3, 2, 2, 2>(a, st);
+    if (stages == 3) return launch_v2<2, 3, 2, 2, 3>(a, st);
     return launch_v2<2, 3, 2, 2, 4>(a, st);
+  }
+  if (stages == 2) return launch_v2<1, 3, 4, 1, 2>(a, st);
+  if (stages == 3) return launch_v2<1, 3, 4, 1, 3>(a, st);
   return launch_v2<1, 3, 4, 1, 4>(a, st);
 }

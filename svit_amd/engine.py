@@ -210,10 +210,12 @@ class Engine:
         st = {"B": B, "Tx": Tx, "n_obj": n_obj, "L0": L, "cols": cols if save else None,
               "blocks": []}
         thw = (T, Ho, Wo)
+        hip.mark("stem")
         for blk in plan.blocks:
             ds = drop_scales[blk.index] if drop_scales is not None else None
             x, thw, sv = self._block_fwd(blk, x, thw, n_obj, ds, save)
             st["blocks"].append(sv)
+            hip.mark("fwd%d" % blk.index)
         y16, y32, mean, rstd = ops.layernorm_fwd(x, f.p("norm.weight"), f.p("norm.bias"),
                                                  want_f32=True, want_bf16=False, save_stats=save)
         st.update(x_last=x if save else None, mean=mean, rstd=rstd, thw=thw)
@@ -293,8 +295,10 @@ class Engine:
                                st["rstd"], f.g("norm.weight"), f.g("norm.bias"))
         if on_ready is not None:
             on_ready(0)
+        hip.mark("bwd_norm")
         for blk in reversed(plan.blocks):
             dx = self._block_bwd(blk, st["blocks"][blk.index], dx, st["n_obj"])
+            hip.mark("bwd%d" % blk.index)
             if on_ready is not None:
                 on_ready(1 + (depth - 1 - blk.index))
         # block-0 input: [cls | patches | objects]

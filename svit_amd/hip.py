@@ -177,6 +177,14 @@ def stop_trace():
     return t
 
 
+def mark(label):
+    """phase marker in the kernel trace (no-op unless bench.py is tracing)."""
+    if _trace is not None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        _trace.append(("mark:" + label, e, e, None))
+
+
 def call(name, *args, meta=None):
     if _trace is None:
         rc = getattr(load(), name)(*args, stream())

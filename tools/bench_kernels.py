@@ -163,3 +163,35 @@ def bench_tn_splits():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tnsplit":
     bench_tn_splits()
+
+
+
+def bench_nt_stages():
+    """NT GEMM: pipeline depth x tile config sweep (svit_debug_set knobs)."""
+    import ctypes as C
+    lib = hip.load()
+    lib.svit_debug_set.restype, lib.svit_debug_set.argtypes = C.c_int32, [C.c_int32, C.c_int32]
+    print("== gemm_nt: us for (stages, cfg) ==")
+    shapes = [(13064, 1152, 384), (13064, 1536, 384), (13064, 384, 1536), (13064, 384, 384),
+              (13064, 384, 1152), (3656, 768, 3072), (3656, 3072, 768), (3656, 2304, 768),
+              (50696, 576, 192), (50696, 192, 576), (201224, 288, 96), (201224, 96, 384)]
+    for (M, N, K) in shapes:
+        a, w = rnd(M, K), rnd(N, K)
+        bias = torch.zeros(N, device=DEV)
+        out = torch.empty(M, N, device=DEV, dtype=BF16)
+        res = []
+        for cfg in (0, 2):
+            if cfg == 0 and N % 192:
+                continue
+            for st in (2, 3, 4):
+                lib.svit_debug_set(0, st)
+                lib.svit_debug_set(1, cfg)
+                us = timeit(lambda: ops.gemm_nt(a, w, bias, hip.EPI_BF16, out=out), iters=10)
+                res.append("c%ds%d:%.1f" % (cfg, st, us))
+        lib.svit_debug_set(0, 0)
+        lib.svit_debug_set(1, -1)
+        print("M=%6d N=%4d K=%4d  " % (M, N, K), " ".join(res))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ntstages":
+    bench_nt_stages()
