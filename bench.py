@@ -97,6 +97,8 @@ def kernel_report(trace, batch):
         a["calls"] += 1
         if meta and meta[0] == "mnk":
             a["flop"] += 2.0 * meta[1] * meta[2] * meta[3]
+        elif meta and meta[0] == "flop":
+            a["flop"] += meta[1]
         elif meta and meta[0] == "attn":
             _, B, h, Nq, Nk, DA = meta
             alg = 2.0 * B * h * Nq * Nk * (96 + 96)        # QK^T + AV at head_dim 96
@@ -124,6 +126,8 @@ def main():
     ap.add_argument("--frames-pass", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-trace", action="store_true")
+    ap.add_argument("--eager", action="store_true",
+                    help="launch every kernel from Python instead of replaying the HIP graphs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -148,8 +152,20 @@ def main():
     x, y = synth_batch(cfg, args.batch, dev, seed=cfg.RNG_SEED + rank)
     core = model.module if hasattr(model, "module") else model
 
-    def step(it):
+    def ce(preds, extra, labels):
+        return torch.nn.functional.cross_entropy(preds, labels)
+
+    graphed = None
+    if not args.eager and not args.frames_pass:
+        from svit_amd.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(model, ce, [x], y)
+
+    def step(it, eager=False):
         optim.set_lr(opt, optim.get_lr_at_epoch(cfg, it / 1000.0))
+        if graphed is not None and not eager:
+            loss, _ = graphed([x], y)       # fwd + CE + bwd (+ all-reduce launches) replayed
+            opt.step()
+            return loss
         logits, extra = model([x], {})
         if args.frames_pass:
             with torch.no_grad():
@@ -189,7 +205,8 @@ def main():
                                "clip+AdamW%s" % (args.frames, args.crop, args.batch,
                                                  " + no-grad frames pass" if args.frames_pass else ""),
                    "global_batch": args.batch * world, "seq_len": None,
-                   "parallelism": "dp%d" % world},
+                   "parallelism": "dp%d" % world,
+                   "launch": "eager" if graphed is None else "hip-graph replay"},
         "loss": round(loss_val, 4),
         "step_mfma_frac": round(clips_per_s / world * STEP_GFLOP_PER_CLIP * 1e9 /
                                 (MFMA_PEAK_TFLOPS * 1e12), 4),
@@ -197,7 +214,7 @@ def main():
     if rank == 0 and not args.no_kernel_trace:
         from svit_amd import hip
         hip.start_trace()
-        step(args.warmup + args.steps)
+        step(args.warmup + args.steps, eager=True)   # per-kernel HIP events need eager launches
         rows, total = kernel_report(hip.stop_trace(), args.batch)
         out["kernels"] = rows[:12]
         out["phases_ms"] = dict(kernel_report.phases)
@@ -216,7 +233,7 @@ def main():
                                     "frac": round(attn["tflops"] / MFMA_PEAK_TFLOPS, 4),
                                     "avg_launch_ms": round(attn["ms"] / attn["calls"], 4)}
     elif world > 1 and not args.no_kernel_trace:
-        step(args.warmup + args.steps)      # keep ranks in lock-step with rank 0's traced step
+        step(args.warmup + args.steps, eager=True)  # keep ranks in lock-step with rank 0's traced step
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.frames, args.crop)
     if world > 1:

@@ -55,6 +55,17 @@ int svit_gemm_nt(const svit_gemm_args* args, void* stream);
 int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, float* dW, int lddw,
                  int M, int N, int K, int splits, float* dbias /* f32 [N] += colsum(A), or NULL */,
                  void* stream);
+/* Several independent wgrad GEMMs in ONE launch (the engine queues a block's Linear and rel-pos
+ * weight gradients and flushes them together: the per-launch accumulator flush is amortised).
+ * Same operand rules as svit_gemm_tn; any count (launched in groups of SVIT_TN_GROUP_MAX).
+ * Replaces the per-layer autograd wgrads of slowfast/models/attention.py:377-409 (qkv, proj),
+ * common.py:26-37 (fc1, fc2) and the rel-pos table grads of attention.py:77-139. */
+#define SVIT_TN_GROUP_MAX 8
+typedef struct {
+  const void* A; const void* B; float* dW; float* dbias;   /* dbias may be NULL */
+  int32_t lda, ldb, lddw, M, N, K;
+} svit_tn_problem;
+int svit_gemm_tn_grouped(const svit_tn_problem* probs, int count, void* stream);
 /* dbias[N] (f32, atomically accumulated) += column sums of bf16 A[M,N]. */
 int svit_colsum_bf16(const void* A, int lda, float* out, int M, int N, void* stream);
 

@@ -137,6 +137,22 @@ static __global__ void svit_reduce_partials_kernel(const float* __restrict__ par
     else dst.ptr[2][i - dst.end[1]] += s;
   }
 }
+// Zero-fill as a kernel (16-byte stores): hipMemsetAsync turns into a memset node under stream
+// capture, and those replay unreliably on ROCm 7.2 (svit_amd/graph.py needs every launch to be a
+// plain kernel node).  bytes must be a multiple of 16 and p 16-byte aligned.
+static __global__ void svit_zero_kernel(uint4* __restrict__ p, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+    p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+static inline void svit_launch_zero(void* p, size_t bytes, hipStream_t st) {
+  const size_t n16 = bytes / 16;
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks == 0) return;
+  hipLaunchKernelGGL(svit_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint4*)p, n16);
+}
+
 static inline void svit_launch_reduce(const float* partial, int nblocks, int n, SvitReduceDst dst,
                                       hipStream_t st) {
   hipLaunchKernelGGL(svit_reduce_partials_kernel, dim3((n + 31) / 32), dim3(32, 8), 0, st, partial,

@@ -16,16 +16,15 @@ constexpr int TN_TN = 128, TN_TK = 96;
 constexpr int TN_ROWA = TN_TN * 2 + 64;  // 320 B: the 4 rows of a tr block hit disjoint banks
 constexpr int TN_ROWB = TN_TK * 2;       // 192 B: conflict-free as is
 
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ A, int lda,
-                                                      const bf16_t* __restrict__ B, int ldb,
-                                                      float* __restrict__ dW, int lddw, int M,
-                                                      int N, int K, int rows_per_split,
-                                                      float* __restrict__ dbias) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2][TN_BM * (TN_ROWA + TN_ROWB)];
+typedef unsigned char tn_lds_t[2][TN_BM * (TN_ROWA + TN_ROWB)];
+
+// One workgroup's share: rows [m_begin, m_end) of the reduction for the 128x96 tile at (n0, k0).
+__device__ __forceinline__ void tn_tile(tn_lds_t& lds, const bf16_t* __restrict__ A, int lda,
+                                        const bf16_t* __restrict__ B, int ldb,
+                                        float* __restrict__ dW, int lddw, int N, int K, int n0,
+                                        int k0, int m_begin, int m_end,
+                                        float* __restrict__ dbias, bool bias_tile) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * TN_TN, k0 = blockIdx.y * TN_TK;
-  const int m_begin = blockIdx.z * rows_per_split;
-  const int m_end = min(M, m_begin + rows_per_split);
   if (m_begin >= m_end) return;
 
   constexpr int A_CH = TN_TN / 8, B_CH = TN_TK / 8;        // 16 / 12 chunks per row
@@ -49,7 +48,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
   };
   // fused bias gradient: column sums of A (= dY) ride along on the k-tile-0 blocks; a thread
   // always stages the same 8-column chunk (tid % 16), so it keeps 8 running sums
-  const bool do_bias = (dbias != nullptr) && (blockIdx.y == 0);
+  const bool do_bias = (dbias != nullptr) && bias_tile;
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto store_tiles = [&](int buf) {
     unsigned char* la = lds[buf];
@@ -130,6 +129,47 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
   }
 }
 
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ A, int lda,
+                                                      const bf16_t* __restrict__ B, int ldb,
+                                                      float* __restrict__ dW, int lddw, int M,
+                                                      int N, int K, int rows_per_split,
+                                                      float* __restrict__ dbias) {
+  __shared__ __attribute__((aligned(16))) tn_lds_t lds;
+  const int m_begin = blockIdx.z * rows_per_split;
+  tn_tile(lds, A, lda, B, ldb, dW, lddw, N, K, blockIdx.x * TN_TN, blockIdx.y * TN_TK, m_begin,
+          min(M, m_begin + rows_per_split), dbias, blockIdx.y == 0);
+}
+
+// Grouped launch: up to SVIT_TN_GROUP_MAX independent weight-gradient GEMMs share one grid, so
+// the machine-wide accumulator flush (every resident workgroup atomically adds its 128x96 fp32
+// tile: ~25 MB per launch, the dominant cost of a short-reduction wgrad) is paid once per group
+// instead of once per GEMM.
+struct TnGroup {
+  svit_tn_problem p[SVIT_TN_GROUP_MAX];
+  int first_block[SVIT_TN_GROUP_MAX + 1];
+  int tiles_n[SVIT_TN_GROUP_MAX];
+  int tiles[SVIT_TN_GROUP_MAX];
+  int rows_per_split[SVIT_TN_GROUP_MAX];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup g) {
+  __shared__ __attribute__((aligned(16))) tn_lds_t lds;
+  const int bid = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < SVIT_TN_GROUP_MAX; ++i)
+    if (i < g.count && bid >= g.first_block[i]) pi = i;
+  const svit_tn_problem& p = g.p[pi];
+  const int local = bid - g.first_block[pi];
+  const int tile = local % g.tiles[pi], split = local / g.tiles[pi];
+  const int tn = tile % g.tiles_n[pi], tk = tile / g.tiles_n[pi];
+  const int m_begin = split * g.rows_per_split[pi];
+  tn_tile(lds, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.dW, p.lddw, p.N, p.K,
+          tn * TN_TN, tk * TN_TK, m_begin, min(p.M, m_begin + g.rows_per_split[pi]), p.dbias,
+          tk == 0);
+}
+
 __global__ void colsum_kernel(const bf16_t* __restrict__ A, int lda, float* __restrict__ out,
                               int M, int N, int rows_per_block) {
   // block (64 x 4): lane -> 2 adjacent columns (one dword), 4 row phases; grid.x = column
@@ -191,6 +231,61 @@ extern "C" int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, floa
   hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)A,
                      lda, (const bf16_t*)B, ldb, dW, lddw, M, N, K, rows_per_split, dbias);
   SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+static int tn_check(const svit_tn_problem& p) {
+  if (!p.A || !p.B || !p.dW) return SVIT_ERR_ARG;
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return SVIT_ERR_SHAPE;
+  if (p.lda % 8 != 0 || p.ldb % 8 != 0 || p.lda < p.N || p.ldb < p.K || p.lddw < p.K)
+    return SVIT_ERR_ALIGN;
+  if (((uintptr_t)p.A | (uintptr_t)p.B) & 15) return SVIT_ERR_ALIGN;
+  return SVIT_OK;
+}
+
+extern "C" int svit_gemm_tn_grouped(const svit_tn_problem* probs, int count, void* stream) {
+  if (!probs || count <= 0) return SVIT_ERR_ARG;
+  for (int i = 0; i < count; ++i) {
+    const int rc = tn_check(probs[i]);
+    if (rc) return rc;
+  }
+  for (int base = 0; base < count; base += SVIT_TN_GROUP_MAX) {
+    TnGroup g;
+    g.count = count - base < SVIT_TN_GROUP_MAX ? count - base : SVIT_TN_GROUP_MAX;
+    long max_steps = 1;
+    for (int i = 0; i < g.count; ++i) {
+      g.p[i] = probs[base + i];
+      g.tiles_n[i] = (g.p[i].N + TN_TN - 1) / TN_TN;
+      g.tiles[i] = g.tiles_n[i] * ((g.p[i].K + TN_TK - 1) / TN_TK);
+      const long st = (g.p[i].M + TN_BM - 1) / TN_BM;
+      if (st > max_steps) max_steps = st;
+    }
+    // Every problem is cut into chunks of `steps` 64-row steps, so all workgroups run equally
+    // long.  Same fitted model as svit_gemm_tn: 0.85 us per step with 512 resident workgroups,
+    // plus the atomic flush of one 128x96 fp32 tile per workgroup at ~0.75 TB/s.
+    double best = 1e30;
+    long best_steps = max_steps;
+    for (long steps = 2; steps <= max_steps; steps += (steps < 32 ? 1 : steps / 16)) {
+      long blocks = 0;
+      for (int i = 0; i < g.count; ++i) {
+        const long st = (g.p[i].M + TN_BM - 1) / TN_BM;
+        blocks += (long)g.tiles[i] * ((st + steps - 1) / steps);
+      }
+      const double t = (double)((blocks + 511) / 512) * steps * 0.85 +
+                       (double)blocks * (TN_TN * TN_TK * 4.0) / 0.75e6;
+      if (t < best) { best = t; best_steps = steps; }
+    }
+    int total = 0;
+    for (int i = 0; i < g.count; ++i) {
+      g.rows_per_split[i] = (int)best_steps * TN_BM;
+      const int splits = (g.p[i].M + g.rows_per_split[i] - 1) / g.rows_per_split[i];
+      g.first_block[i] = total;
+      total += g.tiles[i] * splits;
+    }
+    for (int i = g.count; i <= SVIT_TN_GROUP_MAX; ++i) g.first_block[i] = total;
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, g);
+    SVIT_LAUNCH_CHECK();
+  }
   return SVIT_OK;
 }
 

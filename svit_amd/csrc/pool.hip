@@ -778,8 +778,8 @@ extern "C" int svit_relpos_scatter(const svit_relq_scatter_args* a, void* stream
   if (a->ldd % 8 != 0 || a->off_h < 0 || a->off_w < a->off_h || a->off_t < a->off_w) return SVIT_ERR_ARG;
   const int extra = a->ld - HD;
   const int64_t total = (int64_t)a->B * a->heads * (1 + a->qt * a->qh * a->qw + a->n_obj);
-  hipError_t e = hipMemsetAsync(a->D, 0, (size_t)total * a->ldd * 2, (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
+  if ((uintptr_t)a->D & 15) return SVIT_ERR_ALIGN;
+  svit_launch_zero(a->D, (size_t)total * a->ldd * 2, (hipStream_t)stream);   // ldd % 8 == 0
   const int tpb = 256 / extra;
   hipLaunchKernelGGL(relq_scatter_kernel, dim3((unsigned)((total + tpb - 1) / tpb)), dim3(256), 0,
                      (hipStream_t)stream, *a);

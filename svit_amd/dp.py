@@ -50,6 +50,12 @@ class DataParallel(nn.Module):
             w = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
             self._works.append((w, g if self.average else None))
 
+    def launch_ranks(self):
+        """readiness ranks after which `_on_ready` launches collectives (graph.py cuts the
+        backward graph there)."""
+        n = self.module.flat.n_ranks
+        return {r for r in range(n) if (r + 1) % self.bucket_ranks == 0 or r == n - 1}
+
     def _on_ready(self, rank):
         """engine callback: gradients of readiness rank `rank` are final on this GPU."""
         if self.world_size == 1:

@@ -159,6 +159,7 @@ class Engine:
         self.dev = flat.data.device
         self._rel_cache = {}
         self.patch_w16 = torch.zeros((plan.embed_dim, 448), device=self.dev, dtype=BF16)
+        self._tn = []           # weight-gradient GEMMs queued by the running block backward
 
     # ------------------------------------------------------------------ helpers ----------
     def refresh_weights(self):
@@ -316,10 +317,15 @@ class Engine:
         if on_ready is not None:
             on_ready(depth + 1)
 
+    def _flush_tn(self):
+        """the block's queued weight-gradient GEMMs in one grouped launch (ops.gemm_tn_grouped)"""
+        q, self._tn = self._tn, []
+        ops.gemm_tn_grouped(q)
+
     def _linear_bwd(self, dy16, x16, wname, bname, need_dx, out=None, accumulate=False,
                     epilogue=hip.EPI_F32, aux=None):
         f = self.flat
-        ops.gemm_tn(dy16, x16, f.g(wname), dbias=f.g(bname))
+        self._tn.append((dy16, x16, f.g(wname), f.g(bname)))     # flushed per block, grouped
         if not need_dx:
             return None
         return ops.gemm_nt(dy16, f.wt(wname), None, epilogue, out=out, aux=aux, accumulate=accumulate)
@@ -363,7 +369,7 @@ class Engine:
         for n, m, t, o in zip(names, mats, tabs, offs):
             rows = t.shape[0]
             if m is None:
-                ops.gemm_tn(D[:, o:o + rows], qa2[:, :HD], f.g(n))
+                self._tn.append((D[:, o:o + rows], qa2[:, :HD], f.g(n), None))
             else:
                 d = torch.zeros_like(t)
                 ops.gemm_tn(D[:, o:o + rows], qa2[:, :HD], d)
@@ -393,6 +399,8 @@ class Engine:
             self._linear_bwd(ds16, sv["xn"], pre + "proj.weight", pre + "proj.bias", True, out=dxn,
                              accumulate=True)
             dskip = None
-        return ops.layernorm_bwd(dxn, x, f.p(pre + "norm1.weight"), sv["mean1"], sv["rstd1"],
-                                 f.g(pre + "norm1.weight"), f.g(pre + "norm1.bias"),
-                                 dres=dskip).view(B, N, C)
+        dx = ops.layernorm_bwd(dxn, x, f.p(pre + "norm1.weight"), sv["mean1"], sv["rstd1"],
+                               f.g(pre + "norm1.weight"), f.g(pre + "norm1.bias"),
+                               dres=dskip).view(B, N, C)
+        self._flush_tn()
+        return dx

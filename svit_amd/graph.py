@@ -1,0 +1,153 @@
+"""HIP-graph replay of the SViT training step (forward + loss + backward).
+
+The eager path (svit_amd/model.py) issues ~750 kernel launches per step from Python; most of
+them run for 5-50 us on an MI355X, so the host is as busy as the GPU and every hiccup on the
+host shows up as an idle GPU (profiles/README.md: ~13 % idle at B=8).  The launch schedule is
+static for a fixed input shape, so it is captured ONCE into HIP graphs and replayed:
+
+    step = GraphedTrainStep(model, loss_fun, inputs, labels)
+    for inputs, labels in loader:
+        loss, preds = step(inputs, labels)      # static tensors, overwritten by every replay
+        optimizer.step()                        # eager (lr / bias correction are host scalars)
+
+What is inside the graph(s): bf16 weight refresh, grad-buffer memset, DropPath / dropout sampling
+(torch's graph-safe Philox state), every backbone kernel, the head, `loss_fun`, the head's
+autograd backward and the whole backbone backward.  Same arithmetic as the eager step
+(tools/train_net.py:88-151 of the reference is the loop it replaces).
+
+Data parallel: the backward is cut into one graph per gradient bucket; after each segment's
+replay the wrapper's `_on_ready` hook launches that bucket's all-reduce on RCCL's stream, so the
+exchange overlaps the next segment exactly like in the eager path (svit_amd/dp.py) and no
+collective has to live inside a graph.
+"""
+import gc
+
+import torch
+
+from . import hip
+
+
+class GraphedTrainStep:
+    def __init__(self, model, loss_fun, inputs, labels, warmup=2):
+        """model: SViT or its DataParallel wrapper (train mode); loss_fun(preds, extra, labels) ->
+        scalar; inputs: the reference's `inputs` list ([video f32 [B,3,T,S,S]]); labels: any
+        tensor (or tuple/dict of tensors) `loss_fun` takes -- copied into static buffers."""
+        self.wrapper = model
+        self.core = model.module if hasattr(model, "module") else model
+        if self.core.engine is None:
+            raise hip.SvitHipError("GraphedTrainStep needs a finalized (on-GPU) SViT")
+        if not self.core.training:
+            raise RuntimeError("GraphedTrainStep captures the training step: call model.train() first")
+        self.loss_fun = loss_fun
+        self.dp = model if hasattr(model, "_on_ready") and getattr(model, "world_size", 1) > 1 else None
+        self.x = inputs[0].detach().clone().contiguous()
+        self.labels = _tree_map(lambda t: t.detach().clone(), labels)
+        self.segments = []          # [(CUDAGraph, [readiness ranks final after it])]
+        self.loss = self.preds = self.extra = None
+        self._keepalive = None
+        self._capture(warmup)
+
+    # ------------------------------------------------------------------------------------------
+    def _body(self, boundary):
+        core = self.core
+        eng, flat = core.engine, core.flat
+        x = self.x
+        Tx = x.shape[2] if x.dim() == 5 else 1
+        eng.refresh_weights()
+        flat.grad.zero_()
+        ds = core.sample_drop_scales(x.shape[0], x.device)
+        with torch.no_grad():
+            y, st = eng.forward(x, ds, save=True)
+        n_obj = Tx * core.O
+        feat = torch.cat((y[:, :1], y[:, -n_obj:]), dim=1).requires_grad_(True)
+        # the head runs on fresh leaf aliases of its parameters and explicit autograd.grad instead
+        # of loss.backward(): AccumulateGrad nodes of the real parameters may be pinned to another
+        # stream by an earlier eager step, which a stream capture cannot follow
+        named = list(core.head.named_parameters())
+        alias = {n: p.detach().requires_grad_(True) for n, p in named}
+        with torch.enable_grad():
+            preds, extra = torch.func.functional_call(core.head, alias, (feat,), {"T": Tx})
+            loss = self.loss_fun(preds, extra, self.labels)
+        grads = torch.autograd.grad(loss, [feat] + [alias[n] for n, _ in named], allow_unused=True)
+        with torch.no_grad():
+            for (n, p), g in zip(named, grads[1:]):
+                if g is not None:
+                    p.grad.add_(g)
+            dfeat = grads[0]
+            dy = torch.zeros_like(y)
+            dy[:, :1] = dfeat[:, :1]
+            dy[:, -n_obj:] = dfeat[:, 1:]
+            eng.backward(st, dy, on_ready=boundary)
+        return loss.detach(), preds.detach(), {k: v.detach() for k, v in extra.items()}, (st, feat, dy)
+
+    def _capture(self, warmup):
+        core = self.core
+        core._attach_grads()                      # .grad views of the flat buffer, host side only
+        dev = self.x.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):       # lazy tables / library workspaces materialise here
+                self._body(None)
+        side.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()
+        pool = torch.cuda.graph_pool_handle()
+        cuts = self.dp.launch_ranks() if self.dp is not None else set()
+        state = {"g": torch.cuda.CUDAGraph(), "ranks": []}
+
+        def boundary(rank):
+            state["ranks"].append(rank)
+            if rank in cuts and rank != max(cuts):
+                state["g"].capture_end()
+                self.segments.append((state["g"], state["ranks"]))
+                state["g"], state["ranks"] = torch.cuda.CUDAGraph(), []
+                state["g"].capture_begin(pool=pool)
+
+        with torch.cuda.stream(side):
+            state["g"].capture_begin(pool=pool)
+            try:
+                self.loss, self.preds, self.extra, self._keepalive = self._body(
+                    boundary if self.dp is not None else None)
+            finally:
+                state["g"].capture_end()
+            self.segments.append((state["g"], state["ranks"]))
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+
+    # ------------------------------------------------------------------------------------------
+    def __call__(self, inputs, labels):
+        x = inputs[0]
+        if x.shape != self.x.shape:
+            raise hip.SvitHipError("GraphedTrainStep was captured for input %s, got %s"
+                                   % (tuple(self.x.shape), tuple(x.shape)))
+        if x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x, non_blocking=True)
+        _tree_copy(self.labels, labels)
+        for g, ranks in self.segments:
+            g.replay()
+            if self.dp is not None:
+                for r in ranks:
+                    self.dp._on_ready(r)
+        return self.loss, (self.preds, self.extra)
+
+
+def _tree_map(fn, obj):
+    if torch.is_tensor(obj):
+        return fn(obj)
+    if isinstance(obj, dict):
+        return {k: _tree_map(fn, v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_tree_map(fn, v) for v in obj)
+    return obj
+
+
+def _tree_copy(dst, src):
+    if torch.is_tensor(dst):
+        dst.copy_(src, non_blocking=True)
+    elif isinstance(dst, dict):
+        for k in dst:
+            _tree_copy(dst[k], src[k])
+    elif isinstance(dst, (list, tuple)):
+        for d, s in zip(dst, src):
+            _tree_copy(d, s)

@@ -19,6 +19,11 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 EPI_BF16, EPI_GELU, EPI_RESID, EPI_F32, EPI_DGELU = 0, 1, 2, 3, 4
 
 
+class TnProblem(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("dW", vp), ("dbias", vp), ("lda", i32), ("ldb", i32),
+                ("lddw", i32), ("M", i32), ("N", i32), ("K", i32)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [("A", vp), ("lda", i32), ("W", vp), ("ldw", i32), ("bias", vp), ("out", vp),
                 ("ldo", i32), ("out2", vp), ("ldo2", i32), ("aux", vp), ("ldaux", i32),
@@ -99,6 +104,7 @@ _SIGS = {
     "svit_arch": (C.c_char_p, []),
     "svit_gemm_nt": (i32, [C.POINTER(GemmArgs), vp]),
     "svit_gemm_tn": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "svit_gemm_tn_grouped": (i32, [C.POINTER(TnProblem), i32, vp]),
     "svit_colsum_bf16": (i32, [vp, i32, vp, i32, i32, vp]),
     "svit_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
     "svit_transpose_cast_batched": (i32, [vp, vp, vp, i32, i32, vp]),
@@ -146,8 +152,13 @@ def load():
     return _lib
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_cur_device = torch._C._cuda_getDevice
+
+
 def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """torch's current HIP stream on the current device (the capture stream inside a graph)."""
+    return C.c_void_p(_raw_stream(_cur_device()))
 
 
 def ptr(t):

@@ -94,8 +94,8 @@ class SViTHead(nn.Module):
             x = x * dropout_keep if dropout_keep is not None else F.dropout(x, self.dropout_rate, True)
         B = x.size(0)
         # the reference touches every head parameter so that DDP sees a grad on every rank
-        # (video_model_builder.py:514); same here: image-only heads get exact zeros on video steps
-        x = x + sum(p.sum() for p in self.parameters()) * 0
+        # (video_model_builder.py:514).  Here every parameter's .grad is a view of the flat grad
+        # buffer (SViT._attach_grads), so heads the loss does not reach already hold exact zeros.
         cls, xobj = x[:, 0], x[:, 1:]
         extra = {"obj_desc": xobj.reshape(B, T, -1, xobj.size(-1))}
         logits = self.projection(cls)
@@ -156,6 +156,8 @@ class SViT(nn.Module):
         self.flat = None
         self._grad_ready_hook = None   # set by the data-parallel wrapper (svit_amd/dp.py)
         self._anchor = None
+        self._keep = None
+        self._grad_views = None
 
     # -- parameters are registered under the reference's dotted names ---------------------------
     def _register(self, name, tensor):
@@ -207,7 +209,7 @@ class SViT(nn.Module):
             p.grad = None
         self.flat = flat
         self.engine = Engine(self.plan, flat)
-        self._grads_attached = False
+        self._grad_views = None
         self._anchor = torch.zeros((), device=dev, requires_grad=True)
         return self
 
@@ -217,34 +219,34 @@ class SViT(nn.Module):
         already back-propagated through ordinary autograd: grads it produced into fresh tensors
         (after `optimizer.zero_grad()` dropped ours, tools/train_net.py:133) are adopted."""
         flat = self.flat
-        first = self.cls_token
-        fresh = first.grad is None or first.grad.data_ptr() != flat.g("cls_token").data_ptr()
+        if self._grad_views is None:
+            self._grad_views = [(p, flat.g(n)) for n, p in self.named_parameters()]
+        views = self._grad_views
+        fresh = views[0][0].grad is not views[0][1]
         if fresh:
             flat.grad.zero_()
-        for n, p in self.named_parameters():
-            v = flat.g(n)
-            if p.grad is None:
-                p.grad = v
-            elif p.grad.data_ptr() != v.data_ptr():
+        for p, v in views:
+            g = p.grad
+            if g is v:
+                continue
+            if g is not None:
                 if fresh:
-                    v.copy_(p.grad)
+                    v.copy_(g)
                 else:
-                    v.add_(p.grad)
-                p.grad = v
+                    v.add_(g)
+            p.grad = v
 
     # -- forward ---------------------------------------------------------------------------------
     def sample_drop_scales(self, batch, device):
         """Per-sample stochastic-depth factors floor(keep + U[0,1)) / keep (common.py:46-59)."""
-        out = []
-        for blk in self.plan.blocks:
-            if blk.drop_path <= 0.0 or not self.training:
-                out.append(None)
-                continue
-            keep = 1.0 - blk.drop_path
-            r = torch.rand((2, batch), device=device)
-            m = torch.floor(keep + r) / keep
-            out.append((m[0].contiguous(), m[1].contiguous()))
-        return out
+        blocks = self.plan.blocks
+        if not self.training or all(b.drop_path <= 0.0 for b in blocks):
+            return [None] * len(blocks)
+        if self._keep is None or self._keep.device != torch.device(device):
+            self._keep = torch.tensor([1.0 - b.drop_path for b in blocks], device=device).view(-1, 1, 1)
+        # one launch chain for all blocks: rows (attention branch, MLP branch) per block
+        m = torch.floor(self._keep + torch.rand((len(blocks), 2, batch), device=device)) / self._keep
+        return [(m[i, 0], m[i, 1]) if b.drop_path > 0.0 else None for i, b in enumerate(blocks)]
 
     def forward(self, x, metadata=None, bboxes=None, drop_scales=None, dropout_keep=None):
         if self.engine is None:

@@ -82,6 +82,27 @@ def gemm_tn(a, b, dw, splits=0, dbias=None):
     return dw
 
 
+def gemm_tn_grouped(problems):
+    """problems: [(a[M,N], b[M,K'], dw[N,K] f32, dbias or None)], each as for gemm_tn; all are
+    accumulated by one launch (per group of 8)."""
+    n = len(problems)
+    if n == 0:
+        return
+    arr = (hip.TnProblem * n)()
+    flop = 0.0
+    for i, (a, b, dw, dbias) in enumerate(problems):
+        _chk_rows(a, b)
+        _chk_dev(dw)
+        M, N = a.shape
+        K = dw.shape[-1]
+        assert b.shape[0] == M and b.shape[1] >= K and dw.shape[-2] == N and dw.dtype == F32
+        t = arr[i]
+        t.A, t.B, t.dW, t.dbias = ptr(a), ptr(b), ptr(dw), ptr(dbias)
+        t.lda, t.ldb, t.lddw, t.M, t.N, t.K = a.stride(0), b.stride(0), dw.stride(-2), M, N, K
+        flop += 2.0 * M * N * K
+    hip.call("svit_gemm_tn_grouped", arr, n, meta=("flop", flop))
+
+
 def colsum(a, out):
     _chk_dev(a, out)
     hip.call("svit_colsum_bf16", ptr(a), a.stride(0), ptr(out), a.shape[0], a.shape[1])

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, graphed=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -49,7 +49,16 @@ def _worker(rank, world, port, out):
     per = 4 // world
     x = x_all[rank * per:(rank + 1) * per].cuda()
     y = y_all[rank * per:(rank + 1) * per].cuda()
+    step = None
+    if graphed:
+        from svit_amd.graph import GraphedTrainStep
+        step = GraphedTrainStep(dp, lambda p, e, l: torch.nn.functional.cross_entropy(p, l), [x], y)
+        assert len(step.segments) == (len(dp.launch_ranks()) if world > 1 else 1)
     for _ in range(2):
+        if step is not None:
+            step([x], y)
+            opt.step()
+            continue
         logits, _ = dp([x], {})
         loss = torch.nn.functional.cross_entropy(logits, y)
         opt.zero_grad()
@@ -68,10 +77,10 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def _run(world, out):
+def _run(world, out, graphed=False):
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out, graphed)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -87,5 +96,15 @@ def test_two_ranks_equal_one_rank_on_merged_batch(tmp_path):
     diff = (one - two).abs().max().item()
     scale = (one.abs().max().item())
     assert diff < 2e-3 * scale, (diff, scale)
+    cos = torch.dot(one.double(), two.double()) / (one.double().norm() * two.double().norm())
+    assert cos > 0.999999
+
+
+def test_graphed_two_ranks_equal_eager_one_rank(tmp_path):
+    """HIP-graph segments + all-reduce launches between them (svit_amd/graph.py) on two ranks."""
+    one = _run(1, str(tmp_path / "w1.pt"))
+    two = _run(2, str(tmp_path / "w2g.pt"), graphed=True)
+    diff = (one - two).abs().max().item()
+    assert diff < 2e-3 * one.abs().max().item()
     cos = torch.dot(one.double(), two.double()) / (one.double().norm() * two.double().norm())
     assert cos > 0.999999

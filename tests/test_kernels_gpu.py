@@ -98,6 +98,30 @@ def test_gemm_tn(ops, M, N, K, splits):
     assert rel_err(db, a.float().sum(0) + 1.0) < 2e-4
 
 
+@pytest.mark.parametrize("count", [1, 5, 11])
+def test_gemm_tn_grouped(ops, count):
+    """several wgrads per launch (incl. strided column slices, K tail inside a padded ldb, no
+    bias) == the same GEMMs one by one"""
+    shapes = [(1000, 288, 96), (4100, 384, 1536), (70, 96, 441), (13064, 384, 384), (333, 40, 96),
+              (64, 3072, 768), (2000, 1152, 384), (5000, 96, 96), (129, 128, 96), (8000, 64, 96),
+              (700, 768, 768)][:count]
+    probs, refs = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        wide = rnd("ga%d" % i, (M, N + 16), 1.0, BF16)
+        a = wide[:, 8:8 + N]                                  # row-strided view
+        b = rnd("gb%d" % i, (M, (K + 7) // 8 * 8), 1.0, BF16)
+        dw = torch.full((N, K), 0.5, device=DEV)
+        db = torch.full((N,), 0.25, device=DEV) if i % 3 != 2 else None
+        probs.append((a, b, dw, db))
+        refs.append((a.float().t() @ b.float()[:, :K] + 0.5,
+                     None if db is None else a.float().sum(0) + 0.25))
+    ops.gemm_tn_grouped(probs)
+    for (a, b, dw, db), (rw, rb) in zip(probs, refs):
+        assert rel_err(dw, rw) < 2e-4
+        if db is not None:
+            assert rel_err(db, rb) < 2e-4
+
+
 def test_colsum_cast_scale(ops):
     a = rnd("cs", (1234, 288), 1.0, BF16)
     out = torch.zeros(288, device=DEV)

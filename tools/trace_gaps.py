@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Busy time vs wall span from a rocprofv3 kernel trace (…_kernel_trace.csv).
+
+    python tools/trace_gaps.py gpurun_out/prof/<host>/<pid>_kernel_trace.csv [n_last_dispatches]
+
+Prints the device-busy fraction over the last N dispatches, the idle-gap total, and the kernels
+that most often precede long gaps (launch-bound stretches)."""
+import csv
+import sys
+from collections import defaultdict
+
+
+def main():
+    path = sys.argv[1]
+    n_last = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    rows = rows[-n_last:]
+    span = rows[-1][1] - rows[0][0]
+    busy = 0
+    gaps = defaultdict(lambda: [0, 0])
+    gap_total = 0
+    end = rows[0][0]
+    for s, e, name in rows:
+        if s > end:
+            g = s - end
+            gap_total += g
+            gaps[prev][0] += g
+            gaps[prev][1] += 1
+        busy += max(0, e - max(s, end))
+        end = max(end, e)
+        prev = name.split("(")[0][:70]
+    print("dispatches %d span %.3f ms busy %.3f ms (%.1f%%) idle %.3f ms" %
+          (len(rows), span / 1e6, busy / 1e6, 100.0 * busy / span, gap_total / 1e6))
+    print("idle time by preceding kernel:")
+    for k, (g, c) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:25]:
+        print("  %8.1f us  %5d gaps  avg %6.2f us  %s" % (g / 1e3, c, g / 1e3 / c, k))
+
+
+def window(path, needle, before, after):
+    """Timeline (start us, duration us, gap before us, name) around the last dispatch of the
+    first run of kernels matching `needle` in the final step."""
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    idx = [i for i, r in enumerate(rows) if needle in r[2]]
+    # first match of the last cluster (matches further than 5 ms apart start a new cluster)
+    start = idx[-1]
+    for a, b in zip(reversed(idx[:-1]), reversed(idx[1:])):
+        if rows[b][0] - rows[a][0] > 5_000_000:
+            break
+        start = a
+    lo, hi = max(0, start - before), min(len(rows), start + after)
+    t0 = rows[lo][0]
+    for i in range(lo, hi):
+        s, e, n = rows[i]
+        gap = s - rows[i - 1][1] if i else 0
+        short = n.replace("void ", "").replace("(anonymous namespace)::", "").replace("at::native::", "")[:60]
+        print("%9.1f %8.1f %8.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, gap / 1e3, short))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "--window":
+        window(sys.argv[1], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]))
+        sys.exit(0)
+    main()
