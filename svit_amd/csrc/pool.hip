@@ -104,29 +104,40 @@ __global__ __launch_bounds__(256) void pool_ln_fwd_kernel(svit_pool_args a) {
       is_patch = true;
       const int p = tok - 1;
       px = p % Wo; py = (p / Wo) % Ho; pt = p / (Wo * Ho);
-      for (int kt = 0; kt < 3; ++kt) {
-        const int t = pt - 1 + kt;
-        if (t < 0 || t >= a.T) continue;
-        for (int ky = 0; ky < 3; ++ky) {
-          const int y = py * s - 1 + ky;
-          if (y < 0 || y >= a.H) continue;
+    }
+  }
+  // 27-tap stencil, one t-plane (9 taps x 48 B per lane) per round: every load of a round is
+  // issued before the first FMA consumes one (out-of-volume taps read token 0 and are skipped),
+  // so a lane pays 3 memory round trips instead of 27.
+  if (__any(is_patch)) {
+#pragma unroll 1
+    for (int kt = 0; kt < 3; ++kt) {
+      const int t = pt - 1 + kt;
+      const bool tv = is_patch && t >= 0 && t < a.T;
+      uint4 v[9][3];
+      bool ok[9];
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int x = px * s - 1 + kx;
-            if (x < 0 || x >= a.W) continue;
-            const bf16_t* src = base + (size_t)(1 + (t * a.H + y) * a.W + x) * tok_stride;
-            const float* w = w_lds + ((kt * 3 + ky) * 3 + kx) * HD + c0;
+      for (int k9 = 0; k9 < 9; ++k9) {
+        const int y = py * s - 1 + k9 / 3, x = px * s - 1 + k9 % 3;
+        ok[k9] = tv && y >= 0 && y < a.H && x >= 0 && x < a.W;
+        const int ti = ok[k9] ? 1 + (t * a.H + y) * a.W + x : 0;
+        const bf16_t* src = base + (size_t)ti * tok_stride;
 #pragma unroll
-            for (int v = 0; v < 3; ++v) {
-              float f[8];
-              unpack8(*(const uint4*)(src + v * 8), f);
-              const float4 w0 = *(const float4*)(w + v * 8), w1 = *(const float4*)(w + v * 8 + 4);
-              acc[v * 8 + 0] += f[0] * w0.x; acc[v * 8 + 1] += f[1] * w0.y;
-              acc[v * 8 + 2] += f[2] * w0.z; acc[v * 8 + 3] += f[3] * w0.w;
-              acc[v * 8 + 4] += f[4] * w1.x; acc[v * 8 + 5] += f[5] * w1.y;
-              acc[v * 8 + 6] += f[6] * w1.z; acc[v * 8 + 7] += f[7] * w1.w;
-            }
-          }
+        for (int u = 0; u < 3; ++u) v[k9][u] = *(const uint4*)(src + u * 8);
+      }
+#pragma unroll
+      for (int k9 = 0; k9 < 9; ++k9) {
+        if (!ok[k9]) continue;
+        const float* w = w_lds + (kt * 9 + k9) * HD + c0;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          float f[8];
+          unpack8(v[k9][u], f);
+          const float4 w0 = *(const float4*)(w + u * 8), w1 = *(const float4*)(w + u * 8 + 4);
+          acc[u * 8 + 0] += f[0] * w0.x; acc[u * 8 + 1] += f[1] * w0.y;
+          acc[u * 8 + 2] += f[2] * w0.z; acc[u * 8 + 3] += f[3] * w0.w;
+          acc[u * 8 + 4] += f[4] * w1.x; acc[u * 8 + 5] += f[5] * w1.y;
+          acc[u * 8 + 6] += f[6] * w1.z; acc[u * 8 + 7] += f[7] * w1.w;
         }
       }
     }
@@ -288,7 +299,15 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(svit_pool_ln_bwd_args 
 }
 
 // ---------------------------------------------------------------------------------------
+// Gather form: one input token sums the taps of the output positions that saw it.  Per axis an
+// input coordinate y is hit through ky with (y + 1 - ky) % s == 0: all 3 taps for s = 1, taps
+// {0,2} or {1} for s = 2, at most one tap for s >= 3 -- so the candidate list per axis has
+// NC = 3 / 2 / 1 entries (template S = 1 / 2 / 3 for "any s >= 3") and a lane issues the loads
+// of KTB t-planes (NC*NC candidates each) before it consumes the first one.
+template <int S>
 __global__ __launch_bounds__(256) void pool_dgrad_kernel(svit_pool_dgrad_args a) {
+  constexpr int NC = (S == 1) ? 3 : (S == 2 ? 2 : 1);
+  constexpr int KTB = (S == 1) ? 1 : 3;
   __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];
   __shared__ __attribute__((aligned(16))) float g_lds[HD];
   load_weights(a.conv_w, w_lds, g_lds, a.stride_hw);
@@ -315,31 +334,53 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(svit_pool_dgrad_args a)
     }
   } else {
     const int p = tok - 1, x = p % a.W, y = (p / a.W) % a.H, t = p / (a.W * a.H);
-    for (int kt = 0; kt < 3; ++kt) {
-      const int to = t + 1 - kt;
-      if (to < 0 || to >= a.T) continue;
-      for (int ky = 0; ky < 3; ++ky) {
-        const int yn = y + 1 - ky;
-        if (yn < 0 || yn % s != 0) continue;
-        const int yo = yn / s;
-        if (yo >= Ho) continue;
+    // candidate taps / output coordinates per axis
+    int kyc[NC], yoc[NC], kxc[NC], xoc[NC];
+    bool yv[NC], xv[NC];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int xn = x + 1 - kx;
-          if (xn < 0 || xn % s != 0) continue;
-          const int xo = xn / s;
-          if (xo >= Wo) continue;
-          const bf16_t* src = dp + (size_t)(1 + (to * Ho + yo) * Wo + xo) * HD;
-          const float* w = w_lds + ((kt * 3 + ky) * 3 + kx) * HD + c0;
+    for (int j = 0; j < NC; ++j) {
+      if (S == 1) { kyc[j] = j; kxc[j] = j; }
+      else if (S == 2) { kyc[j] = ((y + 1) & 1) + 2 * j; kxc[j] = ((x + 1) & 1) + 2 * j; }
+      else { kyc[j] = (y + 1) % s; kxc[j] = (x + 1) % s; }
+      const int yn = y + 1 - kyc[j], xn = x + 1 - kxc[j];
+      yoc[j] = yn / s; xoc[j] = xn / s;
+      yv[j] = kyc[j] <= 2 && yn >= 0 && yoc[j] < Ho;
+      xv[j] = kxc[j] <= 2 && xn >= 0 && xoc[j] < Wo;
+    }
+#pragma unroll 1
+    for (int kt0 = 0; kt0 < 3; kt0 += KTB) {
+      uint4 v[KTB][NC * NC][3];
+      bool ok[KTB][NC * NC];
 #pragma unroll
-          for (int v = 0; v < 3; ++v) {
-            float f[8];
-            unpack8(*(const uint4*)(src + v * 8), f);
+      for (int kk = 0; kk < KTB; ++kk) {
+        const int to = t + 1 - (kt0 + kk);
+        const bool tv = to >= 0 && to < a.T;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[v * 8 + e] += f[e] * w[v * 8 + e];
-          }
+        for (int j = 0; j < NC * NC; ++j) {
+          ok[kk][j] = tv && yv[j / NC] && xv[j % NC];
+          const int ti = ok[kk][j] ? 1 + (to * Ho + yoc[j / NC]) * Wo + xoc[j % NC] : 0;
+          const bf16_t* src = dp + (size_t)ti * HD;
+#pragma unroll
+          for (int u = 0; u < 3; ++u) v[kk][j][u] = *(const uint4*)(src + u * 8);
         }
       }
+#pragma unroll
+      for (int kk = 0; kk < KTB; ++kk)
+#pragma unroll
+        for (int j = 0; j < NC * NC; ++j) {
+          if (!ok[kk][j]) continue;
+          const float* w = w_lds + (((kt0 + kk) * 3 + kyc[j / NC]) * 3 + kxc[j % NC]) * HD + c0;
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            float f[8];
+            unpack8(v[kk][j][u], f);
+            const float4 w0 = *(const float4*)(w + u * 8), w1 = *(const float4*)(w + u * 8 + 4);
+            acc[u * 8 + 0] += f[0] * w0.x; acc[u * 8 + 1] += f[1] * w0.y;
+            acc[u * 8 + 2] += f[2] * w0.z; acc[u * 8 + 3] += f[3] * w0.w;
+            acc[u * 8 + 4] += f[4] * w1.x; acc[u * 8 + 5] += f[5] * w1.y;
+            acc[u * 8 + 6] += f[6] * w1.z; acc[u * 8 + 7] += f[7] * w1.w;
+          }
+        }
     }
   }
   const size_t tok_stride = (size_t)3 * a.heads * HD;
@@ -718,8 +759,13 @@ extern "C" int svit_pool_conv_dgrad(const svit_pool_dgrad_args* a, void* stream)
   int rc = check_pool_dims(a->B, a->heads, a->T, a->H, a->W, a->n_obj, a->stride_hw);
   if (rc) return rc;
   const int N = 1 + a->T * a->H * a->W + a->n_obj;
-  hipLaunchKernelGGL(pool_dgrad_kernel, dim3((N + 63) / 64, a->B * a->heads), dim3(256), 0,
-                     (hipStream_t)stream, *a);
+  const dim3 grid((N + 63) / 64, a->B * a->heads);
+  if (a->stride_hw == 1)
+    hipLaunchKernelGGL(pool_dgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  else if (a->stride_hw == 2)
+    hipLaunchKernelGGL(pool_dgrad_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  else
+    hipLaunchKernelGGL(pool_dgrad_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, *a);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }
