@@ -150,6 +150,15 @@ typedef struct {
   float* workspace; int64_t workspace_floats;
 } svit_pool_wgrad_args;
 int svit_pool_conv_wgrad(const svit_pool_wgrad_args* a, void* stream);
+/* The four pooling entry points for q, k and v of one block in ONE launch each (args[0..2] =
+ * which 0, 1, 2; same qkv / B / heads / T / H / W / n_obj, individual strides and outputs).
+ * This is what the engine calls: at the 14x14 and 7x7 stages each stencil is a short latency
+ * chain, so three side by side cost the time of one (attention.py:263-304 runs them serially).
+ * The two-stage reductions use args[0].workspace (>= 1024 * 3 * 27 * 96 floats for wgrad). */
+int svit_pool_ln_fwd_qkv(const svit_pool_args* args3, void* stream);
+int svit_pool_ln_bwd_qkv(const svit_pool_ln_bwd_args* args3, void* stream);
+int svit_pool_conv_dgrad_qkv(const svit_pool_dgrad_args* args3, void* stream);
+int svit_pool_conv_wgrad_qkv(const svit_pool_wgrad_args* args3, void* stream);
 
 /* ------------------------------------------- decomposed rel-pos bias, query side (K9/K10) */
 /* cal_rel_pos_spatial / cal_rel_pos_temporal (attention.py:84-183) restated as

@@ -103,12 +103,12 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 
 // Second stage of the two-stage parameter-gradient reductions: every block of the producing
 // kernel stores its partial sums as one row of `partial` [nblocks][n] with plain stores, then
-// this kernel adds the column sums into up to three destination vectors (segments of n).
+// this kernel adds the column sums into up to six destination vectors (segments of n).
 // (Thousands of blocks atomically adding to the same few hundred addresses serialise at the
 // memory side: MI355X guide, "Global float atomics", contention row.)
 struct SvitReduceDst {
-  float* ptr[3];
-  int end[3];  // exclusive end of each segment within [0, n)
+  float* ptr[6];
+  int end[6];  // exclusive end of each segment within [0, n); unused tail entries = n
 };
 static __global__ void svit_reduce_partials_kernel(const float* __restrict__ partial, int nblocks,
                                                    int n, SvitReduceDst dst) {
@@ -132,9 +132,11 @@ static __global__ void svit_reduce_partials_kernel(const float* __restrict__ par
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
-    if (i < dst.end[0]) dst.ptr[0][i] += s;
-    else if (i < dst.end[1]) dst.ptr[1][i - dst.end[0]] += s;
-    else dst.ptr[2][i - dst.end[1]] += s;
+    int k = 0, lo = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      if (i >= dst.end[j]) { k = j + 1; lo = dst.end[j]; }
+    dst.ptr[k][i - lo] += s;
   }
 }
 // Zero-fill as a kernel (16-byte stores): hipMemsetAsync turns into a memset node under stream

@@ -177,7 +177,7 @@ extern "C" int svit_layernorm_bwd(const float* dy, const float* x, const float* 
   hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy,
                      x, gamma, mean, rstd, dres, dx, workspace, rows, C);
   SVIT_LAUNCH_CHECK();
-  SvitReduceDst dst = {{dgamma, dbeta, dbeta}, {C, 2 * C, 2 * C}};
+  SvitReduceDst dst = {{dgamma, dbeta, dbeta, dbeta, dbeta, dbeta}, {C, 2 * C, 2 * C, 2 * C, 2 * C, 2 * C}};
   svit_launch_reduce(workspace, (int)blocks, 2 * C, dst, (hipStream_t)stream);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;

@@ -67,7 +67,7 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ conv_w, f
 }
 
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pool_ln_fwd_kernel(svit_pool_args a) {
+__device__ __forceinline__ void pool_ln_fwd_body(const svit_pool_args& a) {
   __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];
   __shared__ __attribute__((aligned(16))) float g_lds[HD];
   load_weights(a.conv_w, w_lds, g_lds, a.stride_hw);
@@ -182,8 +182,21 @@ __global__ __launch_bounds__(256) void pool_ln_fwd_kernel(svit_pool_args a) {
   }
 }
 
+__global__ __launch_bounds__(256) void pool_ln_fwd_kernel(svit_pool_args a) { pool_ln_fwd_body(a); }
+
+// q, k and v of one block in one launch (blockIdx.z = which): the three stencils differ only in
+// stride, and at the 14x14 / 7x7 stages each of them is a few-microsecond latency chain, so
+// running them side by side costs the time of the longest one.
+struct PoolFwd3 { svit_pool_args p[3]; };
+__global__ __launch_bounds__(256) void pool_ln_fwd3_kernel(PoolFwd3 g) {
+  const svit_pool_args& a = g.p[blockIdx.z];
+  const int Nout = 1 + a.T * pooled(a.H, a.stride_hw) * pooled(a.W, a.stride_hw) + a.n_obj;
+  if ((int)blockIdx.x * 64 >= Nout) return;
+  pool_ln_fwd_body(a);
+}
+
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pool_ln_bwd_kernel(svit_pool_ln_bwd_args a) {
+__device__ __forceinline__ void pool_ln_bwd_body(const svit_pool_ln_bwd_args& a, float* prow) {
   __shared__ float red[2][HD];
   for (int i = threadIdx.x; i < 2 * HD; i += blockDim.x) (&red[0][0])[i] = 0.f;
   __syncthreads();
@@ -294,8 +307,16 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(svit_pool_ln_bwd_args 
   for (int c = threadIdx.x; c < 2 * HD; c += blockDim.x)
     (&red[0][0])[c] = (&wred[0][0][0])[c] + (&wred[1][0][0])[c] + (&wred[2][0][0])[c] + (&wred[3][0][0])[c];
   __syncthreads();
-  float* prow = a.workspace + (size_t)blockIdx.x * 2 * HD;
   for (int c = threadIdx.x; c < 2 * HD; c += blockDim.x) prow[c] = (&red[0][0])[c];
+}
+__global__ __launch_bounds__(256) void pool_ln_bwd_kernel(svit_pool_ln_bwd_args a) {
+  pool_ln_bwd_body(a, a.workspace + (size_t)blockIdx.x * 2 * HD);
+}
+struct PoolLnBwd3 { svit_pool_ln_bwd_args p[3]; };
+__global__ __launch_bounds__(256) void pool_ln_bwd3_kernel(PoolLnBwd3 g) {
+  // partial rows [block][which][dgamma | dbeta] in the first entry's workspace
+  pool_ln_bwd_body(g.p[blockIdx.y],
+                   g.p[0].workspace + ((size_t)blockIdx.x * 3 + blockIdx.y) * 2 * HD);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -305,7 +326,7 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(svit_pool_ln_bwd_args 
 // NC = 3 / 2 / 1 entries (template S = 1 / 2 / 3 for "any s >= 3") and a lane issues the loads
 // of KTB t-planes (NC*NC candidates each) before it consumes the first one.
 template <int S>
-__global__ __launch_bounds__(256) void pool_dgrad_kernel(svit_pool_dgrad_args a) {
+__device__ __forceinline__ void pool_dgrad_body(const svit_pool_dgrad_args& a) {
   constexpr int NC = (S == 1) ? 3 : (S == 2 ? 2 : 1);
   constexpr int KTB = (S == 1) ? 1 : 3;
   __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];
@@ -389,6 +410,18 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(svit_pool_dgrad_args a)
   for (int v = 0; v < 3; ++v) *(uint4*)(o + v * 8) = pack8(&acc[v * 8]);
 }
 
+template <int S>
+__global__ __launch_bounds__(256) void pool_dgrad_kernel(svit_pool_dgrad_args a) {
+  pool_dgrad_body<S>(a);
+}
+struct PoolDgrad3 { svit_pool_dgrad_args p[3]; };
+__global__ __launch_bounds__(256) void pool_dgrad3_kernel(PoolDgrad3 g) {
+  const svit_pool_dgrad_args& a = g.p[blockIdx.z];
+  if (a.stride_hw == 1) pool_dgrad_body<1>(a);
+  else if (a.stride_hw == 2) pool_dgrad_body<2>(a);
+  else pool_dgrad_body<3>(a);
+}
+
 // ---------------------------------------------------------------------------------------
 // wgrad, LDS-tiled: a block owns an (R x TX) patch of output positions of one (b, head) and
 // walks t; the input halo of three consecutive planes lives in an LDS ring (one new plane slab
@@ -410,9 +443,9 @@ struct WgradTile {
 };
 
 template <int S>
-__global__ __launch_bounds__(192) void pool_wgrad_kernel(svit_pool_wgrad_args a, int n_tiles,
-                                                         int tiles_x, int tiles_y, int t_chunks,
-                                                         int t_len) {
+__device__ __forceinline__ void pool_wgrad_body(const svit_pool_wgrad_args& a, int n_tiles,
+                                                int tiles_x, int tiles_y, int t_chunks, int t_len,
+                                                float* prow_base) {
   using TL = WgradTile<S>;
   constexpr int R = TL::R, TX = TL::TX, CS = TL::CS, RI = TL::RI, CI = TL::CI, PLANE = TL::PLANE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
@@ -537,24 +570,57 @@ __global__ __launch_bounds__(192) void pool_wgrad_kernel(svit_pool_wgrad_args a,
   }
   __syncthreads();
   if (r == 0) {
-    float* prow = a.workspace + (size_t)blockIdx.x * 27 * HD + c * 27;   // [c][tap]
+    float* prow = prow_base + c * 27;   // [c][tap]
 #pragma unroll
     for (int k = 0; k < 27; ++k) prow[k] = acc[k] + comb[k * HD + c];
   }
 }
 
 template <int S>
-static int launch_wgrad(const svit_pool_wgrad_args& a, int Ho, int Wo, hipStream_t st) {
+__global__ __launch_bounds__(192) void pool_wgrad_kernel(svit_pool_wgrad_args a, int n_tiles,
+                                                         int tiles_x, int tiles_y, int t_chunks,
+                                                         int t_len) {
+  pool_wgrad_body<S>(a, n_tiles, tiles_x, tiles_y, t_chunks, t_len,
+                     a.workspace + (size_t)blockIdx.x * 27 * HD);
+}
+struct WgradPlan { int n_tiles, tiles_x, tiles_y, t_chunks, t_len, sclass; };
+struct PoolWgrad3 { svit_pool_wgrad_args p[3]; WgradPlan plan[3]; };
+__global__ __launch_bounds__(192) void pool_wgrad3_kernel(PoolWgrad3 g) {
+  const svit_pool_wgrad_args& a = g.p[blockIdx.y];
+  const WgradPlan& pl = g.plan[blockIdx.y];
+  // partial rows [block][which][c][tap] in the first entry's workspace
+  float* prow = g.p[0].workspace + ((size_t)blockIdx.x * 3 + blockIdx.y) * 27 * HD;
+  if (pl.sclass == 1)
+    pool_wgrad_body<1>(a, pl.n_tiles, pl.tiles_x, pl.tiles_y, pl.t_chunks, pl.t_len, prow);
+  else if (pl.sclass == 2)
+    pool_wgrad_body<2>(a, pl.n_tiles, pl.tiles_x, pl.tiles_y, pl.t_chunks, pl.t_len, prow);
+  else
+    pool_wgrad_body<3>(a, pl.n_tiles, pl.tiles_x, pl.tiles_y, pl.t_chunks, pl.t_len, prow);
+}
+
+template <int S>
+static WgradPlan plan_wgrad(const svit_pool_wgrad_args& a, int Ho, int Wo) {
   using TL = WgradTile<S>;
-  const int tiles_x = (Wo + TL::TX - 1) / TL::TX, tiles_y = (Ho + TL::R - 1) / TL::R;
+  WgradPlan pl;
+  pl.tiles_x = (Wo + TL::TX - 1) / TL::TX;
+  pl.tiles_y = (Ho + TL::R - 1) / TL::R;
   // split the t walk when the (y, x) tiling alone gives too few workgroups
   int t_chunks = 1;
-  while (t_chunks < a.T && (long)tiles_x * tiles_y * a.B * a.heads * t_chunks < 768 &&
+  while (t_chunks < a.T && (long)pl.tiles_x * pl.tiles_y * a.B * a.heads * t_chunks < 768 &&
          a.T / (t_chunks * 2) >= 2)
     t_chunks *= 2;
-  const int t_len = (a.T + t_chunks - 1) / t_chunks;
-  const int n_tiles = tiles_x * tiles_y * a.B * a.heads * t_chunks;
-  int64_t blocks = n_tiles;
+  pl.t_chunks = t_chunks;
+  pl.t_len = (a.T + t_chunks - 1) / t_chunks;
+  pl.n_tiles = pl.tiles_x * pl.tiles_y * a.B * a.heads * t_chunks;
+  pl.sclass = S;
+  return pl;
+}
+
+template <int S>
+static int launch_wgrad(const svit_pool_wgrad_args& a, int Ho, int Wo, hipStream_t st) {
+  using TL = WgradTile<S>;
+  const WgradPlan pl = plan_wgrad<S>(a, Ho, Wo);
+  int64_t blocks = pl.n_tiles;
   if (blocks > 1024) blocks = 1024;
   if (blocks > a.workspace_floats / (27 * HD)) blocks = a.workspace_floats / (27 * HD);
   if (blocks < 1) return SVIT_ERR_ARG;
@@ -566,9 +632,9 @@ static int launch_wgrad(const svit_pool_wgrad_args& a, int Ho, int Wo, hipStream
     configured = true;
   }
   hipLaunchKernelGGL(pool_wgrad_kernel<S>, dim3((unsigned)blocks), dim3(192), TL::LDS_BYTES, st, a,
-                     n_tiles, tiles_x, tiles_y, t_chunks, t_len);
+                     pl.n_tiles, pl.tiles_x, pl.tiles_y, pl.t_chunks, pl.t_len);
   SVIT_LAUNCH_CHECK();
-  SvitReduceDst dst = {{a.dw, a.dw, a.dw}, {27 * HD, 27 * HD, 27 * HD}};
+  SvitReduceDst dst = {{a.dw, a.dw, a.dw, a.dw, a.dw, a.dw}, {27 * HD, 27 * HD, 27 * HD, 27 * HD, 27 * HD, 27 * HD}};
   svit_launch_reduce(a.workspace, (int)blocks, 27 * HD, dst, st);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
@@ -734,6 +800,135 @@ extern "C" int svit_pool_ln_fwd(const svit_pool_args* a, void* stream) {
   return SVIT_OK;
 }
 
+static int check_pool_fwd(const svit_pool_args* a) {
+  if (!a->qkv || !a->conv_w || !a->gamma || !a->beta || !a->out || !a->pre || !a->mean || !a->rstd)
+    return SVIT_ERR_ARG;
+  int rc = check_pool_dims(a->B, a->heads, a->T, a->H, a->W, a->n_obj, a->stride_hw);
+  if (rc) return rc;
+  if (a->which < 0 || a->which > 2 || a->ld_out < HD || a->ld_out % 8 != 0) return SVIT_ERR_ARG;
+  const int Ho = (a->H - 1) / a->stride_hw + 1, Wo = (a->W - 1) / a->stride_hw + 1;
+  if (a->mode == 1) {
+    const int extra = a->ld_out - HD;
+    if (extra % 32 != 0 || extra < Ho + Wo + a->T) return SVIT_ERR_SHAPE;
+  }
+  return SVIT_OK;
+}
+
+extern "C" int svit_pool_ln_fwd_qkv(const svit_pool_args* a3, void* stream) {
+  if (!a3) return SVIT_ERR_ARG;
+  PoolFwd3 g;
+  int max_nout = 0;
+  for (int i = 0; i < 3; ++i) {
+    const int rc = check_pool_fwd(&a3[i]);
+    if (rc) return rc;
+    if (a3[i].B != a3[0].B || a3[i].heads != a3[0].heads) return SVIT_ERR_SHAPE;
+    g.p[i] = a3[i];
+    const int s = a3[i].stride_hw;
+    const int nout = 1 + a3[i].T * ((a3[i].H - 1) / s + 1) * ((a3[i].W - 1) / s + 1) + a3[i].n_obj;
+    if (nout > max_nout) max_nout = nout;
+  }
+  hipLaunchKernelGGL(pool_ln_fwd3_kernel, dim3((max_nout + 63) / 64, a3[0].B * a3[0].heads, 3),
+                     dim3(256), 0, (hipStream_t)stream, g);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+static int check_pool_ln_bwd(const svit_pool_ln_bwd_args* a) {
+  if (!a->pre || !a->mean || !a->rstd || !a->gamma || !a->dpre || !a->dgamma || !a->dbeta)
+    return SVIT_ERR_ARG;
+  if (a->B <= 0 || a->heads <= 0 || a->Nout <= 0) return SVIT_ERR_SHAPE;
+  if (a->d_main && (a->ld_main < HD || a->ld_main % 8 != 0)) return SVIT_ERR_ALIGN;
+  return SVIT_OK;
+}
+
+extern "C" int svit_pool_ln_bwd_qkv(const svit_pool_ln_bwd_args* a3, void* stream) {
+  if (!a3 || !a3[0].workspace) return SVIT_ERR_ARG;
+  PoolLnBwd3 g;
+  int64_t max_total = 0;
+  for (int i = 0; i < 3; ++i) {
+    const int rc = check_pool_ln_bwd(&a3[i]);
+    if (rc) return rc;
+    g.p[i] = a3[i];
+    const int64_t total = (int64_t)a3[i].B * a3[i].heads * a3[i].Nout;
+    if (total > max_total) max_total = total;
+  }
+  int64_t blocks = (max_total + 255) / 256;
+  if (blocks < 128) blocks = (max_total + 63) / 64 < 128 ? (max_total + 63) / 64 : 128;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks > a3[0].workspace_floats / (6 * HD)) blocks = a3[0].workspace_floats / (6 * HD);
+  if (blocks < 1) return SVIT_ERR_ARG;
+  hipLaunchKernelGGL(pool_ln_bwd3_kernel, dim3((unsigned)blocks, 3), dim3(256), 0,
+                     (hipStream_t)stream, g);
+  SVIT_LAUNCH_CHECK();
+  SvitReduceDst dst = {{a3[0].dgamma, a3[0].dbeta, a3[1].dgamma, a3[1].dbeta, a3[2].dgamma, a3[2].dbeta},
+                       {HD, 2 * HD, 3 * HD, 4 * HD, 5 * HD, 6 * HD}};
+  svit_launch_reduce(a3[0].workspace, (int)blocks, 6 * HD, dst, (hipStream_t)stream);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_pool_conv_dgrad_qkv(const svit_pool_dgrad_args* a3, void* stream) {
+  if (!a3) return SVIT_ERR_ARG;
+  PoolDgrad3 g;
+  for (int i = 0; i < 3; ++i) {
+    const svit_pool_dgrad_args* a = &a3[i];
+    if (!a->dpre || !a->conv_w || !a->dqkv || a->which < 0 || a->which > 2) return SVIT_ERR_ARG;
+    const int rc = check_pool_dims(a->B, a->heads, a->T, a->H, a->W, a->n_obj, a->stride_hw);
+    if (rc) return rc;
+    if (a->B != a3[0].B || a->heads != a3[0].heads || a->T != a3[0].T || a->H != a3[0].H ||
+        a->W != a3[0].W || a->n_obj != a3[0].n_obj)
+      return SVIT_ERR_SHAPE;
+    g.p[i] = *a;
+  }
+  const int N = 1 + a3[0].T * a3[0].H * a3[0].W + a3[0].n_obj;
+  hipLaunchKernelGGL(pool_dgrad3_kernel, dim3((N + 63) / 64, a3[0].B * a3[0].heads, 3), dim3(256), 0,
+                     (hipStream_t)stream, g);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_pool_conv_wgrad_qkv(const svit_pool_wgrad_args* a3, void* stream) {
+  if (!a3 || !a3[0].workspace) return SVIT_ERR_ARG;
+  PoolWgrad3 g;
+  int64_t blocks = 1;
+  size_t lds = 0;
+  for (int i = 0; i < 3; ++i) {
+    const svit_pool_wgrad_args* a = &a3[i];
+    if (!a->dpre || !a->qkv || !a->dw || a->which < 0 || a->which > 2) return SVIT_ERR_ARG;
+    const int rc = check_pool_dims(a->B, a->heads, a->T, a->H, a->W, a->n_obj, a->stride_hw);
+    if (rc) return rc;
+    const int Ho = (a->H - 1) / a->stride_hw + 1, Wo = (a->W - 1) / a->stride_hw + 1;
+    g.p[i] = *a;
+    size_t need;
+    if (a->stride_hw == 1) { g.plan[i] = plan_wgrad<1>(*a, Ho, Wo); need = WgradTile<1>::LDS_BYTES; }
+    else if (a->stride_hw == 2) { g.plan[i] = plan_wgrad<2>(*a, Ho, Wo); need = WgradTile<2>::LDS_BYTES; }
+    else { g.plan[i] = plan_wgrad<3>(*a, Ho, Wo); need = WgradTile<3>::LDS_BYTES; }
+    if (need > lds) lds = need;
+    if (g.plan[i].n_tiles > blocks) blocks = g.plan[i].n_tiles;
+  }
+  if (blocks > 1024) blocks = 1024;
+  if (blocks > a3[0].workspace_floats / (3 * 27 * HD)) blocks = a3[0].workspace_floats / (3 * 27 * HD);
+  if (blocks < 1) return SVIT_ERR_ARG;
+  static bool configured = false;
+  if (!configured) {
+    size_t mx = WgradTile<1>::LDS_BYTES;
+    if ((size_t)WgradTile<2>::LDS_BYTES > mx) mx = WgradTile<2>::LDS_BYTES;
+    if ((size_t)WgradTile<3>::LDS_BYTES > mx) mx = WgradTile<3>::LDS_BYTES;
+    hipError_t e = hipFuncSetAttribute((const void*)pool_wgrad3_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  hipLaunchKernelGGL(pool_wgrad3_kernel, dim3((unsigned)blocks, 3), dim3(192), lds,
+                     (hipStream_t)stream, g);
+  SVIT_LAUNCH_CHECK();
+  SvitReduceDst dst = {{a3[0].dw, a3[1].dw, a3[2].dw, a3[2].dw, a3[2].dw, a3[2].dw},
+                       {27 * HD, 2 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD}};
+  svit_launch_reduce(a3[0].workspace, (int)blocks, 3 * 27 * HD, dst, (hipStream_t)stream);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
 extern "C" int svit_pool_ln_bwd(const svit_pool_ln_bwd_args* a, void* stream) {
   if (!a || !a->pre || !a->mean || !a->rstd || !a->gamma || !a->dpre || !a->dgamma || !a->dbeta)
     return SVIT_ERR_ARG;
@@ -748,7 +943,7 @@ extern "C" int svit_pool_ln_bwd(const svit_pool_ln_bwd_args* a, void* stream) {
   if (blocks < 1) return SVIT_ERR_ARG;
   hipLaunchKernelGGL(pool_ln_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
   SVIT_LAUNCH_CHECK();
-  SvitReduceDst dst = {{a->dgamma, a->dbeta, a->dbeta}, {HD, 2 * HD, 2 * HD}};
+  SvitReduceDst dst = {{a->dgamma, a->dbeta, a->dbeta, a->dbeta, a->dbeta, a->dbeta}, {HD, 2 * HD, 2 * HD, 2 * HD, 2 * HD, 2 * HD}};
   svit_launch_reduce(a->workspace, (int)blocks, 2 * HD, dst, (hipStream_t)stream);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
@@ -856,8 +1051,8 @@ extern "C" int svit_relpos_q_bwd(const svit_relq_bwd_args* a, void* stream) {
   if (blocks < 1) return SVIT_ERR_ARG;
   hipLaunchKernelGGL(relq_bwd_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, *a);
   SVIT_LAUNCH_CHECK();
-  SvitReduceDst dst = {{a->drel_h, a->drel_w, a->drel_t},
-                       {a->rows_h * HD, (a->rows_h + a->rows_w) * HD, tab_n}};
+  SvitReduceDst dst = {{a->drel_h, a->drel_w, a->drel_t, a->drel_t, a->drel_t, a->drel_t},
+                       {a->rows_h * HD, (a->rows_h + a->rows_w) * HD, tab_n, tab_n, tab_n, tab_n}};
   svit_launch_reduce(a->workspace, (int)blocks, tab_n, dst, (hipStream_t)stream);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;

@@ -238,12 +238,11 @@ class Engine:
         xn, _, mean1, rstd1 = ops.layernorm_fwd(x, f.p(pre + "norm1.weight"), f.p(pre + "norm1.bias"))
         xn2d = xn.view(B * N, C)
         qkv = ops.gemm_nt(xn2d, f.w(pre + "attn.qkv.weight"), f.p(pre + "attn.qkv.bias"), hip.EPI_BF16)
-        pools = []
-        for which, r, stride, ld, mode in ((0, "q", sq, DA, 0), (1, "k", skv, DA, 1), (2, "v", skv, HD, 0)):
-            pools.append(ops.pool_ln_fwd(
-                qkv, which, f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27),
-                f.p(pre + "attn.norm_%s.weight" % r), f.p(pre + "attn.norm_%s.bias" % r),
-                B, h, thw, n_obj, stride, ld_out=ld, mode=mode))
+        pools = ops.pool_ln_fwd_qkv(
+            qkv, [f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
+            [f.p(pre + "attn.norm_%s.weight" % r) for r in "qkv"],
+            [f.p(pre + "attn.norm_%s.bias" % r) for r in "qkv"],
+            B, h, thw, n_obj, (sq, skv, skv), (DA, DA, HD), (0, 1, 0))
         qa, ka, v = pools[0][0], pools[1][0], pools[2][0]
         idx, mats = self._rel(blk, q_thw, k_thw)
         tabs = self._tables(pre, mats)
@@ -377,18 +376,22 @@ class Engine:
         dq_extra = ops.gemm_nt(D, rcat_t, None, hip.EPI_F32)
         Nk = ka.shape[2]
         dqkv = torch.empty_like(sv["qkv"])
-        for which, r, stride, pre_t, mean, rstd, nout, kw in (
-                (0, "q", sq, preq, mq, rq, Nq, dict(d_main=dqa, ld_main=qa.shape[-1],
-                                                     d_res=dctx, d_extra=dq_extra)),
-                (1, "k", skv, prek, mk, rk, Nk, dict(d_main=dk, ld_main=HD)),
-                (2, "v", skv, prev, mv, rv, Nk, dict(d_main=dv, ld_main=HD))):
-            dpre = ops.pool_ln_bwd(pre_t, mean, rstd, f.p(pre + "attn.norm_%s.weight" % r),
-                                   f.g(pre + "attn.norm_%s.weight" % r),
-                                   f.g(pre + "attn.norm_%s.bias" % r), B, h, nout, **kw)
-            wconv = f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27)
-            ops.pool_conv_dgrad(dpre, wconv, dqkv, which, B, h, thw, n_obj, stride)
-            ops.pool_conv_wgrad(dpre, sv["qkv"], which, f.g(pre + "attn.pool_%s.weight" % r).view(HD, 27),
-                                B, h, thw, n_obj, stride)
+        entries = []
+        for r, pre_t, mean, rstd, nout, kw in (
+                ("q", preq, mq, rq, Nq, dict(d_main=dqa, ld_main=qa.shape[-1], d_res=dctx,
+                                             d_extra=dq_extra)),
+                ("k", prek, mk, rk, Nk, dict(d_main=dk, ld_main=HD)),
+                ("v", prev, mv, rv, Nk, dict(d_main=dv, ld_main=HD))):
+            entries.append(((pre_t, mean, rstd, f.p(pre + "attn.norm_%s.weight" % r),
+                             f.g(pre + "attn.norm_%s.weight" % r),
+                             f.g(pre + "attn.norm_%s.bias" % r), B, h, nout), kw))
+        dpres = ops.pool_ln_bwd_qkv(entries)       # q, k, v side by side: one launch per stage
+        strides = (sq, skv, skv)
+        ops.pool_conv_dgrad_qkv(dpres, [f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
+                                dqkv, B, h, thw, n_obj, strides)
+        ops.pool_conv_wgrad_qkv(dpres, sv["qkv"],
+                                [f.g(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
+                                B, h, thw, n_obj, strides)
         dxn = self._linear_bwd(dqkv, sv["xn"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", True)
         # ---- skip path ------------------------------------------------------------------------
         dskip = dx1

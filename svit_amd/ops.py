@@ -183,9 +183,8 @@ def pooled(n, s):
     return (n - 1) // s + 1
 
 
-def pool_ln_fwd(qkv, which, conv_w, gamma, beta, B, heads, thw, n_obj, stride_hw, ld_out=HD,
-                mode=0, eps=1e-6):
-    """-> out bf16 [B,h,Nout,ld_out], pre bf16 [B,h,Nout,96], mean, rstd f32 [B*h*Nout]."""
+def _pool_fwd_args(a, qkv, which, conv_w, gamma, beta, B, heads, thw, n_obj, stride_hw, ld_out, mode,
+                   eps):
     _chk_dev(qkv, conv_w, gamma, beta)
     T, H, W = thw
     Nout = 1 + T * pooled(H, stride_hw) * pooled(W, stride_hw) + n_obj
@@ -194,19 +193,36 @@ def pool_ln_fwd(qkv, which, conv_w, gamma, beta, B, heads, thw, n_obj, stride_hw
     pre = torch.empty((B, heads, Nout, HD), device=dev, dtype=BF16)
     mean = torch.empty(B * heads * Nout, device=dev, dtype=F32)
     rstd = torch.empty(B * heads * Nout, device=dev, dtype=F32)
-    a = hip.PoolArgs()
     a.qkv, a.which, a.conv_w, a.gamma, a.beta = ptr(qkv), which, ptr(conv_w), ptr(gamma), ptr(beta)
     a.out, a.ld_out, a.pre, a.mean, a.rstd = ptr(out), ld_out, ptr(pre), ptr(mean), ptr(rstd)
     a.B, a.heads, a.T, a.H, a.W, a.n_obj = B, heads, T, H, W, n_obj
     a.stride_hw, a.mode, a.eps = stride_hw, mode, eps
-    hip.call("svit_pool_ln_fwd", C.byref(a))
     return out, pre, mean, rstd
 
 
-def pool_ln_bwd(pre, mean, rstd, gamma, dgamma, dbeta, B, heads, Nout, d_main=None, ld_main=HD,
-                d_res=None, d_extra=None):
+def pool_ln_fwd(qkv, which, conv_w, gamma, beta, B, heads, thw, n_obj, stride_hw, ld_out=HD,
+                mode=0, eps=1e-6):
+    """-> out bf16 [B,h,Nout,ld_out], pre bf16 [B,h,Nout,96], mean, rstd f32 [B*h*Nout]."""
+    a = hip.PoolArgs()
+    res = _pool_fwd_args(a, qkv, which, conv_w, gamma, beta, B, heads, thw, n_obj, stride_hw,
+                         ld_out, mode, eps)
+    hip.call("svit_pool_ln_fwd", C.byref(a))
+    return res
+
+
+def pool_ln_fwd_qkv(qkv, conv_ws, gammas, betas, B, heads, thw, n_obj, strides, ld_outs, modes,
+                    eps=1e-6):
+    """q, k, v pooling + LayerNorm in one launch -> [(out, pre, mean, rstd)] * 3."""
+    arr = (hip.PoolArgs * 3)()
+    res = [_pool_fwd_args(arr[i], qkv, i, conv_ws[i], gammas[i], betas[i], B, heads, thw, n_obj,
+                          strides[i], ld_outs[i], modes[i], eps) for i in range(3)]
+    hip.call("svit_pool_ln_fwd_qkv", arr)
+    return res
+
+
+def _pool_ln_bwd_args(a, pre, mean, rstd, gamma, dgamma, dbeta, B, heads, Nout, d_main=None,
+                      ld_main=HD, d_res=None, d_extra=None):
     dpre = torch.empty((B, heads, Nout, HD), device=pre.device, dtype=BF16)
-    a = hip.PoolLnBwdArgs()
     a.d_main = ptr(d_main)
     a.main_is_f32 = int(d_main is not None and d_main.dtype == F32)
     a.ld_main = ld_main
@@ -216,24 +232,62 @@ def pool_ln_bwd(pre, mean, rstd, gamma, dgamma, dbeta, B, heads, Nout, d_main=No
     a.B, a.heads, a.Nout = B, heads, Nout
     ws = scratch(pre.device)
     a.workspace, a.workspace_floats = ptr(ws), ws.numel()
+    return dpre
+
+
+def pool_ln_bwd(pre, mean, rstd, gamma, dgamma, dbeta, B, heads, Nout, d_main=None, ld_main=HD,
+                d_res=None, d_extra=None):
+    a = hip.PoolLnBwdArgs()
+    dpre = _pool_ln_bwd_args(a, pre, mean, rstd, gamma, dgamma, dbeta, B, heads, Nout, d_main,
+                             ld_main, d_res, d_extra)
     hip.call("svit_pool_ln_bwd", C.byref(a))
     return dpre
 
 
-def pool_conv_dgrad(dpre, conv_w, dqkv, which, B, heads, thw, n_obj, stride_hw):
-    a = hip.PoolDgradArgs()
+def pool_ln_bwd_qkv(entries):
+    """entries: 3 x (args tuple, kwargs dict) of pool_ln_bwd -> [dpre] * 3, one launch."""
+    arr = (hip.PoolLnBwdArgs * 3)()
+    res = [_pool_ln_bwd_args(arr[i], *entries[i][0], **entries[i][1]) for i in range(3)]
+    hip.call("svit_pool_ln_bwd_qkv", arr)
+    return res
+
+
+def _pool_dgrad_args(a, dpre, conv_w, dqkv, which, B, heads, thw, n_obj, stride_hw):
     a.dpre, a.conv_w, a.dqkv, a.which = ptr(dpre), ptr(conv_w), ptr(dqkv), which
     a.B, a.heads, (a.T, a.H, a.W), a.n_obj, a.stride_hw = B, heads, thw, n_obj, stride_hw
+
+
+def pool_conv_dgrad(dpre, conv_w, dqkv, which, B, heads, thw, n_obj, stride_hw):
+    a = hip.PoolDgradArgs()
+    _pool_dgrad_args(a, dpre, conv_w, dqkv, which, B, heads, thw, n_obj, stride_hw)
     hip.call("svit_pool_conv_dgrad", C.byref(a))
 
 
-def pool_conv_wgrad(dpre, qkv, which, dw, B, heads, thw, n_obj, stride_hw):
-    a = hip.PoolWgradArgs()
+def pool_conv_dgrad_qkv(dpres, conv_ws, dqkv, B, heads, thw, n_obj, strides):
+    arr = (hip.PoolDgradArgs * 3)()
+    for i in range(3):
+        _pool_dgrad_args(arr[i], dpres[i], conv_ws[i], dqkv, i, B, heads, thw, n_obj, strides[i])
+    hip.call("svit_pool_conv_dgrad_qkv", arr)
+
+
+def _pool_wgrad_args(a, dpre, qkv, which, dw, B, heads, thw, n_obj, stride_hw):
     a.dpre, a.qkv, a.which, a.dw = ptr(dpre), ptr(qkv), which, ptr(dw)
     a.B, a.heads, (a.T, a.H, a.W), a.n_obj, a.stride_hw = B, heads, thw, n_obj, stride_hw
     ws = scratch(dpre.device)
     a.workspace, a.workspace_floats = ptr(ws), ws.numel()
+
+
+def pool_conv_wgrad(dpre, qkv, which, dw, B, heads, thw, n_obj, stride_hw):
+    a = hip.PoolWgradArgs()
+    _pool_wgrad_args(a, dpre, qkv, which, dw, B, heads, thw, n_obj, stride_hw)
     hip.call("svit_pool_conv_wgrad", C.byref(a))
+
+
+def pool_conv_wgrad_qkv(dpres, qkv, dws, B, heads, thw, n_obj, strides):
+    arr = (hip.PoolWgradArgs * 3)()
+    for i in range(3):
+        _pool_wgrad_args(arr[i], dpres[i], qkv, i, dws[i], B, heads, thw, n_obj, strides[i])
+    hip.call("svit_pool_conv_wgrad_qkv", arr)
 
 
 def relpos_q_fwd(qa, tabs, idx, B, heads, q_thw, k_thw, n_obj, inv_scale):

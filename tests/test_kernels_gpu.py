@@ -258,6 +258,50 @@ def test_pool_ln_fwd_bwd(ops, stride, thw):
     assert cos(dw, wc.grad.reshape(96, 27)) > 0.9995 and rel_err(dw, wc.grad.reshape(96, 27)) < 3e-2
 
 
+@pytest.mark.parametrize("sq,skv,thw", [(1, 2, (2, 8, 8)), (2, 1, (3, 7, 7)), (1, 8, (2, 16, 16)),
+                                         (2, 4, (2, 12, 12))])
+def test_pool_qkv_fused_equals_single(ops, sq, skv, thw):
+    """the one-launch q/k/v entry points (what the engine calls) against the per-tensor ones"""
+    B, h, O = 2, 2, 3
+    qkv = _qkv(B, h, thw, O, "f%d%d" % (sq, skv))
+    ws = [rnd("fw%d" % i, (96, 27), 0.3) for i in range(3)]
+    gs = [rnd("fg%d" % i, (96,), 0.2) + 1.0 for i in range(3)]
+    bs = [rnd("fb%d" % i, (96,), 0.1) for i in range(3)]
+    strides, lds, modes = (sq, skv, skv), (128, 128, 96), (0, 1, 0)
+    fused = ops.pool_ln_fwd_qkv(qkv, ws, gs, bs, B, h, thw, O, strides, lds, modes)
+    single = [ops.pool_ln_fwd(qkv, i, ws[i], gs[i], bs[i], B, h, thw, O, strides[i], ld_out=lds[i],
+                              mode=modes[i]) for i in range(3)]
+    for i, (fu, si) in enumerate(zip(fused, single)):
+        cols = slice(0, 96) if modes[i] == 0 else slice(None)     # q's extra columns: written later
+        assert torch.equal(fu[0][..., cols], si[0][..., cols])
+        assert torch.equal(fu[1], si[1]) and torch.equal(fu[2], si[2]) and torch.equal(fu[3], si[3])
+    entries, refs = [], []
+    dgs = [torch.zeros(96, device=DEV) for _ in range(6)]
+    dbs = [torch.zeros(96, device=DEV) for _ in range(6)]
+    for i in range(3):
+        out, pre, mean, rstd = single[i]
+        Nout = out.shape[2]
+        dout = rnd("fd%d%d" % (i, sq), (B, h, Nout, 96), 1.0, BF16)
+        entries.append(((pre, mean, rstd, gs[i], dgs[i], dbs[i], B, h, Nout), dict(d_main=dout, ld_main=96)))
+        refs.append(ops.pool_ln_bwd(pre, mean, rstd, gs[i], dgs[3 + i], dbs[3 + i], B, h, Nout,
+                                    d_main=dout, ld_main=96))
+    dpres = ops.pool_ln_bwd_qkv(entries)
+    for i in range(3):
+        assert torch.equal(dpres[i], refs[i])
+        assert rel_err(dgs[i], dgs[3 + i]) < 1e-5 and rel_err(dbs[i], dbs[3 + i]) < 1e-5
+    d1, d2 = torch.zeros_like(qkv), torch.zeros_like(qkv)
+    ops.pool_conv_dgrad_qkv(dpres, ws, d1, B, h, thw, O, strides)
+    for i in range(3):
+        ops.pool_conv_dgrad(dpres[i], ws[i], d2, i, B, h, thw, O, strides[i])
+    assert torch.equal(d1, d2)
+    dw1 = [torch.zeros((96, 27), device=DEV) for _ in range(3)]
+    dw2 = [torch.zeros((96, 27), device=DEV) for _ in range(3)]
+    ops.pool_conv_wgrad_qkv(dpres, qkv, dw1, B, h, thw, O, strides)
+    for i in range(3):
+        ops.pool_conv_wgrad(dpres[i], qkv, i, dw2[i], B, h, thw, O, strides[i])
+        assert rel_err(dw1[i], dw2[i]) < 1e-5
+
+
 def test_pool_ln_bwd_three_inputs(ops):
     B, h, Nout = 2, 2, 37
     pre = rnd("pre3", (B, h, Nout, 96), 1.0, BF16)
