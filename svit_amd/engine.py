@@ -291,13 +291,17 @@ class Engine:
         all-reduce of that slice there, overlapping it with the remaining backward."""
         plan, f = self.plan, self.flat
         depth = len(plan.blocks)
-        dx = ops.layernorm_bwd(dy.contiguous(), st["x_last"], f.p("norm.weight"), st["mean"],
-                               st["rstd"], f.g("norm.weight"), f.g("norm.bias"))
+        last = st["blocks"][depth - 1]
+        dx, dx16 = ops.layernorm_bwd(dy.contiguous(), st["x_last"], f.p("norm.weight"), st["mean"],
+                                     st["rstd"], f.g("norm.weight"), f.g("norm.bias"),
+                                     want_bf16=True, row_scale=last["dpm"],
+                                     rows_per_sample=st["x_last"].shape[1])
         if on_ready is not None:
             on_ready(0)
         hip.mark("bwd_norm")
         for blk in reversed(plan.blocks):
-            dx = self._block_bwd(blk, st["blocks"][blk.index], dx, st["n_obj"])
+            below = st["blocks"][blk.index - 1] if blk.index > 0 else None
+            dx, dx16 = self._block_bwd(blk, st["blocks"][blk.index], dx, dx16, st["n_obj"], below)
             hip.mark("bwd%d" % blk.index)
             if on_ready is not None:
                 on_ready(1 + (depth - 1 - blk.index))
@@ -329,7 +333,10 @@ class Engine:
             return None
         return ops.gemm_nt(dy16, f.wt(wname), None, epilogue, out=out, aux=aux, accumulate=accumulate)
 
-    def _block_bwd(self, blk, sv, dx2, n_obj):
+    def _block_bwd(self, blk, sv, dx2, dy, n_obj, below):
+        """dx2: f32 grad of the block output; dy: bf16(DropPath_mlp * dx2) from the producing
+        LayerNorm backward; below: saved state of block index-1 (its MLP DropPath scales the bf16
+        copy of this block's input grad) or None for block 0."""
         f = self.flat
         pre = "blocks.%d." % blk.index
         B, Nq, Co = dx2.shape
@@ -339,15 +346,16 @@ class Engine:
         sq, skv = blk.stride_q[1], blk.stride_kv[1]
         thw, q_thw, k_thw = sv["thw"], sv["q_thw"], sv["k_thw"]
         # ---- MLP branch: x2 = x1 + dp * fc2(gelu(fc1(LN2(x1)))) ------------------------------
-        dy = ops.scale_cast(dx2.view(Mq, Co), sv["dpm"], Nq)
+        dy = dy.view(Mq, Co)
         dh = self._linear_bwd(dy, sv["act"], pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", True,
                               epilogue=hip.EPI_DGELU, aux=sv["hpre"])
         dxn2 = self._linear_bwd(dh, sv["xn2"].view(Mq, Co), pre + "mlp.fc1.weight",
                                 pre + "mlp.fc1.bias", True)
-        dx1 = ops.layernorm_bwd(dxn2, sv["x1"], f.p(pre + "norm2.weight"), sv["mean2"], sv["rstd2"],
-                                f.g(pre + "norm2.weight"), f.g(pre + "norm2.bias"), dres=dx2)
+        dx1, dy = ops.layernorm_bwd(dxn2, sv["x1"], f.p(pre + "norm2.weight"), sv["mean2"],
+                                    sv["rstd2"], f.g(pre + "norm2.weight"), f.g(pre + "norm2.bias"),
+                                    dres=dx2, want_bf16=True, row_scale=sv["dpa"], rows_per_sample=Nq)
+        dy = dy.view(Mq, Co)
         # ---- attention branch: x1 = skip + dp * proj(ctx) ------------------------------------
-        dy = ops.scale_cast(dx1.view(Mq, Co), sv["dpa"], Nq)
         dctx = self._linear_bwd(dy, sv["ctx"].view(Mq, Co), pre + "attn.proj.weight",
                                 pre + "attn.proj.bias", True, epilogue=hip.EPI_BF16)
         (qa, preq, mq, rq), (ka, prek, mk, rk), (v, prev, mv, rv) = sv["pools"]
@@ -402,8 +410,12 @@ class Engine:
             self._linear_bwd(ds16, sv["xn"], pre + "proj.weight", pre + "proj.bias", True, out=dxn,
                              accumulate=True)
             dskip = None
-        dx = ops.layernorm_bwd(dxn, x, f.p(pre + "norm1.weight"), sv["mean1"], sv["rstd1"],
-                               f.g(pre + "norm1.weight"), f.g(pre + "norm1.bias"),
-                               dres=dskip).view(B, N, C)
+        res = ops.layernorm_bwd(dxn, x, f.p(pre + "norm1.weight"), sv["mean1"], sv["rstd1"],
+                                f.g(pre + "norm1.weight"), f.g(pre + "norm1.bias"), dres=dskip,
+                                want_bf16=below is not None,
+                                row_scale=below["dpm"] if below is not None else None,
+                                rows_per_sample=N)
         self._flush_tn()
-        return dx
+        if below is None:
+            return res.view(B, N, C), None
+        return res[0].view(B, N, C), res[1]

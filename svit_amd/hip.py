@@ -111,7 +111,8 @@ _SIGS = {
     "svit_scale_cast": (i32, [vp, vp, vp, i32, i64, i32, vp]),
     "svit_pad_cast_rows": (i32, [vp, vp, i32, i32, i32, vp]),
     "svit_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp]),
-    "svit_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, i64, vp]),
+    "svit_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i64, i32, vp, i64,
+                                 vp]),
     "svit_im2col_patch": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "svit_fill_special_tokens": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "svit_pool_ln_fwd": (i32, [C.POINTER(PoolArgs), vp]),

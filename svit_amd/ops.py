@@ -151,16 +151,20 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6, want_f32=False, want_bf16=True, save
     return y16, y32, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, dx=None):
-    _chk_dev(dy, x, gamma, mean, rstd, dgamma, dbeta, dres, dx)
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, dx=None, want_bf16=False,
+                  row_scale=None, rows_per_sample=0):
+    """-> dx f32, or (dx, bf16(row_scale * dx)) with want_bf16 (operand of the next GEMM)."""
+    _chk_dev(dy, x, gamma, mean, rstd, dgamma, dbeta, dres, dx, row_scale)
     C_ = x.shape[-1]
     rows = x.numel() // C_
     if dx is None:
         dx = torch.empty(x.shape, device=x.device, dtype=F32)
+    dx16 = torch.empty(x.shape, device=x.device, dtype=BF16) if want_bf16 else None
     ws = scratch(x.device)
     hip.call("svit_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres),
-             ptr(dx), ptr(dgamma), ptr(dbeta), rows, C_, ptr(ws), ws.numel())
-    return dx
+             ptr(dx), ptr(dx16), ptr(row_scale), rows_per_sample, ptr(dgamma), ptr(dbeta), rows, C_,
+             ptr(ws), ws.numel())
+    return (dx, dx16) if want_bf16 else dx
 
 
 def im2col_patch(video):

@@ -174,6 +174,16 @@ def test_layernorm(ops, C):
     dx = ops.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dres=dres)
     assert rel_err(dx, xr.grad + dres) < 1e-4
     assert rel_err(dg, gr.grad) < 1e-4 and rel_err(db, br.grad) < 1e-4
+    # fused bf16 operand for the next GEMM: bf16(DropPath scale[row / rows_per_sample] * dx)
+    dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    s = torch.tensor([0.0, 1.25, 2.0, 1.0, 0.5], device=DEV)       # 5 samples of 208 rows (last short)
+    dx2, dx16 = ops.layernorm_bwd(dy, x, g, mean, rstd, dg2, db2, dres=dres, want_bf16=True,
+                                  row_scale=s, rows_per_sample=208)
+    assert torch.equal(dx2, dx)
+    exp = (dx * s[torch.arange(rows, device=DEV) // 208][:, None]).to(BF16)
+    assert torch.equal(dx16, exp)
+    _, dx16b = ops.layernorm_bwd(dy, x, g, mean, rstd, dg2, db2, dres=dres, want_bf16=True)
+    assert torch.equal(dx16b, dx.to(BF16))
 
 
 # -------------------------------------------------------------------- patch embedding ----

@@ -195,3 +195,22 @@ def bench_nt_stages():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ntstages":
     bench_nt_stages()
+
+
+def bench_ln():
+    """LayerNorm fwd / bwd (with the fused bf16 operand) at the residual-stream shapes (us)."""
+    print("== layernorm rows x C: fwd / bwd us, bwd GB/s ==")
+    for rows, C in [(8 * 25153, 96), (8 * 6337, 192), (8 * 1633, 384), (8 * 457, 768)]:
+        x = rnd(rows, C, dtype=torch.float32)
+        dy, dres = rnd(rows, C, dtype=torch.float32), rnd(rows, C, dtype=torch.float32)
+        g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        _, _, mean, rstd = ops.layernorm_fwd(x, g, b)
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        t_f = timeit(lambda: ops.layernorm_fwd(x, g, b))
+        t_b = timeit(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dres=dres, want_bf16=True))
+        gb = rows * C * (4 * 4 + 2) / (t_b * 1e-6) / 1e9
+        print("rows %7d C %4d  fwd %7.1f  bwd %7.1f  (%.0f GB/s)" % (rows, C, t_f, t_b, gb))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ln":
+    bench_ln()
