@@ -30,11 +30,11 @@ const char* svit_arch(void); /* "gfx950" */
  * (slowfast/models/stem_helper.py:309-320). */
 enum {
   SVIT_EPI_BF16 = 0,   /* out(bf16)  = acc + bias                                   */
-  SVIT_EPI_GELU = 1,   /* out2(bf16) = acc + bias ; out(bf16) = gelu_erf(out2)       */
+  SVIT_EPI_GELU = 1,   /* h = acc + bias; out(bf16) = gelu_erf(h); out2(bf16) = gelu_erf'(h) */
   SVIT_EPI_RESID = 2,  /* out(f32)   = aux(f32) + row_scale[row/rows_per_sample]*(acc+bias)
                           (proj / fc2 + DropPath + residual, attention.py:565,570)    */
   SVIT_EPI_F32 = 3,    /* out(f32)   = [out +] acc + bias, optional row remap         */
-  SVIT_EPI_DGELU = 4   /* out(bf16)  = acc * gelu_erf'(aux(bf16))  (fc2 dgrad)        */
+  SVIT_EPI_DGELU = 4   /* out(bf16)  = acc * aux(bf16), aux = the saved gelu_erf'(h) (fc2 dgrad) */
 };
 typedef struct {
   const void* A; int32_t lda;      /* bf16 [M,K] row-major                             */

@@ -95,6 +95,12 @@ __device__ __forceinline__ float gelu_erf(float x) {
   gelu_parts(x, &cdf, &pdf);
   return x * cdf;
 }
+__device__ __forceinline__ void gelu_fwd_grad(float x, float* y, float* dydx) {
+  float cdf, pdf;
+  gelu_parts(x, &cdf, &pdf);
+  *y = x * cdf;
+  *dydx = cdf + x * pdf;
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   float cdf, pdf;
   gelu_parts(x, &cdf, &pdf);

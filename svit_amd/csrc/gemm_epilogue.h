@@ -13,7 +13,41 @@ __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&
                                             int lane, int wave) {
   constexpr int WN = 32 * NB;
   constexpr int EP_LD = WN + 4;
+  constexpr int NIT = 2 * NB;
+  // epilogues that READ a second operand (residual, saved GELU', fp32 accumulate): its 16-row
+  // slab is fetched into registers one slab ahead, so the loads fly while the previous slab is
+  // staged / stored instead of exposing one memory round trip per 4 columns
+  constexpr bool HAS_AUX = (EPI == SVIT_EPI_RESID || EPI == SVIT_EPI_DGELU || EPI == SVIT_EPI_F32);
   float* stg = (float*)smem + wave * (16 * EP_LD);
+  float4 aux_cur[NIT], aux_nxt[NIT];
+  const bool use_aux = HAS_AUX && (EPI != SVIT_EPI_F32 || p.accumulate);
+  auto out_row = [&](int row) -> size_t {
+    if (EPI == SVIT_EPI_F32 && p.remap_L > 0)
+      return (size_t)(row / p.remap_L) * p.remap_N + p.remap_off + (row % p.remap_L);
+    return (size_t)row;
+  };
+  auto fetch_aux = [&](int ih, float4 (&dst)[NIT]) {
+    const int i = ih >> 1, half = ih & 1;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = lane + 64 * it;
+      const int rl = idx / (8 * NB), c4 = idx % (8 * NB);
+      const int row = m0 + wm * 32 * RB + i * 32 + half * 16 + rl;
+      const int col = n0 + wn * WN + c4 * 4;
+      dst[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row >= p.M || col >= p.N) continue;
+      if constexpr (EPI == SVIT_EPI_RESID) {
+        dst[it] = *(const float4*)((const float*)p.aux + (size_t)row * p.ldaux + col);
+      } else if constexpr (EPI == SVIT_EPI_DGELU) {
+        const uint2 h = *(const uint2*)((const bf16_t*)p.aux + (size_t)row * p.ldaux + col);
+        dst[it].x = __uint_as_float(h.x);
+        dst[it].y = __uint_as_float(h.y);
+      } else if constexpr (EPI == SVIT_EPI_F32) {
+        dst[it] = *(const float4*)((const float*)p.out + out_row(row) * p.ldo + col);
+      }
+    }
+  };
+  if (use_aux) fetch_aux(0, aux_cur);
 #pragma unroll
   for (int ih = 0; ih < 2 * RB; ++ih) {
     const int i = ih >> 1, half = ih & 1;
@@ -23,9 +57,10 @@ __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&
       for (int rr = 0; rr < 8; ++rr)
         stg[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] =
             acc[i][j][half * 8 + rr];
+    if (use_aux && ih + 1 < 2 * RB) fetch_aux(ih + 1, aux_nxt);
     __syncthreads();
-#pragma unroll 1
-    for (int it = 0; it < 2 * NB; ++it) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
       const int idx = lane + 64 * it;
       const int rl = idx / (8 * NB), c4 = idx % (8 * NB);
       const int row = m0 + wm * 32 * RB + i * 32 + half * 16 + rl;
@@ -41,35 +76,40 @@ __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&
         o.x = pack_bf16x2(v.x, v.y); o.y = pack_bf16x2(v.z, v.w);
         *(uint2*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = o;
       } else if constexpr (EPI == SVIT_EPI_GELU) {
+        // the exp / cdf of the forward give the derivative for two more FMAs: it is saved
+        // (bf16) instead of the pre-activation, and fc2's dgrad epilogue is one multiply
+        float a0, a1, a2, a3, d0, d1, d2, d3;
+        gelu_fwd_grad(v.x, &a0, &d0); gelu_fwd_grad(v.y, &a1, &d1);
+        gelu_fwd_grad(v.z, &a2, &d2); gelu_fwd_grad(v.w, &a3, &d3);
         uint2 o;
-        o.x = pack_bf16x2(v.x, v.y); o.y = pack_bf16x2(v.z, v.w);
+        o.x = pack_bf16x2(d0, d1); o.y = pack_bf16x2(d2, d3);
         *(uint2*)((bf16_t*)p.out2 + (size_t)row * p.ldo2 + col) = o;
-        o.x = pack_bf16x2(gelu_erf(v.x), gelu_erf(v.y));
-        o.y = pack_bf16x2(gelu_erf(v.z), gelu_erf(v.w));
+        o.x = pack_bf16x2(a0, a1); o.y = pack_bf16x2(a2, a3);
         *(uint2*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = o;
       } else if constexpr (EPI == SVIT_EPI_RESID) {
         const float s = p.row_scale ? p.row_scale[row / p.rows_per_sample] : 1.f;
-        const float4 res = *(const float4*)((const float*)p.aux + (size_t)row * p.ldaux + col);
+        const float4 res = aux_cur[it];
         float4 o;
         o.x = res.x + s * v.x; o.y = res.y + s * v.y; o.z = res.z + s * v.z; o.w = res.w + s * v.w;
         *(float4*)((float*)p.out + (size_t)row * p.ldo + col) = o;
       } else if constexpr (EPI == SVIT_EPI_F32) {
-        size_t orow = row;
-        if (p.remap_L > 0)
-          orow = (size_t)(row / p.remap_L) * p.remap_N + p.remap_off + (row % p.remap_L);
-        float4* o = (float4*)((float*)p.out + orow * p.ldo + col);
+        float4* o = (float4*)((float*)p.out + out_row(row) * p.ldo + col);
         if (p.accumulate) {
-          const float4 old = *o;
+          const float4 old = aux_cur[it];
           v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
         }
         *o = v;
       } else if constexpr (EPI == SVIT_EPI_DGELU) {
-        const uint2 h = *(const uint2*)((const bf16_t*)p.aux + (size_t)row * p.ldaux + col);
+        const uint32_t hx = __float_as_uint(aux_cur[it].x), hy = __float_as_uint(aux_cur[it].y);
         uint2 o;
-        o.x = pack_bf16x2(v.x * gelu_erf_grad(lo_bf16(h.x)), v.y * gelu_erf_grad(hi_bf16(h.x)));
-        o.y = pack_bf16x2(v.z * gelu_erf_grad(lo_bf16(h.y)), v.w * gelu_erf_grad(hi_bf16(h.y)));
+        o.x = pack_bf16x2(v.x * lo_bf16(hx), v.y * hi_bf16(hx));
+        o.y = pack_bf16x2(v.z * lo_bf16(hy), v.w * hi_bf16(hy));
         *(uint2*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = o;
       }
+    }
+    if (use_aux) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) aux_cur[it] = aux_nxt[it];
     }
     if (ih + 1 < 2 * RB) __syncthreads();
   }

@@ -271,7 +271,7 @@ class Engine:
                          hip.EPI_RESID, aux=skip.view(B * Nq, Co), row_scale=dpa, rows_per_sample=Nq)
         x1 = x1.view(B, Nq, Co)
         xn2, _, mean2, rstd2 = ops.layernorm_fwd(x1, f.p(pre + "norm2.weight"), f.p(pre + "norm2.bias"))
-        act, hpre = ops.gemm_nt(xn2.view(B * Nq, Co), f.w(pre + "mlp.fc1.weight"),
+        act, dact = ops.gemm_nt(xn2.view(B * Nq, Co), f.w(pre + "mlp.fc1.weight"),
                                 f.p(pre + "mlp.fc1.bias"), hip.EPI_GELU)
         x2 = ops.gemm_nt(act, f.w(pre + "mlp.fc2.weight"), f.p(pre + "mlp.fc2.bias"), hip.EPI_RESID,
                          aux=x1.view(B * Nq, Co), row_scale=dpm, rows_per_sample=Nq).view(B, Nq, Co)
@@ -280,7 +280,7 @@ class Engine:
             sv = dict(x=x, thw=thw, q_thw=q_thw, k_thw=k_thw, mean1=mean1, rstd1=rstd1, xn=xn2d,
                       qkv=qkv, pools=pools, tabs=tabs, idx=idx, mats=mats, ctx=ctx, lse2=lse2,
                       pool_idx=pool_idx, x1=x1, mean2=mean2, rstd2=rstd2, xn2=xn2, act=act,
-                      hpre=hpre, dpa=dpa, dpm=dpm, Nq=Nq)
+                      dact=dact, dpa=dpa, dpm=dpm, Nq=Nq)
         return x2, q_thw, sv
 
     # ------------------------------------------------------------------ backward ---------
@@ -348,7 +348,7 @@ class Engine:
         # ---- MLP branch: x2 = x1 + dp * fc2(gelu(fc1(LN2(x1)))) ------------------------------
         dy = dy.view(Mq, Co)
         dh = self._linear_bwd(dy, sv["act"], pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", True,
-                              epilogue=hip.EPI_DGELU, aux=sv["hpre"])
+                              epilogue=hip.EPI_DGELU, aux=sv["dact"])
         dxn2 = self._linear_bwd(dh, sv["xn2"].view(Mq, Co), pre + "mlp.fc1.weight",
                                 pre + "mlp.fc1.bias", True)
         dx1, dy = ops.layernorm_bwd(dxn2, sv["x1"], f.p(pre + "norm2.weight"), sv["mean2"],

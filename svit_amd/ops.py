@@ -66,7 +66,7 @@ def gemm_nt(a, w, bias=None, epilogue=hip.EPI_BF16, out=None, out2=None, aux=Non
     g.epilogue, g.accumulate = epilogue, int(accumulate)
     if remap is not None:
         g.remap_L, g.remap_N, g.remap_off = remap
-    hip.call("svit_gemm_nt", C.byref(g), meta=("mnk", M, N, K))
+    hip.call("svit_gemm_nt", C.byref(g), meta=("mnk", M, N, K, epilogue))
     return (out, out2) if epilogue == hip.EPI_GELU else out
 
 
