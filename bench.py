@@ -228,6 +228,16 @@ def main():
                            "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                            "avg_launch_ms": round(dom["ms"] / dom["calls"], 4)}
+        # memory-side bytes per launch: PMC counters cannot be read from inside this process, so
+        # the committed rocprofv3 --pmc summary of the same build is quoted (null if absent)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            t = pmc["bytes_per_launch"][dom["kernel"]]
+            out["roofline"]["traffic"] = t["fetch"] + t["write"]
+            out["roofline"]["traffic_unit"] = "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE)"
+            out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json"
+        except (OSError, KeyError, ValueError):
+            pass
         out["roofline_attn_fwd"] = {"bound": "mfma", "achieved": attn["tflops"],
                                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": round(attn["tflops"] / MFMA_PEAK_TFLOPS, 4),

@@ -72,8 +72,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
   constexpr int PER_TILE = KLoad::PER_WAVE + VLoad::PER_WAVE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.heads, head = bh % a.heads;
-  const int qi = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int wgid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int bh = wgid / gridDim.x, b = bh / a.heads, head = bh % a.heads;
+  const int qtile = wgid % gridDim.x;
+  const int qi = qtile * 128 + wave * 32 + (lane & 31);
   const int qc = min(qi, a.Nq - 1);
   const bf16_t* qa = (const bf16_t*)a.qa + ((size_t)bh * a.Nq) * DA;
   const bf16_t* ka = (const bf16_t*)a.ka + ((size_t)bh * a.Nk) * DA;
@@ -179,8 +181,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(svit_attn_bwd_args
   constexpr int PER_TILE = QLoad::PER_WAVE + OLoad::PER_WAVE + 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-  const int bh = blockIdx.z, b = bh / a.heads, head = bh % a.heads;
-  const int key0 = blockIdx.x * 128;
+  // all key tiles / query splits of one (batch, head) on one XCD: they stream the same Q / dO
+  const int wgid = xcd_remap((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
+                             gridDim.x * gridDim.y * gridDim.z);
+  const int bx = wgid % gridDim.x, by = (wgid / gridDim.x) % gridDim.y;
+  const int bh = wgid / (gridDim.x * gridDim.y), b = bh / a.heads, head = bh % a.heads;
+  const int key0 = bx * 128;
   const int ki = key0 + wave * 32 + (lane & 31);
   const int kc = min(ki, a.Nk - 1);
   const bf16_t* qa = (const bf16_t*)a.qa + ((size_t)bh * a.Nq) * DA;
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(svit_attn_bwd_args
     for (int r = 0; r < 16; ++r) { dk[j][r] = 0.f; dv[j][r] = 0.f; }
 
   const int nqt = (a.Nq + QT - 1) / QT;
-  const int t_begin = blockIdx.y * tiles_per_split;
+  const int t_begin = by * tiles_per_split;
   const int t_end = min(nqt, t_begin + tiles_per_split);
   QLoad qload;
   OLoad oload;

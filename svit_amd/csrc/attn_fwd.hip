@@ -31,8 +31,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(svit_attn_fwd_args a) 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-  const int bh = blockIdx.y, b = bh / a.heads, head = bh % a.heads;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int wgid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int bh = wgid / gridDim.x, b = bh / a.heads, head = bh % a.heads;
+  const int q0 = (wgid % gridDim.x) * 128 + wave * 32;
   const int qi = q0 + (lane & 31);
   const int qc = min(qi, a.Nq - 1);
   const bf16_t* qa = (const bf16_t*)a.qa + ((size_t)bh * a.Nq) * DA;
