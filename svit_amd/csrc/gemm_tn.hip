@@ -155,7 +155,14 @@ struct TnGroup {
 
 __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup g) {
   __shared__ __attribute__((aligned(16))) tn_lds_t lds;
-  const int bid = blockIdx.x;
+  // Logical ids are (problem, split)-major, tile-minor: the tiles of one split walk the SAME
+  // rows in lock-step and re-read each other's A / B column panels (A once per k-tile, B once
+  // per n-tile).  Consecutive logical ids are therefore placed on ONE XCD, so those re-reads
+  // hit its L2 instead of crossing the fabric (rocprofv3 FETCH_SIZE before: 810 MB per launch
+  // against ~230 MB of operands -- the kernel ran at HBM speed).
+  const int nwg = gridDim.x, lin = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+  const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < SVIT_TN_GROUP_MAX; ++i)
@@ -234,6 +241,15 @@ extern "C" int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, floa
   return SVIT_OK;
 }
 
+// cost-model constants of the grouped launch (svit_debug_set keys 2 / 3 for sweeps)
+static double g_tn_step_us = 0.85;      // one 64-row step of a workgroup, 512 resident
+static double g_tn_atomic_tbs = 0.75;   // effective fp32 atomic flush rate, TB/s
+extern "C" int svit_debug_set_tn(int step_us_x100, int atomic_tbs_x100) {
+  if (step_us_x100 > 0) g_tn_step_us = step_us_x100 * 0.01;
+  if (atomic_tbs_x100 > 0) g_tn_atomic_tbs = atomic_tbs_x100 * 0.01;
+  return SVIT_OK;
+}
+
 static int tn_check(const svit_tn_problem& p) {
   if (!p.A || !p.B || !p.dW) return SVIT_ERR_ARG;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return SVIT_ERR_SHAPE;
@@ -271,8 +287,8 @@ extern "C" int svit_gemm_tn_grouped(const svit_tn_problem* probs, int count, voi
         const long st = (g.p[i].M + TN_BM - 1) / TN_BM;
         blocks += (long)g.tiles[i] * ((st + steps - 1) / steps);
       }
-      const double t = (double)((blocks + 511) / 512) * steps * 0.85 +
-                       (double)blocks * (TN_TN * TN_TK * 4.0) / 0.75e6;
+      const double t = (double)((blocks + 511) / 512) * steps * g_tn_step_us +
+                       (double)blocks * (TN_TN * TN_TK * 4.0) / (g_tn_atomic_tbs * 1e6);
       if (t < best) { best = t; best_steps = steps; }
     }
     int total = 0;

@@ -102,10 +102,12 @@ class GraphedTrainStep:
                 state["g"].capture_end()
                 self.segments.append((state["g"], state["ranks"]))
                 state["g"], state["ranks"] = torch.cuda.CUDAGraph(), []
-                state["g"].capture_begin(pool=pool)
+                state["g"].capture_begin(pool=pool, capture_error_mode=mode)
 
+        # "thread_local": the process group's watchdog thread may query events while we capture
+        mode = "thread_local"
         with torch.cuda.stream(side):
-            state["g"].capture_begin(pool=pool)
+            state["g"].capture_begin(pool=pool, capture_error_mode=mode)
             try:
                 self.loss, self.preds, self.extra, self._keepalive = self._body(
                     boundary if self.dp is not None else None)

@@ -214,3 +214,36 @@ def bench_ln():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ln":
     bench_ln()
+
+
+def bench_tn_group():
+    """grouped wgrad launch per block shape under different cost-model constants (us)."""
+    import ctypes as C
+    lib = hip.load()
+    lib.svit_debug_set_tn.restype, lib.svit_debug_set_tn.argtypes = C.c_int32, [C.c_int32, C.c_int32]
+    print("== gemm_tn_grouped: us per block group for (step_us, atomic TB/s) ==")
+    groups = {}
+    for blk, N_in, Nq, Nk, Ci, Co, h, DA in BLOCKS:
+        M, Mq = B * N_in, B * Nq
+        probs = [(Mq, Co, 4 * Co), (Mq, 4 * Co, Co), (Mq, Co, Co), (M, 3 * Co, Ci)]
+        if Ci != Co:
+            probs.append((M, Co, Ci))
+        probs += [(B * h * Nq, 40, 96)] * 3
+        groups[blk] = [(rnd(m, n), rnd(m, k), torch.zeros(n, k, device=DEV), None) for m, n, k in probs]
+    settings = [(85, 75), (60, 75), (120, 75), (85, 40), (85, 130), (60, 130), (120, 40), (40, 130), (170, 75)]
+    print("blk   " + "  ".join("%3d/%3d" % s for s in settings))
+    tot = [0.0] * len(settings)
+    for blk, g in groups.items():
+        row = []
+        for i, (su, at) in enumerate(settings):
+            lib.svit_debug_set_tn(su, at)
+            us = timeit(lambda: ops.gemm_tn_grouped(g), iters=10)
+            row.append(us)
+            tot[i] += us * (10 if blk == 4 else 1)
+        print("blk%-2d " % blk + "  ".join("%7.1f" % u for u in row))
+    print("step  " + "  ".join("%7.0f" % u for u in tot))
+    lib.svit_debug_set_tn(85, 75)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tngroup":
+    bench_tn_group()
