@@ -28,6 +28,7 @@ class DataParallel(nn.Module):
         self._works = []
         self._pending = []
         module._grad_ready_hook = self._on_ready
+        module._grad_ready_ranks = self.launch_ranks()
         if self.world_size > 1:
             self._broadcast_parameters()
 

@@ -160,6 +160,17 @@ class Engine:
         self._rel_cache = {}
         self.patch_w16 = torch.zeros((plan.embed_dim, 448), device=self.dev, dtype=BF16)
         self._tn = []           # weight-gradient GEMMs queued by the running block backward
+        # the grouped weight-gradient GEMM leaves the dgrad chain: it runs on a second stream next
+        # to the latency-bound kernels of the chain (its fp32 atomics execute at the memory side,
+        # so nothing of the chain depends on it) and is joined only where gradients must be final
+        # (all-reduce launch points, end of backward)
+        self._side = None
+        self._side_keep = []
+        self._side_active = False
+        self.overlap_wgrad = False   # measured: TN beside the chain costs more than it hides
+        self.attn_q_splits = 0      # 0 = heuristic; 1 makes the whole backward bit-reproducible
+        self._capture_fork = None   # set by svit_amd/graph.py while it captures: (fn) -> None
+        self._capture_join = None
 
     # ------------------------------------------------------------------ helpers ----------
     def refresh_weights(self):
@@ -284,11 +295,18 @@ class Engine:
         return x2, q_thw, sv
 
     # ------------------------------------------------------------------ backward ---------
-    def backward(self, st, dy, on_ready=None):
+    def backward(self, st, dy, on_ready=None, ready_ranks=None):
         """dy: grad of the normed tokens f32 [B,N_last,C_last]; accumulates every parameter
         gradient into flat.grad.  on_ready(rank) is called when the gradients of readiness rank
         `rank` (arch.readiness_rank) are final -- the data-parallel wrapper launches the
-        all-reduce of that slice there, overlapping it with the remaining backward."""
+        all-reduce of that slice there, overlapping it with the remaining backward.
+        ready_ranks: the ranks at which on_ready really consumes gradients (None = every rank);
+        side-stream wgrad work is joined only there and at the end."""
+        def ready(rank):
+            if on_ready is not None:
+                if ready_ranks is None or rank in ready_ranks:
+                    self._join()
+                on_ready(rank)
         plan, f = self.plan, self.flat
         depth = len(plan.blocks)
         last = st["blocks"][depth - 1]
@@ -296,15 +314,13 @@ class Engine:
                                      st["rstd"], f.g("norm.weight"), f.g("norm.bias"),
                                      want_bf16=True, row_scale=last["dpm"],
                                      rows_per_sample=st["x_last"].shape[1])
-        if on_ready is not None:
-            on_ready(0)
+        ready(0)
         hip.mark("bwd_norm")
         for blk in reversed(plan.blocks):
             below = st["blocks"][blk.index - 1] if blk.index > 0 else None
             dx, dx16 = self._block_bwd(blk, st["blocks"][blk.index], dx, dx16, st["n_obj"], below)
             hip.mark("bwd%d" % blk.index)
-            if on_ready is not None:
-                on_ready(1 + (depth - 1 - blk.index))
+            ready(1 + (depth - 1 - blk.index))
         # block-0 input: [cls | patches | objects]
         B, Tx, L, O, C = st["B"], st["Tx"], st["L0"], plan.objects, plan.embed_dim
         f.g("cls_token").add_(dx[:, 0].sum(0).view(1, 1, C))
@@ -317,13 +333,41 @@ class Engine:
             ops.scale_cast(dx[b, 1:1 + L], dst=dtok[b * L:(b + 1) * L])
         ops.gemm_tn(dtok, st["cols"], f.g("patch_embed.proj.weight").view(C, 441),
                     dbias=f.g("patch_embed.proj.bias"))
-        if on_ready is not None:
-            on_ready(depth + 1)
+        self._join()
+        ready(depth + 1)
+
+    def _fork(self, fn, keep):
+        """run fn() on the side stream, after everything enqueued so far on the current one"""
+        if not self.overlap_wgrad:
+            fn()
+            return
+        if self._capture_fork is not None:      # graph capture: becomes a side-stream replay item
+            self._capture_fork(fn)
+            self._side_active = True
+            return
+        main = torch.cuda.current_stream(self.dev)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            fn()
+        self._side_keep.append(keep)     # operands stay allocated until the join
+        self._side_active = True
+
+    def _join(self):
+        if self._side_active and self._capture_join is not None:
+            self._capture_join()
+            self._side_active = False
+            return
+        if self._side_active:
+            torch.cuda.current_stream(self.dev).wait_stream(self._side)
+            self._side_keep.clear()
+            self._side_active = False
 
     def _flush_tn(self):
         """the block's queued weight-gradient GEMMs in one grouped launch (ops.gemm_tn_grouped)"""
         q, self._tn = self._tn, []
-        ops.gemm_tn_grouped(q)
+        self._fork(lambda: ops.gemm_tn_grouped(q), q)
 
     def _linear_bwd(self, dy16, x16, wname, bname, need_dx, out=None, accumulate=False,
                     epilogue=hip.EPI_F32, aux=None):
@@ -359,7 +403,8 @@ class Engine:
         dctx = self._linear_bwd(dy, sv["ctx"].view(Mq, Co), pre + "attn.proj.weight",
                                 pre + "attn.proj.bias", True, epilogue=hip.EPI_BF16)
         (qa, preq, mq, rq), (ka, prek, mk, rk), (v, prev, mv, rv) = sv["pools"]
-        dqa, dk, dv = ops.attn_bwd(qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE)
+        dqa, dk, dv = ops.attn_bwd(qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE,
+                                   q_splits=self.attn_q_splits)
         # rel-pos backward as GEMMs over the scattered matrix D [tokens, Lpad]
         tabs, mats = sv["tabs"], sv["mats"]
         names = (pre + "attn.rel_pos_h", pre + "attn.rel_pos_w", pre + "attn.rel_pos_t")
@@ -397,9 +442,11 @@ class Engine:
         strides = (sq, skv, skv)
         ops.pool_conv_dgrad_qkv(dpres, [f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
                                 dqkv, B, h, thw, n_obj, strides)
-        ops.pool_conv_wgrad_qkv(dpres, sv["qkv"],
-                                [f.g(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
-                                B, h, thw, n_obj, strides)
+        dws = [f.g(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"]
+        # (stays on the main stream: co-scheduled with NT / TN GEMM workgroups of another queue
+        # this kernel's partial sums were not bit-reproducible -- tools/stress_wgrad3.py; in
+        # stream order it is, and matches the oracle)
+        ops.pool_conv_wgrad_qkv(dpres, sv["qkv"], dws, B, h, thw, n_obj, strides)
         dxn = self._linear_bwd(dqkv, sv["xn"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", True)
         # ---- skip path ------------------------------------------------------------------------
         dskip = dx1

@@ -15,12 +15,15 @@ What is inside the graph(s): bf16 weight refresh, grad-buffer memset, DropPath /
 autograd backward and the whole backbone backward.  Same arithmetic as the eager step
 (tools/train_net.py:88-151 of the reference is the loop it replaces).
 
-Data parallel: the backward is cut into one graph per gradient bucket; after each segment's
-replay the wrapper's `_on_ready` hook launches that bucket's all-reduce on RCCL's stream, so the
-exchange overlaps the next segment exactly like in the eager path (svit_amd/dp.py) and no
-collective has to live inside a graph.
+The capture is cut into segments wherever work leaves the main chain: (a) the engine's
+grouped weight-gradient GEMM launches are replayed eagerly on a side stream next to the following segments -- inside one hipGraph the same fork/join ran slower
+than serial on ROCm 7.2; (b) data parallel: after the segment that finalises a gradient bucket
+the wrapper's `_on_ready` hook launches that bucket's all-reduce on RCCL's stream, overlapping
+the next segment exactly like in the eager path (svit_amd/dp.py) -- no collective lives inside a
+graph.
 """
 import gc
+import warnings
 
 import torch
 
@@ -42,7 +45,7 @@ class GraphedTrainStep:
         self.dp = model if hasattr(model, "_on_ready") and getattr(model, "world_size", 1) > 1 else None
         self.x = inputs[0].detach().clone().contiguous()
         self.labels = _tree_map(lambda t: t.detach().clone(), labels)
-        self.segments = []          # [(CUDAGraph, [readiness ranks final after it])]
+        self.segments = []          # replay items: ("graph", CUDAGraph) | ("side", fn) | ("join", None) | ("ready", ranks)
         self.loss = self.preds = self.extra = None
         self._keepalive = None
         self._capture(warmup)
@@ -77,45 +80,69 @@ class GraphedTrainStep:
             dy = torch.zeros_like(y)
             dy[:, :1] = dfeat[:, :1]
             dy[:, -n_obj:] = dfeat[:, 1:]
-            eng.backward(st, dy, on_ready=boundary)
+            eng.backward(st, dy, on_ready=boundary,
+                         ready_ranks=self.dp.launch_ranks() if self.dp is not None else None)
         return loss.detach(), preds.detach(), {k: v.detach() for k, v in extra.items()}, (st, feat, dy)
 
     def _capture(self, warmup):
         core = self.core
+        eng = core.engine
         core._attach_grads()                      # .grad views of the flat buffer, host side only
         dev = self.x.device
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(cap):
             for _ in range(max(1, warmup)):       # lazy tables / library workspaces materialise here
                 self._body(None)
-        side.synchronize()
+        cap.synchronize()
         gc.collect()
         torch.cuda.empty_cache()
         pool = torch.cuda.graph_pool_handle()
         cuts = self.dp.launch_ranks() if self.dp is not None else set()
-        state = {"g": torch.cuda.CUDAGraph(), "ranks": []}
-
-        def boundary(rank):
-            state["ranks"].append(rank)
-            if rank in cuts and rank != max(cuts):
-                state["g"].capture_end()
-                self.segments.append((state["g"], state["ranks"]))
-                state["g"], state["ranks"] = torch.cuda.CUDAGraph(), []
-                state["g"].capture_begin(pool=pool, capture_error_mode=mode)
-
         # "thread_local": the process group's watchdog thread may query events while we capture
         mode = "thread_local"
-        with torch.cuda.stream(side):
+        state = {"g": None}
+
+        def begin():
+            state["g"] = torch.cuda.CUDAGraph()
             state["g"].capture_begin(pool=pool, capture_error_mode=mode)
-            try:
-                self.loss, self.preds, self.extra, self._keepalive = self._body(
-                    boundary if self.dp is not None else None)
-            finally:
+
+        def end():
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
                 state["g"].capture_end()
-            self.segments.append((state["g"], state["ranks"]))
-        torch.cuda.current_stream(dev).wait_stream(side)
+            if not any("Graph is empty" in str(x.message) for x in w):
+                self.segments.append(("graph", state["g"]))
+
+        def cut(item):
+            """close the running capture, queue `item` for replay, open the next capture"""
+            end()
+            self.segments.append(item)
+            begin()
+
+        seen = []
+
+        def boundary(rank):
+            seen.append(rank)
+            if rank in cuts:
+                cut(("ready", list(seen)))
+                seen.clear()
+
+        eng._capture_fork = lambda fn: cut(("side", fn))
+        eng._capture_join = lambda: cut(("join", None))
+        try:
+            with torch.cuda.stream(cap):
+                begin()
+                try:
+                    self.loss, self.preds, self.extra, self._keepalive = self._body(
+                        boundary if self.dp is not None else None)
+                finally:
+                    end()
+        finally:
+            eng._capture_fork = eng._capture_join = None
+        torch.cuda.current_stream(dev).wait_stream(cap)
         torch.cuda.synchronize(dev)
+        self._side = torch.cuda.Stream(device=dev)
 
     # ------------------------------------------------------------------------------------------
     def __call__(self, inputs, labels):
@@ -126,12 +153,24 @@ class GraphedTrainStep:
         if x.data_ptr() != self.x.data_ptr():
             self.x.copy_(x, non_blocking=True)
         _tree_copy(self.labels, labels)
-        for g, ranks in self.segments:
-            g.replay()
-            if self.dp is not None:
-                for r in ranks:
+        main = torch.cuda.current_stream(self.x.device)
+        for kind, val in self.segments:
+            if kind == "graph":
+                val.replay()
+            elif kind == "side":        # parameter-gradient work next to the following segments
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    val()
+            elif kind == "join":
+                main.wait_stream(self._side)
+            else:                       # "ready": this bucket's gradients are final -> all-reduce
+                for r in val:
                     self.dp._on_ready(r)
         return self.loss, (self.preds, self.extra)
+
+    @property
+    def n_graphs(self):
+        return sum(1 for k, _ in self.segments if k == "graph")
 
 
 def _tree_map(fn, obj):

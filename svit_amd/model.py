@@ -68,7 +68,8 @@ class _Backbone(torch.autograd.Function):
             raise RuntimeError("backward through an SViT forward that was run without grad")
         model._attach_grads()
         with torch.no_grad():
-            model.engine.backward(ctx.st, dy, on_ready=model._grad_ready_hook)
+            model.engine.backward(ctx.st, dy, on_ready=model._grad_ready_hook,
+                                  ready_ranks=model._grad_ready_ranks)
         ctx.st = None
         return None, None, None, None, None
 
@@ -155,6 +156,7 @@ class SViT(nn.Module):
         self.engine = None
         self.flat = None
         self._grad_ready_hook = None   # set by the data-parallel wrapper (svit_amd/dp.py)
+        self._grad_ready_ranks = None  # ranks at which that hook launches collectives
         self._anchor = None
         self._keep = None
         self._grad_views = None

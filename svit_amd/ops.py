@@ -16,9 +16,10 @@ HD = 96
 _scratch = {}
 
 
-def scratch(device, floats=8 * 1024 * 1024):
-    """Per-device fp32 scratch for the two-stage parameter-gradient reductions (32 MB)."""
-    key = (device.index, floats)
+def scratch(device, floats=8 * 1024 * 1024, tag="main"):
+    """Per-device fp32 scratch for the two-stage parameter-gradient reductions (32 MB); `tag`
+    names an independent buffer for work that runs on another stream."""
+    key = (device.index, floats, tag)
     buf = _scratch.get(key)
     if buf is None:
         buf = torch.empty(floats, device=device, dtype=F32)
@@ -274,10 +275,10 @@ def pool_conv_dgrad_qkv(dpres, conv_ws, dqkv, B, heads, thw, n_obj, strides):
     hip.call("svit_pool_conv_dgrad_qkv", arr)
 
 
-def _pool_wgrad_args(a, dpre, qkv, which, dw, B, heads, thw, n_obj, stride_hw):
+def _pool_wgrad_args(a, dpre, qkv, which, dw, B, heads, thw, n_obj, stride_hw, ws=None):
     a.dpre, a.qkv, a.which, a.dw = ptr(dpre), ptr(qkv), which, ptr(dw)
     a.B, a.heads, (a.T, a.H, a.W), a.n_obj, a.stride_hw = B, heads, thw, n_obj, stride_hw
-    ws = scratch(dpre.device)
+    ws = scratch(dpre.device) if ws is None else ws
     a.workspace, a.workspace_floats = ptr(ws), ws.numel()
 
 
@@ -287,10 +288,10 @@ def pool_conv_wgrad(dpre, qkv, which, dw, B, heads, thw, n_obj, stride_hw):
     hip.call("svit_pool_conv_wgrad", C.byref(a))
 
 
-def pool_conv_wgrad_qkv(dpres, qkv, dws, B, heads, thw, n_obj, strides):
+def pool_conv_wgrad_qkv(dpres, qkv, dws, B, heads, thw, n_obj, strides, ws=None):
     arr = (hip.PoolWgradArgs * 3)()
     for i in range(3):
-        _pool_wgrad_args(arr[i], dpres[i], qkv, i, dws[i], B, heads, thw, n_obj, strides[i])
+        _pool_wgrad_args(arr[i], dpres[i], qkv, i, dws[i], B, heads, thw, n_obj, strides[i], ws)
     hip.call("svit_pool_conv_wgrad_qkv", arr)
 
 

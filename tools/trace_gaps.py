@@ -64,7 +64,26 @@ def window(path, needle, before, after):
         print("%9.1f %8.1f %8.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, gap / 1e3, short))
 
 
+def around(path, needle, limit):
+    """which kernels run right before / after each dispatch matching `needle` (histogram)"""
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    sh = lambda n: n.replace("void ", "").replace("(anonymous namespace)::", "").replace("at::native::", "")[:44]
+    hist = defaultdict(int)
+    for i, r in enumerate(rows):
+        if needle in r[2] and 0 < i < len(rows) - 1:
+            hist[(sh(rows[i - 1][2]), sh(rows[i + 1][2]), (r[1] - r[0]) // 1000)] += 1
+    for k, v in sorted(hist.items(), key=lambda kv: -kv[1])[:limit]:
+        print("%5d x  prev=%-46s next=%-46s dur~%d us" % (v, k[0], k[1], k[2]))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "--around":
+        around(sys.argv[1], sys.argv[3], int(sys.argv[4]))
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "--window":
         window(sys.argv[1], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]))
         sys.exit(0)
