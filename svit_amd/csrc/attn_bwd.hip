@@ -1,12 +1,12 @@
 // Fused pooled attention, backward (flash-style recompute) -- gfx950.
 //
-// Three launches (all on the caller's stream):
-//   1. delta[q]  = sum_c dctx[q,c] * (ctx[q,c] - q_pooled[q,c])        (rowsum(dO * O)),
-//      stored as (lse2, delta) pairs in the caller's scratch
-//   2. dq kernel : per 32-query wave, sweep K/V tiles: S^T, P^T = exp2(c*S - lse2),
+// Two launches (both on the caller's stream):
+//   1. dq kernel : first delta[q] = sum_c dctx[q,c] * (ctx[q,c] - q_pooled[q,c]) (rowsum(dO*O)),
+//                  kept in a register and stored as (lse2, delta) pairs in the caller's scratch
+//                  for launch 2; then per 32-query wave, sweep K/V tiles: S^T, P^T = exp2(c*S - lse2),
 //                  dP^T = V dO^T, dS^T = P^T (dP^T - delta) * scale, dQa^T += Ka^T dS^T.
 //                  Query on the lane => P/dS reach the next MFMA as B operands in registers.
-//   3. dkv kernel: per 32-key wave (128 keys per block), sweep 32-query tiles of a query
+//   2. dkv kernel: per 32-key wave (128 keys per block), sweep 32-query tiles of a query
 //                  chunk: S, P, dP, dS with the KEY on the lane; dV^T += dO^T P, dK^T += Q^T dS
 //                  accumulate in registers over the whole sweep; chunks of the query range run
 //                  in different blocks and meet in fp32 atomics shaped as whole 384-byte rows
@@ -20,44 +20,6 @@ namespace {
 using namespace attn;
 constexpr int KT = 64;   // keys per tile (dq kernel)
 constexpr int QT = 32;   // queries per tile (dkv kernel)
-
-__device__ __forceinline__ float quad_sum4(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  return v;
-}
-
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ ctx,
-                                                         const bf16_t* __restrict__ dctx,
-                                                         const bf16_t* __restrict__ qa, int ldq,
-                                                         const float* __restrict__ lse2,
-                                                         float* __restrict__ delta, int B,
-                                                         int heads, int Nq) {
-  const int64_t total = (int64_t)B * heads * Nq;
-  const int64_t row = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
-  const int sub = threadIdx.x & 3, c0 = sub * 24;
-  float acc = 0.f;
-  if (row < total) {
-    const int tok = (int)(row % Nq);
-    const int bh = (int)(row / Nq), b = bh / heads, head = bh % heads;
-    const size_t off = ((size_t)b * Nq + tok) * heads * HD + head * HD + c0;
-#pragma unroll
-    for (int v = 0; v < 3; ++v) {
-      const uint4 o = *(const uint4*)(ctx + off + v * 8);
-      const uint4 d = *(const uint4*)(dctx + off + v * 8);
-      uint4 q = make_uint4(0, 0, 0, 0);
-      if (tok > 0) q = *(const uint4*)(qa + row * ldq + c0 + v * 8);
-      acc += lo_bf16(d.x) * (lo_bf16(o.x) - lo_bf16(q.x)) + hi_bf16(d.x) * (hi_bf16(o.x) - hi_bf16(q.x));
-      acc += lo_bf16(d.y) * (lo_bf16(o.y) - lo_bf16(q.y)) + hi_bf16(d.y) * (hi_bf16(o.y) - hi_bf16(q.y));
-      acc += lo_bf16(d.z) * (lo_bf16(o.z) - lo_bf16(q.z)) + hi_bf16(d.z) * (hi_bf16(o.z) - hi_bf16(q.z));
-      acc += lo_bf16(d.w) * (lo_bf16(o.w) - lo_bf16(q.w)) + hi_bf16(d.w) * (hi_bf16(o.w) - hi_bf16(q.w));
-    }
-  }
-  acc = quad_sum4(acc);
-  // (lse2, delta) pairs: one 8-byte record per query row for the two sweep kernels
-  if (row < total && sub == 0) ((float2*)delta)[row] = make_float2(lse2[row], acc);
-}
 
 // ---------------------------------------------------------------------------------------
 // dq kernel.  K/V tiles travel HBM -> LDS by LDS-DMA (no staging registers), two stages, one
@@ -82,14 +44,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
   const bf16_t* vv = (const bf16_t*)a.v + ((size_t)bh * a.Nk) * HD;
   const bf16_t* dor = (const bf16_t*)a.dctx + ((size_t)b * a.Nq + qc) * a.heads * HD + head * HD;
   const float c = a.scale * 1.4426950408889634f;
-  const float2 ld = ((const float2*)a.delta)[(size_t)bh * a.Nq + qc];   // (lse2, delta)
-  const float lse = ld.x, dlt = ld.y;
+  const float lse = a.lse2[(size_t)bh * a.Nq + qc];
 
   bf16x8_t qf[KS], dof[6];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(qa + (size_t)qc * DA + ks * 16 + hh * 8);
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks) dof[ks] = *(const bf16x8_t*)(dor + ks * 16 + hh * 8);
+  // delta = rowsum(dO . O) with O = ctx - q (residual pooling adds q to every token but cls):
+  // folded in here (was a separate pre-pass); each half-wave lane holds 48 of the 96 channels.
+  // The (lse2, delta) pair is also what the dkv kernel streams, so it is written back once.
+  float dlt;
+  {
+    const bf16_t* orow = (const bf16_t*)a.ctx + ((size_t)b * a.Nq + qc) * a.heads * HD + head * HD;
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+      const uint4 o = *(const uint4*)(orow + ks * 16 + hh * 8);
+      const uint4 d = __builtin_bit_cast(uint4, dof[ks]);
+      uint4 q = __builtin_bit_cast(uint4, qf[ks]);
+      if (qc == 0) q = make_uint4(0, 0, 0, 0);
+      part += lo_bf16(d.x) * (lo_bf16(o.x) - lo_bf16(q.x)) + hi_bf16(d.x) * (hi_bf16(o.x) - hi_bf16(q.x));
+      part += lo_bf16(d.y) * (lo_bf16(o.y) - lo_bf16(q.y)) + hi_bf16(d.y) * (hi_bf16(o.y) - hi_bf16(q.y));
+      part += lo_bf16(d.z) * (lo_bf16(o.z) - lo_bf16(q.z)) + hi_bf16(d.z) * (hi_bf16(o.z) - hi_bf16(q.z));
+      part += lo_bf16(d.w) * (lo_bf16(o.w) - lo_bf16(q.w)) + hi_bf16(d.w) * (hi_bf16(o.w) - hi_bf16(q.w));
+    }
+    dlt = part + __shfl_xor(part, 32, 64);
+    if (hh == 0 && qi < a.Nq) ((float2*)a.delta)[(size_t)bh * a.Nq + qi] = make_float2(lse, dlt);
+  }
 
   // Pin the register operands NOW: their first use must not sit inside the tile loop, or the
   // compiler's wait for them (vmcnt(0)) would drain the LDS-DMA pipeline every iteration.
@@ -321,11 +303,6 @@ int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  const int64_t rows = (int64_t)a.B * a.heads * a.Nq;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, st,
-                     (const bf16_t*)a.ctx, (const bf16_t*)a.dctx, (const bf16_t*)a.qa, DA, a.lse2,
-                     a.delta, a.B, a.heads, a.Nq);
-  SVIT_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_bwd_dq_kernel<DA>, dim3((a.Nq + 127) / 128, a.B * a.heads), dim3(256),
                      lds_dq, st, a);
   SVIT_LAUNCH_CHECK();
@@ -335,10 +312,11 @@ int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
   if (splits <= 0) {
     // every split adds a full [128 keys x 192] fp32 tile per block with atomics (~1.3 TB/s
     // chip-wide), so split the query range only as far as needed to fill the chip
-    // ~2 blocks per CU, but keep >= 8 query tiles per block to amortise the epilogue
+    // (measured, tools/bench_kernels.py attnsplits: ~1 block per CU is the sweet spot), and
+    // keep >= 4 query tiles per block to amortise the epilogue
     const int base = key_blocks * a.B * a.heads;
-    splits = (512 + base - 1) / base;
-    if (splits > nqt / 8) splits = nqt / 8;
+    splits = (256 + base - 1) / base;
+    if (splits > nqt / 4) splits = nqt / 4;
   }
   if (splits > nqt) splits = nqt;
   if (splits < 1) splits = 1;

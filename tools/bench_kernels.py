@@ -247,3 +247,22 @@ def bench_tn_group():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tngroup":
     bench_tn_group()
+
+
+def bench_attn_splits():
+    """attention backward: forced query-split counts of the dkv kernel (us, whole backward)."""
+    print("== attn_bwd us by q_splits (0 = heuristic) ==")
+    for blk, Nin, Nq, Nk, Ci, Co, h, DA in BLOCKS:
+        qa, ka, v = rnd(B, h, Nq, DA), rnd(B, h, Nk, DA), rnd(B, h, Nk, 96)
+        scale = 96 ** -0.5
+        ctx, lse2 = ops.attn_fwd(qa, ka, v, scale)
+        dctx = rnd(B, Nq, h * 96)
+        res = []
+        for sp in (0, 1, 2, 3, 4, 6, 8):
+            us = timeit(lambda: ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=sp), iters=10)
+            res.append("%d:%.0f" % (sp, us))
+        print("blk%-2d h=%d Nq=%6d Nk=%5d  " % (blk, h, Nq, Nk) + "  ".join(res))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "attnsplits":
+    bench_attn_splits()
