@@ -78,9 +78,12 @@ int svit_transpose_cast_batched(const float* src_base, void* dst_base, const int
                                 int n_mats, int max_tiles, void* stream);
 /* dst(bf16)[R,ldd] = [src(f32)[R,C] | 0]: row-padded bf16 copy (patch-embed weight 441 -> 448). */
 int svit_pad_cast_rows(const float* src, void* dst, int R, int C, int ldd, void* stream);
-/* dst(bf16)[r,:] = scale[r/rows_per_sample] * src(f32)[r,:]   (DropPath backward). */
+/* dst(bf16)[r,:] = scale[r/rows_per_sample] * src(f32)[row(r),:]   (DropPath backward).
+ * row(r) = r, or with gather_L > 0 the row gather (r / L) * gather_N + gather_off + r % L
+ * (the patch rows [1, 1+L) of every sample of a [B, N, C] token tensor in one launch). */
 int svit_scale_cast(const float* src, void* dst, const float* row_scale, int rows_per_sample,
-                    int64_t rows, int cols, void* stream);
+                    int64_t rows, int cols, int gather_L, int gather_N, int gather_off,
+                    void* stream);
 
 /* ---------------------------------------------------------------- LayerNorm (K3) ------ */
 /* nn.LayerNorm(eps=1e-6): attention.py:501,531; video_model_builder.py:69,233. */

@@ -50,14 +50,17 @@ __global__ void transpose_cast_kernel(const float* __restrict__ src_base,
 
 __global__ void scale_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
                                   const float* __restrict__ row_scale, int rows_per_sample,
-                                  int64_t rows, int cols) {
+                                  int64_t rows, int cols, int gather_L, int gather_N,
+                                  int gather_off) {
   const int cpr = cols >> 2;  // float4 chunks per row
   const int64_t total = rows * cpr;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int64_t r = i / cpr;
     const float s = row_scale ? row_scale[r / rows_per_sample] : 1.f;
-    const float4 v = ((const float4*)src)[i];
+    // optional row gather: output row r reads source row (r / L) * N + off + r % L
+    const int64_t sr = gather_L > 0 ? (r / gather_L) * gather_N + gather_off + r % gather_L : r;
+    const float4 v = ((const float4*)src)[sr * cpr + (i - r * cpr)];
     uint2 o;
     o.x = pack_bf16x2(v.x * s, v.y * s);
     o.y = pack_bf16x2(v.z * s, v.w * s);
@@ -77,33 +80,60 @@ __global__ void pad_cast_rows_kernel(const float* __restrict__ src, bf16_t* __re
 }
 
 // ---- patch embedding im2col: Conv3d(3->96, k(3,7,7), s(2,4,4), p(1,3,3)) -----------------
-__global__ void im2col_patch_kernel(const float* __restrict__ video, bf16_t* __restrict__ cols,
-                                    int B, int T, int H, int W, int To, int Ho, int Wo) {
-  const int64_t total = (int64_t)B * To * Ho * Wo * 56;  // 56 chunks of 8 columns per row
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int chunk = (int)(i % 56);
-    int64_t m = i / 56;
-    const int xo = (int)(m % Wo); m /= Wo;
-    const int yo = (int)(m % Ho); m /= Ho;
-    const int to = (int)(m % To);
-    const int b = (int)(m / To);
-    float v[8];
+// One workgroup = one output row line (b, to, yo, all xo): the 3 x 3 x 7 input rows it needs are
+// fetched once with coalesced float4 loads into an LDS image (bf16, 3 zero columns of padding on
+// each side), then every 8-column chunk of the [Wo, 448] output is assembled from LDS and stored
+// as one 16-byte vector.  (The direct version issued eight scattered 4-byte gathers per chunk.)
+constexpr int I2C_MAXW = 256;                 // widest input row supported by the LDS image
+__global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ video,
+                                                           bf16_t* __restrict__ cols, int B, int T,
+                                                           int H, int W, int To, int Ho, int Wo) {
+  __shared__ bf16_t img[63][I2C_MAXW + 8];    // [(c*3+kt)*7+ky][3 + x]
+  const int yo = blockIdx.x % Ho, to = (blockIdx.x / Ho) % To, b = blockIdx.x / (Ho * To);
+  const int ldw = W + 6;
+  // zero the horizontal padding, then load the rows (zero rows outside the volume)
+  for (int i = threadIdx.x; i < 63 * 6; i += 256) {
+    const int r = i / 6, p = i % 6;
+    img[r][p < 3 ? p : W + p] = 0;
+  }
+  if ((W & 3) || ((uintptr_t)video & 15)) {        // odd widths: scalar loads
+    for (int i = threadIdx.x; i < 63 * W; i += 256) {
+      const int r = i / W, x = i % W;
+      const int ky = r % 7, kt = (r / 7) % 3, c = r / 21;
+      const int t = to * 2 - 1 + kt, y = yo * 4 - 3 + ky;
+      float v = 0.f;
+      if (t >= 0 && t < T && y >= 0 && y < H)
+        v = video[(((int64_t)b * 3 + c) * T + t) * H * W + (int64_t)y * W + x];
+      img[r][3 + x] = f32_to_bf16(v);
+    }
+  }
+  const int w4 = ((W & 3) || ((uintptr_t)video & 15)) ? 0 : (W >> 2);
+  for (int i = threadIdx.x; i < 63 * w4; i += 256) {
+    const int r = i / w4, x4 = i % w4;
+    const int ky = r % 7, kt = (r / 7) % 3, c = r / 21;
+    const int t = to * 2 - 1 + kt, y = yo * 4 - 3 + ky;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t >= 0 && t < T && y >= 0 && y < H)
+      v = *(const float4*)(video + (((int64_t)b * 3 + c) * T + t) * H * W + (int64_t)y * W + x4 * 4);
+    bf16_t* d = &img[r][3 + x4 * 4];
+    d[0] = f32_to_bf16(v.x); d[1] = f32_to_bf16(v.y); d[2] = f32_to_bf16(v.z); d[3] = f32_to_bf16(v.w);
+  }
+  __syncthreads();
+  (void)ldw;
+  bf16_t* out = cols + (((int64_t)b * To + to) * Ho + yo) * Wo * 448;
+  for (int i = threadIdx.x; i < Wo * 56; i += 256) {
+    const int xo = i / 56, chunk = i % 56;
+    bf16_t v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int col = chunk * 8 + e;
-      v[e] = 0.f;
-      if (col < 441) {
-        const int kx = col % 7, ky = (col / 7) % 7, kt = (col / 49) % 3, c = col / 147;
-        const int t = to * 2 - 1 + kt, y = yo * 4 - 3 + ky, x = xo * 4 - 3 + kx;
-        if (t >= 0 && t < T && y >= 0 && y < H && x >= 0 && x < W)
-          v[e] = video[(((int64_t)b * 3 + c) * T + t) * H * W + (int64_t)y * W + x];
-      }
+      const int kx = col % 7, r = col / 7;          // r = (c*3+kt)*7+ky for col < 441
+      v[e] = col < 441 ? img[r][xo * 4 + kx] : (bf16_t)0;
     }
     uint4 o;
-    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-    ((uint4*)cols)[i] = o;
+    o.x = (uint32_t)v[0] | ((uint32_t)v[1] << 16); o.y = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+    o.z = (uint32_t)v[4] | ((uint32_t)v[5] << 16); o.w = (uint32_t)v[6] | ((uint32_t)v[7] << 16);
+    ((uint4*)out)[i] = o;
   }
 }
 
@@ -297,12 +327,14 @@ extern "C" int svit_transpose_cast_batched(const float* src_base, void* dst_base
 }
 
 extern "C" int svit_scale_cast(const float* src, void* dst, const float* row_scale,
-                               int rows_per_sample, int64_t rows, int cols, void* stream) {
+                               int rows_per_sample, int64_t rows, int cols, int gather_L,
+                               int gather_N, int gather_off, void* stream) {
   if (!src || !dst || rows <= 0 || cols <= 0 || cols % 4 != 0) return SVIT_ERR_ARG;
   if (row_scale && rows_per_sample <= 0) return SVIT_ERR_ARG;
+  if (gather_L < 0 || (gather_L > 0 && (gather_N < gather_L || gather_off < 0))) return SVIT_ERR_ARG;
   hipLaunchKernelGGL(scale_cast_kernel, dim3(grid_for(rows * (cols / 4), 256)), dim3(256), 0,
                      (hipStream_t)stream, src, (bf16_t*)dst, row_scale, rows_per_sample, rows,
-                     cols);
+                     cols, gather_L, gather_N, gather_off);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }
@@ -319,8 +351,8 @@ extern "C" int svit_im2col_patch(const float* video, void* cols, int B, int T, i
                                  void* stream) {
   if (!video || !cols || B <= 0 || T <= 0 || H <= 0 || W <= 0) return SVIT_ERR_ARG;
   const int To = (T + 2 - 3) / 2 + 1, Ho = (H + 6 - 7) / 4 + 1, Wo = (W + 6 - 7) / 4 + 1;
-  const int64_t total = (int64_t)B * To * Ho * Wo * 56;
-  hipLaunchKernelGGL(im2col_patch_kernel, dim3(grid_for(total, 256, 65535)), dim3(256), 0,
+  if (W > I2C_MAXW) return SVIT_ERR_SHAPE;
+  hipLaunchKernelGGL(im2col_patch_kernel, dim3((unsigned)(B * To * Ho)), dim3(256), 0,
                      (hipStream_t)stream, video, (bf16_t*)cols, B, T, H, W, To, Ho, Wo);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;

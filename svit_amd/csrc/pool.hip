@@ -699,14 +699,24 @@ __global__ __launch_bounds__(256) void relq_gather_kernel(svit_relq_gather_args 
 
 // backward as GEMMs: scatter d(relq) into the dense-but-sparse matrix D [tokens, Lpad] whose
 // column sections are the rows of the h / w / t tables; then dR = D^T q (svit_gemm_tn) and
-// dq = D R (svit_gemm_nt).  D is zero-filled by the launcher.
+// dq = D R (svit_gemm_nt).  D is zero-filled by the same kernel.
 __global__ __launch_bounds__(256) void relq_scatter_kernel(svit_relq_scatter_args a) {
   const int extra = a.ld - HD;
   const int Lq = a.qt * a.qh * a.qw, Nq = 1 + Lq + a.n_obj;
   const int J = a.kh + a.kw + a.kt;
   const int tok_per_block = 256 / extra;
   const int64_t total = (int64_t)a.B * a.heads * Nq;
-  const int64_t row = (int64_t)blockIdx.x * tok_per_block + threadIdx.x / extra;
+  const int64_t row0 = (int64_t)blockIdx.x * tok_per_block;
+  // the block's rows of D are one contiguous chunk: zero it with 16-byte stores, then scatter
+  // (a row holds only J non-zeros at distinct columns)
+  {
+    const int64_t rows_here = min((int64_t)tok_per_block, total - row0);
+    uint4* chunk = (uint4*)((bf16_t*)a.D + row0 * a.ldd);
+    const int n16 = (int)(rows_here * a.ldd / 8);
+    for (int i = threadIdx.x; i < n16; i += 256) chunk[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+  const int64_t row = row0 + threadIdx.x / extra;
   const int j = threadIdx.x % extra;
   if (row >= total || j >= J) return;
   const int tok = (int)(row % Nq);
@@ -1020,7 +1030,6 @@ extern "C" int svit_relpos_scatter(const svit_relq_scatter_args* a, void* stream
   const int extra = a->ld - HD;
   const int64_t total = (int64_t)a->B * a->heads * (1 + a->qt * a->qh * a->qw + a->n_obj);
   if ((uintptr_t)a->D & 15) return SVIT_ERR_ALIGN;
-  svit_launch_zero(a->D, (size_t)total * a->ldd * 2, (hipStream_t)stream);   // ldd % 8 == 0
   const int tpb = 256 / extra;
   hipLaunchKernelGGL(relq_scatter_kernel, dim3((unsigned)((total + tpb - 1) / tpb)), dim3(256), 0,
                      (hipStream_t)stream, *a);

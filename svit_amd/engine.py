@@ -328,9 +328,7 @@ class Engine:
         f.g("object_queries").add_(dobj.sum((0, 1)).view(1, O, C))
         if Tx > 1:
             f.g("pos_embed_temporal").add_(dobj.sum((0, 2)).view(1, Tx, C))
-        dtok = torch.empty((B * L, C), device=self.dev, dtype=BF16)
-        for b in range(B):
-            ops.scale_cast(dx[b, 1:1 + L], dst=dtok[b * L:(b + 1) * L])
+        dtok = ops.scale_cast(dx, gather=(L, 1))       # patch rows of every clip -> bf16 [B*L, C]
         ops.gemm_tn(dtok, st["cols"], f.g("patch_embed.proj.weight").view(C, 441),
                     dbias=f.g("patch_embed.proj.bias"))
         self._join()

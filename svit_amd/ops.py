@@ -130,12 +130,23 @@ def pad_cast_rows(src, dst):
     return dst
 
 
-def scale_cast(src, row_scale=None, rows_per_sample=0, dst=None):
+def scale_cast(src, row_scale=None, rows_per_sample=0, dst=None, gather=None):
+    """bf16(row_scale * src).  gather=(L, off): src is [B, N, C] and only rows [off, off+L) of
+    every sample are converted -> dst [B*L, C]."""
     _chk_dev(src, row_scale, dst)
-    rows, cols = src.shape[:-1].numel(), src.shape[-1]
+    cols = src.shape[-1]
+    if gather is None:
+        rows, gl, gn, go = src.shape[:-1].numel(), 0, 0, 0
+        shape = src.shape
+    else:
+        gl, go = gather
+        gn = src.shape[-2]
+        rows = src.shape[0] * gl
+        shape = (rows, cols)
     if dst is None:
-        dst = torch.empty(src.shape, device=src.device, dtype=BF16)
-    hip.call("svit_scale_cast", ptr(src), ptr(dst), ptr(row_scale), rows_per_sample, rows, cols)
+        dst = torch.empty(shape, device=src.device, dtype=BF16)
+    hip.call("svit_scale_cast", ptr(src), ptr(dst), ptr(row_scale), rows_per_sample, rows, cols,
+             gl, gn, go)
     return dst
 
 

@@ -135,6 +135,8 @@ def test_colsum_cast_scale(ops):
     ref = (x.reshape(3, 100, 96) * s[:, None, None]).to(BF16).reshape(300, 96)
     assert torch.equal(got, ref)
     assert torch.equal(ops.scale_cast(x.reshape(300, 96)), x.reshape(300, 96).to(BF16))
+    got = ops.scale_cast(x, gather=(40, 3))                # rows [3, 43) of each of the 6 samples
+    assert torch.equal(got, x[:, 3:43].reshape(240, 96).to(BF16))
 
 
 def test_transpose_cast_batched(ops):
