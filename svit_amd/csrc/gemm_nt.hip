@@ -26,7 +26,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int RB, int NB, int WAVES_M, int WAVES_N, int STAGES, int EPI>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_nt_v2_kernel(svit_gemm_args p) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N > 4 ? 1 : 2)) void
+gemm_nt_v2_kernel(svit_gemm_args p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = 32 * RB * WAVES_M, WN = 32 * NB, BN = WN * WAVES_N;
   // rows per stage, padded so that every wave issues the same number of loads per stage (the
@@ -91,25 +92,32 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_nt_v2_kernel(sv
                                     // (b) everyone finished reading tile kt-1's buffer
     if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
     const unsigned char* st = smem + (kt % STAGES) * STAGE_BYTES;
+    // all fragment reads of the tile first, then the MFMAs back to back: left to itself the
+    // compiler reused two fragment registers and put a full `s_waitcnt lgkmcnt(0)` in front of
+    // nearly every MFMA (four exposed LDS round trips per tile)
+    bf16x8_t af[BK2 / 16][RB], wf[BK2 / 16][NB];
 #pragma unroll
     for (int ks = 0; ks < BK2 / 16; ++ks) {
       const int ch = 2 * ks + (lane >> 5);
-      bf16x8_t af[RB], wf[NB];
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         const int r = a_row + i * 32;
-        af[i] = *(const bf16x8_t*)(st + r * 64 + 16 * (ch ^ ((r >> 2) & 3)));
+        af[ks][i] = *(const bf16x8_t*)(st + r * 64 + 16 * (ch ^ ((r >> 2) & 3)));
       }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const int r = w_row + j * 32;
-        wf[j] = *(const bf16x8_t*)(st + r * 64 + 16 * (ch ^ ((r >> 2) & 3)));
+        wf[ks][j] = *(const bf16x8_t*)(st + r * 64 + 16 * (ch ^ ((r >> 2) & 3)));
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < BK2 / 16; ++ks)
 #pragma unroll
       for (int i = 0; i < RB; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) acc[i][j] = mfma32(af[i], wf[j], acc[i][j]);
-    }
+        for (int j = 0; j < NB; ++j) acc[i][j] = mfma32(af[ks][i], wf[ks][j], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();   // all LDS reads of the last tiles done before the epilogue reuses LDS
   nt_epilogue<RB, NB, EPI>(p, acc, smem, m0, n0, wm, wn, lane, wave);
@@ -177,9 +185,13 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
   if ((a.epilogue == SVIT_EPI_RESID || a.epilogue == SVIT_EPI_DGELU) && !a.aux) return SVIT_ERR_ARG;
   if (a.epilogue == SVIT_EPI_RESID && a.row_scale && a.rows_per_sample <= 0) return SVIT_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  // Tile choice (measured on MI355X, tools/bench_kernels.py gemm2): 128x192 blocks (2x2 waves
+  // Tile choice (measured on MI355X, tools/bench_kernels.py ntstages): 128x192 blocks (2x2 waves
   // of 64x96) win whenever they still give >= 1 tile per CU; otherwise, and for N = 96 (mod
-  // 192), 128x96 blocks (4 waves of 32x96) double the number of workgroups.
+  // 192), 128x96 blocks (4 waves of 32x96) double the number of workgroups.  A 256x192 / 8-wave
+  // tile (fewer LDS-fill bytes per flop) was measured too and never won.  At M = 13064 every
+  // variant lands within 10 % of the others: the bound is the per-CU LDS fill rate (~40 GB/s
+  // per CU, ~10 TB/s chip-wide for the mix of L2 and Infinity-Cache hits), not the pipeline
+  // depth, the fragment-read scheduling or the tile shape.
   bool big = a.N % 192 == 0 && (long)((a.M + 127) / 128) * (a.N / 192) >= 256;
   if (g_nt_force_cfg == 0 && a.N % 192 == 0) big = true;
   if (g_nt_force_cfg == 2) big = false;
