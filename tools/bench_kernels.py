@@ -266,3 +266,36 @@ def bench_attn_splits():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "attnsplits":
     bench_attn_splits()
+
+
+def bench_relq():
+    """query-side rel-pos forward: VALU kernel vs GEMM + gather (us)."""
+    from svit_amd.engine import _rel_index
+    print("== relq fwd: valu kernel | gemm + gather ==")
+    cfgs = [(0, 1, (8, 56, 56), (8, 7, 7)), (2, 2, (8, 28, 28), (8, 7, 7)), (4, 4, (8, 14, 14), (8, 7, 7)),
+            (14, 8, (8, 7, 7), (8, 14, 14)), (15, 8, (8, 7, 7), (8, 7, 7))]
+    for blk, h, q_thw, k_thw in cfgs:
+        Lq = q_thw[0] * q_thw[1] * q_thw[2]
+        J = sum(k_thw)
+        ld = 128 if J <= 32 else 160
+        Nq = 1 + Lq + 64
+        qa = rnd(B, h, Nq, ld)
+        rows = [2 * max(q_thw[i], k_thw[i]) - 1 for i in (1, 2, 0)]
+        tabs = [torch.randn(r, 96, device=DEV) * 0.1 for r in rows]
+        idx = [_rel_index(q_thw[1], k_thw[1]).to(DEV).contiguous(), _rel_index(q_thw[2], k_thw[2]).to(DEV).contiguous(),
+               _rel_index(q_thw[0], k_thw[0]).to(DEV).contiguous()]
+        t_v = timeit(lambda: ops.relpos_q_fwd(qa, tabs, idx, B, h, q_thw, k_thw, 64, 96 ** 0.5))
+        lp = (sum(rows) + 95) // 96 * 96
+        rcat = torch.zeros(lp, 96, device=DEV, dtype=BF16)
+        rcat[:sum(rows)] = torch.cat(tabs).to(BF16)
+        offs = (0, rows[0], rows[0] + rows[1])
+
+        def gg():
+            P = ops.gemm_nt(qa.view(B * h * Nq, ld)[:, :96], rcat, None, hip.EPI_BF16)
+            ops.relpos_gather(P, qa, idx, offs, B, h, q_thw, k_thw, 64, 96 ** 0.5)
+        t_g = timeit(gg)
+        print("blk%-2d h=%d Nq=%6d J=%2d  valu %7.1f | gemm+gather %7.1f" % (blk, h, Nq, J, t_v, t_g))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "relq":
+    bench_relq()
