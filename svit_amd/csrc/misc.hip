@@ -180,19 +180,22 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
     } else {
       const int p = tok - 1, xo = p % Wo, yo = (p / Wo) % Ho, t = p / (Wo * Ho);
       best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-      for (int ky = 0; ky < 3; ++ky) {
-        const int yy = yo * 2 - 1 + ky;
-        if (yy < 0 || yy >= H) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-          const int xx = xo * 2 - 1 + kx;
-          if (xx < 0 || xx >= W) continue;
-          const float4 v = xb[(int64_t)(1 + (t * H + yy) * W + xx) * c4 + cc];
-          const unsigned char tap = (unsigned char)(ky * 3 + kx);
-          if (v.x > best.x) { best.x = v.x; bi.x = tap; }
-          if (v.y > best.y) { best.y = v.y; bi.y = tap; }
-          if (v.z > best.z) { best.z = v.z; bi.z = tap; }
-          if (v.w > best.w) { best.w = v.w; bi.w = tap; }
-        }
+      float4 v[9];                     // all nine taps in flight before the first compare
+      bool ok[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int yy = yo * 2 - 1 + k / 3, xx = xo * 2 - 1 + k % 3;
+        ok[k] = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        v[k] = xb[ok[k] ? (int64_t)(1 + (t * H + yy) * W + xx) * c4 + cc : (int64_t)cc];
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        if (!ok[k]) continue;
+        const unsigned char tap = (unsigned char)k;
+        if (v[k].x > best.x) { best.x = v[k].x; bi.x = tap; }
+        if (v[k].y > best.y) { best.y = v[k].y; bi.y = tap; }
+        if (v[k].z > best.z) { best.z = v[k].z; bi.z = tap; }
+        if (v[k].w > best.w) { best.w = v[k].w; bi.w = tap; }
       }
     }
     ((float4*)y)[i] = best;
@@ -221,23 +224,28 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
       g = db[(int64_t)(1 + T * Ho * Wo + (tok - 1 - T * H * W)) * c4 + cc];
     } else {
       const int p = tok - 1, xx = p % W, yy = (p / W) % H, t = p / (W * H);
-      for (int yo = (yy >> 1); yo <= (yy >> 1) + 1; ++yo) {
-        if (yo < 0 || yo >= Ho) continue;
-        const int ky = yy - (yo * 2 - 1);
-        if (ky < 0 || ky > 2) continue;
-        for (int xo = (xx >> 1); xo <= (xx >> 1) + 1; ++xo) {
-          if (xo < 0 || xo >= Wo) continue;
-          const int kx = xx - (xo * 2 - 1);
-          if (kx < 0 || kx > 2) continue;
-          const unsigned char tap = (unsigned char)(ky * 3 + kx);
-          const int64_t o = (int64_t)(1 + (t * Ho + yo) * Wo + xo) * c4 + cc;
-          const float4 d = db[o];
-          const uchar4 s = ib[o];
-          if (s.x == tap) g.x += d.x;
-          if (s.y == tap) g.y += d.y;
-          if (s.z == tap) g.z += d.z;
-          if (s.w == tap) g.w += d.w;
-        }
+      // the (<= 2 x 2) candidate windows: all four loads are issued before the first compare
+      float4 d[4];
+      uchar4 s[4];
+      unsigned char tap[4];
+      bool ok[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int yo = (yy >> 1) + (k >> 1), xo = (xx >> 1) + (k & 1);
+        const int ky = yy - (yo * 2 - 1), kx = xx - (xo * 2 - 1);
+        ok[k] = yo < Ho && xo < Wo && ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2;
+        tap[k] = (unsigned char)(ky * 3 + kx);
+        const int64_t o = ok[k] ? (int64_t)(1 + (t * Ho + yo) * Wo + xo) * c4 + cc : cc;
+        d[k] = db[o];
+        s[k] = ib[o];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!ok[k]) continue;
+        if (s[k].x == tap[k]) g.x += d[k].x;
+        if (s[k].y == tap[k]) g.y += d[k].y;
+        if (s[k].z == tap[k]) g.z += d[k].z;
+        if (s[k].w == tap[k]) g.w += d[k].w;
       }
     }
     ((float4*)dx)[i] = g;
