@@ -166,6 +166,12 @@ int svit_pool_ln_fwd_qkv(const svit_pool_args* args3, void* stream);
 int svit_pool_ln_bwd_qkv(const svit_pool_ln_bwd_args* args3, void* stream);
 int svit_pool_conv_dgrad_qkv(const svit_pool_dgrad_args* args3, void* stream);
 int svit_pool_conv_wgrad_qkv(const svit_pool_wgrad_args* args3, void* stream);
+/* Steps 2 + 3 together (what the engine calls): for the small planes (14x14 / 7x7 stages, strides
+ * 1 or 2) ONE kernel walks the input tokens once with dpre in LDS and produces dqkv and the
+ * three dw (fp32 atomics); larger planes fall through to the two streaming launches above.
+ * dgrad3[i] / wgrad3[i] describe the same `which` = i (same dpre, stride, dims). */
+int svit_pool_conv_bwd_qkv(const svit_pool_dgrad_args* dgrad3, const svit_pool_wgrad_args* wgrad3,
+                           void* stream);
 
 /* ------------------------------------------- decomposed rel-pos bias, query side (K9/K10) */
 /* cal_rel_pos_spatial / cal_rel_pos_temporal (attention.py:84-183) restated as

@@ -641,6 +641,177 @@ static int launch_wgrad(const svit_pool_wgrad_args& a, int Ho, int Wo, hipStream
 }
 
 // ---------------------------------------------------------------------------------------
+// Small-plane pooling backward (the 14x14 / 7x7 stages, 12 of 16 blocks): conv dgrad AND conv
+// wgrad of q, k, v in ONE launch.  Both consume the same 3x3x3 neighbourhood of dpre, so a
+// workgroup keeps dpre of one (batch, head) for a 24-channel group in LDS (<= ~100 KB), walks
+// the INPUT tokens once and, per valid tap, does  dx[in] += w[tap] * dpre[out]  and
+// dw[tap] += x[in] * dpre[out]  from the same LDS read.  Thread = (channel pair, token lane);
+// the 27 weights and 27 weight-gradient accumulators of both channels live in registers (tap
+// indices are compile-time: stride 2 dispatches on the input parity).  dw leaves through fp32
+// atomics (<= 64 adders per address).  Replaces pool_dgrad3 + pool_wgrad3 + a reduce launch
+// (~110 us -> one latency-light kernel) where the planes are small.
+struct PoolBwdSmall {
+  svit_pool_dgrad_args d[3];
+  const void* qkv;
+  float* dw[3];
+  int nsplit[3];
+};
+
+template <int S, int PY, int PX>
+__device__ __forceinline__ void pbs_taps(const bf16_t* dp, int cp, int t, int y, int x, int T,
+                                         int Ho, int Wo, float x0, float x1, const float (&w0)[27],
+                                         const float (&w1)[27], float (&dw0)[27], float (&dw1)[27],
+                                         float& a0, float& a1) {
+  // branch-free: every candidate tap reads LDS (row 0 when it falls outside the volume) and an
+  // invalid tap contributes zeros -- all reads are in flight before the first FMA
+  int rowb[3][3];
+  bool rv[3][3], xv[3];
+  int xo[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int xn = x + 1 - kx;
+    xo[kx] = S == 2 ? (xn >> 1) : xn;
+    xv[kx] = xn >= 0 && xo[kx] < Wo;
+  }
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt) {
+    const int to = t + 1 - kt;
+    const bool tv = to >= 0 && to < T;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yn = y + 1 - ky;
+      const int yo = S == 2 ? (yn >> 1) : yn;
+      rv[kt][ky] = tv && yn >= 0 && yo < Ho;
+      rowb[kt][ky] = 1 + (to * Ho + yo) * Wo;
+    }
+  }
+  uint32_t v[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const int kt = k / 9, ky = (k / 3) % 3, kx = k % 3;
+    v[k] = 0u;
+    if (S == 2 && ((ky & 1) != PY || (kx & 1) != PX)) continue;       // compile-time
+    const bool ok = rv[kt][ky] && xv[kx];
+    const int row = ok ? rowb[kt][ky] + xo[kx] : 0;
+    const uint32_t r = *(const uint32_t*)(dp + (size_t)row * 24 + 2 * cp);
+    v[k] = ok ? r : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const int ky = (k / 3) % 3, kx = k % 3;
+    if (S == 2 && ((ky & 1) != PY || (kx & 1) != PX)) continue;       // compile-time
+    const float d0 = lo_bf16(v[k]), d1 = hi_bf16(v[k]);
+    a0 += w0[k] * d0; a1 += w1[k] * d1;
+    dw0[k] += x0 * d0; dw1[k] += x1 * d1;
+  }
+}
+
+template <int S>
+__device__ __forceinline__ void pool_bwd_small_body(const PoolBwdSmall& g, int which, int bh,
+                                                    int group, int split, unsigned char* smem) {
+  const svit_pool_dgrad_args& a = g.d[which];
+  const int tid = threadIdx.x, cp = tid % 12, tl = tid / 12;      // 192 threads: 12 pairs x 16
+  const int c = group * 24 + 2 * cp;
+  const int s = a.stride_hw;
+  const int Ho = pooled(a.H, s), Wo = pooled(a.W, s);
+  const int L = a.T * a.H * a.W, Lo = a.T * Ho * Wo;
+  const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
+  const int b = bh / a.heads, head = bh % a.heads;
+  bf16_t* dp = (bf16_t*)smem;                                     // [Nout][24]
+  const bf16_t* dsrc = (const bf16_t*)a.dpre + (size_t)bh * Nout * HD + group * 24;
+  for (int i = tid; i < Nout * 3; i += 192) {
+    const int tok = i / 3, ch = i % 3;
+    *(uint4*)(dp + (size_t)tok * 24 + ch * 8) = *(const uint4*)(dsrc + (size_t)tok * HD + ch * 8);
+  }
+  float w0[27], w1[27], dw0[27], dw1[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    w0[k] = a.conv_w[(size_t)c * 27 + k];
+    w1[k] = a.conv_w[(size_t)(c + 1) * 27 + k];
+    dw0[k] = 0.f; dw1[k] = 0.f;
+  }
+  float nt[3], nh[3], ipt, iph;
+  obj_counts(1, nt, &ipt);
+  obj_counts(s, nh, &iph);
+  const float onorm = ipt * iph * iph;
+  float g0 = 0.f, g1 = 0.f;                 // object gain of the two channels
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const float coef = nt[k / 9] * nh[(k / 3) % 3] * nh[k % 3] * onorm;
+    g0 += w0[k] * coef; g1 += w1[k] * coef;
+  }
+  __syncthreads();
+  const size_t tok_stride = (size_t)3 * a.heads * HD;
+  const size_t col = ((size_t)which * a.heads + head) * HD + c;
+  const bf16_t* xin = (const bf16_t*)g.qkv + (size_t)b * N * tok_stride + col;
+  bf16_t* dxo = (bf16_t*)a.dqkv + (size_t)b * N * tok_stride + col;
+  const int per = (N + g.nsplit[which] - 1) / g.nsplit[which];
+  const int begin = split * per, end = min(N, begin + per);
+  float go0 = 0.f, go1 = 0.f;
+  // x of the NEXT token is fetched while the current one is processed: one exposed global round
+  // trip per token would otherwise dominate (a wave has a SIMD almost to itself here)
+  uint32_t xnext = 0u;
+  if (begin + tl < end) xnext = *(const uint32_t*)(xin + (size_t)(begin + tl) * tok_stride);
+  for (int tok = begin + tl; tok < end; tok += 16) {
+    const uint32_t xv = xnext;
+    if (tok + 16 < end) xnext = *(const uint32_t*)(xin + (size_t)(tok + 16) * tok_stride);
+    float a0 = 0.f, a1 = 0.f;
+    if (tok == 0) {
+      const uint32_t v = *(const uint32_t*)(dp + 2 * cp);
+      a0 = lo_bf16(v); a1 = hi_bf16(v);
+    } else if (tok > L) {
+      const uint32_t v = *(const uint32_t*)(dp + (size_t)(1 + Lo + (tok - 1 - L)) * 24 + 2 * cp);
+      const float d0 = lo_bf16(v), d1 = hi_bf16(v);
+      a0 = d0 * g0; a1 = d1 * g1;
+      go0 += d0 * lo_bf16(xv); go1 += d1 * hi_bf16(xv);
+    } else {
+      const int p = tok - 1, x = p % a.W, y = (p / a.W) % a.H, t = p / (a.W * a.H);
+      const float x0 = lo_bf16(xv), x1 = hi_bf16(xv);
+      if (S == 1) {
+        pbs_taps<1, 0, 0>(dp, cp, t, y, x, a.T, Ho, Wo, x0, x1, w0, w1, dw0, dw1, a0, a1);
+      } else {
+        const int py = (y + 1) & 1, px = (x + 1) & 1;   // taps with ky = py (mod 2), kx = px (mod 2)
+        if (py == 0 && px == 0) pbs_taps<2, 0, 0>(dp, cp, t, y, x, a.T, Ho, Wo, x0, x1, w0, w1, dw0, dw1, a0, a1);
+        else if (py == 0) pbs_taps<2, 0, 1>(dp, cp, t, y, x, a.T, Ho, Wo, x0, x1, w0, w1, dw0, dw1, a0, a1);
+        else if (px == 0) pbs_taps<2, 1, 0>(dp, cp, t, y, x, a.T, Ho, Wo, x0, x1, w0, w1, dw0, dw1, a0, a1);
+        else pbs_taps<2, 1, 1>(dp, cp, t, y, x, a.T, Ho, Wo, x0, x1, w0, w1, dw0, dw1, a0, a1);
+      }
+    }
+    *(uint32_t*)(dxo + (size_t)tok * tok_stride) = pack_bf16x2(a0, a1);
+  }
+  // object tokens' closed-form share of dw, then the 16 token lanes meet in LDS
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const float coef = nt[k / 9] * nh[(k / 3) % 3] * nh[k % 3] * onorm;
+    dw0[k] += go0 * coef; dw1[k] += go1 * coef;
+  }
+  __syncthreads();                              // everyone is done reading dp
+  float* red = (float*)smem;                    // [16][12][54]
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    red[(tl * 12 + cp) * 54 + k] = dw0[k];
+    red[(tl * 12 + cp) * 54 + 27 + k] = dw1[k];
+  }
+  __syncthreads();
+  for (int o = tid; o < 12 * 54; o += 192) {
+    float sum = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) sum += red[l * 648 + o];
+    const int pair = o / 54, k2 = o % 54;
+    const int ch = group * 24 + 2 * pair + (k2 >= 27 ? 1 : 0);
+    atomicAdd(g.dw[which] + (size_t)ch * 27 + (k2 % 27), sum);
+  }
+}
+
+__global__ __launch_bounds__(192) void pool_bwd_small_kernel(PoolBwdSmall g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_pbs[];
+  const int which = blockIdx.y, group = blockIdx.z >> 1, split = blockIdx.z & 1;
+  if (split >= g.nsplit[which]) return;
+  if (g.d[which].stride_hw == 1) pool_bwd_small_body<1>(g, which, blockIdx.x, group, split, smem_pbs);
+  else pool_bwd_small_body<2>(g, which, blockIdx.x, group, split, smem_pbs);
+}
+
+// ---------------------------------------------------------------------------------------
 // query side of the decomposed relative-position bias
 __global__ __launch_bounds__(256) void relq_fwd_kernel(svit_relq_args a) {
   const int extra = a.ld - HD;               // 32 or 64 columns
@@ -935,6 +1106,54 @@ extern "C" int svit_pool_conv_wgrad_qkv(const svit_pool_wgrad_args* a3, void* st
   SvitReduceDst dst = {{a3[0].dw, a3[1].dw, a3[2].dw, a3[2].dw, a3[2].dw, a3[2].dw},
                        {27 * HD, 2 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD}};
   svit_launch_reduce(a3[0].workspace, (int)blocks, 3 * 27 * HD, dst, (hipStream_t)stream);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_pool_conv_bwd_qkv(const svit_pool_dgrad_args* d3, const svit_pool_wgrad_args* w3,
+                                      void* stream) {
+  if (!d3 || !w3) return SVIT_ERR_ARG;
+  bool small = true;
+  size_t lds = 16 * 648 * sizeof(float);
+  for (int i = 0; i < 3; ++i) {
+    const svit_pool_dgrad_args& d = d3[i];
+    const svit_pool_wgrad_args& w = w3[i];
+    if (!d.dpre || !d.conv_w || !d.dqkv || !w.qkv || !w.dw || d.which != i || w.which != i)
+      return SVIT_ERR_ARG;
+    const int rc = check_pool_dims(d.B, d.heads, d.T, d.H, d.W, d.n_obj, d.stride_hw);
+    if (rc) return rc;
+    if (w.dpre != d.dpre || w.stride_hw != d.stride_hw || w.qkv != w3[0].qkv) return SVIT_ERR_ARG;
+    const int Ho = (d.H - 1) / d.stride_hw + 1, Wo = (d.W - 1) / d.stride_hw + 1;
+    const size_t need = (size_t)(1 + d.T * Ho * Wo + d.n_obj) * 48;
+    if (need > lds) lds = need;
+    if (d.stride_hw > 2) small = false;
+  }
+  const int N = 1 + d3[0].T * d3[0].H * d3[0].W + d3[0].n_obj;
+  // measured (tools/bench_kernels.py poolbwd): the fused kernel wins at the 7x7 stage (78 vs
+  // 126 us) and loses from 14x14 on (155 vs 108 us: two channels per thread do not amortise
+  // the tap addressing the way the streaming dgrad's 24 channels per lane do)
+  if (lds > 112 * 1024 || N > 1024) small = false;
+  if (!small) {   // large planes: the streaming kernels
+    int rc = svit_pool_conv_dgrad_qkv(d3, stream);
+    if (rc) return rc;
+    return svit_pool_conv_wgrad_qkv(w3, stream);
+  }
+  PoolBwdSmall g;
+  for (int i = 0; i < 3; ++i) {
+    g.d[i] = d3[i];
+    g.dw[i] = w3[i].dw;
+    g.nsplit[i] = d3[i].stride_hw == 1 ? 2 : 1;     // 27 taps per token vs <= 12
+  }
+  g.qkv = w3[0].qkv;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)pool_bwd_small_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  hipLaunchKernelGGL(pool_bwd_small_kernel, dim3(d3[0].B * d3[0].heads, 3, 8), dim3(192), lds,
+                     (hipStream_t)stream, g);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }

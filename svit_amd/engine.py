@@ -438,13 +438,12 @@ class Engine:
                              f.g(pre + "attn.norm_%s.bias" % r), B, h, nout), kw))
         dpres = ops.pool_ln_bwd_qkv(entries)       # q, k, v side by side: one launch per stage
         strides = (sq, skv, skv)
-        ops.pool_conv_dgrad_qkv(dpres, [f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
-                                dqkv, B, h, thw, n_obj, strides)
-        dws = [f.g(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"]
-        # (stays on the main stream: co-scheduled with NT / TN GEMM workgroups of another queue
-        # this kernel's partial sums were not bit-reproducible -- tools/stress_wgrad3.py; in
-        # stream order it is, and matches the oracle)
-        ops.pool_conv_wgrad_qkv(dpres, sv["qkv"], dws, B, h, thw, n_obj, strides)
+        # conv dgrad + conv wgrad: one kernel with dpre in LDS for the small planes (blocks >= 4),
+        # the two streaming launches otherwise (decided inside the library)
+        ops.pool_conv_bwd_qkv(dpres, [f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
+                              dqkv, sv["qkv"],
+                              [f.g(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
+                              B, h, thw, n_obj, strides)
         dxn = self._linear_bwd(dqkv, sv["xn"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", True)
         # ---- skip path ------------------------------------------------------------------------
         dskip = dx1

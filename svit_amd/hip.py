@@ -123,6 +123,7 @@ _SIGS = {
     "svit_pool_ln_bwd_qkv": (i32, [C.POINTER(PoolLnBwdArgs), vp]),
     "svit_pool_conv_dgrad_qkv": (i32, [C.POINTER(PoolDgradArgs), vp]),
     "svit_pool_conv_wgrad_qkv": (i32, [C.POINTER(PoolWgradArgs), vp]),
+    "svit_pool_conv_bwd_qkv": (i32, [C.POINTER(PoolDgradArgs), C.POINTER(PoolWgradArgs), vp]),
     "svit_relpos_q_fwd": (i32, [C.POINTER(RelqArgs), vp]),
     "svit_relpos_q_bwd": (i32, [C.POINTER(RelqBwdArgs), vp]),
     "svit_relpos_scatter": (i32, [C.POINTER(RelqScatterArgs), vp]),

@@ -306,6 +306,16 @@ def pool_conv_wgrad_qkv(dpres, qkv, dws, B, heads, thw, n_obj, strides, ws=None)
     hip.call("svit_pool_conv_wgrad_qkv", arr)
 
 
+def pool_conv_bwd_qkv(dpres, conv_ws, dqkv, qkv, dws, B, heads, thw, n_obj, strides):
+    """conv dgrad + conv wgrad of q, k, v: one fused kernel for small planes, else two launches."""
+    da = (hip.PoolDgradArgs * 3)()
+    wa = (hip.PoolWgradArgs * 3)()
+    for i in range(3):
+        _pool_dgrad_args(da[i], dpres[i], conv_ws[i], dqkv, i, B, heads, thw, n_obj, strides[i])
+        _pool_wgrad_args(wa[i], dpres[i], qkv, i, dws[i], B, heads, thw, n_obj, strides[i])
+    hip.call("svit_pool_conv_bwd_qkv", da, wa)
+
+
 def relpos_q_fwd(qa, tabs, idx, B, heads, q_thw, k_thw, n_obj, inv_scale):
     a = hip.RelqArgs()
     a.qa, a.ld = ptr(qa), qa.shape[-1]

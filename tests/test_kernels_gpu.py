@@ -314,6 +314,32 @@ def test_pool_qkv_fused_equals_single(ops, sq, skv, thw):
         assert rel_err(dw1[i], dw2[i]) < 1e-5
 
 
+@pytest.mark.parametrize("sq,skv,thw,B,h", [(1, 2, (4, 14, 14), 2, 4), (2, 1, (2, 14, 14), 2, 8),
+                                             (1, 1, (3, 7, 7), 3, 2), (2, 2, (2, 9, 11), 2, 2),
+                                             (1, 4, (2, 16, 16), 2, 2)])
+def test_pool_conv_bwd_fused_small_planes(ops, sq, skv, thw, B, h):
+    """dgrad + wgrad in one kernel (dpre in LDS) == the two streaming launches; the last case
+    (stride 4) must take the fall-through path"""
+    O = 5
+    qkv = _qkv(B, h, thw, O, "s%d%d" % (sq, skv))
+    ws = [rnd("sw%d" % i, (96, 27), 0.3) for i in range(3)]
+    strides = (sq, skv, skv)
+    dpres = []
+    for i, s in enumerate(strides):
+        Nout = 1 + thw[0] * ops.pooled(thw[1], s) * ops.pooled(thw[2], s) + O
+        dpres.append(rnd("sd%d%d" % (i, s), (B, h, Nout, 96), 1.0, BF16))
+    d_ref = torch.zeros_like(qkv)
+    ops.pool_conv_dgrad_qkv(dpres, ws, d_ref, B, h, thw, O, strides)
+    dw_ref = [torch.zeros((96, 27), device=DEV) for _ in range(3)]
+    ops.pool_conv_wgrad_qkv(dpres, qkv, dw_ref, B, h, thw, O, strides)
+    d_got = torch.full_like(qkv, 7.0)                       # every element must be overwritten
+    dw_got = [torch.full((96, 27), 0.5, device=DEV) for _ in range(3)]
+    ops.pool_conv_bwd_qkv(dpres, ws, d_got, qkv, dw_got, B, h, thw, O, strides)
+    assert rel_err(d_got.float(), d_ref.float()) < 1e-2
+    for i in range(3):
+        assert rel_err(dw_got[i] - 0.5, dw_ref[i]) < 2e-4
+
+
 def test_pool_ln_bwd_three_inputs(ops):
     B, h, Nout = 2, 2, 37
     pre = rnd("pre3", (B, h, Nout, 96), 1.0, BF16)

@@ -299,3 +299,26 @@ def bench_relq():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "relq":
     bench_relq()
+
+
+def bench_pool_bwd():
+    """conv dgrad + wgrad of q, k, v: two streaming launches vs the fused small-plane kernel (us)."""
+    print("== pool conv backward q/k/v: dgrad3 + wgrad3 | fused ==")
+    cfgs = [(4, 4, (8, 14, 14), 1, 2), (14, 8, (8, 14, 14), 2, 1), (15, 8, (8, 7, 7), 1, 1)]
+    n_obj = 64
+    for blk, h, thw, sq, skv in cfgs:
+        N = 1 + thw[0] * thw[1] * thw[2] + n_obj
+        qkv = rnd(B, N, 3, h, 96)
+        ws = [torch.randn(96, 27, device=DEV) * 0.2 for _ in range(3)]
+        strides = (sq, skv, skv)
+        dpres = [rnd(B, h, 1 + thw[0] * ops.pooled(thw[1], s) * ops.pooled(thw[2], s) + n_obj, 96) for s in strides]
+        dqkv = torch.empty_like(qkv)
+        dws = [torch.zeros(96, 27, device=DEV) for _ in range(3)]
+        t_d = timeit(lambda: ops.pool_conv_dgrad_qkv(dpres, ws, dqkv, B, h, thw, n_obj, strides))
+        t_w = timeit(lambda: ops.pool_conv_wgrad_qkv(dpres, qkv, dws, B, h, thw, n_obj, strides))
+        t_f = timeit(lambda: ops.pool_conv_bwd_qkv(dpres, ws, dqkv, qkv, dws, B, h, thw, n_obj, strides))
+        print("blk%-2d h=%d N=%5d sq=%d skv=%d  dgrad3 %6.1f + wgrad3 %6.1f | fused %6.1f" % (blk, h, N, sq, skv, t_d, t_w, t_f))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "poolbwd":
+    bench_pool_bwd()
