@@ -67,16 +67,14 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ conv_w, f
 }
 
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void pool_ln_fwd_body(const svit_pool_args& a) {
-  __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];
-  __shared__ __attribute__((aligned(16))) float g_lds[HD];
-  load_weights(a.conv_w, w_lds, g_lds, a.stride_hw);
+__device__ __forceinline__ void pool_ln_fwd_body(const svit_pool_args& a, const float* w_lds,
+                                                 const float* g_lds, int tb) {
   const int s = a.stride_hw;
   const int Ho = pooled(a.H, s), Wo = pooled(a.W, s);
   const int L = a.T * a.H * a.W, Lo = a.T * Ho * Wo;
   const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
   const int bh = blockIdx.y, b = bh / a.heads, head = bh % a.heads;
-  const int tok = blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int tok = tb * 64 + (threadIdx.x >> 2);
   const int sub = threadIdx.x & 3, c0 = sub * 24;
   const bool live = tok < Nout;
   const bf16_t* qkv = (const bf16_t*)a.qkv;
@@ -182,17 +180,28 @@ __device__ __forceinline__ void pool_ln_fwd_body(const svit_pool_args& a) {
   }
 }
 
-__global__ __launch_bounds__(256) void pool_ln_fwd_kernel(svit_pool_args a) { pool_ln_fwd_body(a); }
+// Workgroups are persistent over token blocks (blockIdx.x strides by gridDim.x): the conv weights
+// go to LDS once per workgroup instead of once per 64 tokens.
+__global__ __launch_bounds__(256) void pool_ln_fwd_kernel(svit_pool_args a) {
+  __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];
+  __shared__ __attribute__((aligned(16))) float g_lds[HD];
+  load_weights(a.conv_w, w_lds, g_lds, a.stride_hw);
+  const int Nout = 1 + a.T * pooled(a.H, a.stride_hw) * pooled(a.W, a.stride_hw) + a.n_obj;
+  for (int tb = blockIdx.x; tb * 64 < Nout; tb += gridDim.x) pool_ln_fwd_body(a, w_lds, g_lds, tb);
+}
 
 // q, k and v of one block in one launch (blockIdx.z = which): the three stencils differ only in
 // stride, and at the 14x14 / 7x7 stages each of them is a few-microsecond latency chain, so
 // running them side by side costs the time of the longest one.
 struct PoolFwd3 { svit_pool_args p[3]; };
 __global__ __launch_bounds__(256) void pool_ln_fwd3_kernel(PoolFwd3 g) {
+  __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];
+  __shared__ __attribute__((aligned(16))) float g_lds[HD];
   const svit_pool_args& a = g.p[blockIdx.z];
   const int Nout = 1 + a.T * pooled(a.H, a.stride_hw) * pooled(a.W, a.stride_hw) + a.n_obj;
   if ((int)blockIdx.x * 64 >= Nout) return;
-  pool_ln_fwd_body(a);
+  load_weights(a.conv_w, w_lds, g_lds, a.stride_hw);
+  for (int tb = blockIdx.x; tb * 64 < Nout; tb += gridDim.x) pool_ln_fwd_body(a, w_lds, g_lds, tb);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -326,18 +335,16 @@ __global__ __launch_bounds__(256) void pool_ln_bwd3_kernel(PoolLnBwd3 g) {
 // NC = 3 / 2 / 1 entries (template S = 1 / 2 / 3 for "any s >= 3") and a lane issues the loads
 // of KTB t-planes (NC*NC candidates each) before it consumes the first one.
 template <int S>
-__device__ __forceinline__ void pool_dgrad_body(const svit_pool_dgrad_args& a) {
+__device__ __forceinline__ void pool_dgrad_body(const svit_pool_dgrad_args& a, const float* w_lds,
+                                                const float* g_lds, int tb) {
   constexpr int NC = (S == 1) ? 3 : (S == 2 ? 2 : 1);
   constexpr int KTB = (S == 1) ? 1 : 3;
-  __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];
-  __shared__ __attribute__((aligned(16))) float g_lds[HD];
-  load_weights(a.conv_w, w_lds, g_lds, a.stride_hw);
   const int s = a.stride_hw;
   const int Ho = pooled(a.H, s), Wo = pooled(a.W, s);
   const int L = a.T * a.H * a.W, Lo = a.T * Ho * Wo;
   const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
   const int bh = blockIdx.y, b = bh / a.heads, head = bh % a.heads;
-  const int tok = blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int tok = tb * 64 + (threadIdx.x >> 2);
   const int sub = threadIdx.x & 3, c0 = sub * 24;
   if (tok >= N) return;
   const bf16_t* dp = (const bf16_t*)a.dpre + (size_t)bh * Nout * HD + c0;
@@ -411,15 +418,26 @@ __device__ __forceinline__ void pool_dgrad_body(const svit_pool_dgrad_args& a) {
 }
 
 template <int S>
+__device__ __forceinline__ void pool_dgrad_loop(const svit_pool_dgrad_args& a, float* w_lds,
+                                                float* g_lds) {
+  load_weights(a.conv_w, w_lds, g_lds, a.stride_hw);       // once per (persistent) workgroup
+  const int N = 1 + a.T * a.H * a.W + a.n_obj;
+  for (int tb = blockIdx.x; tb * 64 < N; tb += gridDim.x) pool_dgrad_body<S>(a, w_lds, g_lds, tb);
+}
+template <int S>
 __global__ __launch_bounds__(256) void pool_dgrad_kernel(svit_pool_dgrad_args a) {
-  pool_dgrad_body<S>(a);
+  __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];
+  __shared__ __attribute__((aligned(16))) float g_lds[HD];
+  pool_dgrad_loop<S>(a, w_lds, g_lds);
 }
 struct PoolDgrad3 { svit_pool_dgrad_args p[3]; };
 __global__ __launch_bounds__(256) void pool_dgrad3_kernel(PoolDgrad3 g) {
+  __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];
+  __shared__ __attribute__((aligned(16))) float g_lds[HD];
   const svit_pool_dgrad_args& a = g.p[blockIdx.z];
-  if (a.stride_hw == 1) pool_dgrad_body<1>(a);
-  else if (a.stride_hw == 2) pool_dgrad_body<2>(a);
-  else pool_dgrad_body<3>(a);
+  if (a.stride_hw == 1) pool_dgrad_loop<1>(a, w_lds, g_lds);
+  else if (a.stride_hw == 2) pool_dgrad_loop<2>(a, w_lds, g_lds);
+  else pool_dgrad_loop<3>(a, w_lds, g_lds);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -958,6 +976,16 @@ __global__ __launch_bounds__(256) void relq_bwd_kernel(svit_relq_bwd_args a) {
 }
 }  // namespace
 
+// grid.x of the persistent stencil kernels: token blocks are dealt round-robin to workgroups so
+// that about 1024 workgroups (2 per CU on two resident rounds) exist in total
+static unsigned persistent_x(int token_blocks, int other_dims) {
+  const long total = (long)token_blocks * other_dims;
+  const long chunks = (total + 1023) / 1024;
+  long x = (token_blocks + chunks - 1) / chunks;
+  if (x < 1) x = 1;
+  return (unsigned)x;
+}
+
 static int check_pool_dims(int B, int heads, int T, int H, int W, int n_obj, int s) {
   if (B <= 0 || heads <= 0 || T <= 0 || H <= 0 || W <= 0 || n_obj < 0 || s < 1) return SVIT_ERR_SHAPE;
   return SVIT_OK;
@@ -975,8 +1003,8 @@ extern "C" int svit_pool_ln_fwd(const svit_pool_args* a, void* stream) {
     if (extra % 32 != 0 || extra < Ho + Wo + a->T) return SVIT_ERR_SHAPE;
   }
   const int Nout = 1 + a->T * Ho * Wo + a->n_obj;
-  hipLaunchKernelGGL(pool_ln_fwd_kernel, dim3((Nout + 63) / 64, a->B * a->heads), dim3(256), 0,
-                     (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(pool_ln_fwd_kernel, dim3(persistent_x((Nout + 63) / 64, a->B * a->heads),
+                                              a->B * a->heads), dim3(256), 0, (hipStream_t)stream, *a);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }
@@ -1008,8 +1036,9 @@ extern "C" int svit_pool_ln_fwd_qkv(const svit_pool_args* a3, void* stream) {
     const int nout = 1 + a3[i].T * ((a3[i].H - 1) / s + 1) * ((a3[i].W - 1) / s + 1) + a3[i].n_obj;
     if (nout > max_nout) max_nout = nout;
   }
-  hipLaunchKernelGGL(pool_ln_fwd3_kernel, dim3((max_nout + 63) / 64, a3[0].B * a3[0].heads, 3),
-                     dim3(256), 0, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(pool_ln_fwd3_kernel,
+                     dim3(persistent_x((max_nout + 63) / 64, a3[0].B * a3[0].heads * 3),
+                          a3[0].B * a3[0].heads, 3), dim3(256), 0, (hipStream_t)stream, g);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }
@@ -1062,8 +1091,9 @@ extern "C" int svit_pool_conv_dgrad_qkv(const svit_pool_dgrad_args* a3, void* st
     g.p[i] = *a;
   }
   const int N = 1 + a3[0].T * a3[0].H * a3[0].W + a3[0].n_obj;
-  hipLaunchKernelGGL(pool_dgrad3_kernel, dim3((N + 63) / 64, a3[0].B * a3[0].heads, 3), dim3(256), 0,
-                     (hipStream_t)stream, g);
+  hipLaunchKernelGGL(pool_dgrad3_kernel,
+                     dim3(persistent_x((N + 63) / 64, a3[0].B * a3[0].heads * 3),
+                          a3[0].B * a3[0].heads, 3), dim3(256), 0, (hipStream_t)stream, g);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }
@@ -1183,7 +1213,7 @@ extern "C" int svit_pool_conv_dgrad(const svit_pool_dgrad_args* a, void* stream)
   int rc = check_pool_dims(a->B, a->heads, a->T, a->H, a->W, a->n_obj, a->stride_hw);
   if (rc) return rc;
   const int N = 1 + a->T * a->H * a->W + a->n_obj;
-  const dim3 grid((N + 63) / 64, a->B * a->heads);
+  const dim3 grid(persistent_x((N + 63) / 64, a->B * a->heads), a->B * a->heads);
   if (a->stride_hw == 1)
     hipLaunchKernelGGL(pool_dgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, *a);
   else if (a->stride_hw == 2)
