@@ -155,10 +155,17 @@ def main():
     def ce(preds, extra, labels):
         return torch.nn.functional.cross_entropy(preds, labels)
 
-    graphed = None
+    graphed, launch_note = None, "eager"
     if not args.eager and not args.frames_pass:
         from svit_amd.graph import GraphedTrainStep
-        graphed = GraphedTrainStep(model, ce, [x], y)
+        try:
+            graphed = GraphedTrainStep(model, ce, [x], y)
+            launch_note = "hip-graph replay"
+        except Exception as exc:            # never lose a measurement to a capture problem
+            print("graph capture failed (%s: %s); falling back to eager launches"
+                  % (type(exc).__name__, exc), file=sys.stderr)
+            torch.cuda.synchronize()
+            launch_note = "eager (graph capture failed: %s)" % type(exc).__name__
 
     def step(it, eager=False):
         optim.set_lr(opt, optim.get_lr_at_epoch(cfg, it / 1000.0))
@@ -206,7 +213,7 @@ def main():
                                                  " + no-grad frames pass" if args.frames_pass else ""),
                    "global_batch": args.batch * world, "seq_len": None,
                    "parallelism": "dp%d" % world,
-                   "launch": "eager" if graphed is None else "hip-graph replay"},
+                   "launch": launch_note},
         "loss": round(loss_val, 4),
         "step_mfma_frac": round(clips_per_s / world * STEP_GFLOP_PER_CLIP * 1e9 /
                                 (MFMA_PEAK_TFLOPS * 1e12), 4),
