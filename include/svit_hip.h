@@ -60,7 +60,7 @@ int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, float* dW, int 
  * Same operand rules as svit_gemm_tn; any count (launched in groups of SVIT_TN_GROUP_MAX).
  * Replaces the per-layer autograd wgrads of slowfast/models/attention.py:377-409 (qkv, proj),
  * common.py:26-37 (fc1, fc2) and the rel-pos table grads of attention.py:77-139. */
-#define SVIT_TN_GROUP_MAX 8
+#define SVIT_TN_GROUP_MAX 16
 typedef struct {
   const void* A; const void* B; float* dW; float* dbias;   /* dbias may be NULL */
   int32_t lda, ldb, lddw, M, N, K;

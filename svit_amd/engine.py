@@ -305,6 +305,7 @@ class Engine:
         def ready(rank):
             if on_ready is not None:
                 if ready_ranks is None or rank in ready_ranks:
+                    self._flush_tn()            # gradients must be final here
                     self._join()
                 on_ready(rank)
         plan, f = self.plan, self.flat
@@ -331,6 +332,7 @@ class Engine:
         dtok = ops.scale_cast(dx, gather=(L, 1))       # patch rows of every clip -> bf16 [B*L, C]
         ops.gemm_tn(dtok, st["cols"], f.g("patch_embed.proj.weight").view(C, 441),
                     dbias=f.g("patch_embed.proj.bias"))
+        self._flush_tn()
         self._join()
         ready(depth + 1)
 
@@ -362,9 +364,14 @@ class Engine:
             self._side_keep.clear()
             self._side_active = False
 
-    def _flush_tn(self):
-        """the block's queued weight-gradient GEMMs in one grouped launch (ops.gemm_tn_grouped)"""
+    def _flush_tn(self, force=True):
+        """queued weight-gradient GEMMs in one grouped launch (ops.gemm_tn_grouped).  Two blocks
+        share a launch (<= 16 problems): the machine-wide accumulator flush is paid half as often."""
+        if not force and len(self._tn) <= 8:
+            return
         q, self._tn = self._tn, []
+        if not q:
+            return
         self._fork(lambda: ops.gemm_tn_grouped(q), q)
 
     def _linear_bwd(self, dy16, x16, wname, bname, need_dx, out=None, accumulate=False,
@@ -459,7 +466,7 @@ class Engine:
                                 want_bf16=below is not None,
                                 row_scale=below["dpm"] if below is not None else None,
                                 rows_per_sample=N)
-        self._flush_tn()
+        self._flush_tn(force=False)
         if below is None:
             return res.view(B, N, C), None
         return res[0].view(B, N, C), res[1]
