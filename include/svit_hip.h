@@ -85,6 +85,16 @@ int svit_scale_cast(const float* src, void* dst, const float* row_scale, int row
                     int64_t rows, int cols, int gather_L, int gather_N, int gather_off,
                     void* stream);
 
+/* ------------------------------------------- deferred second-stage reductions ---------- */
+/* svit_layernorm_bwd, svit_pool_ln_bwd(_qkv) and svit_pool_conv_wgrad(_qkv) finish with a
+ * "reduce partial rows" launch.  Between svit_reduce_defer(1) and svit_reduce_flush() those
+ * launches are queued (host side) and run as ONE launch at the flush -- the engine brackets a
+ * transformer block's backward with them.  While deferred, every producer must be given its own
+ * workspace region (the rows are read at the flush), and the gradients are final only after
+ * the flush.  svit_reduce_defer(0) flushes too.  Not thread-safe (one engine thread). */
+int svit_reduce_defer(int on, void* stream);
+int svit_reduce_flush(void* stream);
+
 /* ---------------------------------------------------------------- LayerNorm (K3) ------ */
 /* nn.LayerNorm(eps=1e-6): attention.py:501,531; video_model_builder.py:69,233. */
 int svit_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16,

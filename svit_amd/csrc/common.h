@@ -116,35 +116,10 @@ struct SvitReduceDst {
   float* ptr[6];
   int end[6];  // exclusive end of each segment within [0, n); unused tail entries = n
 };
-static __global__ void svit_reduce_partials_kernel(const float* __restrict__ partial, int nblocks,
-                                                   int n, SvitReduceDst dst) {
-  // block (32 columns x 8 row lanes): coalesced 128-byte row segments, 8x4 rows in flight
-  __shared__ float red[8][33];
-  const int i = blockIdx.x * 32 + threadIdx.x;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (i < n) {
-    int b = threadIdx.y;
-    for (; b + 24 < nblocks; b += 32) {
-      s0 += partial[(size_t)b * n + i];
-      s1 += partial[(size_t)(b + 8) * n + i];
-      s2 += partial[(size_t)(b + 16) * n + i];
-      s3 += partial[(size_t)(b + 24) * n + i];
-    }
-    for (; b < nblocks; b += 8) s0 += partial[(size_t)b * n + i];
-  }
-  red[threadIdx.y][threadIdx.x] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (threadIdx.y == 0 && i < n) {
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
-    int k = 0, lo = 0;
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-      if (i >= dst.end[j]) { k = j + 1; lo = dst.end[j]; }
-    dst.ptr[k][i - lo] += s;
-  }
-}
+// Defined in misc.hip: launches the reduce now, or -- between svit_reduce_defer(1) and
+// svit_reduce_flush() -- queues it so that all reduces of a transformer block run as ONE launch.
+void svit_launch_reduce(const float* partial, int nblocks, int n, SvitReduceDst dst, hipStream_t st);
+
 // Zero-fill as a kernel (16-byte stores): hipMemsetAsync turns into a memset node under stream
 // capture, and those replay unreliably on ROCm 7.2 (svit_amd/graph.py needs every launch to be a
 // plain kernel node).  bytes must be a multiple of 16 and p 16-byte aligned.
@@ -161,8 +136,3 @@ static inline void svit_launch_zero(void* p, size_t bytes, hipStream_t st) {
   hipLaunchKernelGGL(svit_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint4*)p, n16);
 }
 
-static inline void svit_launch_reduce(const float* partial, int nblocks, int n, SvitReduceDst dst,
-                                      hipStream_t st) {
-  hipLaunchKernelGGL(svit_reduce_partials_kernel, dim3((n + 31) / 32), dim3(32, 8), 0, st, partial,
-                     nblocks, n, dst);
-}

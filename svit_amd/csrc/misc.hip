@@ -252,6 +252,54 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
   }
 }
 
+// ---- second stage of the two-stage parameter-gradient reductions --------------------------
+// One job = column sums of `partial` [nblocks][n] added into up to six destination vectors.  Up
+// to SVIT_REDUCE_MAX_JOBS jobs share a launch (blockIdx.y = job): a transformer block's backward
+// produces four of them (two LayerNorms, pooled-LN, conv wgrad), each latency-bound alone.
+constexpr int SVIT_REDUCE_MAX_JOBS = 6;
+struct SvitReduceJob {
+  const float* partial;
+  int nblocks, n;
+  SvitReduceDst dst;
+};
+struct SvitReduceBatch {
+  SvitReduceJob job[SVIT_REDUCE_MAX_JOBS];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void svit_reduce_partials_kernel(SvitReduceBatch batch) {
+  // block (32 columns x 8 row lanes): coalesced 128-byte row segments, 8x4 rows in flight
+  __shared__ float red[8][33];
+  const SvitReduceJob& j = batch.job[blockIdx.y];
+  const float* __restrict__ partial = j.partial;
+  const int nblocks = j.nblocks, n = j.n;
+  if ((int)blockIdx.x * 32 >= n) return;
+  const int i = blockIdx.x * 32 + threadIdx.x;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int b = threadIdx.y;
+    for (; b + 24 < nblocks; b += 32) {
+      s0 += partial[(size_t)b * n + i];
+      s1 += partial[(size_t)(b + 8) * n + i];
+      s2 += partial[(size_t)(b + 16) * n + i];
+      s3 += partial[(size_t)(b + 24) * n + i];
+    }
+    for (; b < nblocks; b += 8) s0 += partial[(size_t)b * n + i];
+  }
+  red[threadIdx.y][threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (threadIdx.y == 0 && i < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
+    int k = 0, lo = 0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      if (i >= j.dst.end[q]) { k = q + 1; lo = j.dst.end[q]; }
+    j.dst.ptr[k][i - lo] += s;
+  }
+}
+
 // ---- optimiser tail ---------------------------------------------------------------------
 // Deterministic two-stage sum of squares: replicas of a data-parallel job must compute the
 // bit-identical clip coefficient from their (identical, all-reduced) gradients, so no atomics.
@@ -396,6 +444,53 @@ extern "C" int svit_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, 
   const int64_t total = (int64_t)B * (1 + T * H * W + n_obj) * (C / 4);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, dy, idx, dx, B, T, H, W, Ho, Wo, n_obj, C);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+static SvitReduceBatch g_reduce_batch;   // host-side queue (one engine thread per process)
+static bool g_reduce_defer = false;
+
+static void reduce_launch(const SvitReduceBatch& b, hipStream_t st) {
+  int max_n = 0;
+  for (int i = 0; i < b.count; ++i)
+    if (b.job[i].n > max_n) max_n = b.job[i].n;
+  hipLaunchKernelGGL(svit_reduce_partials_kernel, dim3((max_n + 31) / 32, b.count), dim3(32, 8), 0,
+                     st, b);
+}
+
+void svit_launch_reduce(const float* partial, int nblocks, int n, SvitReduceDst dst, hipStream_t st) {
+  SvitReduceJob job = {partial, nblocks, n, dst};
+  if (g_reduce_defer) {
+    if (g_reduce_batch.count == SVIT_REDUCE_MAX_JOBS) {      // queue full: run what we have
+      reduce_launch(g_reduce_batch, st);
+      g_reduce_batch.count = 0;
+    }
+    g_reduce_batch.job[g_reduce_batch.count++] = job;
+    return;
+  }
+  SvitReduceBatch one;
+  one.job[0] = job;
+  one.count = 1;
+  reduce_launch(one, st);
+}
+
+extern "C" int svit_reduce_defer(int on, void* stream) {
+  // leaving deferred mode flushes (see svit_reduce_flush)
+  if (!on && g_reduce_batch.count) {
+    reduce_launch(g_reduce_batch, (hipStream_t)stream);
+    g_reduce_batch.count = 0;
+  }
+  g_reduce_defer = on != 0;
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_reduce_flush(void* stream) {
+  if (g_reduce_batch.count) {
+    reduce_launch(g_reduce_batch, (hipStream_t)stream);
+    g_reduce_batch.count = 0;
+  }
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }

@@ -160,6 +160,12 @@ class Engine:
         self._rel_cache = {}
         self.patch_w16 = torch.zeros((plan.embed_dim, 448), device=self.dev, dtype=BF16)
         self._tn = []           # weight-gradient GEMMs queued by the running block backward
+        # a block's four second-stage reductions (LN2, pooled LN, conv wgrad, LN1) run as one
+        # deferred launch: each producer gets its own region of this scratch (floats)
+        self._red_ws = torch.empty(18 * 1024 * 1024, device=self.dev, dtype=F32)
+        M1 = 1024 * 1024
+        self._red_regions = {"ln2": (0, 4 * M1), "ln1": (4 * M1, 8 * M1), "pln": (8 * M1, 9 * M1),
+                             "wgrad": (9 * M1, 18 * M1)}
         # the grouped weight-gradient GEMM leaves the dgrad chain: it runs on a second stream next
         # to the latency-bound kernels of the chain (its fp32 atomics execute at the memory side,
         # so nothing of the chain depends on it) and is joined only where gradients must be final
@@ -336,6 +342,10 @@ class Engine:
         self._join()
         ready(depth + 1)
 
+    def _rws(self, key):
+        a, b = self._red_regions[key]
+        return self._red_ws[a:b]
+
     def _fork(self, fn, keep):
         """run fn() on the side stream, after everything enqueued so far on the current one"""
         if not self.overlap_wgrad:
@@ -394,6 +404,7 @@ class Engine:
         M, Mq = B * N, B * Nq
         sq, skv = blk.stride_q[1], blk.stride_kv[1]
         thw, q_thw, k_thw = sv["thw"], sv["q_thw"], sv["k_thw"]
+        ops.reduce_defer(True)      # this block's second-stage reductions: one launch at its end
         # ---- MLP branch: x2 = x1 + dp * fc2(gelu(fc1(LN2(x1)))) ------------------------------
         dy = dy.view(Mq, Co)
         dh = self._linear_bwd(dy, sv["act"], pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", True,
@@ -402,7 +413,8 @@ class Engine:
                                 pre + "mlp.fc1.bias", True)
         dx1, dy = ops.layernorm_bwd(dxn2, sv["x1"], f.p(pre + "norm2.weight"), sv["mean2"],
                                     sv["rstd2"], f.g(pre + "norm2.weight"), f.g(pre + "norm2.bias"),
-                                    dres=dx2, want_bf16=True, row_scale=sv["dpa"], rows_per_sample=Nq)
+                                    dres=dx2, want_bf16=True, row_scale=sv["dpa"], rows_per_sample=Nq,
+                                    ws=self._rws("ln2"))
         dy = dy.view(Mq, Co)
         # ---- attention branch: x1 = skip + dp * proj(ctx) ------------------------------------
         dctx = self._linear_bwd(dy, sv["ctx"].view(Mq, Co), pre + "attn.proj.weight",
@@ -443,14 +455,14 @@ class Engine:
             entries.append(((pre_t, mean, rstd, f.p(pre + "attn.norm_%s.weight" % r),
                              f.g(pre + "attn.norm_%s.weight" % r),
                              f.g(pre + "attn.norm_%s.bias" % r), B, h, nout), kw))
-        dpres = ops.pool_ln_bwd_qkv(entries)       # q, k, v side by side: one launch per stage
+        dpres = ops.pool_ln_bwd_qkv(entries, ws=self._rws("pln"))   # q, k, v: one launch per stage
         strides = (sq, skv, skv)
         # conv dgrad + conv wgrad: one kernel with dpre in LDS for the small planes (blocks >= 4),
         # the two streaming launches otherwise (decided inside the library)
         ops.pool_conv_bwd_qkv(dpres, [f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
                               dqkv, sv["qkv"],
                               [f.g(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
-                              B, h, thw, n_obj, strides)
+                              B, h, thw, n_obj, strides, ws=self._rws("wgrad"))
         dxn = self._linear_bwd(dqkv, sv["xn"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", True)
         # ---- skip path ------------------------------------------------------------------------
         dskip = dx1
@@ -465,7 +477,8 @@ class Engine:
                                 f.g(pre + "norm1.weight"), f.g(pre + "norm1.bias"), dres=dskip,
                                 want_bf16=below is not None,
                                 row_scale=below["dpm"] if below is not None else None,
-                                rows_per_sample=N)
+                                rows_per_sample=N, ws=self._rws("ln1"))
+        ops.reduce_defer(False)     # runs the queued reductions
         self._flush_tn(force=False)
         if below is None:
             return res.view(B, N, C), None

@@ -104,6 +104,11 @@ def gemm_tn_grouped(problems):
     hip.call("svit_gemm_tn_grouped", arr, n, meta=("flop", flop))
 
 
+def reduce_defer(on):
+    """queue (1) / run (0) the second-stage reduce launches of the backward kernels"""
+    hip.call("svit_reduce_defer", int(on))
+
+
 def colsum(a, out):
     _chk_dev(a, out)
     hip.call("svit_colsum_bf16", ptr(a), a.stride(0), ptr(out), a.shape[0], a.shape[1])
@@ -164,7 +169,7 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6, want_f32=False, want_bf16=True, save
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, dx=None, want_bf16=False,
-                  row_scale=None, rows_per_sample=0):
+                  row_scale=None, rows_per_sample=0, ws=None):
     """-> dx f32, or (dx, bf16(row_scale * dx)) with want_bf16 (operand of the next GEMM)."""
     _chk_dev(dy, x, gamma, mean, rstd, dgamma, dbeta, dres, dx, row_scale)
     C_ = x.shape[-1]
@@ -172,7 +177,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, dx=None, w
     if dx is None:
         dx = torch.empty(x.shape, device=x.device, dtype=F32)
     dx16 = torch.empty(x.shape, device=x.device, dtype=BF16) if want_bf16 else None
-    ws = scratch(x.device)
+    ws = scratch(x.device) if ws is None else ws
     hip.call("svit_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres),
              ptr(dx), ptr(dx16), ptr(row_scale), rows_per_sample, ptr(dgamma), ptr(dbeta), rows, C_,
              ptr(ws), ws.numel())
@@ -237,7 +242,7 @@ def pool_ln_fwd_qkv(qkv, conv_ws, gammas, betas, B, heads, thw, n_obj, strides, 
 
 
 def _pool_ln_bwd_args(a, pre, mean, rstd, gamma, dgamma, dbeta, B, heads, Nout, d_main=None,
-                      ld_main=HD, d_res=None, d_extra=None):
+                      ld_main=HD, d_res=None, d_extra=None, ws=None):
     dpre = torch.empty((B, heads, Nout, HD), device=pre.device, dtype=BF16)
     a.d_main = ptr(d_main)
     a.main_is_f32 = int(d_main is not None and d_main.dtype == F32)
@@ -246,7 +251,7 @@ def _pool_ln_bwd_args(a, pre, mean, rstd, gamma, dgamma, dbeta, B, heads, Nout, 
     a.pre, a.mean, a.rstd, a.gamma = ptr(pre), ptr(mean), ptr(rstd), ptr(gamma)
     a.dpre, a.dgamma, a.dbeta = ptr(dpre), ptr(dgamma), ptr(dbeta)
     a.B, a.heads, a.Nout = B, heads, Nout
-    ws = scratch(pre.device)
+    ws = scratch(pre.device) if ws is None else ws
     a.workspace, a.workspace_floats = ptr(ws), ws.numel()
     return dpre
 
@@ -260,10 +265,10 @@ def pool_ln_bwd(pre, mean, rstd, gamma, dgamma, dbeta, B, heads, Nout, d_main=No
     return dpre
 
 
-def pool_ln_bwd_qkv(entries):
+def pool_ln_bwd_qkv(entries, ws=None):
     """entries: 3 x (args tuple, kwargs dict) of pool_ln_bwd -> [dpre] * 3, one launch."""
     arr = (hip.PoolLnBwdArgs * 3)()
-    res = [_pool_ln_bwd_args(arr[i], *entries[i][0], **entries[i][1]) for i in range(3)]
+    res = [_pool_ln_bwd_args(arr[i], *entries[i][0], ws=ws, **entries[i][1]) for i in range(3)]
     hip.call("svit_pool_ln_bwd_qkv", arr)
     return res
 
@@ -306,13 +311,13 @@ def pool_conv_wgrad_qkv(dpres, qkv, dws, B, heads, thw, n_obj, strides, ws=None)
     hip.call("svit_pool_conv_wgrad_qkv", arr)
 
 
-def pool_conv_bwd_qkv(dpres, conv_ws, dqkv, qkv, dws, B, heads, thw, n_obj, strides):
+def pool_conv_bwd_qkv(dpres, conv_ws, dqkv, qkv, dws, B, heads, thw, n_obj, strides, ws=None):
     """conv dgrad + conv wgrad of q, k, v: one fused kernel for small planes, else two launches."""
     da = (hip.PoolDgradArgs * 3)()
     wa = (hip.PoolWgradArgs * 3)()
     for i in range(3):
         _pool_dgrad_args(da[i], dpres[i], conv_ws[i], dqkv, i, B, heads, thw, n_obj, strides[i])
-        _pool_wgrad_args(wa[i], dpres[i], qkv, i, dws[i], B, heads, thw, n_obj, strides[i])
+        _pool_wgrad_args(wa[i], dpres[i], qkv, i, dws[i], B, heads, thw, n_obj, strides[i], ws)
     hip.call("svit_pool_conv_bwd_qkv", da, wa)
 
 
