@@ -246,7 +246,7 @@ typedef struct {
   const void* qa; const void* ka; const void* v; const void* ctx; const void* dctx;
   const float* lse2; float* delta;  /* delta: f32 [B,h,Nq,2] scratch ((lse2, rowsum(dO*O)) pairs) */
   void* dqa;                        /* bf16 [B,h,Nq,DA]                                  */
-  float* dk; float* dv;             /* f32 [B,h,Nk,96], accumulated atomically (pre-zeroed) */
+  float* dk; float* dv;             /* f32 [B,h,Nk,96], OVERWRITTEN (cleared inside when split) */
   int32_t B, heads, Nq, Nk, DA, q_splits; float scale;
 } svit_attn_bwd_args;
 int svit_attn_bwd(const svit_attn_bwd_args* a, void* stream);

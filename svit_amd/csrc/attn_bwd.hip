@@ -26,7 +26,7 @@ constexpr int QT = 32;   // queries per tile (dkv kernel)
 // raw barrier per tile behind a counted vmcnt; 2 blocks per CU (2 waves per SIMD) so one
 // wave's exp/convert VALU work overlaps the other's MFMAs.
 template <int DA>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args a, int zero_dkv) {
   constexpr int KS = DA / 16, NP = DA / 32;
   constexpr int K_BYTES = KT * DA * 2, V_BYTES = KT * HD * 2, STAGE = K_BYTES + V_BYTES;
   using KLoad = GldsTile<KT, DA, 4>;
@@ -34,6 +34,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
   constexpr int PER_TILE = KLoad::PER_WAVE + VLoad::PER_WAVE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  if (zero_dkv) {   // the dkv launch that follows accumulates with atomics: clear dk / dv here
+    const size_t n4 = (size_t)a.B * a.heads * a.Nk * HD / 4;
+    const size_t nthr = (size_t)gridDim.x * gridDim.y * 256;
+    const size_t me = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid;
+    for (size_t i = me; i < n4; i += nthr) {
+      ((float4*)a.dk)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      ((float4*)a.dv)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
   const int wgid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
   const int bh = wgid / gridDim.x, b = bh / a.heads, head = bh % a.heads;
   const int qtile = wgid % gridDim.x;
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(svit_attn_bwd_args
     if (gridDim.y == 1) {   // this block owns its keys outright: plain coalesced row stores
       for (int i = tid; i < 128 * HD; i += 256) {
         const int kr = i / HD, d = i % HD;
-        if (key0 + kr < a.Nk) dst[(size_t)(key0 + kr) * HD + d] += obuf[kr * OUT_LD + d];
+        if (key0 + kr < a.Nk) dst[(size_t)(key0 + kr) * HD + d] = obuf[kr * OUT_LD + d];
       }
     } else {
       for (int i = tid; i < 128 * HD; i += 256) {
@@ -303,9 +312,6 @@ int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<DA>, dim3((a.Nq + 127) / 128, a.B * a.heads), dim3(256),
-                     lds_dq, st, a);
-  SVIT_LAUNCH_CHECK();
   const int nqt = (a.Nq + QT - 1) / QT;
   const int key_blocks = (a.Nk + 127) / 128;
   int splits = a.q_splits;
@@ -322,6 +328,10 @@ int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
   if (splits < 1) splits = 1;
   int tiles_per_split = (nqt + splits - 1) / splits;
   splits = (nqt + tiles_per_split - 1) / tiles_per_split;
+  if (((uintptr_t)a.dk | (uintptr_t)a.dv) & 15) return SVIT_ERR_ALIGN;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<DA>, dim3((a.Nq + 127) / 128, a.B * a.heads), dim3(256),
+                     lds_dq, st, a, splits > 1 ? 1 : 0);
+  SVIT_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<DA>, dim3(key_blocks, splits, a.B * a.heads), dim3(256),
                      lds_kv, st, a, tiles_per_split);
   SVIT_LAUNCH_CHECK();

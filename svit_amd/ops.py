@@ -403,7 +403,7 @@ def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0):
     Nk = ka.shape[2]
     dev = qa.device
     dqa = torch.empty((B, heads, Nq, DA), device=dev, dtype=BF16)
-    dkv = torch.zeros((2, B, heads, Nk, HD), device=dev, dtype=F32)
+    dkv = torch.empty((2, B, heads, Nk, HD), device=dev, dtype=F32)   # cleared by the library
     delta = torch.empty((B, heads, Nq, 2), device=dev, dtype=F32)
     a = hip.AttnBwdArgs()
     a.qa, a.ka, a.v, a.ctx, a.dctx, a.lse2 = (ptr(t) for t in (qa, ka, v, ctx, dctx, lse2))
