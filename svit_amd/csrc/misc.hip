@@ -268,23 +268,29 @@ struct SvitReduceBatch {
 };
 
 __global__ __launch_bounds__(256) void svit_reduce_partials_kernel(SvitReduceBatch batch) {
-  // block (32 columns x 8 row lanes): coalesced 128-byte row segments, 8x4 rows in flight
+  // block (32 columns x 8 row lanes): coalesced 128-byte row segments, 8x4 rows in flight.
+  // blockIdx.z cuts long row ranges into chunks (their sums meet in fp32 atomics), so a job with
+  // ~1000 partial rows is not one serial sweep per column block.
   __shared__ float red[8][33];
   const SvitReduceJob& j = batch.job[blockIdx.y];
   const float* __restrict__ partial = j.partial;
-  const int nblocks = j.nblocks, n = j.n;
+  const int n = j.n;
   if ((int)blockIdx.x * 32 >= n) return;
+  const int chunks = min((int)gridDim.z, max(1, j.nblocks / 96));
+  if ((int)blockIdx.z >= chunks) return;
+  const int per = (j.nblocks + chunks - 1) / chunks;
+  const int r0 = blockIdx.z * per, r1 = min(j.nblocks, r0 + per);
   const int i = blockIdx.x * 32 + threadIdx.x;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < n) {
-    int b = threadIdx.y;
-    for (; b + 24 < nblocks; b += 32) {
+    int b = r0 + threadIdx.y;
+    for (; b + 24 < r1; b += 32) {
       s0 += partial[(size_t)b * n + i];
       s1 += partial[(size_t)(b + 8) * n + i];
       s2 += partial[(size_t)(b + 16) * n + i];
       s3 += partial[(size_t)(b + 24) * n + i];
     }
-    for (; b < nblocks; b += 8) s0 += partial[(size_t)b * n + i];
+    for (; b < r1; b += 8) s0 += partial[(size_t)b * n + i];
   }
   red[threadIdx.y][threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
@@ -296,7 +302,8 @@ __global__ __launch_bounds__(256) void svit_reduce_partials_kernel(SvitReduceBat
 #pragma unroll
     for (int q = 0; q < 5; ++q)
       if (i >= j.dst.end[q]) { k = q + 1; lo = j.dst.end[q]; }
-    j.dst.ptr[k][i - lo] += s;
+    if (chunks == 1) j.dst.ptr[k][i - lo] += s;
+    else atomicAdd(j.dst.ptr[k] + (i - lo), s);
   }
 }
 
@@ -455,8 +462,14 @@ static void reduce_launch(const SvitReduceBatch& b, hipStream_t st) {
   int max_n = 0;
   for (int i = 0; i < b.count; ++i)
     if (b.job[i].n > max_n) max_n = b.job[i].n;
-  hipLaunchKernelGGL(svit_reduce_partials_kernel, dim3((max_n + 31) / 32, b.count), dim3(32, 8), 0,
-                     st, b);
+  int max_rows = 0;
+  for (int i = 0; i < b.count; ++i)
+    if (b.job[i].nblocks > max_rows) max_rows = b.job[i].nblocks;
+  int z = max_rows / 96;
+  if (z < 1) z = 1;
+  if (z > 8) z = 8;
+  hipLaunchKernelGGL(svit_reduce_partials_kernel, dim3((max_n + 31) / 32, b.count, z), dim3(32, 8),
+                     0, st, b);
 }
 
 void svit_launch_reduce(const float* partial, int nblocks, int n, SvitReduceDst dst, hipStream_t st) {
