@@ -80,7 +80,34 @@ def around(path, needle, limit):
         print("%5d x  prev=%-46s next=%-46s dur~%d us" % (v, k[0], k[1], k[2]))
 
 
+def blocks(path):
+    """backward of the last step split at the fc2-dgrad GEMMs (epilogue 4 = first kernel of a
+    transformer block's backward): per block total and its five longest kernels"""
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    sh = lambda n: n.replace("void ", "").replace("(anonymous namespace)::", "").replace("at::native::", "").split("(")[0][:34]
+    marks = [i for i, r in enumerate(rows) if ", 4>(svit_gemm_args)" in r[2]]
+    marks = marks[-16:]
+    last_adam = max(i for i, r in enumerate(rows) if "adamw_kernel" in r[2])
+    bounds = marks + [last_adam]
+    for b, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+        agg = defaultdict(lambda: [0, 0])
+        for s, e, n in rows[lo:hi]:
+            agg[sh(n)][0] += e - s
+            agg[sh(n)][1] += 1
+        tot = sum(v[0] for v in agg.values())
+        top = sorted(agg.items(), key=lambda kv: -kv[1][0])[:6]
+        print("bwd block %2d: %7.1f us | " % (15 - b, tot / 1e3) +
+              "  ".join("%s %.0f(%d)" % (k, v[0] / 1e3, v[1]) for k, v in top))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "--blocks":
+        blocks(sys.argv[1])
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "--around":
         around(sys.argv[1], sys.argv[3], int(sys.argv[4]))
         sys.exit(0)
