@@ -80,60 +80,61 @@ __global__ void pad_cast_rows_kernel(const float* __restrict__ src, bf16_t* __re
 }
 
 // ---- patch embedding im2col: Conv3d(3->96, k(3,7,7), s(2,4,4), p(1,3,3)) -----------------
-// One workgroup = one output row line (b, to, yo, all xo): the 3 x 3 x 7 input rows it needs are
-// fetched once with coalesced float4 loads into an LDS image (bf16, 3 zero columns of padding on
-// each side), then every 8-column chunk of the [Wo, 448] output is assembled from LDS and stored
-// as one 16-byte vector.  (The direct version issued eight scattered 4-byte gathers per chunk.)
-constexpr int I2C_MAXW = 256;                 // widest input row supported by the LDS image
+// One workgroup = one output row line (b, to, yo, all xo), walked in chunks of 62 output
+// positions: the 3 x 3 x 7 input rows a chunk needs are fetched once with coalesced float4 loads
+// into an LDS image (bf16; columns outside the frame are zero), then every 8-column chunk of the
+// [Wo, 448] output is assembled from LDS and stored as one 16-byte vector.  (The direct version
+// issued eight scattered 4-byte gathers per chunk.)
+constexpr int I2C_XO = 62;                    // output positions per chunk
+constexpr int I2C_COLS = I2C_XO * 4 + 4;      // image columns: x in [xc0*4 - 4, xc0*4 + 248)
 __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ video,
                                                            bf16_t* __restrict__ cols, int B, int T,
                                                            int H, int W, int To, int Ho, int Wo) {
-  __shared__ bf16_t img[63][I2C_MAXW + 8];    // [(c*3+kt)*7+ky][3 + x]
+  __shared__ bf16_t img[63][I2C_COLS + 4];    // [(c*3+kt)*7+ky][x - x_start]
   const int yo = blockIdx.x % Ho, to = (blockIdx.x / Ho) % To, b = blockIdx.x / (Ho * To);
-  const int ldw = W + 6;
-  // zero the horizontal padding, then load the rows (zero rows outside the volume)
-  for (int i = threadIdx.x; i < 63 * 6; i += 256) {
-    const int r = i / 6, p = i % 6;
-    img[r][p < 3 ? p : W + p] = 0;
-  }
-  if ((W & 3) || ((uintptr_t)video & 15)) {        // odd widths: scalar loads
-    for (int i = threadIdx.x; i < 63 * W; i += 256) {
-      const int r = i / W, x = i % W;
-      const int ky = r % 7, kt = (r / 7) % 3, c = r / 21;
-      const int t = to * 2 - 1 + kt, y = yo * 4 - 3 + ky;
-      float v = 0.f;
-      if (t >= 0 && t < T && y >= 0 && y < H)
-        v = video[(((int64_t)b * 3 + c) * T + t) * H * W + (int64_t)y * W + x];
-      img[r][3 + x] = f32_to_bf16(v);
-    }
-  }
-  const int w4 = ((W & 3) || ((uintptr_t)video & 15)) ? 0 : (W >> 2);
-  for (int i = threadIdx.x; i < 63 * w4; i += 256) {
-    const int r = i / w4, x4 = i % w4;
-    const int ky = r % 7, kt = (r / 7) % 3, c = r / 21;
-    const int t = to * 2 - 1 + kt, y = yo * 4 - 3 + ky;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t >= 0 && t < T && y >= 0 && y < H)
-      v = *(const float4*)(video + (((int64_t)b * 3 + c) * T + t) * H * W + (int64_t)y * W + x4 * 4);
-    bf16_t* d = &img[r][3 + x4 * 4];
-    d[0] = f32_to_bf16(v.x); d[1] = f32_to_bf16(v.y); d[2] = f32_to_bf16(v.z); d[3] = f32_to_bf16(v.w);
-  }
-  __syncthreads();
-  (void)ldw;
+  const bool vec = !(W & 3) && !((uintptr_t)video & 15);
   bf16_t* out = cols + (((int64_t)b * To + to) * Ho + yo) * Wo * 448;
-  for (int i = threadIdx.x; i < Wo * 56; i += 256) {
-    const int xo = i / 56, chunk = i % 56;
-    bf16_t v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int col = chunk * 8 + e;
-      const int kx = col % 7, r = col / 7;          // r = (c*3+kt)*7+ky for col < 441
-      v[e] = col < 441 ? img[r][xo * 4 + kx] : (bf16_t)0;
+  for (int xc0 = 0; xc0 < Wo; xc0 += I2C_XO) {
+    const int x_start = xc0 * 4 - 4;
+    if (xc0) __syncthreads();                 // the previous chunk's readers are done
+    if (vec) {
+      for (int i = threadIdx.x; i < 63 * (I2C_COLS / 4); i += 256) {
+        const int r = i / (I2C_COLS / 4), x4 = i % (I2C_COLS / 4);
+        const int ky = r % 7, kt = (r / 7) % 3, c = r / 21;
+        const int t = to * 2 - 1 + kt, y = yo * 4 - 3 + ky, x = x_start + x4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < T && y >= 0 && y < H && x >= 0 && x < W)
+          v = *(const float4*)(video + (((int64_t)b * 3 + c) * T + t) * H * W + (int64_t)y * W + x);
+        bf16_t* d = &img[r][x4 * 4];
+        d[0] = f32_to_bf16(v.x); d[1] = f32_to_bf16(v.y); d[2] = f32_to_bf16(v.z); d[3] = f32_to_bf16(v.w);
+      }
+    } else {                                  // odd widths / unaligned base: scalar loads
+      for (int i = threadIdx.x; i < 63 * I2C_COLS; i += 256) {
+        const int r = i / I2C_COLS, xi = i % I2C_COLS;
+        const int ky = r % 7, kt = (r / 7) % 3, c = r / 21;
+        const int t = to * 2 - 1 + kt, y = yo * 4 - 3 + ky, x = x_start + xi;
+        float v = 0.f;
+        if (t >= 0 && t < T && y >= 0 && y < H && x >= 0 && x < W)
+          v = video[(((int64_t)b * 3 + c) * T + t) * H * W + (int64_t)y * W + x];
+        img[r][xi] = f32_to_bf16(v);
+      }
     }
-    uint4 o;
-    o.x = (uint32_t)v[0] | ((uint32_t)v[1] << 16); o.y = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
-    o.z = (uint32_t)v[4] | ((uint32_t)v[5] << 16); o.w = (uint32_t)v[6] | ((uint32_t)v[7] << 16);
-    ((uint4*)out)[i] = o;
+    __syncthreads();
+    const int n_xo = min(I2C_XO, Wo - xc0);
+    for (int i = threadIdx.x; i < n_xo * 56; i += 256) {
+      const int xl = i / 56, chunk = i % 56;
+      bf16_t v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = chunk * 8 + e;
+        const int kx = col % 7, r = col / 7;          // r = (c*3+kt)*7+ky for col < 441
+        v[e] = col < 441 ? img[r][xl * 4 + 1 + kx] : (bf16_t)0;   // x = xo*4 - 3 + kx
+      }
+      uint4 o;
+      o.x = (uint32_t)v[0] | ((uint32_t)v[1] << 16); o.y = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+      o.z = (uint32_t)v[4] | ((uint32_t)v[5] << 16); o.w = (uint32_t)v[6] | ((uint32_t)v[7] << 16);
+      ((uint4*)out)[(size_t)(xc0 + xl) * 56 + chunk] = o;
+    }
   }
 }
 
@@ -414,7 +415,6 @@ extern "C" int svit_im2col_patch(const float* video, void* cols, int B, int T, i
                                  void* stream) {
   if (!video || !cols || B <= 0 || T <= 0 || H <= 0 || W <= 0) return SVIT_ERR_ARG;
   const int To = (T + 2 - 3) / 2 + 1, Ho = (H + 6 - 7) / 4 + 1, Wo = (W + 6 - 7) / 4 + 1;
-  if (W > I2C_MAXW) return SVIT_ERR_SHAPE;
   hipLaunchKernelGGL(im2col_patch_kernel, dim3((unsigned)(B * To * Ho)), dim3(256), 0,
                      (hipStream_t)stream, video, (bf16_t*)cols, B, T, H, W, To, Ho, Wo);
   SVIT_LAUNCH_CHECK();

@@ -189,10 +189,12 @@ def test_layernorm(ops, C):
 
 
 # -------------------------------------------------------------------- patch embedding ----
-def test_patch_embed(ops):
+@pytest.mark.parametrize("T,H,W", [(4, 36, 36), (2, 24, 312), (3, 30, 39)])
+def test_patch_embed(ops, T, H, W):
+    """square crop, a row wider than one LDS chunk (BASELINE 312^2 crop) and an odd width"""
     from svit_amd import hip
-    B, T, S = 2, 4, 36
-    video = rnd("vid", (B, 3, T, S, S), 1.7)
+    B = 2
+    video = rnd("vid%d" % W, (B, 3, T, H, W), 1.7)
     w = rnd("pw", (96, 3, 3, 7, 7), 0.08)
     bias = rnd("pb", (96,), 0.05)
     cols, (To, Ho, Wo) = ops.im2col_patch(video)

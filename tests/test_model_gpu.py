@@ -19,6 +19,8 @@ from tests import smoke_impl as S
     (4, 88, 2, False),     # odd sizes: rel-pos tables interpolated in blocks >= 3
     (4, 64, 3, True),      # T=1 frames path of a 4-frame model (rel_pos_t interpolated to 1 row)
     (8, 224, 1, False),    # BASELINE config 1 (C1)
+    (32, 224, 1, False),   # BASELINE config 4: long clip (T' = 16, J = 30 / 44 bias columns)
+    (16, 312, 1, False),   # BASELINE config 5: 312^2 crop (78x78 patches, interpolated tables)
 ])
 def test_step_parity_vs_oracle(frames, crop, batch, frames_path):
     res = S.compare_step(frames, crop, batch, frames_path)
