@@ -324,3 +324,28 @@ def bench_pool_bwd():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "poolbwd":
     bench_pool_bwd()
+
+
+def bench_pool_fwd3():
+    """q/k/v pooling forward in one launch vs three (us)."""
+    print("== pool_ln_fwd: three launches | fused ==")
+    cfgs = [(0, 1, (8, 56, 56), 1, 8), (1, 2, (8, 56, 56), 2, 4), (2, 2, (8, 28, 28), 1, 4), (3, 4, (8, 28, 28), 2, 2),
+            (4, 4, (8, 14, 14), 1, 2), (14, 8, (8, 14, 14), 2, 1), (15, 8, (8, 7, 7), 1, 1)]
+    n_obj = 64
+    for blk, h, thw, sq, skv in cfgs:
+        N = 1 + thw[0] * thw[1] * thw[2] + n_obj
+        qkv = rnd(B, N, 3, h, 96)
+        ws = [torch.randn(96, 27, device=DEV) * 0.2 for _ in range(3)]
+        g = [torch.ones(96, device=DEV) for _ in range(3)]
+        b = [torch.zeros(96, device=DEV) for _ in range(3)]
+        J = 2 * ops.pooled(thw[1], skv) + thw[0]
+        da = 128 if J <= 32 else 160
+        strides, lds, modes = (sq, skv, skv), (da, da, 96), (0, 1, 0)
+        t3 = sum(timeit(lambda i=i: ops.pool_ln_fwd(qkv, i, ws[i], g[i], b[i], B, h, thw, n_obj, strides[i],
+                                                    ld_out=lds[i], mode=modes[i])) for i in range(3))
+        tf = timeit(lambda: ops.pool_ln_fwd_qkv(qkv, ws, g, b, B, h, thw, n_obj, strides, lds, modes))
+        print("blk%-2d h=%d N=%6d sq=%d skv=%d  3 launches %6.1f | fused %6.1f" % (blk, h, N, sq, skv, t3, tf))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "poolfwd":
+    bench_pool_fwd3()
