@@ -42,14 +42,35 @@ __device__ __forceinline__ float quad_sum(float v) {
   return v;
 }
 
-// LDS image of the conv weights, tap-major so one lane reads its 24 channels contiguously
+// LDS image of the conv weights, tap-major so one lane reads its 24 channels contiguously.
+// Entries are "selector weights": bf16(w) sits in the half of a dword that matches the channel's
+// position inside a packed bf16 pair (even channel: low half, odd: high half, other half zero),
+// so  acc = v_dot2c_f32_bf16(packed_pair, entry, acc)  multiplies exactly that channel -- no
+// bf16->f32 unpacking in the stencil loops (it cost twice as many VALU ops as the FMAs).  The
+// weights are thereby rounded to bf16, as CUDA autocast does for the reference's Conv3d.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ float dot2_sel(uint32_t pair, uint32_t sel, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pair),
+                                         __builtin_bit_cast(bf16x2_t, sel), acc, false);
+}
+// acc[8u .. 8u+7] += v (8 packed bf16 channels) * the selector weights at w
+__device__ __forceinline__ void fma8_sel(float (&acc)[24], int u, const uint4 v, const float* w) {
+  const uint4 w0 = *(const uint4*)(w + u * 8), w1 = *(const uint4*)(w + u * 8 + 4);
+  acc[u * 8 + 0] = dot2_sel(v.x, w0.x, acc[u * 8 + 0]);
+  acc[u * 8 + 1] = dot2_sel(v.x, w0.y, acc[u * 8 + 1]);
+  acc[u * 8 + 2] = dot2_sel(v.y, w0.z, acc[u * 8 + 2]);
+  acc[u * 8 + 3] = dot2_sel(v.y, w0.w, acc[u * 8 + 3]);
+  acc[u * 8 + 4] = dot2_sel(v.z, w1.x, acc[u * 8 + 4]);
+  acc[u * 8 + 5] = dot2_sel(v.z, w1.y, acc[u * 8 + 5]);
+  acc[u * 8 + 6] = dot2_sel(v.w, w1.z, acc[u * 8 + 6]);
+  acc[u * 8 + 7] = dot2_sel(v.w, w1.w, acc[u * 8 + 7]);
+}
 __device__ __forceinline__ void load_weights(const float* __restrict__ conv_w, float* w_lds,
                                              float* g_lds, int stride_hw) {
   for (int i = threadIdx.x; i < 27 * HD; i += blockDim.x) {
     const int c = i / 27, tap = i % 27;
-    w_lds[tap * HD + c] = conv_w[i];
+    w_lds[tap * HD + c] = __uint_as_float((uint32_t)f32_to_bf16(conv_w[i]) << (16 * (c & 1)));
   }
-  __syncthreads();
   if (g_lds) {
     float nt[3], nh[3], ipt, iph;
     obj_counts(1, nt, &ipt);
@@ -59,11 +80,11 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ conv_w, f
       for (int kt = 0; kt < 3; ++kt)
         for (int ky = 0; ky < 3; ++ky)
           for (int kx = 0; kx < 3; ++kx)
-            g += w_lds[((kt * 3 + ky) * 3 + kx) * HD + c] * nt[kt] * nh[ky] * nh[kx];
+            g += conv_w[c * 27 + (kt * 3 + ky) * 3 + kx] * nt[kt] * nh[ky] * nh[kx];
       g_lds[c] = g * ipt * iph * iph;
     }
-    __syncthreads();
   }
+  __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -128,15 +149,7 @@ __device__ __forceinline__ void pool_ln_fwd_body(const svit_pool_args& a, const 
         if (!ok[k9]) continue;
         const float* w = w_lds + (kt * 9 + k9) * HD + c0;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-          float f[8];
-          unpack8(v[k9][u], f);
-          const float4 w0 = *(const float4*)(w + u * 8), w1 = *(const float4*)(w + u * 8 + 4);
-          acc[u * 8 + 0] += f[0] * w0.x; acc[u * 8 + 1] += f[1] * w0.y;
-          acc[u * 8 + 2] += f[2] * w0.z; acc[u * 8 + 3] += f[3] * w0.w;
-          acc[u * 8 + 4] += f[4] * w1.x; acc[u * 8 + 5] += f[5] * w1.y;
-          acc[u * 8 + 6] += f[6] * w1.z; acc[u * 8 + 7] += f[7] * w1.w;
-        }
+        for (int u = 0; u < 3; ++u) fma8_sel(acc, u, v[k9][u], w);
       }
     }
   }
@@ -334,19 +347,65 @@ __global__ __launch_bounds__(256) void pool_ln_bwd3_kernel(PoolLnBwd3 g) {
 // {0,2} or {1} for s = 2, at most one tap for s >= 3 -- so the candidate list per axis has
 // NC = 3 / 2 / 1 entries (template S = 1 / 2 / 3 for "any s >= 3") and a lane issues the loads
 // of KTB t-planes (NC*NC candidates each) before it consumes the first one.
+// the tap loop of one input token: NCY x NCX candidate (ky, kx) pairs per t-plane, KTB planes of
+// loads in flight
+template <int S, int NCY, int NCX>
+__device__ __forceinline__ void dgrad_taps(const bf16_t* dp, const float* w_lds, int c0, int t, int T,
+                                           int Ho, int Wo, const int* kyc, const int* yoc,
+                                           const bool* yv, const int* kxc, const int* xoc,
+                                           const bool* xv, float (&acc)[24]) {
+  constexpr int KTB = (S == 1) ? 1 : 3;
+#pragma unroll 1
+  for (int kt0 = 0; kt0 < 3; kt0 += KTB) {
+    uint4 v[KTB][NCY * NCX][3];
+    bool ok[KTB][NCY * NCX];
+#pragma unroll
+    for (int kk = 0; kk < KTB; ++kk) {
+      const int to = t + 1 - (kt0 + kk);
+      const bool tv = to >= 0 && to < T;
+#pragma unroll
+      for (int j = 0; j < NCY * NCX; ++j) {
+        ok[kk][j] = tv && yv[j / NCX] && xv[j % NCX];
+        const int ti = ok[kk][j] ? 1 + (to * Ho + yoc[j / NCX]) * Wo + xoc[j % NCX] : 0;
+        const bf16_t* src = dp + (size_t)ti * HD;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) v[kk][j][u] = *(const uint4*)(src + u * 8);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < KTB; ++kk)
+#pragma unroll
+      for (int j = 0; j < NCY * NCX; ++j) {
+        if (!ok[kk][j]) continue;
+        const float* w = w_lds + (((kt0 + kk) * 3 + kyc[j / NCX]) * 3 + kxc[j % NCX]) * HD + c0;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) fma8_sel(acc, u, v[kk][j][u], w);
+      }
+  }
+}
+
 template <int S>
 __device__ __forceinline__ void pool_dgrad_body(const svit_pool_dgrad_args& a, const float* w_lds,
                                                 const float* g_lds, int tb) {
   constexpr int NC = (S == 1) ? 3 : (S == 2 ? 2 : 1);
-  constexpr int KTB = (S == 1) ? 1 : 3;
   const int s = a.stride_hw;
   const int Ho = pooled(a.H, s), Wo = pooled(a.W, s);
   const int L = a.T * a.H * a.W, Lo = a.T * Ho * Wo;
   const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
   const int bh = blockIdx.y, b = bh / a.heads, head = bh % a.heads;
-  const int tok = tb * 64 + (threadIdx.x >> 2);
+  int tok = tb * 64 + (threadIdx.x >> 2);
   const int sub = threadIdx.x & 3, c0 = sub * 24;
   if (tok >= N) return;
+  // stride 2, even planes: walk the patch tokens parity class by parity class ((y+1)&1, (x+1)&1),
+  // so that (almost) every wave holds tokens of ONE class and loads only that class's taps
+  // (2x2, 2x1, 1x2 or 1x1 per t-plane instead of the generic 2x2 with half of them dummies)
+  const bool classed = S == 2 && !(a.H & 1) && !(a.W & 1);
+  if (classed && tok >= 1 && tok <= L) {
+    const int Lq = L >> 2, cls = (tok - 1) / Lq, i = (tok - 1) % Lq;
+    const int W2 = a.W >> 1, H2 = a.H >> 1;
+    const int x2 = i % W2, y2 = (i / W2) % H2, tt = i / (W2 * H2);
+    tok = 1 + (tt * a.H + 2 * y2 + (cls >> 1)) * a.W + 2 * x2 + (cls & 1);
+  }
   const bf16_t* dp = (const bf16_t*)a.dpre + (size_t)bh * Nout * HD + c0;
   float acc[24];
 #pragma unroll
@@ -375,40 +434,19 @@ __device__ __forceinline__ void pool_dgrad_body(const svit_pool_dgrad_args& a, c
       yv[j] = kyc[j] <= 2 && yn >= 0 && yoc[j] < Ho;
       xv[j] = kxc[j] <= 2 && xn >= 0 && xoc[j] < Wo;
     }
-#pragma unroll 1
-    for (int kt0 = 0; kt0 < 3; kt0 += KTB) {
-      uint4 v[KTB][NC * NC][3];
-      bool ok[KTB][NC * NC];
-#pragma unroll
-      for (int kk = 0; kk < KTB; ++kk) {
-        const int to = t + 1 - (kt0 + kk);
-        const bool tv = to >= 0 && to < a.T;
-#pragma unroll
-        for (int j = 0; j < NC * NC; ++j) {
-          ok[kk][j] = tv && yv[j / NC] && xv[j % NC];
-          const int ti = ok[kk][j] ? 1 + (to * Ho + yoc[j / NC]) * Wo + xoc[j % NC] : 0;
-          const bf16_t* src = dp + (size_t)ti * HD;
-#pragma unroll
-          for (int u = 0; u < 3; ++u) v[kk][j][u] = *(const uint4*)(src + u * 8);
-        }
+    if (S == 2) {
+      const int py = (y + 1) & 1, px = (x + 1) & 1;
+      const int fy = __builtin_amdgcn_readfirstlane(py), fx = __builtin_amdgcn_readfirstlane(px);
+      if (__all(py == fy && px == fx)) {       // one parity class in this wave (the common case)
+        if (fy == 0 && fx == 0) dgrad_taps<S, NC, NC>(dp, w_lds, c0, t, a.T, Ho, Wo, kyc, yoc, yv, kxc, xoc, xv, acc);
+        else if (fy == 0) dgrad_taps<S, NC, 1>(dp, w_lds, c0, t, a.T, Ho, Wo, kyc, yoc, yv, kxc, xoc, xv, acc);
+        else if (fx == 0) dgrad_taps<S, 1, NC>(dp, w_lds, c0, t, a.T, Ho, Wo, kyc, yoc, yv, kxc, xoc, xv, acc);
+        else dgrad_taps<S, 1, 1>(dp, w_lds, c0, t, a.T, Ho, Wo, kyc, yoc, yv, kxc, xoc, xv, acc);
+      } else {
+        dgrad_taps<S, NC, NC>(dp, w_lds, c0, t, a.T, Ho, Wo, kyc, yoc, yv, kxc, xoc, xv, acc);
       }
-#pragma unroll
-      for (int kk = 0; kk < KTB; ++kk)
-#pragma unroll
-        for (int j = 0; j < NC * NC; ++j) {
-          if (!ok[kk][j]) continue;
-          const float* w = w_lds + (((kt0 + kk) * 3 + kyc[j / NC]) * 3 + kxc[j % NC]) * HD + c0;
-#pragma unroll
-          for (int u = 0; u < 3; ++u) {
-            float f[8];
-            unpack8(v[kk][j][u], f);
-            const float4 w0 = *(const float4*)(w + u * 8), w1 = *(const float4*)(w + u * 8 + 4);
-            acc[u * 8 + 0] += f[0] * w0.x; acc[u * 8 + 1] += f[1] * w0.y;
-            acc[u * 8 + 2] += f[2] * w0.z; acc[u * 8 + 3] += f[3] * w0.w;
-            acc[u * 8 + 4] += f[4] * w1.x; acc[u * 8 + 5] += f[5] * w1.y;
-            acc[u * 8 + 6] += f[6] * w1.z; acc[u * 8 + 7] += f[7] * w1.w;
-          }
-        }
+    } else {
+      dgrad_taps<S, NC, NC>(dp, w_lds, c0, t, a.T, Ho, Wo, kyc, yoc, yv, kxc, xoc, xv, acc);
     }
   }
   const size_t tok_stride = (size_t)3 * a.heads * HD;
