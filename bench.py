@@ -156,10 +156,10 @@ def main():
         return torch.nn.functional.cross_entropy(preds, labels)
 
     graphed, launch_note = None, "eager"
-    if not args.eager and not args.frames_pass:
+    if not args.eager:
         from svit_amd.graph import GraphedTrainStep
         try:
-            graphed = GraphedTrainStep(model, ce, [x], y)
+            graphed = GraphedTrainStep(model, ce, [x], y, frames_pass=args.frames_pass)
             launch_note = "hip-graph replay"
         except Exception as exc:            # never lose a measurement to a capture problem
             print("graph capture failed (%s: %s); falling back to eager launches"

@@ -95,7 +95,11 @@ def get_cfg():
     c.DIST_BACKEND = "nccl"
     c.DDP_FIND_UNUSED_PARAMETERS = False
     c.LOG_PERIOD = 10
-    c.SVIT = CfgNode({"O": 4, "LAMBDA_NODES": 1.0, "LAMBDA_EDGES": 1.0, "LAMBDA_CON": 1.0})
+    # CONSISTENCY is this build's switch for the paper's frame-clip consistency loss: "" keeps the
+    # as-released behaviour (the frames pass runs, its output is unused),
+    # "l1" / "l2" weight |obj_desc(video) - obj_desc(frames)| with LAMBDA_CON (losses.py:127-136)
+    c.SVIT = CfgNode({"O": 4, "LAMBDA_NODES": 1.0, "LAMBDA_EDGES": 1.0, "LAMBDA_CON": 1.0,
+                      "CONSISTENCY": ""})
     c.DATA = CfgNode({"NUM_FRAMES": 8, "TRAIN_CROP_SIZE": 224, "TEST_CROP_SIZE": 256,
                       "INPUT_CHANNEL_NUM": [3, 3], "MEAN": [0.45, 0.45, 0.45],
                       "STD": [0.225, 0.225, 0.225], "SAMPLING_RATE": 8})

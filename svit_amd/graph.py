@@ -31,10 +31,14 @@ from . import hip
 
 
 class GraphedTrainStep:
-    def __init__(self, model, loss_fun, inputs, labels, warmup=2):
+    def __init__(self, model, loss_fun, inputs, labels, warmup=2, frames_pass=False):
         """model: SViT or its DataParallel wrapper (train mode); loss_fun(preds, extra, labels) ->
         scalar; inputs: the reference's `inputs` list ([video f32 [B,3,T,S,S]]); labels: any
-        tensor (or tuple/dict of tensors) `loss_fun` takes -- copied into static buffers."""
+        tensor (or tuple/dict of tensors) `loss_fun` takes -- copied into static buffers.
+        frames_pass: also run the reference's no-grad single-frame forward of every clip
+        (tools/train_net.py:105-110) inside the graph; its outputs reach `loss_fun` as
+        extra["frames_output"] = {"preds", "extra_preds"} (the consistency-loss operand)."""
+        self.frames_pass = frames_pass
         self.wrapper = model
         self.core = model.module if hasattr(model, "module") else model
         if self.core.engine is None:
@@ -68,8 +72,19 @@ class GraphedTrainStep:
         # stream by an earlier eager step, which a stream capture cannot follow
         named = list(core.head.named_parameters())
         alias = {n: p.detach().requires_grad_(True) for n, p in named}
+        frames_out = None
+        if self.frames_pass and Tx > 1:
+            with torch.no_grad():       # B*T single frames through the same kernels (T' = 1)
+                xf = x.transpose(1, 2).flatten(0, 1).unsqueeze(2)
+                fy, _ = eng.forward(xf, core.sample_drop_scales(xf.shape[0], x.device), save=False)
+                ffeat = torch.cat((fy[:, :1], fy[:, -core.O:]), dim=1)
+                fp, fe = core.head(ffeat, T=1)
+                frames_out = {"preds": fp, "extra_preds": fe}
         with torch.enable_grad():
             preds, extra = torch.func.functional_call(core.head, alias, (feat,), {"T": Tx})
+            if frames_out is not None:
+                extra = dict(extra)
+                extra["frames_output"] = frames_out
             loss = self.loss_fun(preds, extra, self.labels)
         grads = torch.autograd.grad(loss, [feat] + [alias[n] for n, _ in named], allow_unused=True)
         with torch.no_grad():
@@ -82,7 +97,8 @@ class GraphedTrainStep:
             dy[:, -n_obj:] = dfeat[:, 1:]
             eng.backward(st, dy, on_ready=boundary,
                          ready_ranks=self.dp.launch_ranks() if self.dp is not None else None)
-        return loss.detach(), preds.detach(), {k: v.detach() for k, v in extra.items()}, (st, feat, dy)
+        return (loss.detach(), preds.detach(),
+                {k: v.detach() for k, v in extra.items() if torch.is_tensor(v)}, (st, feat, dy))
 
     def _capture(self, warmup):
         core = self.core

@@ -14,6 +14,12 @@ def get_lambdas_dict(cfg):
            "loss_contact_state": cfg.SVIT.LAMBDA_EDGES}
     if cfg.TRAIN.FORWARD_VIDEO_FRAMES:
         ret["video_image_boxes_l1_loss"] = cfg.SVIT.LAMBDA_CON
+        # extension: make the consistency term live
+        mode = getattr(cfg.SVIT, "CONSISTENCY", "")
+        if mode in ("l1", "l2"):
+            ret["video_image_desc_%s_loss" % mode] = cfg.SVIT.LAMBDA_CON
+        elif mode:
+            raise NotImplementedError("SVIT.CONSISTENCY must be '', 'l1' or 'l2'")
     return ret
 
 

@@ -73,3 +73,39 @@ def test_graphed_step_with_droppath_trains():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < losses[0], losses
+
+
+def test_graphed_step_with_frames_pass_and_consistency():
+    """the no-grad single-frame pass inside the replayed step, feeding the
+    frame-clip consistency loss; must equal the eager sequence of tools/train_net.py:98-124."""
+    from svit_amd import losses
+    from svit_amd.graph import GraphedTrainStep
+    cfg, model, spec, sd = S.build_hip_model(4, 64)
+    cfg.SVIT.CONSISTENCY = "l1"
+    fn = losses.VideoImageLoss(cfg)
+    x, y = P.frames(2, 4, 64).cuda(), P.labels(2).cuda()
+
+    def loss_fun(preds, extra, labels):
+        return fn.total(fn(preds, extra, labels, {}))
+
+    # eager reference
+    model.flat.grad.zero_()
+    logits, extra = model([x], {})
+    with torch.no_grad():
+        fp, fe = model([x.transpose(1, 2).flatten(0, 1).unsqueeze(2)], {})
+    extra["frames_output"] = {"preds": fp, "extra_preds": fe}
+    d = fn(logits, extra, y, {})
+    assert "video_image_desc_l1_loss" in d and float(d["video_image_desc_l1_loss"]) > 0
+    ref_loss = fn.total(d)
+    ref_loss.backward()
+    torch.cuda.synchronize()
+    ref_grad = model.flat.grad.clone()
+
+    step = GraphedTrainStep(model, loss_fun, [x], y, frames_pass=True)
+    loss, (preds, ex) = step([x], y)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * max(1.0, abs(float(ref_loss)))
+    assert S.cosine(model.flat.grad, ref_grad) > 0.99999
+    plain = GraphedTrainStep(model, lambda p, e, l: torch.nn.functional.cross_entropy(p, l), [x], y)
+    loss_plain, _ = plain([x], y)
+    assert float(loss) > float(loss_plain)            # the consistency term is really in there
