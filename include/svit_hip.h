@@ -30,7 +30,7 @@ const char* svit_arch(void); /* "gfx950" */
  * (slowfast/models/stem_helper.py:309-320). */
 enum {
   SVIT_EPI_BF16 = 0,   /* out(bf16)  = acc + bias                                   */
-  SVIT_EPI_GELU = 1,   /* h = acc + bias; out(bf16) = gelu_erf(h); out2(bf16) = gelu_erf'(h) */
+  SVIT_EPI_GELU = 1,   /* h = acc + bias; out(bf16) = gelu_erf(h); out2(bf16) = gelu_erf'(h) (out2 may be NULL) */
   SVIT_EPI_RESID = 2,  /* out(f32)   = aux(f32) + row_scale[row/rows_per_sample]*(acc+bias)
                           (proj / fc2 + DropPath + residual, attention.py:565,570)    */
   SVIT_EPI_F32 = 3,    /* out(f32)   = [out +] acc + bias, optional row remap         */
@@ -124,7 +124,8 @@ int svit_fill_special_tokens(float* x, const float* cls, const float* objq, cons
  * LayerNorm(96) on every token (attention.py:13-65, 263-304).
  * in : qkv bf16 [B, N, 3, h, 96]  (which = 0/1/2 selects q/k/v)
  * out: bf16 [B, h, Nout, ld_out] columns 0..95 = LN(pooled); pre: bf16 [B,h,Nout,96]
- *      pre-LN pooled values (saved for backward); mean/rstd f32 [B*h*Nout].
+ *      pre-LN pooled values (saved for backward); mean/rstd f32 [B*h*Nout]; pre, mean and rstd
+ *      may all be NULL (no-grad passes: nothing is saved).
  * mode 1 (keys) additionally writes the one-hot key coordinates at columns
  *      96 + [y | kh + x | kh + kw + t] used by the in-MFMA relative-position bias. */
 typedef struct {

@@ -77,13 +77,16 @@ __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&
         *(uint2*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = o;
       } else if constexpr (EPI == SVIT_EPI_GELU) {
         // the exp / cdf of the forward give the derivative for two more FMAs: it is saved
-        // (bf16) instead of the pre-activation, and fc2's dgrad epilogue is one multiply
+        // (bf16) instead of the pre-activation, and fc2's dgrad epilogue is one multiply.
+        // out2 == NULL (no-grad passes): only gelu(h) is produced.
         float a0, a1, a2, a3, d0, d1, d2, d3;
         gelu_fwd_grad(v.x, &a0, &d0); gelu_fwd_grad(v.y, &a1, &d1);
         gelu_fwd_grad(v.z, &a2, &d2); gelu_fwd_grad(v.w, &a3, &d3);
         uint2 o;
-        o.x = pack_bf16x2(d0, d1); o.y = pack_bf16x2(d2, d3);
-        *(uint2*)((bf16_t*)p.out2 + (size_t)row * p.ldo2 + col) = o;
+        if (p.out2) {
+          o.x = pack_bf16x2(d0, d1); o.y = pack_bf16x2(d2, d3);
+          *(uint2*)((bf16_t*)p.out2 + (size_t)row * p.ldo2 + col) = o;
+        }
         o.x = pack_bf16x2(a0, a1); o.y = pack_bf16x2(a2, a3);
         *(uint2*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = o;
       } else if constexpr (EPI == SVIT_EPI_RESID) {

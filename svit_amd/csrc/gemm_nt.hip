@@ -181,7 +181,6 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
   if (a.bias && ((uintptr_t)a.bias & 15)) return SVIT_ERR_ALIGN;
   if (a.aux && (a.ldaux % 4 != 0 || ((uintptr_t)a.aux & 15))) return SVIT_ERR_ALIGN;
   if (a.out2 && (a.ldo2 % 4 != 0 || ((uintptr_t)a.out2 & 15))) return SVIT_ERR_ALIGN;
-  if (a.epilogue == SVIT_EPI_GELU && !a.out2) return SVIT_ERR_ARG;
   if ((a.epilogue == SVIT_EPI_RESID || a.epilogue == SVIT_EPI_DGELU) && !a.aux) return SVIT_ERR_ARG;
   if (a.epilogue == SVIT_EPI_RESID && a.row_scale && a.rows_per_sample <= 0) return SVIT_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;

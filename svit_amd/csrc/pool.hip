@@ -166,9 +166,9 @@ __device__ __forceinline__ void pool_ln_fwd_body(const svit_pool_args& a, const 
   const float rstd = rsqrtf(quad_sum(sq) * (1.f / HD) + a.eps);
   if (!live) return;
   const size_t orow = (size_t)bh * Nout + tok;
-  if (sub == 0) { a.mean[orow] = mean; a.rstd[orow] = rstd; }
+  if (sub == 0 && a.mean) { a.mean[orow] = mean; a.rstd[orow] = rstd; }
   bf16_t* outp = (bf16_t*)a.out + orow * a.ld_out + c0;
-  bf16_t* prep = (bf16_t*)a.pre + orow * HD + c0;
+  bf16_t* prep = a.pre ? (bf16_t*)a.pre + orow * HD + c0 : nullptr;   // NULL: nothing saved
 #pragma unroll
   for (int v = 0; v < 3; ++v) {
     float o[8];
@@ -176,7 +176,7 @@ __device__ __forceinline__ void pool_ln_fwd_body(const svit_pool_args& a, const 
     for (int e = 0; e < 8; ++e)
       o[e] = (acc[v * 8 + e] - mean) * rstd * a.gamma[c0 + v * 8 + e] + a.beta[c0 + v * 8 + e];
     *(uint4*)(outp + v * 8) = pack8(o);
-    *(uint4*)(prep + v * 8) = pack8(&acc[v * 8]);
+    if (prep) *(uint4*)(prep + v * 8) = pack8(&acc[v * 8]);
   }
   if (a.mode == 1) {  // one-hot key coordinates [y | kh+x | kh+kw+t], zeros elsewhere
     const int extra = a.ld_out - HD, per = extra / 4;
@@ -1048,8 +1048,9 @@ extern "C" int svit_pool_ln_fwd(const svit_pool_args* a, void* stream) {
 }
 
 static int check_pool_fwd(const svit_pool_args* a) {
-  if (!a->qkv || !a->conv_w || !a->gamma || !a->beta || !a->out || !a->pre || !a->mean || !a->rstd)
-    return SVIT_ERR_ARG;
+  if (!a->qkv || !a->conv_w || !a->gamma || !a->beta || !a->out) return SVIT_ERR_ARG;
+  if ((a->pre == nullptr) != (a->mean == nullptr) || (a->mean == nullptr) != (a->rstd == nullptr))
+    return SVIT_ERR_ARG;     // the saved-for-backward trio is all-or-nothing
   int rc = check_pool_dims(a->B, a->heads, a->T, a->H, a->W, a->n_obj, a->stride_hw);
   if (rc) return rc;
   if (a->which < 0 || a->which > 2 || a->ld_out < HD || a->ld_out % 8 != 0) return SVIT_ERR_ARG;

@@ -252,14 +252,15 @@ class Engine:
         DA = HD + 32 if J <= 32 else HD + 64
         if J > 64:
             raise hip.SvitHipError("key grid %s too large for the in-MFMA rel-pos bias" % (k_thw,))
-        xn, _, mean1, rstd1 = ops.layernorm_fwd(x, f.p(pre + "norm1.weight"), f.p(pre + "norm1.bias"))
+        xn, _, mean1, rstd1 = ops.layernorm_fwd(x, f.p(pre + "norm1.weight"), f.p(pre + "norm1.bias"),
+                                                save_stats=save)
         xn2d = xn.view(B * N, C)
         qkv = ops.gemm_nt(xn2d, f.w(pre + "attn.qkv.weight"), f.p(pre + "attn.qkv.bias"), hip.EPI_BF16)
         pools = ops.pool_ln_fwd_qkv(
             qkv, [f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
             [f.p(pre + "attn.norm_%s.weight" % r) for r in "qkv"],
             [f.p(pre + "attn.norm_%s.bias" % r) for r in "qkv"],
-            B, h, thw, n_obj, (sq, skv, skv), (DA, DA, HD), (0, 1, 0))
+            B, h, thw, n_obj, (sq, skv, skv), (DA, DA, HD), (0, 1, 0), save=save)
         qa, ka, v = pools[0][0], pools[1][0], pools[2][0]
         idx, mats = self._rel(blk, q_thw, k_thw)
         tabs = self._tables(pre, mats)
@@ -287,9 +288,10 @@ class Engine:
         x1 = ops.gemm_nt(ctx.view(B * Nq, Co), f.w(pre + "attn.proj.weight"), f.p(pre + "attn.proj.bias"),
                          hip.EPI_RESID, aux=skip.view(B * Nq, Co), row_scale=dpa, rows_per_sample=Nq)
         x1 = x1.view(B, Nq, Co)
-        xn2, _, mean2, rstd2 = ops.layernorm_fwd(x1, f.p(pre + "norm2.weight"), f.p(pre + "norm2.bias"))
+        xn2, _, mean2, rstd2 = ops.layernorm_fwd(x1, f.p(pre + "norm2.weight"), f.p(pre + "norm2.bias"),
+                                                 save_stats=save)
         act, dact = ops.gemm_nt(xn2.view(B * Nq, Co), f.w(pre + "mlp.fc1.weight"),
-                                f.p(pre + "mlp.fc1.bias"), hip.EPI_GELU)
+                                f.p(pre + "mlp.fc1.bias"), hip.EPI_GELU, save=save)
         x2 = ops.gemm_nt(act, f.w(pre + "mlp.fc2.weight"), f.p(pre + "mlp.fc2.bias"), hip.EPI_RESID,
                          aux=x1.view(B * Nq, Co), row_scale=dpm, rows_per_sample=Nq).view(B, Nq, Co)
         sv = None

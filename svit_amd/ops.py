@@ -43,7 +43,7 @@ def _chk_dev(*ts):
 
 
 def gemm_nt(a, w, bias=None, epilogue=hip.EPI_BF16, out=None, out2=None, aux=None,
-            row_scale=None, rows_per_sample=0, accumulate=False, remap=None):
+            row_scale=None, rows_per_sample=0, accumulate=False, remap=None, save=True):
     """C = A[M,K] @ W[N,K]^T with a fused epilogue (see include/svit_hip.h).  `a` may be a
     column slice of a wider matrix (row-strided view)."""
     _chk_rows(a)
@@ -54,7 +54,7 @@ def gemm_nt(a, w, bias=None, epilogue=hip.EPI_BF16, out=None, out2=None, aux=Non
     if out is None:
         dt = F32 if epilogue in (hip.EPI_RESID, hip.EPI_F32) else BF16
         out = torch.empty((M, N), device=a.device, dtype=dt)
-    if epilogue == hip.EPI_GELU and out2 is None:
+    if epilogue == hip.EPI_GELU and out2 is None and save:
         out2 = torch.empty((M, N), device=a.device, dtype=BF16)
     g = hip.GemmArgs()
     g.A, g.lda, g.W, g.ldw = ptr(a), a.stride(0), ptr(w), w.stride(0)
@@ -205,15 +205,15 @@ def pooled(n, s):
 
 
 def _pool_fwd_args(a, qkv, which, conv_w, gamma, beta, B, heads, thw, n_obj, stride_hw, ld_out, mode,
-                   eps):
+                   eps, save=True):
     _chk_dev(qkv, conv_w, gamma, beta)
     T, H, W = thw
     Nout = 1 + T * pooled(H, stride_hw) * pooled(W, stride_hw) + n_obj
     dev = qkv.device
     out = torch.empty((B, heads, Nout, ld_out), device=dev, dtype=BF16)
-    pre = torch.empty((B, heads, Nout, HD), device=dev, dtype=BF16)
-    mean = torch.empty(B * heads * Nout, device=dev, dtype=F32)
-    rstd = torch.empty(B * heads * Nout, device=dev, dtype=F32)
+    pre = torch.empty((B, heads, Nout, HD), device=dev, dtype=BF16) if save else None
+    mean = torch.empty(B * heads * Nout, device=dev, dtype=F32) if save else None
+    rstd = torch.empty(B * heads * Nout, device=dev, dtype=F32) if save else None
     a.qkv, a.which, a.conv_w, a.gamma, a.beta = ptr(qkv), which, ptr(conv_w), ptr(gamma), ptr(beta)
     a.out, a.ld_out, a.pre, a.mean, a.rstd = ptr(out), ld_out, ptr(pre), ptr(mean), ptr(rstd)
     a.B, a.heads, a.T, a.H, a.W, a.n_obj = B, heads, T, H, W, n_obj
@@ -232,11 +232,12 @@ def pool_ln_fwd(qkv, which, conv_w, gamma, beta, B, heads, thw, n_obj, stride_hw
 
 
 def pool_ln_fwd_qkv(qkv, conv_ws, gammas, betas, B, heads, thw, n_obj, strides, ld_outs, modes,
-                    eps=1e-6):
-    """q, k, v pooling + LayerNorm in one launch -> [(out, pre, mean, rstd)] * 3."""
+                    eps=1e-6, save=True):
+    """q, k, v pooling + LayerNorm in one launch -> [(out, pre, mean, rstd)] * 3 (the last three
+    are None with save=False: no-grad passes keep nothing for a backward)."""
     arr = (hip.PoolArgs * 3)()
     res = [_pool_fwd_args(arr[i], qkv, i, conv_ws[i], gammas[i], betas[i], B, heads, thw, n_obj,
-                          strides[i], ld_outs[i], modes[i], eps) for i in range(3)]
+                          strides[i], ld_outs[i], modes[i], eps, save) for i in range(3)]
     hip.call("svit_pool_ln_fwd_qkv", arr)
     return res
 
