@@ -133,6 +133,7 @@ __device__ __forceinline__ void pool_ln_fwd_body(const svit_pool_args& a, const 
     for (int kt = 0; kt < 3; ++kt) {
       const int t = pt - 1 + kt;
       const bool tv = is_patch && t >= 0 && t < a.T;
+      if (!__any(tv)) continue;        // whole wave outside the volume (T' = 1; clip borders)
       uint4 v[9][3];
       bool ok[9];
 #pragma unroll
@@ -359,6 +360,10 @@ __device__ __forceinline__ void dgrad_taps(const bf16_t* dp, const float* w_lds,
   for (int kt0 = 0; kt0 < 3; kt0 += KTB) {
     uint4 v[KTB][NCY * NCX][3];
     bool ok[KTB][NCY * NCX];
+    if (KTB == 1) {                    // whole wave outside the volume (T' = 1; clip borders)
+      const int to0 = t + 1 - kt0;
+      if (!__any(to0 >= 0 && to0 < T)) continue;
+    }
 #pragma unroll
     for (int kk = 0; kk < KTB; ++kk) {
       const int to = t + 1 - (kt0 + kk);
