@@ -101,11 +101,12 @@ int svit_layernorm_fwd(const float* x, const float* gamma, const float* beta, vo
                        float* y_f32, float* mean, float* rstd, int64_t rows, int C, float eps,
                        void* stream);
 /* dx = [dres +] LN'(dy); dgamma/dbeta += column sums (two-stage: per-block partial rows in
- * `workspace`, then one reduce launch -- no same-address atomics). dy is f32.
+ * `workspace`, then one reduce launch -- no same-address atomics). dy is f32 or bf16.
  * dx_bf16 (optional): also bf16(row_scale[row / rows_per_sample] * dx) -- the DropPath-scaled
  * operand of the next backward GEMM (common.py:46-59), fused instead of a separate cast pass;
  * row_scale may be NULL (scale 1). */
-int svit_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+int svit_layernorm_bwd(const void* dy /* f32, or bf16 when dy_is_bf16 */, int dy_is_bf16,
+                       const float* x, const float* gamma, const float* mean,
                        const float* rstd, const float* dres, float* dx, void* dx_bf16,
                        const float* row_scale, int rows_per_sample, float* dgamma,
                        float* dbeta, int64_t rows, int C, float* workspace,

@@ -100,8 +100,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // Backward: same row mapping as the forward (NCH chunks per lane, HALF = one row per 32-lane
 // half for C <= 128), two rows in flight per (half-)wave.
-template <int NCH, bool HALF>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy,
+template <int NCH, bool HALF, bool DYB>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_,
                                                      const float* __restrict__ x,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ mean_in,
@@ -147,7 +147,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         xv[k][i] = dv[k][i] = rv[k][i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < nch) {
           xv[k][i] = ((const float4*)(x + rowk[k] * C))[c];
-          dv[k][i] = ((const float4*)(dy + rowk[k] * C))[c];
+          if (DYB) {      // the dgrad GEMM wrote bf16 (as autocast does): half the bytes
+            const uint2 h = ((const uint2*)((const bf16_t*)dy_ + rowk[k] * C))[c];
+            dv[k][i] = make_float4(lo_bf16(h.x), hi_bf16(h.x), lo_bf16(h.y), hi_bf16(h.y));
+          } else {
+            dv[k][i] = ((const float4*)((const float*)dy_ + rowk[k] * C))[c];
+          }
           if (dres) rv[k][i] = ((const float4*)(dres + rowk[k] * C))[c];
         }
       }
@@ -244,7 +249,7 @@ extern "C" int svit_layernorm_fwd(const float* x, const float* gamma, const floa
   return SVIT_OK;
 }
 
-extern "C" int svit_layernorm_bwd(const float* dy, const float* x, const float* gamma,
+extern "C" int svit_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* gamma,
                                   const float* mean, const float* rstd, const float* dres,
                                   float* dx, void* dx_bf16, const float* row_scale,
                                   int rows_per_sample, float* dgamma, float* dbeta, int64_t rows,
@@ -262,9 +267,16 @@ extern "C" int svit_layernorm_bwd(const float* dy, const float* x, const float* 
   if (blocks > workspace_floats / (2 * C)) blocks = workspace_floats / (2 * C);
   if (blocks < 1) return SVIT_ERR_ARG;
 #define SVIT_LN_BWD(NCH, HALF)                                                                  \
-  hipLaunchKernelGGL((ln_bwd_kernel<NCH, HALF>), dim3((unsigned)blocks), dim3(256), 0,              \
-                     (hipStream_t)stream, dy, x, gamma, mean, rstd, dres, dx, (bf16_t*)dx_bf16,     \
-                     row_scale, rows_per_sample, workspace, rows, C)
+  do {                                                                                            \
+    if (dy_is_bf16)                                                                               \
+      hipLaunchKernelGGL((ln_bwd_kernel<NCH, HALF, true>), dim3((unsigned)blocks), dim3(256), 0,  \
+                         (hipStream_t)stream, dy, x, gamma, mean, rstd, dres, dx,                 \
+                         (bf16_t*)dx_bf16, row_scale, rows_per_sample, workspace, rows, C);       \
+    else                                                                                          \
+      hipLaunchKernelGGL((ln_bwd_kernel<NCH, HALF, false>), dim3((unsigned)blocks), dim3(256), 0, \
+                         (hipStream_t)stream, dy, x, gamma, mean, rstd, dres, dx,                 \
+                         (bf16_t*)dx_bf16, row_scale, rows_per_sample, workspace, rows, C);       \
+  } while (0)
   if (C <= 128) SVIT_LN_BWD(1, true);
   else if (C <= 256) SVIT_LN_BWD(1, false);
   else if (C <= 512) SVIT_LN_BWD(2, false);

@@ -412,7 +412,7 @@ class Engine:
         dh = self._linear_bwd(dy, sv["act"], pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", True,
                               epilogue=hip.EPI_DGELU, aux=sv["dact"])
         dxn2 = self._linear_bwd(dh, sv["xn2"].view(Mq, Co), pre + "mlp.fc1.weight",
-                                pre + "mlp.fc1.bias", True)
+                                pre + "mlp.fc1.bias", True, epilogue=hip.EPI_BF16)   # bf16 like autocast
         dx1, dy = ops.layernorm_bwd(dxn2, sv["x1"], f.p(pre + "norm2.weight"), sv["mean2"],
                                     sv["rstd2"], f.g(pre + "norm2.weight"), f.g(pre + "norm2.bias"),
                                     dres=dx2, want_bf16=True, row_scale=sv["dpa"], rows_per_sample=Nq,
@@ -465,7 +465,9 @@ class Engine:
                               dqkv, sv["qkv"],
                               [f.g(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
                               B, h, thw, n_obj, strides, ws=self._rws("wgrad"))
-        dxn = self._linear_bwd(dqkv, sv["xn"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", True)
+        # (bf16 unless the dim-change projection accumulates into it below)
+        dxn = self._linear_bwd(dqkv, sv["xn"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", True,
+                               epilogue=hip.EPI_F32 if blk.has_proj else hip.EPI_BF16)
         # ---- skip path ------------------------------------------------------------------------
         dskip = dx1
         if blk.pools_q:

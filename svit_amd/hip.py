@@ -113,8 +113,8 @@ _SIGS = {
     "svit_reduce_defer": (i32, [i32, vp]),
     "svit_reduce_flush": (i32, [vp]),
     "svit_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp]),
-    "svit_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i64, i32, vp, i64,
-                                 vp]),
+    "svit_layernorm_bwd": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i64, i32, vp,
+                                 i64, vp]),
     "svit_im2col_patch": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "svit_fill_special_tokens": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "svit_pool_ln_fwd": (i32, [C.POINTER(PoolArgs), vp]),

@@ -178,7 +178,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, dx=None, w
         dx = torch.empty(x.shape, device=x.device, dtype=F32)
     dx16 = torch.empty(x.shape, device=x.device, dtype=BF16) if want_bf16 else None
     ws = scratch(x.device) if ws is None else ws
-    hip.call("svit_layernorm_bwd", ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres),
+    assert dy.dtype in (F32, BF16)
+    hip.call("svit_layernorm_bwd", ptr(dy), int(dy.dtype == BF16), ptr(x), ptr(gamma), ptr(mean),
+             ptr(rstd), ptr(dres),
              ptr(dx), ptr(dx16), ptr(row_scale), rows_per_sample, ptr(dgamma), ptr(dbeta), rows, C_,
              ptr(ws), ws.numel())
     return (dx, dx16) if want_bf16 else dx

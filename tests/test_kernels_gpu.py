@@ -186,6 +186,12 @@ def test_layernorm(ops, C):
     assert torch.equal(dx16, exp)
     _, dx16b = ops.layernorm_bwd(dy, x, g, mean, rstd, dg2, db2, dres=dres, want_bf16=True)
     assert torch.equal(dx16b, dx.to(BF16))
+    # bf16 upstream gradient (what the dgrad GEMM writes): same result as its f32 widening
+    dg3, db3 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dg4, db4 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dxa = ops.layernorm_bwd(dy.to(BF16), x, g, mean, rstd, dg3, db3, dres=dres)
+    dxb = ops.layernorm_bwd(dy.to(BF16).float(), x, g, mean, rstd, dg4, db4, dres=dres)
+    assert torch.equal(dxa, dxb) and rel_err(dg3, dg4) < 1e-6 and rel_err(db3, db4) < 1e-6
 
 
 # -------------------------------------------------------------------- patch embedding ----
