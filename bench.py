@@ -37,6 +37,19 @@ def synth_batch(cfg, batch, device, seed):
     return x.to(device), y.to(device)
 
 
+def synth_image_batch(cfg, batch, device, seed):
+    """an image rank's batch: stills [B,3,1,S,S]; cxcywh boxes with centres
+    U[.25,.75], sizes U[.1,.4], ~10 % empty rows; contact states in {-1, 0, 3}."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    s = cfg.DATA.TRAIN_CROP_SIZE
+    x = torch.randn(batch, 3, 1, s, s, generator=g)
+    box = torch.cat((torch.rand(batch, 1, 4, 2, generator=g) * 0.5 + 0.25,
+                     torch.rand(batch, 1, 4, 2, generator=g) * 0.3 + 0.1), -1)
+    box[torch.rand(batch, 1, 4, generator=g) < 0.1] = 0.0
+    contact = torch.tensor([-1, 0, 3])[torch.randint(0, 3, (batch, 2), generator=g)]
+    return x.to(device), {"haog_bboxes": box.to(device), "contact_state": contact.to(device)}
+
+
 def usable_cores():
     """CPU share of this process: affinity mask capped by the cgroup cpu quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -124,6 +137,10 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--crop", type=int, default=224)
     ap.add_argument("--frames-pass", action="store_true")
+    ap.add_argument("--image-ranks", type=int, default=0,
+                    help="the published recipe's heterogeneous layout: the LAST k ranks train still "
+                         "images with the HAOG losses (IMAGE_TRAIN.GPU_IDS; SURVEY 8(f) rank 2)")
+    ap.add_argument("--image-batch", type=int, default=63, help="images per image rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-trace", action="store_true")
     ap.add_argument("--eager", action="store_true",
@@ -145,21 +162,33 @@ def main():
     from svit_amd import config, optim
     from svit_amd.model import build_model
     cfg = config.ssv2_cfg(num_frames=args.frames, crop=args.crop, num_gpus=world)
+    cfg.IMAGE_TRAIN.GPU_IDS = list(range(world - args.image_ranks, world))
+    from svit_amd.dp import rank_role
+    is_image = rank_role(cfg, local_rank).is_image
     torch.manual_seed(cfg.RNG_SEED)
     model = build_model(cfg, gpu_id=local_rank)
     model.train()
     opt = optim.construct_optimizer(model, cfg)
-    x, y = synth_batch(cfg, args.batch, dev, seed=cfg.RNG_SEED + rank)
-    core = model.module if hasattr(model, "module") else model
+    if is_image:
+        from svit_amd import losses
+        x, y = synth_image_batch(cfg, args.image_batch, dev, seed=cfg.RNG_SEED + rank)
+        haog = losses.VideoImageLoss(cfg, is_video_rank=False)
 
-    def ce(preds, extra, labels):
-        return torch.nn.functional.cross_entropy(preds, labels)
+        def ce(preds, extra, labels):            # this rank's loss: sum_k lambda_k * HAOG loss_k
+            return haog.total(haog(preds, extra, None, labels))
+    else:
+        x, y = synth_batch(cfg, args.batch, dev, seed=cfg.RNG_SEED + rank)
+
+        def ce(preds, extra, labels):
+            return torch.nn.functional.cross_entropy(preds, labels)
+    core = model.module if hasattr(model, "module") else model
+    frames_pass = args.frames_pass and not is_image    # stills have no frames pass (train_net.py:105)
 
     graphed, launch_note = None, "eager"
     if not args.eager:
         from svit_amd.graph import GraphedTrainStep
         try:
-            graphed = GraphedTrainStep(model, ce, [x], y, frames_pass=args.frames_pass)
+            graphed = GraphedTrainStep(model, ce, [x], y, frames_pass=frames_pass)
             launch_note = "hip-graph replay"
         except Exception as exc:            # never lose a measurement to a capture problem
             print("graph capture failed (%s: %s); falling back to eager launches"
@@ -174,10 +203,10 @@ def main():
             opt.step()
             return loss
         logits, extra = model([x], {})
-        if args.frames_pass:
+        if frames_pass:
             with torch.no_grad():
                 model([x.transpose(1, 2).flatten(0, 1).unsqueeze(2)], {})
-        loss = torch.nn.functional.cross_entropy(logits, y)
+        loss = ce(logits, extra, y)
         opt.zero_grad()
         loss.backward()
         opt.step()
@@ -201,7 +230,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     ms_per_step = dt / args.steps * 1e3
-    clips_per_s = args.batch * world * args.steps / dt
+    n_vid = world - args.image_ranks
+    clips_per_s = args.batch * n_vid * args.steps / dt
 
     out = {
         "metric": "clips/sec (fwd+bwd) SViT %dx%d^2 bf16" % (args.frames, args.crop),
@@ -215,9 +245,21 @@ def main():
                    "parallelism": "dp%d" % world,
                    "launch": launch_note},
         "loss": round(loss_val, 4),
-        "step_mfma_frac": round(clips_per_s / world * STEP_GFLOP_PER_CLIP * 1e9 /
+        "step_mfma_frac": round(clips_per_s / max(1, n_vid) * STEP_GFLOP_PER_CLIP * 1e9 /
                                 (MFMA_PEAK_TFLOPS * 1e12), 4),
     }
+    if args.image_ranks:
+        # heterogeneous layout: `value` counts the clips of the video ranks only
+        out["config"]["workload"] += "; %d image rank(s) x %d stills with HAOG losses" % (
+            args.image_ranks, args.image_batch)
+        out["config"]["global_batch"] = args.batch * n_vid
+        out["config"]["parallelism"] = "dp%d (%d video + %d image ranks)" % (world, n_vid, args.image_ranks)
+        out["images_per_s"] = round(args.image_batch * args.image_ranks * args.steps / dt, 2)
+        if n_vid == 0:     # image ranks only: a side measurement (load balance of the recipe)
+            out.update({"metric": "images/sec (fwd+bwd) SViT image rank 1x%d^2 bf16" % args.crop,
+                        "value": out["images_per_s"], "unit": "images/s"})
+        args.no_kernel_trace = args.no_kernel_trace or is_image or world > 1
+        args.no_cpu_baseline = True
     if rank == 0 and not args.no_kernel_trace:
         from svit_amd import hip
         hip.start_trace()

@@ -271,6 +271,23 @@ int svit_sumsq(const float* g, int64_t n, float* sumsq, float* workspace,
 int svit_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq,
                     float max_norm, float lr, float beta1, float beta2, float eps, float wd,
                     int step, float grad_scale, void* stream);
+
+/* ------------------------------------------------ image-rank HAOG losses ---- */
+/* boxes_loss_ + contact-state CE of VideoImageLoss._haog_loss (slowfast/models/losses.py:50-93,
+ * 138-155; slowfast/utils/box_ops.py:10-77) without the reference's boolean-index host syncs:
+ * masks stay arithmetic, shapes fixed, so the image rank's step replays as a HIP graph.
+ * pred f32 [R,5] (objectness logit, sigmoid cx,cy,w,h), tar f32 [R,4] (all-zero row = empty),
+ * contact f32 [Rc,5] logits, contact_tar int64 [Rc] (<0 ignored).  One launch writes
+ * losses f32 [8] = {l1, bce, giou, contact CE, #boxes, #contacts, #targets>4, 0} and the unit
+ * gradients g_l1/g_giou f32 [R,4], g_bce f32 [R], g_contact f32 [Rc,5]. */
+int svit_haog_loss(const float* pred, const float* tar, const float* contact,
+                   const int64_t* contact_tar, float* losses, float* g_l1, float* g_bce,
+                   float* g_giou, float* g_contact, int R, int Rc, void* stream);
+/* dpred [R,5] = up[1]*g_bce | up[0]*g_l1 + up[2]*g_giou ; dcontact = up[3]*g_contact, with
+ * `upstream` f32 [4] on the device (d total / d {l1, bce, giou, contact}). */
+int svit_haog_loss_bwd(const float* upstream, const float* g_l1, const float* g_bce,
+                       const float* g_giou, const float* g_contact, float* dpred,
+                       float* dcontact, int R, int Rc, void* stream);
 #ifdef __cplusplus
 }
 #endif

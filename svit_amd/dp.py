@@ -7,9 +7,30 @@ handful of large contiguous slices launched from the backward schedule itself (a
 14, ... 0) on RCCL's stream while the remaining blocks are still back-propagating.  xGMI is
 point-to-point: few, large messages are the right shape for it (no 25 MB bucket heuristics).
 """
+import collections
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
+
+RankRole = collections.namedtuple("RankRole", "is_image data_rank replicas batch_size dataset")
+
+
+def rank_role(cfg, local_rank):
+    """Which data a rank trains on in the published recipe (slowfast/datasets/loader.py:186-201):
+    GPUs listed in cfg.IMAGE_TRAIN.GPU_IDS train still images with the HAOG losses, the others
+    train clips with CE; each group shards ITS global batch over its own members.  The gradient
+    exchange is the same flat all-reduce over all ranks -- every `param.grad` is a view of the
+    flat buffer that `zero_grad` clears, so heads a rank's loss does not reach contribute exact
+    zeros (what the reference obtains with its `0 * sum(params)` touches,
+    video_model_builder.py:359,514)."""
+    img = sorted(cfg.IMAGE_TRAIN.GPU_IDS)
+    vid = [i for i in range(cfg.NUM_GPUS) if i not in img]
+    is_image = local_rank in img
+    group = img if is_image else vid
+    bs = cfg.IMAGE_TRAIN.BATCH_SIZE if is_image else cfg.TRAIN.BATCH_SIZE
+    return RankRole(is_image, group.index(local_rank), len(group), int(bs / max(1, len(group))),
+                    "multi_images" if is_image else cfg.TRAIN.DATASET)
 
 
 class DataParallel(nn.Module):

@@ -136,6 +136,8 @@ _SIGS = {
     "svit_maxpool_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "svit_sumsq": (i32, [vp, i64, vp, vp, i64, vp]),
     "svit_adamw_step": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, i32, f32, vp]),
+    "svit_haog_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "svit_haog_loss_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
 }
 EXPORTS = tuple(sorted(_SIGS))
 

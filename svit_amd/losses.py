@@ -56,6 +56,29 @@ def boxes_loss_(pred, tar):
     return loss_l1, loss_mask, loss_giou
 
 
+class _HaogLossHip(torch.autograd.Function):
+    """The four HAOG losses in one launch on the device (svit_haog_loss, include/svit_hip.h):
+    arithmetic masks instead of the reference's `pred[mask]` / `if mask.sum() > 0`, i.e. no host
+    sync and fixed shapes, so an image rank's step can be replayed as a HIP graph."""
+
+    @staticmethod
+    def forward(ctx, pred, tar, contact, contact_tar):
+        from . import ops
+        pred, contact = pred.contiguous(), contact.contiguous()
+        losses, unit = ops.haog_loss_fwd(pred, tar.contiguous().float(), contact,
+                                         contact_tar.contiguous())
+        ctx.unit, ctx.shapes = unit, (pred.shape, contact.shape)
+        parts, stats = losses[:4].clone(), losses[4:].clone()
+        ctx.mark_non_differentiable(stats)
+        return parts, stats          # parts = (l1, bce, giou, contact CE)
+
+    @staticmethod
+    def backward(ctx, d_parts, _):
+        from . import ops
+        dpred, dcontact = ops.haog_loss_bwd(d_parts.contiguous().float(), ctx.unit, *ctx.shapes)
+        return dpred, None, dcontact, None
+
+
 class VideoImageLoss(nn.Module):
     """losses.py:119-168.  `is_video_rank` replaces the reference's local-rank test
     (`du.get_local_rank() not in cfg.IMAGE_TRAIN.GPU_IDS`)."""
@@ -81,6 +104,14 @@ class VideoImageLoss(nn.Module):
         return ret
 
     def _haog_loss(self, extra_preds, metadata):
+        if extra_preds["pred_bboxes"].is_cuda and self.reduction == "mean":   # product path: one fused launch
+            parts, stats = _HaogLossHip.apply(
+                extra_preds["pred_bboxes"], metadata["haog_bboxes"],
+                extra_preds["pred_contact_state"], metadata["contact_state"])
+            self.last_stats = stats     # device-side: #boxes, #contacts, #out-of-range targets
+            return {"boxes_l1_loss": parts[0], "boxes_bce_loss": parts[1],
+                    "boxes_giou_loss": parts[2], "loss_contact_state": parts[3]}
+        # host tensors (configuration / unit tests of the loss plumbing): plain torch ops
         l1, bce, giou = boxes_loss_(extra_preds["pred_bboxes"], metadata["haog_bboxes"])
         ret = {"boxes_l1_loss": l1, "boxes_bce_loss": bce, "boxes_giou_loss": giou}
         pred = extra_preds["pred_contact_state"].flatten(0, 2)

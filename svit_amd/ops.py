@@ -442,3 +442,28 @@ def sumsq(g, out):
 def adamw_step(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
     hip.call("svit_adamw_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(sumsq_t), max_norm,
              lr, beta1, beta2, eps, wd, step, grad_scale)
+
+
+# ---------------------------------------------------------------- image-rank HAOG losses ----
+def haog_loss_fwd(pred, tar, contact, contact_tar):
+    """-> (losses f32 [8], (g_l1, g_bce, g_giou, g_contact)); see include/svit_hip.h."""
+    R, Rc = pred.numel() // 5, contact.numel() // 5
+    assert pred.dtype == F32 and tar.dtype == F32 and contact.dtype == F32
+    assert contact_tar.dtype == torch.int64 and tar.numel() == R * 4 and contact_tar.numel() == Rc
+    dev = pred.device
+    losses = torch.empty(8, dtype=F32, device=dev)
+    g_l1, g_giou = torch.empty((R, 4), dtype=F32, device=dev), torch.empty((R, 4), dtype=F32, device=dev)
+    g_bce, g_contact = torch.empty(R, dtype=F32, device=dev), torch.empty((Rc, 5), dtype=F32, device=dev)
+    hip.call("svit_haog_loss", ptr(pred), ptr(tar), ptr(contact), ptr(contact_tar), ptr(losses),
+             ptr(g_l1), ptr(g_bce), ptr(g_giou), ptr(g_contact), R, Rc)
+    return losses, (g_l1, g_bce, g_giou, g_contact)
+
+
+def haog_loss_bwd(upstream, unit, pred_shape, contact_shape):
+    g_l1, g_bce, g_giou, g_contact = unit
+    R, Rc = g_bce.numel(), g_contact.numel() // 5
+    dpred = torch.empty(pred_shape, dtype=F32, device=g_bce.device)
+    dcontact = torch.empty(contact_shape, dtype=F32, device=g_bce.device)
+    hip.call("svit_haog_loss_bwd", ptr(upstream), ptr(g_l1), ptr(g_bce), ptr(g_giou),
+             ptr(g_contact), ptr(dpred), ptr(dcontact), R, Rc)
+    return dpred, dcontact

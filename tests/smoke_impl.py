@@ -27,25 +27,42 @@ def cosine(a, b):
     return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
 
 
-def compare_step(num_frames=4, crop=64, batch=2, frames_path=False, verbose=False):
-    """-> dict of parity numbers (HIP bf16 path vs fp32 oracle) for one video CE step."""
+def compare_step(num_frames=4, crop=64, batch=2, frames_path=False, verbose=False, image=False):
+    """-> dict of parity numbers (HIP bf16 path vs fp32 oracle) for one video CE step, or
+    (image=True) one image-rank step: still images, HAOG box / contact losses."""
     cfg, model, spec, sd = build_hip_model(num_frames, crop)
-    x = P.frames(batch, 1 if frames_path else num_frames, crop)
+    x = P.frames(batch, 1 if (frames_path or image) else num_frames, crop)
     y = P.labels(batch)
     logits, extra = model([x.cuda()], {})
-    loss = torch.nn.functional.cross_entropy(logits, y.cuda())
+    parts = {}
+    if image:
+        from svit_amd import losses
+        meta = P.haog_meta(batch)
+        fn = losses.VideoImageLoss(cfg, is_video_rank=False)
+        parts = fn(logits, extra, None, {k: v.cuda() for k, v in meta.items()})
+        loss = fn.total(parts)
+    else:
+        loss = torch.nn.functional.cross_entropy(logits, y.cuda())
     model.zero_grad(set_to_none=True)
     loss.backward()
     torch.cuda.synchronize()
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     lg, ex = R.forward(p, spec, x, training=True)
-    ls = R.video_loss(lg, y)
+    if image:
+        ls, ref_parts = R.image_loss(ex, meta, R.loss_weights(cfg.SVIT.LAMBDA_NODES,
+                                                              cfg.SVIT.LAMBDA_EDGES))
+    else:
+        ls = R.video_loss(lg, y)
     ls.backward()
     out = {"logits_maxabs": float((logits.detach().cpu() - lg.detach()).abs().max()),
            "logits_cos": cosine(logits.detach(), lg.detach()),
            "loss_abs": abs(float(loss.detach()) - float(ls.detach())),
            "obj_desc_cos": cosine(extra["obj_desc"].detach(), ex["obj_desc"].detach()),
            "obj_desc_maxabs": float((extra["obj_desc"].detach().cpu() - ex["obj_desc"].detach()).abs().max())}
+    if image:
+        out["loss_rel"] = out["loss_abs"] / abs(float(ls.detach()))
+        out["parts_abs"] = {k: abs(float(parts[k].detach()) - float(v.detach()))
+                            for k, v in ref_parts.items()}
     named = dict(model.named_parameters())
     gmax = max(float(v.grad.abs().max()) for v in p.values() if v.grad is not None)
     worst, worst_name = 1.0, ""

@@ -108,3 +108,86 @@ def test_graphed_two_ranks_equal_eager_one_rank(tmp_path):
     assert diff < 2e-3 * one.abs().max().item()
     cos = torch.dot(one.double(), two.double()) / (one.double().norm() * two.double().norm())
     assert cos > 0.999999
+
+
+# ---- heterogeneous ranks of the published recipe: rank 0 trains clips with
+# CE, rank 1 still images with the HAOG losses; ONE flat all-reduce averages both gradients.
+def _hetero_worker(rank, world, port, out, graphed):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import procedural as P
+    from oracle import svit_ref as R
+    from svit_amd import config, losses
+    from svit_amd.dp import DataParallel, rank_role
+    from svit_amd.model import MODEL_REGISTRY
+    cfg = config.ssv2_cfg(num_frames=4, crop=64, num_gpus=2)
+    cfg.MVIT.DROPPATH_RATE = 0.0
+    cfg.MODEL.DROPOUT_RATE = 0.0
+    cfg.IMAGE_TRAIN.GPU_IDS, cfg.IMAGE_TRAIN.BATCH_SIZE, cfg.TRAIN.BATCH_SIZE = [1], 3, 2
+    model = MODEL_REGISTRY.get("SViT")(cfg).cuda()
+    model.load_state_dict(P.state_dict(R.param_shapes(R.make_spec(4, 64, drop_path_rate=0.0,
+                                                                  dropout_rate=0.0))))
+    dp = DataParallel(model, bucket_ranks=4) if world > 1 else model
+
+    def batch(role):
+        if role.is_image:
+            meta = {k: v.cuda() for k, v in P.haog_meta(role.batch_size).items()}
+            return P.frames(role.batch_size, 1, 64).cuda(), meta
+        return P.frames(role.batch_size, 4, 64).cuda(), P.labels(role.batch_size).cuda()
+
+    def loss_of(role):
+        fn = losses.VideoImageLoss(cfg, is_video_rank=not role.is_image)
+        return lambda preds, extra, labels: fn.total(fn(preds, extra, labels, labels))
+
+    def run(role):
+        x, lab = batch(role)
+        assert x.shape[0] == (3 if role.is_image else 2)
+        if graphed:
+            from svit_amd.graph import GraphedTrainStep
+            step = GraphedTrainStep(dp, loss_of(role), [x], lab)
+            step([x], lab)
+            step([x], lab)                     # replayed twice: grads are re-zeroed inside
+        else:
+            preds, extra = dp([x], {})
+            loss = loss_of(role)(preds, extra, lab)
+            model.zero_grad()
+            loss.backward()
+        torch.cuda.synchronize()
+        return model.flat.grad.detach().cpu().clone()
+
+    if world == 1:                             # reference: both roles on one rank, averaged
+        g = 0.5 * (run(rank_role(cfg, 0)) + run(rank_role(cfg, 1)))
+    else:
+        g = run(rank_role(cfg, rank))
+        both = [torch.zeros_like(g) for _ in range(world)]
+        dist.all_gather(both, g)
+        assert torch.equal(both[0], both[1])
+    if rank == 0:
+        torch.save(g, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_video_rank_plus_image_rank(tmp_path, graphed):
+    def go(world, name):
+        port = _free_port()
+        ctx = mp.get_context("spawn")
+        out = str(tmp_path / name)
+        procs = [ctx.Process(target=_hetero_worker, args=(r, world, port, out, graphed))
+                 for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(600)
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        return torch.load(out)
+    one, two = go(1, "h1.pt"), go(2, "h2.pt")
+    assert float(one.abs().max()) > 0
+    assert float((one - two).abs().max()) < 2e-3 * float(one.abs().max())
+    cos = torch.dot(one.double(), two.double()) / (one.double().norm() * two.double().norm())
+    assert cos > 0.99999

@@ -52,3 +52,42 @@ def test_consistency_switch(mode):
 def test_bad_mode_raises():
     with pytest.raises(NotImplementedError):
         losses.get_lambdas_dict(_cfg("huber"))
+
+
+def test_rank_roles_of_the_published_recipe():
+    """slowfast/datasets/loader.py:186-201 with configs/ssv2.yaml: GPUs 0-6 train 9 clips each,
+    GPU 7 trains 63 still images."""
+    from svit_amd import dp
+    cfg = config.ssv2_cfg(num_frames=16, crop=224, num_gpus=8)
+    roles = [dp.rank_role(cfg, r) for r in range(8)]
+    assert [r.is_image for r in roles] == [False] * 7 + [True]
+    assert [r.data_rank for r in roles] == [0, 1, 2, 3, 4, 5, 6, 0]
+    assert [r.replicas for r in roles] == [7] * 7 + [1]
+    assert [r.batch_size for r in roles] == [9] * 7 + [63]
+    cfg.IMAGE_TRAIN.GPU_IDS = [2, 5]
+    cfg.IMAGE_TRAIN.BATCH_SIZE, cfg.TRAIN.BATCH_SIZE = 64, 48
+    roles = [dp.rank_role(cfg, r) for r in range(8)]
+    assert [r.is_image for r in roles] == [False, False, True, False, False, True, False, False]
+    assert roles[5].data_rank == 1 and roles[5].batch_size == 32 and roles[6].data_rank == 4
+    assert roles[6].batch_size == 8 and roles[6].replicas == 6
+
+
+def test_image_rank_loss_host_path_matches_oracle():
+    """the boolean-index formulation kept for host tensors == oracle restatement (pinned by the
+    reference's numbers in tests/test_oracle_golden.py)."""
+    from oracle import procedural as P
+    from oracle import svit_ref as R
+    cfg = config.ssv2_cfg(num_frames=4, crop=64)
+    meta = P.haog_meta(5)
+    g = torch.Generator().manual_seed(5)
+    extra = {"pred_bboxes": torch.cat((torch.randn(5, 1, 4, 1, generator=g),
+                                       torch.rand(5, 1, 4, 4, generator=g) * 0.5 + 0.2), -1),
+             "pred_contact_state": torch.randn(5, 1, 2, 5, generator=g)}
+    fn = losses.VideoImageLoss(cfg, is_video_rank=False)
+    fn.train()
+    d = fn(None, extra, None, meta)
+    total, parts = R.image_loss(extra, meta, R.loss_weights(cfg.SVIT.LAMBDA_NODES, cfg.SVIT.LAMBDA_EDGES))
+    assert set(d) == set(parts)
+    for k in parts:
+        assert torch.allclose(d[k], parts[k], atol=1e-6), k
+    assert torch.allclose(fn.total(d), total, atol=1e-5)

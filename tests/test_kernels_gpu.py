@@ -529,3 +529,52 @@ def test_clip_adamw(ops):
         ops.adamw_step(p, g, m, v, ss, 1.0, 1e-3, 0.9, 0.999, 1e-8, 1e-4, step)
         R.clip_and_adamw_step(pw, {"w": g.cpu()}, st, 1e-3, step, 1.0, lambda n_, s_: 1e-4)
         assert float((p.cpu() - pw["w"]).abs().max()) < 2e-6
+
+
+# ------------------------------------------------------------ image-rank HAOG losses ----
+@pytest.mark.parametrize("case", ["mixed", "all_empty", "ties"])
+def test_haog_loss_fused(ops, case):
+    """svit_haog_loss (+_bwd) against the boolean-index torch formulation of the reference
+    (svit_amd.losses host path == slowfast/models/losses.py:50-93,138-155), values and grads."""
+    from svit_amd import config, losses
+    cfg = config.ssv2_cfg(num_frames=4, crop=64)
+    B, T = 7, 1
+    g = torch.Generator().manual_seed(11)
+    boxes = torch.rand(B, T, 4, 4, generator=g) * 0.5 + 0.2
+    logit = torch.randn(B, T, 4, 1, generator=g)
+    contact = torch.randn(B, T, 2, 5, generator=g)
+    tar = torch.rand(B, T, 4, 4, generator=g) * 0.5 + 0.2
+    tar[torch.rand(B, T, 4, generator=g) > 0.6] = 0.0
+    ctar = torch.randint(-1, 5, (B, 2), generator=g)
+    if case == "all_empty":
+        tar.zero_()
+        ctar.fill_(-1)
+    if case == "ties":                      # prediction == target: min/max ties, |d| = 0
+        tar[0] = boxes[0]
+        tar[1, 0, :, :2] = boxes[1, 0, :, :2]
+    res = {}
+    for dev in ("cpu", DEV):
+        pb = torch.cat((logit, boxes), -1).to(dev).requires_grad_(True)
+        pc = contact.clone().to(dev).requires_grad_(True)
+        fn = losses.VideoImageLoss(cfg, is_video_rank=False)
+        d = fn(None, {"pred_bboxes": pb, "pred_contact_state": pc}, None,
+               {"haog_bboxes": tar.to(dev), "contact_state": ctar.to(dev)})
+        total = fn.total(d)
+        if total.requires_grad:
+            total.backward()
+        res[dev] = ({k: float(v.detach()) for k, v in d.items()}, float(total.detach()),
+                    pb.grad.cpu() if pb.grad is not None else torch.zeros_like(pb).cpu(),
+                    pc.grad.cpu() if pc.grad is not None else torch.zeros_like(pc).cpu(), fn)
+    ref, got = res["cpu"], res[DEV]
+    for k, v in ref[0].items():
+        assert abs(got[0][k] - v) <= 2e-6 + 1e-5 * abs(v), (k, got[0][k], v)
+    assert abs(got[1] - ref[1]) <= 1e-5 * max(1.0, abs(ref[1]))
+    assert float((got[2] - ref[2]).abs().max()) <= 1e-6 + 1e-5 * float(ref[2].abs().max())
+    assert float((got[3] - ref[3]).abs().max()) <= 1e-6 + 1e-5 * float(ref[3].abs().max())
+    stats = got[4].last_stats.cpu()
+    valid = int((~(tar == 0).all(-1)).sum())
+    assert int(stats[0]) == valid and int(stats[1]) == int((ctar >= 0).sum()) and int(stats[2]) == 0
+    if case == "all_empty":
+        assert got[0]["boxes_l1_loss"] == 0.0 and got[0]["boxes_giou_loss"] == 0.0
+        assert got[0]["loss_contact_state"] == 0.0 and float(got[3].abs().max()) == 0.0
+        assert float(got[2][..., 1:].abs().max()) == 0.0 and float(got[2][..., 0].abs().max()) > 0

@@ -28,6 +28,17 @@ def test_step_parity_vs_oracle(frames, crop, batch, frames_path):
     S.check(res)
 
 
+def test_image_rank_step_parity_vs_oracle():
+    """a still-image batch [B,3,1,S,S] with the HAOG box / contact losses
+    (fused svit_haog_loss) -- losses and every parameter gradient against the fp32 oracle, whose
+    image loss is itself pinned by the reference's numbers (tests/test_oracle_golden.py)."""
+    res = S.compare_step(4, 64, 3, image=True)
+    print(res)
+    S.check(res)
+    assert res["loss_rel"] < 2e-2, res
+    assert all(v < 2e-2 for v in res["parts_abs"].values()), res
+
+
 @pytest.mark.parametrize("name", ["tiny", "c1", "tiny_odd"])
 def test_against_reference_golden(name, manifest, golden_dir):
     """Same closed-form weights/inputs as oracle/gen_golden.py fed to the reference."""
