@@ -288,6 +288,24 @@ int svit_haog_loss(const float* pred, const float* tar, const float* contact,
 int svit_haog_loss_bwd(const float* upstream, const float* g_l1, const float* g_bce,
                        const float* g_giou, const float* g_contact, float* dpred,
                        float* dcontact, int R, int Rc, void* stream);
+
+/* ---------------------------------------- multi-view test ensemble ---------- */
+/* TestMeter.update_stats (slowfast/utils/meters.py:303-336) for one batch, on the device: clip n
+ * belongs to video clip_ids[n] / num_clips; video_preds[v] (f32 [V,C]) += preds[n] (mode 0, "sum")
+ * or = max(.,.) (mode 1, "max") in BATCH ORDER (bit-identical to the reference's sequential
+ * loop), video_labels[v] = labels[n], clip_count[v] += 1.  `repeat` folds the batch's clips of a
+ * video cyclically that many times (de-duplicated NUM_ENSEMBLE_VIEWS).  err int32 [4]:
+ * {clip ids out of range, label conflicts (the reference's assert), labels out of range, 0},
+ * incremented, never cleared. */
+int svit_ensemble_update(const float* preds, const int64_t* labels, const int64_t* clip_ids,
+                         int N, int C, int num_clips, int num_videos, int mode, int repeat,
+                         float* video_preds, int64_t* video_labels, int64_t* clip_count,
+                         int* err, void* stream);
+/* metrics.topks_correct (slowfast/utils/metrics.py:9-50): counts[i] += #videos whose label is
+ * among the ks[i] best scores (ties: lower class index first).  ks int32 [nk] on the device,
+ * nk <= 8; counts int32 [nk] pre-zeroed. */
+int svit_topk_correct(const float* video_preds, const int64_t* video_labels, int V, int C,
+                      const int* ks, int nk, int* counts, int* err, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -326,6 +326,76 @@ def run_loss_optim_cases(out_dir, manifest):
     print("loss/optim worst disagreement:", max(agree.values()), agree, flush=True)
 
 
+def run_meter_case(out_dir, manifest):
+    """The reference's own TestMeter / topks_correct / uniform_crop on a seeded stream of clip
+    predictions: 12 videos x (2 ensemble views x 3 crops), 29 classes,
+    batches of 8 clips in dataset order and in a shuffled order, "sum" and "max"."""
+    ref_shim.install()
+    import importlib.util
+    import slowfast.utils.meters as meters
+    import slowfast.utils.metrics as metrics
+    # slowfast.datasets is a stub package (its __init__ pulls decoders the image lacks): point it
+    # at the real directory so that the unmodified transform.py (and the two augmentation files it
+    # imports) load from the reference tree; torchvision.transforms is plumbing uniform_crop never
+    # touches
+    tv = sys.modules["torchvision"]
+    tv.transforms = ref_shim._mod("torchvision.transforms")
+    tv.transforms.functional = ref_shim._mod("torchvision.transforms.functional")
+    sys.modules["slowfast.datasets"].__path__ = [ref_shim.REFERENCE_ROOT + "/slowfast/datasets"]
+    import slowfast.datasets.transform as transform
+    import meter_ref
+    V, views, crops, C, bs = 12, 2, 3, 29, 8
+    n = V * views * crops
+    u = P.hash_uniform("meter:preds", n * C).astype(np.float32).reshape(n, C)
+    probs = torch.softmax(torch.from_numpy(u) * 3.0, dim=1)
+    labels_v = torch.from_numpy(((P.hash_uniform("meter:labels", V) + 1) * 0.5 * C).astype(np.int64)).clamp_(0, C - 1)
+    # make the label the strongest class for about half of the videos so top-1/5 are not trivial
+    for v in range(0, V, 2):
+        probs[v * views * crops:(v + 1) * views * crops, labels_v[v]] += 0.08
+    order = {"ordered": np.arange(n),
+             "shuffled": np.argsort(P.hash_uniform("meter:perm", n), kind="stable")}
+    arrays = {"probs": probs.numpy(), "labels_v": labels_v.numpy()}
+    agree = {}
+    for oname, perm in order.items():
+        arrays["perm_" + oname] = perm.astype(np.int64)
+        for method in ("sum", "max"):
+            m = meters.TestMeter(V, views * crops, C, (n + bs - 1) // bs, ensemble_method=method)
+            r = meter_ref.TestMeterRef(V, views * crops, C, ensemble_method=method)
+            for a in range(0, n, bs):
+                ids = torch.from_numpy(perm[a:a + bs].astype(np.int64))
+                lab = labels_v[ids // (views * crops)]
+                m.update_stats(probs[ids], lab, ids)
+                r.update_stats(probs[ids].numpy(), lab.numpy(), ids.numpy())
+            m.finalize_metrics(ks=(1, 5))
+            key = "%s_%s" % (oname, method)
+            arrays[key + "_video_preds"] = m.video_preds.numpy()
+            arrays[key + "_clip_count"] = m.clip_count.numpy()
+            arrays[key + "_video_labels"] = m.video_labels.numpy()
+            correct = [int(c) for c in metrics.topks_correct(m.video_preds, m.video_labels, (1, 5))]
+            arrays[key + "_topk_correct"] = np.array(correct, np.int64)
+            rstats, rcorrect = r.finalize_metrics((1, 5))
+            assert np.array_equal(r.video_preds, m.video_preds.numpy()), key       # bit-exact
+            assert np.array_equal(r.clip_count, m.clip_count.numpy()) and rcorrect == correct
+            assert rstats["top1_acc"] == m.stats["top1_acc"] and rstats["top5_acc"] == m.stats["top5_acc"]
+            agree[key] = {"top1_acc": m.stats["top1_acc"], "top5_acc": m.stats["top5_acc"],
+                          "correct": correct}
+    # uniform_crop of the reference: offsets recovered from a coordinate image
+    crops_tab = []
+    for (h, w, size) in [(224, 298, 224), (312, 415, 312), (300, 224, 224), (224, 224, 224), (225, 301, 224)]:
+        yy, xx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+        img = torch.stack([yy, xx]).float().unsqueeze(0)            # [1, 2, H, W]
+        for sidx in range(3):
+            c, _ = transform.uniform_crop(img, size, sidx)
+            y0, x0 = int(c[0, 0, 0, 0]), int(c[0, 1, 0, 0])
+            assert (y0, x0) == meter_ref.uniform_crop_offsets(h, w, size, sidx)
+            crops_tab.append([h, w, size, sidx, y0, x0])
+    arrays["crop_offsets"] = np.array(crops_tab, np.int64)
+    np.savez_compressed(os.path.join(out_dir, "meter.npz"), **arrays)
+    manifest["meter"] = {"videos": V, "ensemble_views": views, "spatial_crops": crops, "classes": C,
+                         "batch": bs, "results": agree}
+    print("meter", agree)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(HERE, "..", "tests", "golden"))
@@ -356,6 +426,8 @@ def main():
         run_model_case("tiny_frames", 4, 64, 3, args.out, manifest, frames_path=True)
     if on("loss_optim"):
         run_loss_optim_cases(args.out, manifest)
+    if on("meter"):
+        run_meter_case(args.out, manifest)
     if on("c1"):
         run_model_case("c1", 8, 224, 1, args.out, manifest, eval_too=True)
     if on("c2_fwd"):

@@ -174,7 +174,8 @@ def install():
     _mod("fvcore.nn.flop_count", flop_count=None)
     _mod("fvcore.nn.precise_bn", get_bn_modules=None, update_bn_stats=None)
     import json
-    _mod("simplejson", dumps=json.dumps, loads=json.loads)
+    _mod("simplejson", loads=json.loads,
+         dumps=lambda o, **kw: json.dumps(o, sort_keys=kw.get("sort_keys", False)))
     _mod("torchvision")
     _mod("torchvision.ops")
     _mod("torchvision.ops.boxes",
@@ -182,6 +183,7 @@ def install():
     ds = _mod("slowfast.datasets")
     ds.__path__ = []
     _mod("slowfast.datasets.utils", pack_pathway_output=lambda cfg, frames: [frames])
+    _mod("slowfast.datasets.ava_helper")     # AVA plumbing imported (not used) by utils/meters.py
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
 

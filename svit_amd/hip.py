@@ -138,6 +138,8 @@ _SIGS = {
     "svit_adamw_step": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, i32, f32, vp]),
     "svit_haog_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "svit_haog_loss_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "svit_ensemble_update": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "svit_topk_correct": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, vp]),
 }
 EXPORTS = tuple(sorted(_SIGS))
 

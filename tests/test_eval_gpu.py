@@ -1,0 +1,173 @@
+"""Multi-view test ensemble on the device (svit_amd/evaluate.py) against the
+reference's own TestMeter / topks_correct results (tests/golden/meter.npz) and the CPU oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from oracle import meter_ref
+from oracle import procedural as P
+from oracle import svit_ref as R
+from tests import smoke_impl as S
+
+
+def _stream(golden_dir, manifest):
+    g = np.load(os.path.join(golden_dir, "meter.npz"))
+    m = manifest["meter"]
+    return g, m, m["ensemble_views"] * m["spatial_crops"]
+
+
+@pytest.mark.parametrize("order", ["ordered", "shuffled"])
+@pytest.mark.parametrize("method", ["sum", "max"])
+def test_device_meter_bit_exact_vs_reference(order, method, golden_dir, manifest):
+    from svit_amd.evaluate import TestMeter
+    g, m, num_clips = _stream(golden_dir, manifest)
+    probs, labels_v, perm = torch.from_numpy(g["probs"]), torch.from_numpy(g["labels_v"]), g["perm_" + order]
+    meter = TestMeter(m["videos"], num_clips, m["classes"], 1, ensemble_method=method)
+    for a in range(0, len(perm), m["batch"]):
+        ids = torch.from_numpy(perm[a:a + m["batch"]])
+        meter.update_stats(probs[ids].cuda(), labels_v[ids // num_clips].cuda(), ids.cuda())
+    key = "%s_%s" % (order, method)
+    assert np.array_equal(meter.video_preds.cpu().numpy(), g[key + "_video_preds"])     # bit-exact
+    assert np.array_equal(meter.clip_count.cpu().numpy(), g[key + "_clip_count"])
+    assert np.array_equal(meter.video_labels.cpu().numpy(), g[key + "_video_labels"])
+    assert meter.topks_correct((1, 5)) == list(g[key + "_topk_correct"])
+    stats = meter.finalize_metrics((1, 5))
+    want = m["results"][key]
+    assert stats["top1_acc"] == want["top1_acc"] and stats["top5_acc"] == want["top5_acc"]
+    meter.reset()
+    assert float(meter.video_preds.abs().max()) == 0 and int(meter.clip_count.sum()) == 0
+
+
+def test_deduplicated_views_fold_like_the_full_stream():
+    """30 listed clips per video = 3 unique crops x 10 identical views: folding the 3 unique ones
+    cyclically 10 times must equal the reference's 30 sequential additions bit for bit."""
+    from svit_amd.evaluate import TestMeter
+    V, crops, views, C = 5, 3, 10, 174
+    g = torch.Generator().manual_seed(2)
+    uniq = torch.softmax(torch.randn(V * crops, C, generator=g), dim=1)
+    labels_v = torch.randint(0, C, (V,), generator=g)
+    ref = meter_ref.TestMeterRef(V, crops * views, C)
+    table = meter_ref.test_views(V, views, crops)
+    ids = np.arange(len(table))
+    full = torch.stack([uniq[v * crops + s] for v, s in table])
+    for a in range(0, len(ids), 8):                                     # the reference's stream
+        sl = ids[a:a + 8]
+        ref.update_stats(full[sl].numpy(), labels_v[sl // (crops * views)].numpy(), sl)
+    meter = TestMeter(V, crops, C, 1)
+    uid = torch.arange(V * crops)
+    for a in range(0, V * crops, 6):                                    # two videos per batch
+        sl = uid[a:a + 6]
+        meter.update_stats(uniq[sl].cuda(), labels_v[sl // crops].cuda(), sl.cuda(), repeat=views)
+    assert np.array_equal(meter.video_preds.cpu().numpy(), ref.video_preds)
+    assert np.array_equal(meter.clip_count.cpu().numpy(), ref.clip_count)
+    assert meter.topks_correct((1, 5)) == ref.finalize_metrics((1, 5))[1]
+
+
+def test_meter_reports_what_the_reference_asserts():
+    from svit_amd.evaluate import TestMeter
+    meter = TestMeter(4, 3, 7, 1)
+    p = torch.rand(3, 7).cuda()
+    meter.update_stats(p, torch.tensor([2, 2, 3]).cuda(), torch.tensor([0, 1, 2]).cuda())  # label flips
+    with pytest.raises(AssertionError):
+        meter.finalize_metrics((1, 5))
+    meter = TestMeter(4, 3, 7, 1)
+    meter.update_stats(p, torch.tensor([2, 2, 2]).cuda(), torch.tensor([0, 1, 12]).cuda())  # video 4 of 4
+    with pytest.raises(IndexError):
+        meter.finalize_metrics((1, 5))
+    with pytest.raises(NotImplementedError):
+        TestMeter(4, 3, 7, 1, ensemble_method="mean")
+    with pytest.raises(ValueError):
+        TestMeter(4, 3, 7, 1).update_stats(torch.rand(3, 6).cuda(), torch.zeros(3).cuda(), torch.zeros(3).cuda())
+
+
+def test_three_crop_ensemble_end_to_end():
+    """perform_test on a tiny model: 3 videos x 3 spatial crops (dedupe: x10 views folded), eval
+    probabilities of the HIP path vs the fp32 oracle through the oracle's meter."""
+    from svit_amd import evaluate
+    cfg, model, spec, sd = S.build_hip_model(4, 64, train=False)
+    V, crops = 3, cfg.TEST.NUM_SPATIAL_CROPS
+    wide = P.tensor("input:wide", (V, 3, 4, 64, 85), amp=1.0)
+    labels_v = torch.tensor([5, 17, 101])
+    clips = evaluate.spatial_crops(wide.cuda(), 64, crops)               # [9,3,4,64,64]
+    for v in range(V):
+        for s in range(3):
+            y, x = meter_ref.uniform_crop_offsets(64, 85, 64, s)
+            assert torch.equal(clips[v * 3 + s].cpu(), wide[v, :, :, y:y + 64, x:x + 64])
+    ids = torch.arange(V * crops)
+    loader = [([clips[a:a + 4]], labels_v[ids[a:a + 4] // crops].cuda(), ids[a:a + 4].cuda(), {})
+              for a in range(0, V * crops, 4)]
+    meter = evaluate.TestMeter(V, crops, cfg.MODEL.NUM_CLASSES, len(loader))
+    evaluate.perform_test(loader, model, meter, cfg)
+    ref = meter_ref.TestMeterRef(V, crops * cfg.TEST.NUM_ENSEMBLE_VIEWS, cfg.MODEL.NUM_CLASSES)
+    with torch.no_grad():
+        probs, _ = R.forward({k: v for k, v in sd.items()}, spec, clips.cpu(), training=False)
+    for rep in range(cfg.TEST.NUM_ENSEMBLE_VIEWS):
+        ref.update_stats(probs.numpy(), labels_v[ids // crops].numpy(),
+                         (ids // crops * crops * cfg.TEST.NUM_ENSEMBLE_VIEWS + rep * crops + ids % crops).numpy())
+    got = meter.video_preds.cpu().numpy()
+    assert np.array_equal(meter.clip_count.cpu().numpy(), ref.clip_count)          # 30 per video
+    np.testing.assert_allclose(got, ref.video_preds, atol=0.03)      # sums of 30 probabilities
+    assert S.cosine(torch.from_numpy(got), torch.from_numpy(ref.video_preds)) > 0.999
+    # the device top-k equals the oracle's counting rule applied to the same scores
+    assert meter.topks_correct((1, 5)) == meter_ref.topks_correct(got, labels_v.numpy(), (1, 5))
+    assert set(meter.stats) == {"split", "top1_acc", "top5_acc"}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _merge_worker(rank, world, port, golden_dir, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from svit_amd.evaluate import TestMeter
+    g = np.load(os.path.join(golden_dir, "meter.npz"))
+    probs, labels_v, perm = torch.from_numpy(g["probs"]), torch.from_numpy(g["labels_v"]), g["perm_shuffled"]
+    meter = TestMeter(12, 6, 29, 1)
+    for i, a in enumerate(range(0, len(perm), 8)):
+        if i % world != rank:                     # DistributedSampler-like split of the batches
+            continue
+        ids = torch.from_numpy(perm[a:a + 8])
+        meter.update_stats(probs[ids].cuda(), labels_v[ids // 6].cuda(), ids.cuda())
+    meter.all_reduce()
+    stats = meter.finalize_metrics((1, 5))
+    if rank == 0:
+        torch.save({"preds": meter.video_preds.cpu(), "count": meter.clip_count.cpu(),
+                    "labels": meter.video_labels.cpu(), "stats": stats}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_merge_with_one_allreduce(tmp_path, golden_dir, manifest):
+    port, out = _free_port(), str(tmp_path / "m.pt")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_merge_worker, args=(r, 2, port, golden_dir, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    res = torch.load(out)
+    g = np.load(os.path.join(golden_dir, "meter.npz"))
+    np.testing.assert_allclose(res["preds"].numpy(), g["shuffled_sum_video_preds"], rtol=1e-6, atol=1e-7)
+    assert np.array_equal(res["count"].numpy(), g["shuffled_sum_clip_count"])
+    assert np.array_equal(res["labels"].numpy(), g["shuffled_sum_video_labels"])
+    want = manifest["meter"]["results"]["shuffled_sum"]
+    assert res["stats"]["top1_acc"] == want["top1_acc"] and res["stats"]["top5_acc"] == want["top5_acc"]

@@ -179,3 +179,39 @@ def test_shape_tables():
     assert sum(int(np.prod(v)) for v in R.param_shapes(s8).values()) == 34360504
     s5 = R.make_spec(16, 312)
     assert [b.rel_sp_rows for b in s5.blocks][3] == 37 and s5.blocks[15].rel_sp_rows == 17
+
+
+def test_meter_restatement_vs_reference_golden(manifest, golden_dir):
+    """oracle/meter_ref.py (TestMeter, topks_correct, uniform_crop offsets, view table) against
+    the numbers the reference's own classes produced (oracle/gen_golden.py::run_meter_case), and
+    the host-side copies in svit_amd/evaluate.py."""
+    from oracle import meter_ref
+    from svit_amd import config, evaluate
+    g = np.load(os.path.join(golden_dir, "meter.npz"))
+    m = manifest["meter"]
+    num_clips = m["ensemble_views"] * m["spatial_crops"]
+    for order in ("ordered", "shuffled"):
+        perm = g["perm_" + order]
+        for method in ("sum", "max"):
+            r = meter_ref.TestMeterRef(m["videos"], num_clips, m["classes"], method)
+            for a in range(0, len(perm), m["batch"]):
+                ids = perm[a:a + m["batch"]]
+                r.update_stats(g["probs"][ids], g["labels_v"][ids // num_clips], ids)
+            key = "%s_%s" % (order, method)
+            assert np.array_equal(r.video_preds, g[key + "_video_preds"])          # bit-exact
+            assert np.array_equal(r.clip_count, g[key + "_clip_count"])
+            assert np.array_equal(r.video_labels, g[key + "_video_labels"])
+            stats, correct = r.finalize_metrics((1, 5))
+            assert correct == list(g[key + "_topk_correct"])
+            assert stats["top1_acc"] == m["results"][key]["top1_acc"]
+            assert stats["top5_acc"] == m["results"][key]["top5_acc"]
+    for h, w, size, sidx, y0, x0 in g["crop_offsets"]:
+        assert meter_ref.uniform_crop_offsets(int(h), int(w), int(size), int(sidx)) == (y0, x0)
+        assert evaluate.uniform_crop_offsets(int(h), int(w), int(size), int(sidx)) == (y0, x0)
+    cfg = config.ssv2_cfg(16, 224)
+    assert evaluate.unique_views(cfg) == (3, 10)
+    views = meter_ref.test_views(2, 10, 3)
+    assert len(views) == 60 and views[31] == (1, 1) and {s for _, s in views} == {0, 1, 2}
+    with pytest.raises(AssertionError):
+        bad = meter_ref.TestMeterRef(2, 3, 4)
+        bad.update_stats(np.ones((2, 4), np.float32), [1, 2], [0, 1])
