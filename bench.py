@@ -141,6 +141,9 @@ def main():
                     help="the published recipe's heterogeneous layout: the LAST k ranks train still "
                          "images with the HAOG losses (IMAGE_TRAIN.GPU_IDS; SURVEY 8(f) rank 2)")
     ap.add_argument("--image-batch", type=int, default=63, help="images per image rank")
+    ap.add_argument("--u8", action="store_true",
+                    help="feed decoded uint8 frames [B,T,S,S,3]; normalisation fused into the patch "
+                         "embedding (svit_amd/input.py; SURVEY 8(f) rank 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-trace", action="store_true")
     ap.add_argument("--eager", action="store_true",
@@ -181,6 +184,14 @@ def main():
 
         def ce(preds, extra, labels):
             return torch.nn.functional.cross_entropy(preds, labels)
+    if args.u8:
+        if is_image or args.frames_pass:
+            raise SystemExit("--u8 is wired for the clip step only")
+        from svit_amd.input import U8Clips
+        g = torch.Generator(device="cpu").manual_seed(cfg.RNG_SEED + rank)
+        x = U8Clips(torch.randint(0, 256, (args.batch, args.frames, args.crop, args.crop, 3),
+                                  generator=g, dtype=torch.uint8).to(dev), args.crop,
+                    mean=cfg.DATA.MEAN, std=cfg.DATA.STD)
     core = model.module if hasattr(model, "module") else model
     frames_pass = args.frames_pass and not is_image    # stills have no frames pass (train_net.py:105)
 
@@ -243,7 +254,7 @@ def main():
                                                  " + no-grad frames pass" if args.frames_pass else ""),
                    "global_batch": args.batch * world, "seq_len": None,
                    "parallelism": "dp%d" % world,
-                   "launch": launch_note},
+                   "launch": launch_note, "input": "uint8 frames" if args.u8 else "fp32 clips"},
         "loss": round(loss_val, 4),
         "step_mfma_frac": round(clips_per_s / max(1, n_vid) * STEP_GFLOP_PER_CLIP * 1e9 /
                                 (MFMA_PEAK_TFLOPS * 1e12), 4),

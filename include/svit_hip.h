@@ -116,6 +116,15 @@ int svit_layernorm_bwd(const void* dy /* f32, or bf16 when dy_is_bf16 */, int dy
 /* im2col for Conv3d(3->96, k(3,7,7), s(2,4,4), p(1,3,3)) (stem_helper.py:309-320):
  * video f32 [B,3,T,H,W] -> cols bf16 [B*T'*H'*W', 448] (441 taps, zero-padded to 448). */
 int svit_im2col_patch(const float* video, void* cols, int B, int T, int H, int W, void* stream);
+/* The same operand straight from decoded uint8 frames: frames u8
+ * [V,T,Hs,Ws,3] (T H W C per video, `frames_bytes` = size of the buffer), lut bf16 [3,256] =
+ * bf16((u/255 - mean[c]) / std[c]) (datasets/utils.py:287-303), crops int32 [B,3] = (source video,
+ * y0, x0) per output clip (transform.py:327-342; NULL: clip b = video b at (0,0)); the S x S
+ * window is normalised, zero-padded and laid out as cols bf16 [B*T'*S'*S', 448]. The crop table
+ * is NOT range-checked on the device: the caller guarantees y0 + S <= Hs, x0 + S <= Ws, v < V. */
+int svit_im2col_patch_u8(const uint8_t* frames, int64_t frames_bytes, const void* lut,
+                         const int32_t* crops, void* cols, int B, int T, int Hs, int Ws, int S,
+                         void* stream);
 /* cls / object token rows of the block-0 input (video_model_builder.py:326-363). */
 int svit_fill_special_tokens(float* x, const float* cls, const float* objq, const float* pos_t,
                              int B, int N, int L, int Tx, int O, int C, int add_pos, void* stream);

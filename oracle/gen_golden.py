@@ -396,6 +396,57 @@ def run_meter_case(out_dir, manifest):
     print("meter", agree)
 
 
+def run_layout_case(out_dir, manifest):
+    """Checkpoint / optimizer-state layout of the reference: the order of
+    `named_parameters()`, the param groups `construct_optimizer` builds, and the structure of the
+    file `cu.save_checkpoint` writes -- names, shapes, dtypes and a few digests (data, no code)."""
+    import shutil
+    import tempfile
+    ref_shim.install()
+    import slowfast.models.optimizer as optim
+    import slowfast.utils.checkpoint as cu
+    cfg, model, shapes, sd = build_reference(16, 224)
+    names = [n for n, _ in model.named_parameters()]
+    opt = optim.construct_optimizer(model, cfg)
+    for i, (n, p) in enumerate(model.named_parameters()):        # one step so the state exists
+        p.grad = 1e-3 * P.tensor("layout:grad:" + n, tuple(p.shape))
+    opt.step()
+    tmp = tempfile.mkdtemp(prefix="svit_layout_")
+    try:
+        path = cu.save_checkpoint(tmp, model, opt, 4, cfg, scaler=torch.cuda.amp.GradScaler(enabled=False))
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    osd = ck["optimizer_state"]
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    order = [name_of[id(p)] for g in opt.param_groups for p in g["params"]]   # state index -> name
+    groups = [{k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in g.items()}
+              for g in osd["param_groups"]]
+    st0 = osd["state"][0]
+    layout = {
+        "file_name": os.path.basename(path),
+        "top_level_keys": sorted(ck.keys()), "epoch": ck["epoch"],
+        "cfg_type": type(ck["cfg"]).__name__,
+        "named_parameters": names,
+        "model_state_keys": list(ck["model_state"].keys()),
+        "shapes": {n: list(shapes[n]) for n in names},
+        "param_groups": groups,
+        "state_entry_keys": sorted(st0.keys()),
+        "state_step": {"type": type(st0["step"]).__name__, "value": float(st0["step"]),
+                       "dtype": str(getattr(st0["step"], "dtype", ""))},
+        "scaler_state": {k: (v if not torch.is_tensor(v) else float(v)) for k, v in ck["scaler_state"].items()},
+        "optimizer_order": order,
+        "digests": {order[j]: {"index": j, "param": P.digest(ck["model_state"][order[j]]),
+                               "exp_avg": P.digest(osd["state"][j]["exp_avg"]),
+                               "exp_avg_sq": P.digest(osd["state"][j]["exp_avg_sq"])}
+                    for j in range(0, len(order), 57)},
+    }
+    json.dump(layout, open(os.path.join(out_dir, "layout.json"), "w"), indent=1, sort_keys=True)
+    manifest["layout"] = {"file": "layout.json", "params": len(names),
+                          "groups": [len(g["params"]) for g in groups]}
+    print("layout", manifest["layout"], layout["state_step"], layout["top_level_keys"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(HERE, "..", "tests", "golden"))
@@ -428,6 +479,8 @@ def main():
         run_loss_optim_cases(args.out, manifest)
     if on("meter"):
         run_meter_case(args.out, manifest)
+    if on("layout"):
+        run_layout_case(args.out, manifest)
     if on("c1"):
         run_model_case("c1", 8, 224, 1, args.out, manifest, eval_too=True)
     if on("c2_fwd"):

@@ -161,9 +161,8 @@ def param_shapes(plan: Plan):
         s[p + "attn.qkv.bias"] = (3 * b.dim_out,)
         s[p + "attn.proj.weight"] = (b.dim_out, b.dim_out)
         s[p + "attn.proj.bias"] = (b.dim_out,)
-        for r in "qkv":
+        for r in "qkv":      # attention.py:263-304 registers pool_q, norm_q, pool_k, norm_k, ...
             s[p + "attn.pool_%s.weight" % r] = (HEAD_DIM, 1, 3, 3, 3)
-        for r in "qkv":
             s[p + "attn.norm_%s.weight" % r] = (HEAD_DIM,)
             s[p + "attn.norm_%s.bias" % r] = (HEAD_DIM,)
         s[p + "norm2.weight"] = (b.dim_out,)

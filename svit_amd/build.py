@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libsvit_hip.so")
 SOURCES = ["gemm_nt.hip", "gemm_tn.hip", "norm.hip", "misc.hip", "pool.hip", "attn_fwd.hip", "attn_bwd.hip",
-           "loss.hip", "meter.hip"]
+           "loss.hip", "meter.hip", "input.hip"]
 HEADERS = ["common.h", "attn_common.h", "gemm_epilogue.h", os.path.join("..", "..", "include", "svit_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffast-math",

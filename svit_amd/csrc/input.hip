@@ -1,0 +1,97 @@
+// Input pipeline fused into the patch embedding -- gfx950.
+//
+// The reference normalises decoded uint8 frames on the host ((u/255 - mean)/std,
+// slowfast/datasets/utils.py:287-303), permutes T H W C -> C T H W, crops (transform.py:288-348)
+// and ships fp32 clips to the GPU (misc.iter_to_cuda, slowfast/utils/misc.py:374-387): 4 bytes
+// per sample over PCIe and HBM, plus a materialised copy per spatial crop.  Here the clip stays
+// uint8 [V,T,Hs,Ws,3] in HBM; normalisation is a 3 x 256-entry table (built with the reference's
+// own fp32 operation order, so the values are bit-identical), the crop is an (y0, x0) offset per
+// output clip, and both are applied while the im2col rows of Conv3d(3->96, k(3,7,7), s(2,4,4),
+// p(1,3,3)) (stem_helper.py:309-320) are assembled -- same [rows, 448] bf16 operand as
+// svit_im2col_patch, a quarter of the input bytes, no per-crop copy.
+#include "common.h"
+#include "../../include/svit_hip.h"
+
+namespace {
+constexpr int XO = 62;                  // output positions per chunk
+constexpr int COLS = XO * 4 + 4;        // clip columns held per chunk: x in [xc0*4 - 4, xc0*4 + 248)
+
+__global__ __launch_bounds__(256) void im2col_patch_u8_kernel(
+    const uint8_t* __restrict__ frames, int64_t frames_bytes, const bf16_t* __restrict__ lut,
+    const int32_t* __restrict__ crops, bf16_t* __restrict__ cols, int T, int Hs, int Ws, int S,
+    int To, int Ho, int Wo) {
+  __shared__ bf16_t img[63][COLS + 4];  // [(c*3+kt)*7+ky][x - x_start], normalised, 0 = padding
+  __shared__ bf16_t tab[768];
+  const int yo = blockIdx.x % Ho, to = (blockIdx.x / Ho) % To, b = blockIdx.x / (Ho * To);
+  const int v = crops ? crops[b * 3] : b, y0 = crops ? crops[b * 3 + 1] : 0,
+            x0 = crops ? crops[b * 3 + 2] : 0;
+  for (int i = threadIdx.x; i < 768; i += 256) tab[i] = lut[i];
+  bf16_t* out = cols + (((int64_t)b * To + to) * Ho + yo) * Wo * 448;
+  for (int xc0 = 0; xc0 < Wo; xc0 += XO) {
+    const int x_start = xc0 * 4 - 4;
+    __syncthreads();                    // table ready / previous chunk's readers done
+    // zero the image (padding), then drop the in-frame bytes of each (kt, ky) line: the three
+    // channels of a pixel are adjacent bytes, so a line is one contiguous span of COLS*3 bytes
+    for (int i = threadIdx.x; i < 63 * (COLS + 4) / 2; i += 256) ((uint32_t*)img)[i] = 0u;
+    __syncthreads();
+    for (int line = 0; line < 21; ++line) {
+      const int ky = line % 7, kt = line / 7;
+      const int t = to * 2 - 1 + kt, y = yo * 4 - 3 + ky;
+      if (t < 0 || t >= T || y < 0 || y >= S) continue;          // uniform over the block
+      const int xa = max(x_start, 0), xb = min(x_start + COLS, S);   // clip columns in the frame
+      if (xb <= xa) continue;
+      const int64_t base = ((((int64_t)v * T + t) * Hs + (y0 + y)) * Ws + (x0 + xa)) * 3;
+      const int nbytes = (xb - xa) * 3;
+      const int64_t a0 = base & ~(int64_t)3;                       // aligned 4-byte words
+      const int nwords = (int)((base + nbytes - a0 + 3) >> 2);
+      for (int w = threadIdx.x; w < nwords; w += 256) {
+        const int64_t addr = a0 + 4 * (int64_t)w;
+        uint32_t word = 0;
+        if (addr + 4 <= frames_bytes) {
+          word = *(const uint32_t*)(frames + addr);
+        } else {                                                    // last bytes of the buffer
+          for (int k = 0; k < 4; ++k)
+            if (addr + k < frames_bytes) word |= (uint32_t)frames[addr + k] << (8 * k);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int j = (int)(addr + k - base);                    // byte index inside the span
+          if (j < 0 || j >= nbytes) continue;
+          const int px = j / 3, c = j - px * 3;
+          img[(c * 3 + kt) * 7 + ky][xa - x_start + px] = tab[c * 256 + ((word >> (8 * k)) & 255u)];
+        }
+      }
+    }
+    __syncthreads();
+    const int n_xo = min(XO, Wo - xc0);
+    for (int i = threadIdx.x; i < n_xo * 56; i += 256) {
+      const int xl = i / 56, chunk = i % 56;
+      bf16_t e8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = chunk * 8 + e;
+        const int kx = col % 7, r = col / 7;
+        e8[e] = col < 441 ? img[r][xl * 4 + 1 + kx] : (bf16_t)0;   // x = xo*4 - 3 + kx
+      }
+      uint4 o;
+      o.x = (uint32_t)e8[0] | ((uint32_t)e8[1] << 16); o.y = (uint32_t)e8[2] | ((uint32_t)e8[3] << 16);
+      o.z = (uint32_t)e8[4] | ((uint32_t)e8[5] << 16); o.w = (uint32_t)e8[6] | ((uint32_t)e8[7] << 16);
+      ((uint4*)out)[(size_t)(xc0 + xl) * 56 + chunk] = o;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int svit_im2col_patch_u8(const uint8_t* frames, int64_t frames_bytes, const void* lut,
+                                    const int32_t* crops, void* cols, int B, int T, int Hs,
+                                    int Ws, int S, void* stream) {
+  if (!frames || !lut || !cols) return SVIT_ERR_ARG;
+  if (B <= 0 || T <= 0 || Hs <= 0 || Ws <= 0 || S <= 0 || S > Hs || S > Ws) return SVIT_ERR_SHAPE;
+  if ((uintptr_t)frames & 3) return SVIT_ERR_ALIGN;
+  const int To = (T + 2 - 3) / 2 + 1, Ho = (S + 6 - 7) / 4 + 1, Wo = (S + 6 - 7) / 4 + 1;
+  hipLaunchKernelGGL(im2col_patch_u8_kernel, dim3((unsigned)(B * To * Ho)), dim3(256), 0,
+                     (hipStream_t)stream, frames, frames_bytes, (const bf16_t*)lut, crops,
+                     (bf16_t*)cols, T, Hs, Ws, S, To, Ho, Wo);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}

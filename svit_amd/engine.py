@@ -13,6 +13,7 @@ import math
 import torch
 
 from . import arch, hip, ops
+from .input import U8Clips
 
 HD = arch.HEAD_DIM
 F32, BF16 = torch.float32, torch.bfloat16
@@ -208,13 +209,17 @@ class Engine:
 
     # ------------------------------------------------------------------ forward ----------
     def forward(self, video, drop_scales=None, save=True):
-        """video f32 [B,3,Tx,S,S] -> (normed tokens f32 [B,N_last,C_last], saved-state dict)."""
+        """video f32 [B,3,Tx,S,S] (or U8Clips) -> (normed tokens f32 [B,N_last,C_last], saved-state dict)."""
         plan, f = self.plan, self.flat
-        if video.dim() == 4:
-            video = video.unsqueeze(2)
-        video = video.contiguous().to(F32)
-        B, _, Tx = video.shape[:3]
-        cols, (To, Ho, Wo) = ops.im2col_patch(video)
+        if isinstance(video, U8Clips):       # decoded uint8 frames + crop table (svit_amd/input.py)
+            B, _, Tx = video.shape[:3]
+            cols, (To, Ho, Wo) = ops.im2col_patch_u8(video)
+        else:
+            if video.dim() == 4:
+                video = video.unsqueeze(2)
+            video = video.contiguous().to(F32)
+            B, _, Tx = video.shape[:3]
+            cols, (To, Ho, Wo) = ops.im2col_patch(video)
         T = plan.num_frames // plan.patch_stride[0] if Tx > 1 else Tx  # from cfg, builder:322
         if To != T:
             raise hip.SvitHipError("clip has %d frames but cfg.DATA.NUM_FRAMES=%d" % (Tx, plan.num_frames))

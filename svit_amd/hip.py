@@ -116,6 +116,7 @@ _SIGS = {
     "svit_layernorm_bwd": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i64, i32, vp,
                                  i64, vp]),
     "svit_im2col_patch": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "svit_im2col_patch_u8": (i32, [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "svit_fill_special_tokens": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "svit_pool_ln_fwd": (i32, [C.POINTER(PoolArgs), vp]),
     "svit_pool_ln_bwd": (i32, [C.POINTER(PoolLnBwdArgs), vp]),

@@ -196,6 +196,19 @@ def im2col_patch(video):
     return cols, (To, Ho, Wo)
 
 
+def im2col_patch_u8(clips):
+    """svit_amd.input.U8Clips -> the same [rows, 448] bf16 operand as im2col_patch."""
+    fr = clips.frames
+    _chk_dev(fr)
+    V, T, Hs, Ws, _ = fr.shape
+    B, S = clips.crops.shape[0], clips.size
+    To, Ho, Wo = (T - 1) // 2 + 1, (S - 1) // 4 + 1, (S - 1) // 4 + 1
+    cols = torch.empty((B * To * Ho * Wo, 448), device=fr.device, dtype=BF16)
+    hip.call("svit_im2col_patch_u8", ptr(fr), fr.numel(), ptr(clips.lut), ptr(clips.crops),
+             ptr(cols), B, T, Hs, Ws, S)
+    return cols, (To, Ho, Wo)
+
+
 def fill_special_tokens(x, cls, objq, pos_t, L, Tx, O, add_pos):
     B, N, C_ = x.shape
     hip.call("svit_fill_special_tokens", ptr(x), ptr(cls), ptr(objq), ptr(pos_t), B, N, L, Tx, O,

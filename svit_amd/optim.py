@@ -80,14 +80,58 @@ class FusedClipAdamW:
         """host value of the last clipped step's global grad norm (forces a sync; logging only)."""
         return float(self.sumsq.sqrt()) * self.grad_scale
 
+    # ---- checkpoint format of torch.optim.AdamW as the reference builds it -------------------
+    def _order(self):
+        """state index -> parameter name: the reference's two groups (decayed, then 1-D / bias;
+        slowfast/models/optimizer.py:39-72), each in named_parameters() order."""
+        named = [(n, tuple(p.shape)) for n, p in self.model.named_parameters()]
+        from .model import _weight_decayed
+        dec = [n for n, s in named if _weight_decayed(n, s)]
+        return dec, [n for n, s in named if not _weight_decayed(n, s)]
+
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
-                "param_groups": [{k: v for k, v in g.items()} for g in self.param_groups]}
+        """The dict torch.optim.AdamW.state_dict() yields for the reference's optimizer (what a
+        released .pyth holds under "optimizer_state"): per-parameter step / exp_avg / exp_avg_sq
+        (views of the flat moment buffers) and two param groups of indices."""
+        dec, rest = self._order()
+        state = {}
+        if self.step_count > 0:
+            for j, n in enumerate(dec + rest):
+                state[j] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.flat.view(self.exp_avg, n),
+                            "exp_avg_sq": self.flat.view(self.exp_avg_sq, n)}
+        groups, base = [], 0
+        for g, names in zip(self.param_groups, (dec, rest)):
+            if not names:
+                continue
+            groups.append({"lr": g["lr"], "betas": tuple(self.betas), "eps": self.eps,
+                           "weight_decay": g["weight_decay"], "amsgrad": False, "maximize": False,
+                           "foreach": None, "capturable": False, "differentiable": False,
+                           "fused": None, "decoupled_weight_decay": True,
+                           "params": list(range(base, base + len(names)))})
+            base += len(names)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self.step_count = sd["step"]
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        dec, rest = self._order()
+        order = dec + rest
+        n_listed = sum(len(g["params"]) for g in sd["param_groups"])
+        if n_listed != len(order):
+            raise ValueError("optimizer state lists %d parameters, the model has %d" % (n_listed, len(order)))
+        state = sd["state"]
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        step = 0
+        for j, n in enumerate(order):
+            ent = state.get(j, state.get(str(j)))
+            if ent is None:
+                continue
+            self.flat.view(self.exp_avg, n).copy_(ent["exp_avg"])
+            self.flat.view(self.exp_avg_sq, n).copy_(ent["exp_avg_sq"])
+            step = max(step, int(ent["step"]))
+        self.step_count = step
+        for g, src in zip(self.param_groups, sd["param_groups"]):
+            g["lr"] = src["lr"]
 
 
 def construct_optimizer(model, cfg):

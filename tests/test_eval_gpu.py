@@ -171,3 +171,40 @@ def test_two_ranks_merge_with_one_allreduce(tmp_path, golden_dir, manifest):
     assert np.array_equal(res["labels"].numpy(), g["shuffled_sum_video_labels"])
     want = manifest["meter"]["results"]["shuffled_sum"]
     assert res["stats"]["top1_acc"] == want["top1_acc"] and res["stats"]["top5_acc"] == want["top5_acc"]
+
+
+def test_uint8_frames_equal_reference_normalised_clips():
+    """model([U8Clips]) == model([fp32 crops normalised like
+    datasets/utils.py:287-303]) -- identical patch-embed operand, hence identical probabilities --
+    and the 3-crop ensemble runs from ONE uint8 copy of each video."""
+    from svit_amd import evaluate
+    from svit_amd.input import spatial_crops_u8
+    cfg, model, spec, sd = S.build_hip_model(4, 64, train=False)
+    g = torch.Generator().manual_seed(9)
+    u8 = torch.randint(0, 256, (2, 4, 64, 85, 3), generator=g, dtype=torch.uint8)
+    clips = spatial_crops_u8(u8.cuda(), 64, 3, mean=cfg.DATA.MEAN, std=cfg.DATA.STD)
+    assert tuple(clips.shape) == (6, 3, 4, 64, 64)
+    t = u8.float() / 255.0
+    t = (t - torch.tensor(cfg.DATA.MEAN)) / torch.tensor(cfg.DATA.STD)
+    wide = t.permute(0, 4, 1, 2, 3).contiguous().cuda()
+    ref_clips = evaluate.spatial_crops(wide, 64, 3)
+    with torch.no_grad():
+        p_u8, e_u8 = model([clips], {})
+        p_f32, e_f32 = model([ref_clips], {})
+    assert torch.equal(p_u8, p_f32) and torch.equal(e_u8["pred_bboxes"], e_f32["pred_bboxes"])
+    # and against the fp32 oracle on the reference-normalised crops
+    with torch.no_grad():
+        probs, _ = R.forward(dict(sd), spec, ref_clips.cpu(), training=False)
+    np.testing.assert_allclose(p_u8.cpu().numpy(), probs.numpy(), atol=4e-3)
+    # training step through the uint8 input: same gradients as through the fp32 clips
+    model.train()
+    y = torch.tensor([3, 50, 7, 9, 100, 20]).cuda()
+    grads = []
+    for inp in (clips, ref_clips):
+        model.zero_grad(set_to_none=True)
+        logits, _ = model([inp], {})
+        torch.nn.functional.cross_entropy(logits, y).backward()
+        torch.cuda.synchronize()
+        grads.append(model.flat.grad.detach().clone())
+    assert S.cosine(grads[0], grads[1]) > 0.99999
+    assert float((grads[0] - grads[1]).abs().max()) <= 2e-3 * float(grads[1].abs().max())

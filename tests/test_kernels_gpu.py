@@ -578,3 +578,39 @@ def test_haog_loss_fused(ops, case):
         assert got[0]["boxes_l1_loss"] == 0.0 and got[0]["boxes_giou_loss"] == 0.0
         assert got[0]["loss_contact_state"] == 0.0 and float(got[3].abs().max()) == 0.0
         assert float(got[2][..., 1:].abs().max()) == 0.0 and float(got[2][..., 0].abs().max()) > 0
+
+
+# ------------------------------------------------- uint8 input fused into the patch embed ----
+def _ref_normalize(u8, mean, std):
+    """slowfast/datasets/utils.py:287-303 (tensor_normalize), then T H W C -> C T H W."""
+    t = u8.float()
+    t = t / 255.0
+    t = t - torch.tensor(mean)
+    t = t / torch.tensor(std)
+    return t.permute(0, 4, 1, 2, 3).contiguous()        # [V,3,T,H,W]
+
+
+@pytest.mark.parametrize("V,T,Hs,Ws,S,table", [
+    (2, 4, 70, 93, 64, [(0, 3, 5), (1, 0, 29), (0, 6, 0), (1, 6, 29)]),
+    (1, 2, 312, 415, 312, [(0, 0, 0), (0, 0, 52), (0, 0, 103)]),      # C5: three 312^2 crops, 2 chunks/row
+    (3, 1, 64, 64, 64, None),                                           # stills, identity crops
+    (1, 3, 41, 59, 37, [(0, 4, 22), (0, 1, 0)]),                        # odd sizes
+])
+def test_im2col_patch_u8_bit_exact(ops, V, T, Hs, Ws, S, table):
+    from svit_amd.input import U8Clips
+    g = torch.Generator().manual_seed(V * 1000 + S)
+    u8 = torch.randint(0, 256, (V, T, Hs, Ws, 3), generator=g, dtype=torch.uint8)
+    mean, std = [0.45, 0.40, 0.5], [0.225, 0.25, 0.2]
+    clips = U8Clips(u8.cuda(), S, None if table is None else torch.tensor(table, dtype=torch.int32),
+                    mean=mean, std=std)
+    cols, thw = ops.im2col_patch_u8(clips)
+    f32 = _ref_normalize(u8, mean, std)
+    tab = table if table is not None else [(v, 0, 0) for v in range(V)]
+    crops = torch.stack([f32[v, :, :, y:y + S, x:x + S] for v, y, x in tab]).cuda().contiguous()
+    ref_cols, ref_thw = ops.im2col_patch(crops)
+    assert thw == ref_thw and clips.shape == crops.shape
+    assert torch.equal(cols.view(torch.int16), ref_cols.view(torch.int16))
+    with pytest.raises(ValueError):
+        U8Clips(u8.cuda(), S, torch.tensor([[0, Hs - S + 1, 0]], dtype=torch.int32))
+    with pytest.raises(ValueError):
+        U8Clips(u8.float().cuda(), S)
