@@ -190,7 +190,11 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
   // tile (fewer LDS-fill bytes per flop) was measured too and never won.  At M = 13064 every
   // variant lands within 10 % of the others: the bound is the per-CU LDS fill rate (~40 GB/s
   // per CU, ~10 TB/s chip-wide for the mix of L2 and Infinity-Cache hits), not the pipeline
-  // depth, the fragment-read scheduling or the tile shape.
+  // depth, the fragment-read scheduling or the tile shape.  Also measured and rejected: a
+  // row-stationary form for K <= 384 (8-wave workgroups, A rows held in registers as MFMA
+  // fragments, only W streamed through a 4-deep LDS ring: 4x fewer fill bytes per flop) --
+  // 0.6-0.9x the speed of these tiles on every shape of the model: one barrier-locked workgroup
+  // per CU leaves nothing to overlap its epilogues and barriers with.
   bool big = a.N % 192 == 0 && (long)((a.M + 127) / 128) * (a.N / 192) >= 256;
   if (g_nt_force_cfg == 0 && a.N % 192 == 0) big = true;
   if (g_nt_force_cfg == 2) big = false;

@@ -40,7 +40,11 @@ def cos(got, ref):
 
 # ------------------------------------------------------------------------------ GEMMs ----
 @pytest.mark.parametrize("M,K,N", [(300, 96, 96), (9000, 96, 96), (500, 384, 192), (257, 448, 96),
-                                   (1000, 192, 576), (130, 768, 3072), (8200, 96, 288)])
+                                   (1000, 192, 576), (130, 768, 3072), (8200, 96, 288),
+                                   # the shapes of the 14x14 / 28x28 stages, ragged M
+                                   (3001, 384, 1152), (2500, 384, 384), (5000, 192, 768),
+                                   (1100, 192, 576), (4099, 96, 384), (2049, 384, 288),
+                                   (13064, 384, 1536)])
 def test_gemm_nt_epilogues(ops, M, K, N):
     from svit_amd import hip
     a = rnd("a%d" % M, (M, K), 1.0, BF16)
