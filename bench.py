@@ -156,11 +156,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs (not used by the driver): SVIT_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and
+    # SVIT_BENCH_BACKEND=gloo replaces RCCL, so the N > 1 code path can be run on a one-GPU box
+    share = os.environ.get("SVIT_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("SVIT_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from svit_amd import config, optim
     from svit_amd.model import build_model
@@ -169,7 +177,12 @@ def main():
     from svit_amd.dp import rank_role
     is_image = rank_role(cfg, local_rank).is_image
     torch.manual_seed(cfg.RNG_SEED)
-    model = build_model(cfg, gpu_id=local_rank)
+    if share and world > 1:        # build_model asserts NUM_GPUS <= visible devices (build.py:28-35)
+        from svit_amd.dp import DataParallel
+        from svit_amd.model import MODEL_REGISTRY
+        model = DataParallel(MODEL_REGISTRY.get(cfg.MODEL.MODEL_NAME)(cfg).cuda(dev_index))
+    else:
+        model = build_model(cfg, gpu_id=dev_index)
     model.train()
     opt = optim.construct_optimizer(model, cfg)
     if is_image:
