@@ -488,6 +488,21 @@ def test_attention_fwd_bwd(ops, Nq, Nk, DA, h):
         assert cos(dv, vr.grad) > 0.999 and rel_err(dv, vr.grad) < 4e-2
 
 
+@pytest.mark.parametrize("Nk", [64, 128, 130, 457])
+def test_attention_fwd_eight_wave_path(ops, Nk):
+    """grids of >= 200 256-query workgroups at DA = 160 take the 8-wave / 3-stage forward kernel
+    (what the 28x28 -> 14x14 blocks of the B = 8 step run): 1, 2, 3 (ragged) and 8 key tiles."""
+    B, h, Nq, DA = 8, 2, 3300, 160
+    scale = 96 ** -0.5
+    qa = rnd("wq", (B, h, Nq, DA), 1.0, BF16)
+    ka = rnd("wk%d" % Nk, (B, h, Nk, DA), 1.0, BF16)
+    v = rnd("wv%d" % Nk, (B, h, Nk, 96), 1.0, BF16)
+    ctx, lse2 = ops.attn_fwd(qa, ka, v, scale)
+    ref, s = _attn_ref(qa.cpu(), ka.cpu(), v.cpu(), scale)
+    assert rel_err(ctx, ref) < 2e-2 and cos(ctx, ref) > 0.9999
+    assert rel_err(lse2, torch.logsumexp(s, dim=-1) * math.log2(math.e)) < 1e-3
+
+
 def test_attention_large_scores(ops):
     """Online-softmax rescale path: one key dominates late in the sweep (forces max jumps)."""
     B, h, Nq, Nk, DA = 1, 1, 64, 200, 128
