@@ -173,6 +173,8 @@ def main():
     from svit_amd import config, optim
     from svit_amd.model import build_model
     cfg = config.ssv2_cfg(num_frames=args.frames, crop=args.crop, num_gpus=world)
+    if not 0 <= args.image_ranks <= world:
+        raise SystemExit("--image-ranks must be between 0 and --gpus")
     cfg.IMAGE_TRAIN.GPU_IDS = list(range(world - args.image_ranks, world))
     from svit_amd.dp import rank_role
     is_image = rank_role(cfg, local_rank).is_image

@@ -66,7 +66,7 @@ class _HaogLossHip(torch.autograd.Function):
         from . import ops
         pred, contact = pred.contiguous(), contact.contiguous()
         losses, unit = ops.haog_loss_fwd(pred, tar.contiguous().float(), contact,
-                                         contact_tar.contiguous())
+                                         contact_tar.contiguous().long())
         ctx.unit, ctx.shapes = unit, (pred.shape, contact.shape)
         parts, stats = losses[:4].clone(), losses[4:].clone()
         ctx.mark_non_differentiable(stats)
