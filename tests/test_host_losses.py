@@ -91,3 +91,20 @@ def test_image_rank_loss_host_path_matches_oracle():
     for k in parts:
         assert torch.allclose(d[k], parts[k], atol=1e-6), k
     assert torch.allclose(fn.total(d), total, atol=1e-5)
+
+
+def test_nan_checks():
+    """misc.check_nan_losses (reference semantics) and the periodic device-side watch."""
+    from svit_amd import misc
+    misc.check_nan_losses(torch.tensor(1.5))
+    with pytest.raises(RuntimeError, match="NaN"):
+        misc.check_nan_losses(torch.tensor(float("nan")), extra_msg="x")
+    w = misc.NanWatch("cpu", period=4)
+    for v in (0.5, 0.25, float("nan")):
+        w.update(torch.tensor(v))                 # no sync, no raise before the period ends
+    with pytest.raises(RuntimeError, match="first at step 2"):
+        w.update(torch.tensor(0.1))
+    ok = misc.NanWatch("cpu", period=2)
+    for v in (1.0, 2.0, 3.0, 4.0):
+        ok.update(torch.tensor(v))
+    ok.check()
