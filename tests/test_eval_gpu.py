@@ -208,3 +208,35 @@ def test_uint8_frames_equal_reference_normalised_clips():
         grads.append(model.flat.grad.detach().clone())
     assert S.cosine(grads[0], grads[1]) > 0.99999
     assert float((grads[0] - grads[1]).abs().max()) <= 2e-3 * float(grads[1].abs().max())
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_device_meter_random_streams_bit_exact(seed):
+    """seeded random streams: any batch size, several clips of one video inside a batch,
+    interleaved videos, both ensemble methods, folded repeats -- bit-identical to the restatement
+    of the reference's sequential loop."""
+    from svit_amd.evaluate import TestMeter
+    rng = np.random.default_rng(seed)
+    V, num_clips, C = int(rng.integers(3, 40)), int(rng.integers(1, 7)), int(rng.integers(2, 300))
+    method = "sum" if seed % 2 == 0 else "max"
+    repeat = int(rng.integers(1, 4))
+    labels_v = rng.integers(0, C, V)
+    ids_all = rng.permutation(V * num_clips)
+    meter = TestMeter(V, num_clips, C, 1, ensemble_method=method)
+    ref = meter_ref.TestMeterRef(V, num_clips, C, method)
+    a = 0
+    while a < len(ids_all):
+        n = int(rng.integers(1, 33))
+        ids = ids_all[a:a + n]
+        a += n
+        preds = rng.random((len(ids), C), dtype=np.float32)
+        lab = labels_v[ids // num_clips]
+        meter.update_stats(torch.from_numpy(preds).cuda(), torch.from_numpy(lab).cuda(),
+                           torch.from_numpy(ids).cuda(), repeat=repeat)
+        for _ in range(repeat):          # cyclic fold == the batch replayed `repeat` times in order
+            ref.update_stats(preds, lab, ids)
+    assert np.array_equal(meter.video_preds.cpu().numpy(), ref.video_preds)
+    assert np.array_equal(meter.clip_count.cpu().numpy(), ref.clip_count)
+    assert np.array_equal(meter.video_labels.cpu().numpy(), ref.video_labels)
+    ks = (1, min(5, C))
+    assert meter.topks_correct(ks) == ref.finalize_metrics(ks)[1]
