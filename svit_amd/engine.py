@@ -104,6 +104,14 @@ class FlatParams:
         off, lpad, offs = self.rel_slots[pre]
         return self.wT16[off:off + HD * lpad].view(HD, lpad), lpad, offs
 
+    def rel_tables32(self, pre):
+        """fp32 [h+w+t rows, 96] view of the block's three (adjacent) rel-pos tables."""
+        names = [pre + "attn.rel_pos_" + a for a in "hwt"]
+        offs = [self.slots[n][0] for n in names]
+        rows = [self.slots[n][2][0] for n in names]
+        assert offs[1] == offs[0] + rows[0] * HD and offs[2] == offs[1] + rows[1] * HD
+        return self.data[offs[0]:offs[0] + sum(rows) * HD].view(sum(rows), HD)
+
     def rel_cat(self, pre):
         """bf16 [Lpad96, 96] view of the block's three rel-pos tables (adjacent slots of the
         mirror; rows past h+w+t belong to other parameters and are never gathered),
@@ -195,7 +203,19 @@ class Engine:
             need = [2 * max(q_thw[i], k_thw[i]) - 1 for i in (1, 2, 0)]
             have = [blk.rel_sp_rows, blk.rel_sp_rows, blk.rel_t_rows]
             mats = [None if n == h else _resize_matrix(h, n).to(self.dev) for n, h in zip(need, have)]
-            ent = ([t.contiguous().to(self.dev) for t in idx], mats)
+            mcat = None
+            if any(m is not None for m in mats):
+                # one [lp96, h+w+t rows] matrix (resize blocks / identities on the diagonal, zero
+                # pad rows) turns "interpolate three tables, concatenate, pad, cast" into a
+                # single small matmul on the adjacent fp32 tables (the
+                # per-block interpolation plumbing of the T' = 1 and 312^2 paths, batched)
+                lp = (sum(need) + 95) // 96 * 96
+                mcat = torch.zeros((lp, sum(have)), device=self.dev)
+                r0 = c0 = 0
+                for n, h, m in zip(need, have, mats):
+                    mcat[r0:r0 + n, c0:c0 + h] = torch.eye(h, device=self.dev) if m is None else m
+                    r0, c0 = r0 + n, c0 + h
+            ent = ([t.contiguous().to(self.dev) for t in idx], mats, mcat, tuple(need))
             self._rel_cache[key] = ent
         return ent
 
@@ -267,17 +287,17 @@ class Engine:
             [f.p(pre + "attn.norm_%s.bias" % r) for r in "qkv"],
             B, h, thw, n_obj, (sq, skv, skv), (DA, DA, HD), (0, 1, 0), save=save)
         qa, ka, v = pools[0][0], pools[1][0], pools[2][0]
-        idx, mats = self._rel(blk, q_thw, k_thw)
-        tabs = self._tables(pre, mats)
+        idx, mats, mcat, need = self._rel(blk, q_thw, k_thw)
         # rel-pos query side: P = q . Rcat^T on the MFMA GEMM, then a 2-byte gather per (q, j)
-        if all(m is None for m in mats):
+        if mcat is None:
+            tabs = self._tables(pre, mats)
             rcat, rows_off = f.rel_cat(pre)
-        else:   # interpolated tables (odd crops, T=1 frames pass): tiny torch plumbing
-            rows = [t.shape[0] for t in tabs]
-            lp = (sum(rows) + 95) // 96 * 96
-            rcat = torch.zeros((lp, HD), device=self.dev, dtype=BF16)
-            rcat[:sum(rows)] = torch.cat(tabs, 0).to(BF16)
-            rows_off = (0, rows[0], rows[0] + rows[1])
+        else:   # interpolated tables (odd crops, T=1 frames pass): one matmul + one cast
+            r32 = mcat @ f.rel_tables32(pre)
+            rcat = r32.to(BF16)
+            rows_off = (0, need[0], need[0] + need[1])
+            tabs = [r32[rows_off[0]:rows_off[0] + need[0]], r32[rows_off[1]:rows_off[1] + need[1]],
+                    r32[rows_off[2]:rows_off[2] + need[2]]]
         P = ops.gemm_nt(qa.view(B * h * Nq, DA)[:, :HD], rcat, None, hip.EPI_BF16)
         ops.relpos_gather(P, qa, idx, rows_off, B, h, q_thw, k_thw, n_obj, 1.0 / SCALE)
         ctx, lse2 = ops.attn_fwd(qa, ka, v, SCALE)
