@@ -57,10 +57,12 @@ def relerr(a, b, floor=1e-6):
     return maxabs(a, b) / max(float(b.detach().abs().max()), floor)
 
 
-def store(arrays, digests, key, t):
+def store(arrays, digests, key, t, sample=False):
     t = t.detach()
     if t.numel() <= SMALL:
         arrays[key] = t.to(torch.float32).numpy()
+    elif sample:        # strided sample of a large tensor (P.sample_of rebuilds the same indices)
+        arrays["sample:" + key] = P.sample_of(t).to(torch.float32).numpy()
     digests[key] = P.digest(t)
 
 
@@ -154,7 +156,7 @@ def run_model_case(name, num_frames, crop, batch, out_dir, manifest, backward=Tr
         store(arrays, digests, "block%d" % i, taps_ref["block%d" % i])
     if backward:
         for k, v in model.named_parameters():
-            store(arrays, digests, "grad:" + k, v.grad)
+            store(arrays, digests, "grad:" + k, v.grad, sample=True)
 
     # ---- eval mode -------------------------------------------------------------------
     if eval_too:
@@ -447,6 +449,229 @@ def run_layout_case(out_dir, manifest):
     print("layout", manifest["layout"], layout["state_step"], layout["top_level_keys"])
 
 
+def _grads_of(total, named):
+    gs = torch.autograd.grad(total, [v for _, v in named], retain_graph=True, allow_unused=True)
+    return {k: (g if g is not None else torch.zeros_like(v)) for (k, v), g in zip(named, gs)}
+
+
+def run_consistency_case(out_dir, manifest):
+    """The reference's own frame-clip consistency term (losses.py:127-136) on the tiny model:
+    clip forward with grad, the no-grad single-frame pass of tools/train_net.py:105-110, then
+    `VideoImageLoss._consistency_loss` called directly with the l1 / l2 keys present in its
+    lambda table (as released `get_lambdas_dict` never produces them).
+    Records the values, the total CE + LAMBDA_CON * consistency, and its gradients."""
+    torch.manual_seed(0)
+    cfg, model, shapes, sd = build_reference(4, 64, extra=("TRAIN.FORWARD_VIDEO_FRAMES", True))
+    spec = R.make_spec(num_frames=4, crop=64, drop_path_rate=0.0, dropout_rate=0.0)
+    from slowfast.models import losses as L
+    from slowfast.utils import misc
+    B = 2
+    x, y = P.frames(B, 4, 64), P.labels(B)
+    model.train()
+    logits, extra = model([x], {})
+    with torch.no_grad():
+        _fp, fextra = model([x.transpose(1, 2).flatten(0, 1).unsqueeze(2)], {})
+    lf = L.VideoImageLoss(cfg)
+    lf._is_vid = True
+    lf.train()
+    lam = float(cfg.SVIT.LAMBDA_CON)
+    named = list(model.named_parameters())
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lg, ex = R.forward(p, spec, x, training=True)
+    with torch.no_grad():
+        _, fex = R.forward({k: v.detach() for k, v in p.items()}, spec,
+                           x.transpose(1, 2).flatten(0, 1).unsqueeze(2), training=True)
+    arrays, digests, agree, info = {}, {}, {}, {"lambda_con": lam, "batch": B}
+    store(arrays, digests, "frames_obj_desc", fextra["obj_desc"], sample=True)
+    agree["frames_obj_desc"] = maxabs(fex["obj_desc"], fextra["obj_desc"])
+    for mode in ("l1", "l2"):
+        key = "video_image_desc_%s_loss" % mode
+        lf._lambda = dict(misc.get_lambdas_dict(cfg))
+        lf._lambda[key] = lam
+        parts = lf._consistency_loss(extra, fextra)
+        assert list(parts) == [key]
+        ce = lf.ce_loss(logits, y)
+        total = ce + lam * parts[key]
+        grads = _grads_of(total, named)
+        con = R.consistency_loss(ex, fex, mode)
+        tot = R.video_loss(lg, y) + lam * con
+        rgr = _grads_of(tot, list(p.items()))
+        agree[mode + "_value"] = maxabs(con, parts[key])
+        agree[mode + "_total"] = maxabs(tot, total)
+        gmax = max(float(g.abs().max()) for g in grads.values())
+        agree[mode + "_grad_rel_worst"] = max(relerr(rgr[k], grads[k], floor=1e-5 * gmax) for k in grads)
+        info[mode] = {"value": float(parts[key]), "ce": float(ce), "total": float(total)}
+        for k, g in grads.items():
+            store(arrays, digests, "%s:grad:%s" % (mode, k), g, sample=True)
+    np.savez_compressed(os.path.join(out_dir, "consistency.npz"), **arrays)
+    manifest["consistency"] = {"num_frames": 4, "crop": 64, "restatement_vs_reference_maxabs": agree,
+                               "info": info, "digests": digests}
+    print("consistency worst disagreement:", max(agree.values()), info, flush=True)
+
+
+HOT_CFG_SECTIONS = ("DATA", "MODEL", "MVIT", "SVIT", "SOLVER", "TRAIN", "TEST", "IMAGE_TRAIN")
+
+
+def _plain(v):
+    if isinstance(v, dict):
+        return {k: _plain(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_plain(x) for x in v]
+    return v
+
+
+def run_cfg_case(out_dir, manifest):
+    """The reference's `get_cfg()` + configs/ssv2.yaml, hot-path sections only, as plain JSON
+    (defaults.py:12-1173; ssv2.yaml).  Also what two yacs-style coercion traps of that yaml
+    become after the merge: `PATCH_KERNEL: (3, 7, 7)` and `BASE_LR: 2e-4` are YAML strings."""
+    ref_shim.install()
+    from slowfast.config.defaults import get_cfg
+    import yaml
+    cfg = get_cfg()
+    defaults = {k: _plain(cfg[k]) for k in HOT_CFG_SECTIONS}
+    top_defaults = {k: _plain(v) for k, v in cfg.items() if not isinstance(v, dict)}
+    cfg.merge_from_file(ref_shim.REFERENCE_ROOT + "/configs/ssv2.yaml")
+    merged = {k: _plain(cfg[k]) for k in HOT_CFG_SECTIONS}
+    top = {k: _plain(v) for k, v in cfg.items() if not isinstance(v, dict)}
+    raw = yaml.safe_load(open(ref_shim.REFERENCE_ROOT + "/configs/ssv2.yaml"))
+    traps = {"MVIT.PATCH_KERNEL": {"yaml_type": type(raw["MVIT"]["PATCH_KERNEL"]).__name__,
+                                   "yaml_value": raw["MVIT"]["PATCH_KERNEL"],
+                                   "merged": _plain(cfg.MVIT.PATCH_KERNEL),
+                                   "merged_type": type(cfg.MVIT.PATCH_KERNEL).__name__},
+             "SOLVER.BASE_LR": {"yaml_type": type(raw["SOLVER"]["BASE_LR"]).__name__,
+                                "yaml_value": raw["SOLVER"]["BASE_LR"],
+                                "merged": cfg.SOLVER.BASE_LR,
+                                "merged_type": type(cfg.SOLVER.BASE_LR).__name__}}
+    out = {"sections": list(HOT_CFG_SECTIONS), "defaults": defaults, "top_level_defaults": top_defaults,
+           "merged": merged, "top_level": top, "traps": traps,
+           "yaml_sections": {k: sorted(v) for k, v in raw.items() if isinstance(v, dict)}}
+    json.dump(out, open(os.path.join(out_dir, "cfg.json"), "w"), indent=1, sort_keys=True)
+    manifest["cfg"] = {"file": "cfg.json", "sections": list(HOT_CFG_SECTIONS), "traps": traps}
+    print("cfg", traps, flush=True)
+
+
+def run_module_cases(out_dir, manifest):
+    """Known-answer tests of the reference's own modules, taken from the tiny
+    model's submodules with closed-form inputs and upstream gradients: PatchEmbed
+    (stem_helper.py:290-320), MultiScaleAttention (attention.py:331-466) of blocks 1 and 15,
+    MultiScaleBlock (attention.py:557-571) of blocks 0 (plain), 1 and 3 (dim change + q pooling),
+    15, and SViTHead train / eval (video_model_builder.py:507-551).  Outputs, input gradients and
+    every parameter gradient are stored (digest + strided sample) and compared with the
+    restatement (oracle/svit_ref.py)."""
+    torch.manual_seed(0)
+    cfg, model, shapes, sd = build_reference(4, 64)
+    spec = R.make_spec(num_frames=4, crop=64, drop_path_rate=0.0, dropout_rate=0.0)
+    model.train()
+    arrays, digests, agree, meta = {}, {}, {}, {}
+    B, O = 2, 4
+    n_obj = 4 * O
+
+    def pgrads(mod, prefix):
+        return {prefix + k: v.grad for k, v in mod.named_parameters()}
+
+    def rest(names):
+        return {k: sd[k].clone().requires_grad_(True) for k in names}
+
+    # ---- PatchEmbed -------------------------------------------------------------------------
+    x = P.frames(B, 4, 64, tag="kat")
+    model.zero_grad()
+    tok, shp = model.patch_embed(x)
+    g = P.tensor("kat:patch:g", tuple(tok.shape), 1.0)
+    tok.backward(g)
+    pr = rest(["patch_embed.proj.weight", "patch_embed.proj.bias"])
+    y = torch.nn.functional.conv3d(x, pr["patch_embed.proj.weight"], pr["patch_embed.proj.bias"],
+                                   stride=spec.patch_stride, padding=spec.patch_pad)
+    tk = y.flatten(2).transpose(1, 2)
+    tk.backward(g)
+    agree["patch_out"] = maxabs(tk, tok)
+    store(arrays, digests, "patch:out", tok, sample=True)
+    for k, v in pgrads(model.patch_embed, "patch_embed.").items():
+        agree["patch_d" + k.split(".")[-1]] = relerr(pr[k].grad, v)
+        store(arrays, digests, "patch:grad:" + k, v, sample=True)
+    meta["patch"] = {"conv_shape": [int(v) for v in shp], "batch": B}
+
+    # shapes entering each block of the tiny model
+    thw_in, dims = {}, {}
+    thw = (2, 16, 16)
+    for b in spec.blocks:
+        thw_in[b.index], dims[b.index] = thw, b.dim_in
+        thw = (thw[0], R.pooled_size(thw[1], b.stride_q[1]), R.pooled_size(thw[2], b.stride_q[2]))
+
+    # ---- MultiScaleAttention / MultiScaleBlock -------------------------------------------------
+    for kind, idxs in (("attn", (1, 15)), ("block", (0, 1, 3, 15))):
+        for i in idxs:
+            b = spec.blocks[i]
+            t, hh, ww = thw_in[i]
+            N = 1 + t * hh * ww + n_obj
+            tag = "%s%d" % (kind, i)
+            xin = P.tensor("kat:%s:x" % tag, (B, N, dims[i]), 1.0)
+            xr = xin.clone().requires_grad_(True)
+            model.zero_grad()
+            mod = model.blocks[i].attn if kind == "attn" else model.blocks[i]
+            out, thw_o = mod(xr, list(thw_in[i]))
+            g = P.tensor("kat:%s:g" % tag, tuple(out.shape), 1.0)
+            out.backward(g)
+            pre = "blocks.%d." % i + ("attn." if kind == "attn" else "")
+            names = [k for k in sd if k.startswith(pre)]
+            pr = rest(names)
+            xo = xin.clone().requires_grad_(True)
+            if kind == "attn":
+                o2, thw2 = R.attention(pr, pre, b, xo, thw_in[i], n_obj)
+            else:
+                o2, thw2 = R.block(pr, b, xo, thw_in[i], n_obj)
+            o2.backward(g)
+            assert tuple(thw2) == tuple(thw_o)
+            agree[tag + "_out"] = relerr(o2, out)
+            agree[tag + "_dx"] = relerr(xo.grad, xr.grad)
+            gmax = max(float(v.grad.abs().max()) for v in mod.parameters())
+            worst = 0.0
+            for k, v in pgrads(mod, pre).items():
+                worst = max(worst, relerr(pr[k].grad, v, floor=1e-5 * gmax))
+                store(arrays, digests, "%s:grad:%s" % (tag, k), v, sample=True)
+            agree[tag + "_dparam_worst"] = worst
+            store(arrays, digests, tag + ":out", out, sample=True)
+            store(arrays, digests, tag + ":dx", xr.grad, sample=True)
+            meta[tag] = {"thw_in": list(thw_in[i]), "thw_out": [int(v) for v in thw_o], "N": N,
+                         "dim_in": dims[i], "out_shape": list(out.shape), "n_obj": n_obj}
+
+    # ---- SViTHead ----------------------------------------------------------------------------
+    feat = P.tensor("kat:head:x", (B, 1 + n_obj, 768), 1.0)
+    hn = [k for k in sd if k.startswith("head.")]
+    for training in (True, False):
+        tag = "head_train" if training else "head_eval"
+        model.head.train(training)
+        fr = feat.clone().requires_grad_(True)
+        model.zero_grad()
+        lg, ex = model.head(fr)
+        pr = rest(hn)
+        fo = feat.clone().requires_grad_(True)
+        lg2, ex2 = R.head(pr, spec, fo, 4, training)
+        outs = {"logits": (lg, lg2), "pred_bboxes": (ex["pred_bboxes"], ex2["pred_bboxes"]),
+                "pred_contact_state": (ex["pred_contact_state"], ex2["pred_contact_state"]),
+                "obj_desc": (ex["obj_desc"], ex2["obj_desc"])}
+        tot = tot2 = 0.0
+        for k, (a, a2) in outs.items():
+            agree["%s_%s" % (tag, k)] = maxabs(a2, a)
+            store(arrays, digests, "%s:%s" % (tag, k), a, sample=True)
+            gk = P.tensor("kat:head:g:" + k, tuple(a.shape), 1.0)
+            tot = tot + (a * gk).sum()
+            tot2 = tot2 + (a2 * gk).sum()
+        if training:
+            tot.backward()
+            tot2.backward()
+            agree[tag + "_dx"] = relerr(fo.grad, fr.grad)
+            store(arrays, digests, tag + ":dx", fr.grad, sample=True)
+            for k, v in pgrads(model.head, "head.").items():
+                agree[tag + "_d" + k] = relerr(pr[k].grad, v)
+                store(arrays, digests, "%s:grad:%s" % (tag, k), v, sample=True)
+    model.head.train(True)
+    np.savez_compressed(os.path.join(out_dir, "modules.npz"), **arrays)
+    manifest["modules"] = {"num_frames": 4, "crop": 64, "batch": B, "meta": meta,
+                           "restatement_vs_reference_maxabs": agree, "digests": digests}
+    print("modules worst disagreement:", max(agree.values()),
+          {k: "%.2e" % v for k, v in agree.items() if v > 1e-4}, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(HERE, "..", "tests", "golden"))
@@ -485,6 +710,14 @@ def main():
         run_model_case("c1", 8, 224, 1, args.out, manifest, eval_too=True)
     if on("c2_fwd"):
         run_model_case("c2_fwd", 16, 224, 1, args.out, manifest, backward=False)
+    if on("c2"):       # the config the headline metric is quoted on: forward AND backward
+        run_model_case("c2", 16, 224, 1, args.out, manifest)
+    if on("consistency"):
+        run_consistency_case(args.out, manifest)
+    if on("cfg"):
+        run_cfg_case(args.out, manifest)
+    if on("modules"):
+        run_module_cases(args.out, manifest)
     if on("c2_frames"):
         run_model_case("c2_frames", 16, 224, 2, args.out, manifest, backward=False,
                        frames_path=True)

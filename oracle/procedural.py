@@ -103,6 +103,13 @@ def haog_meta(batch, frames_t=1, objects=4, tag="haog"):
     return {"haog_bboxes": box, "contact_state": contact}
 
 
+def sample_of(t, k=256):
+    """Strided sample (<= k elements) of a large tensor: what the golden files keep of tensors too
+    big to store whole (gradients of the 16x224^2 model, module KAT outputs)."""
+    t = t.detach().reshape(-1)
+    return t[::max(t.numel() // k, 1)][:k]
+
+
 def digest(t, k=8):
     """Small fingerprint of a tensor: stats + first/strided elements + a hashed projection."""
     t = t.detach().to(torch.float64).reshape(-1)

@@ -489,6 +489,19 @@ def video_loss(logits, labels):
     return F.cross_entropy(logits, labels)
 
 
+def consistency_loss(extra, frames_extra, mode="l1"):
+    """VideoImageLoss._consistency_loss (losses.py:127-136): the clip's object descriptors
+    against those of the no-grad single-frame pass (train_net.py:105-110), reshaped
+    [B*T,1,O,d] -> [B,T,O,d] and detached; mean-reduced L1 ("l1") or squared error ("l2")."""
+    pred = extra["obj_desc"]
+    tar = frames_extra["obj_desc"].reshape(pred.shape).detach()
+    if mode == "l1":
+        return F.l1_loss(pred, tar, reduction="mean")
+    if mode == "l2":
+        return F.mse_loss(pred, tar, reduction="mean")
+    raise ValueError(mode)
+
+
 def image_loss(extra, meta, weights=None):
     w = weights or loss_weights()
     parts = haog_losses(extra, meta)

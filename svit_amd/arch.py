@@ -112,6 +112,8 @@ def build_plan(cfg) -> Plan:
             out.append([i] + skv)
         cfg.MVIT.POOL_KV_STRIDE = out
     stride_kv = [[] for _ in range(depth)]
+    if cfg.MVIT.POOL_KV_STRIDE is None:
+        raise NotImplementedError("MVIT.POOL_KV_STRIDE or POOL_KV_STRIDE_ADAPTIVE must be set")
     for row in cfg.MVIT.POOL_KV_STRIDE:
         stride_kv[row[0]] = list(row[1:])
     input_size = [plan.num_frames // plan.patch_stride[0], plan.crop // plan.patch_stride[1],

@@ -23,6 +23,12 @@ def close_digest(t, d, rtol=2e-4, atol=1e-6):
     np.testing.assert_allclose(got["strided"], d["strided"], rtol=0, atol=rtol * 25 * scale + atol)
 
 
+def close_sample(t, ref, rel=3e-3):
+    """strided sample of a large tensor (oracle/procedural.py::sample_of) against the golden one"""
+    got = P.sample_of(t).numpy()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=rel * float(np.abs(ref).max()) + 1e-7)
+
+
 def run_case(case, name, golden_dir, backward):
     spec = R.make_spec(num_frames=case["num_frames"], crop=case["crop"],
                        drop_path_rate=0.4 if case["drop"] else 0.0,
@@ -53,7 +59,7 @@ def run_case(case, name, golden_dir, backward):
 
 
 @pytest.mark.parametrize("name", ["tiny", "tiny_drop", "tiny_odd", "tiny_frames", "c1",
-                                  "c2_fwd", "c2_frames"])
+                                  "c2_fwd", "c2_frames", "c2"])
 def test_model_case(name, manifest, golden_dir):
     case = manifest["cases"][name]
     for k, v in case["restatement_vs_reference_maxabs"].items():
@@ -78,6 +84,8 @@ def test_model_case(name, manifest, golden_dir):
             if "grad:" + k in arrays:
                 np.testing.assert_allclose(g.numpy(), arrays["grad:" + k], rtol=0,
                                            atol=2e-3 * float(np.abs(arrays["grad:" + k]).max()) + 1e-7)
+            if "sample:grad:" + k in arrays:      # strided sample of a large gradient
+                close_sample(g, arrays["sample:grad:" + k])
 
 
 @pytest.mark.parametrize("name", ["tiny", "c1"])
@@ -215,3 +223,187 @@ def test_meter_restatement_vs_reference_golden(manifest, golden_dir):
     with pytest.raises(AssertionError):
         bad = meter_ref.TestMeterRef(2, 3, 4)
         bad.update_stats(np.ones((2, 4), np.float32), [1, 2], [0, 1])
+
+
+def test_consistency_loss_vs_reference_golden(manifest, golden_dir):
+    """oracle.consistency_loss (+ the T=1 frames pass that feeds it) against the numbers the
+    reference's own `VideoImageLoss._consistency_loss` produced (losses.py:127-136), values and
+    the gradients of CE + LAMBDA_CON * consistency."""
+    c = manifest["consistency"]
+    for k, v in c["restatement_vs_reference_maxabs"].items():
+        assert v < 5e-3, (k, v)
+    a = np.load(os.path.join(golden_dir, "consistency.npz"))
+    spec = R.make_spec(num_frames=4, crop=64, drop_path_rate=0.0, dropout_rate=0.0)
+    sd = P.state_dict(R.param_shapes(spec))
+    B, lam = c["info"]["batch"], c["info"]["lambda_con"]
+    x, y = P.frames(B, 4, 64), P.labels(B)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    logits, extra = R.forward(p, spec, x, training=True)
+    with torch.no_grad():
+        _, fextra = R.forward(sd, spec, x.transpose(1, 2).flatten(0, 1).unsqueeze(2), training=True)
+    assert tuple(fextra["obj_desc"].shape) == (B * 4, 1, 4, 768)
+    close_digest(fextra["obj_desc"], c["digests"]["frames_obj_desc"])
+    for mode in ("l1", "l2"):
+        con = R.consistency_loss(extra, fextra, mode)
+        assert abs(float(con.detach()) - c["info"][mode]["value"]) < 2e-5
+        total = R.video_loss(logits, y) + lam * con
+        assert abs(float(total.detach()) - c["info"][mode]["total"]) < 1e-4
+        names = list(p)
+        grads = torch.autograd.grad(total, [p[k] for k in names], retain_graph=True, allow_unused=True)
+        dg = c["digests"]
+        gmax = max(dg["%s:grad:%s" % (mode, k)]["l2"] for k in names)
+        for k, g in zip(names, grads):
+            d = dg["%s:grad:%s" % (mode, k)]
+            g = g if g is not None else torch.zeros_like(p[k])
+            if d["l2"] < 1e-5 * gmax:
+                assert float(g.norm()) < 1e-4 * gmax
+                continue
+            close_digest(g, d, rtol=1e-3)
+
+
+def _module_inputs(meta, tag, dim):
+    return P.tensor("kat:%s:x" % tag, (2, meta["N"], dim), 1.0)
+
+
+def test_module_kats_vs_reference_golden(manifest, golden_dir):
+    """PatchEmbed, MultiScaleAttention, MultiScaleBlock and SViTHead of the reference (outputs,
+    input gradients, parameter gradients recorded by oracle/gen_golden.py::run_module_cases)
+    against the restatement's functions on the same closed-form tensors."""
+    m = manifest["modules"]
+    for k, v in m["restatement_vs_reference_maxabs"].items():
+        assert v < 5e-3, (k, v)
+    a = np.load(os.path.join(golden_dir, "modules.npz"))
+    dg = m["digests"]
+    spec = R.make_spec(num_frames=4, crop=64, drop_path_rate=0.0, dropout_rate=0.0)
+    sd = P.state_dict(R.param_shapes(spec))
+
+    def check(key, t, rtol=1e-3):
+        close_digest(t, dg[key], rtol=rtol)
+        if "sample:" + key in a:
+            close_sample(t, a["sample:" + key])
+        elif key in a:
+            np.testing.assert_allclose(t.detach().numpy(), a[key], rtol=0,
+                                       atol=3e-3 * float(np.abs(a[key]).max()) + 1e-7)
+
+    # PatchEmbed
+    x = P.frames(2, 4, 64, tag="kat")
+    w = sd["patch_embed.proj.weight"].clone().requires_grad_(True)
+    b = sd["patch_embed.proj.bias"].clone().requires_grad_(True)
+    y = torch.nn.functional.conv3d(x, w, b, stride=spec.patch_stride, padding=spec.patch_pad)
+    assert list(y.shape) == m["meta"]["patch"]["conv_shape"]
+    tok = y.flatten(2).transpose(1, 2)
+    tok.backward(P.tensor("kat:patch:g", tuple(tok.shape), 1.0))
+    check("patch:out", tok)
+    check("patch:grad:patch_embed.proj.weight", w.grad)
+    check("patch:grad:patch_embed.proj.bias", b.grad)
+    # attention / block
+    for tag, meta in m["meta"].items():
+        if not (tag.startswith("attn") or tag.startswith("block")):
+            continue
+        kind = "attn" if tag.startswith("attn") else "block"
+        i = int(tag[len(kind):])
+        blk = spec.blocks[i]
+        pre = "blocks.%d." % i + ("attn." if kind == "attn" else "")
+        pr = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith(pre)}
+        xin = _module_inputs(meta, tag, meta["dim_in"]).requires_grad_(True)
+        fn = R.attention if kind == "attn" else R.block
+        args = (pr, pre, blk, xin, tuple(meta["thw_in"]), meta["n_obj"]) if kind == "attn" else \
+            (pr, blk, xin, tuple(meta["thw_in"]), meta["n_obj"])
+        out, thw = fn(*args)
+        assert list(thw) == meta["thw_out"] and list(out.shape) == meta["out_shape"]
+        out.backward(P.tensor("kat:%s:g" % tag, tuple(out.shape), 1.0))
+        check(tag + ":out", out)
+        check(tag + ":dx", xin.grad)
+        gmax = max(dg["%s:grad:%s" % (tag, k)]["l2"] for k in pr)
+        for k, v in pr.items():
+            if dg["%s:grad:%s" % (tag, k)]["l2"] < 1e-5 * gmax:
+                continue
+            check("%s:grad:%s" % (tag, k), v.grad, rtol=2e-3)
+    # head
+    feat = P.tensor("kat:head:x", (2, 17, 768), 1.0)
+    for training in (True, False):
+        tag = "head_train" if training else "head_eval"
+        pr = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("head.")}
+        f = feat.clone().requires_grad_(True)
+        lg, ex = R.head(pr, spec, f, 4, training)
+        outs = {"logits": lg, "pred_bboxes": ex["pred_bboxes"],
+                "pred_contact_state": ex["pred_contact_state"], "obj_desc": ex["obj_desc"]}
+        tot = 0.0
+        for k, v in outs.items():
+            check("%s:%s" % (tag, k), v)
+            tot = tot + (v * P.tensor("kat:head:g:" + k, tuple(v.shape), 1.0)).sum()
+        if training:
+            tot.backward()
+            check(tag + ":dx", f.grad)
+            for k, v in pr.items():
+                check("%s:grad:%s" % (tag, k), v.grad)
+
+
+def test_cfg_schema_pinned_to_reference(manifest, golden_dir, tmp_path):
+    """tests/golden/cfg.json = the reference's get_cfg() + configs/ssv2.yaml (hot-path sections,
+    defaults.py:12-1173).  `ssv2_cfg()` must equal the merged tree key for key, `get_cfg()` the
+    defaults, and `merge_from_file` must coerce the two yacs traps of that yaml the same way."""
+    import json
+    from svit_amd import config
+    ref = json.load(open(os.path.join(golden_dir, "cfg.json")))
+
+    def plain(v):
+        if isinstance(v, dict):
+            return {k: plain(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [plain(x) for x in v]
+        return v
+
+    def compare(ours, theirs, path):
+        missing = [k for k in theirs if k not in ours]
+        assert not missing, "%s: keys missing in svit_amd.config: %s" % (path, missing)
+        for k, v in theirs.items():
+            if isinstance(v, dict):
+                compare(ours[k], v, path + "." + k)
+            else:
+                assert plain(ours[k]) == v, ("%s.%s" % (path, k), plain(ours[k]), v)
+                assert type(plain(ours[k])) is type(v), ("%s.%s" % (path, k), type(ours[k]), type(v))
+
+    base = config.get_cfg()
+    for sec in ref["sections"]:
+        compare(base[sec], ref["defaults"][sec], sec)
+    cfg = config.ssv2_cfg(num_gpus=ref["top_level"]["NUM_GPUS"])
+    for sec in ref["sections"]:
+        compare(cfg[sec], ref["merged"][sec], sec)
+        extra = set(cfg[sec]) - set(ref["merged"][sec])
+        assert extra <= {"CONSISTENCY"}, (sec, extra)     # the build's one added key
+    for k in ("NUM_GPUS", "RNG_SEED", "DDP_FIND_UNUSED_PARAMETERS", "OUTPUT_DIR", "DIST_BACKEND",
+              "NUM_SHARDS", "SHARD_ID", "LOG_PERIOD"):
+        assert plain(cfg[k]) == ref["top_level"][k], k
+    # the two yacs traps, through OUR merge_from_file, written exactly as the yaml writes them
+    t = ref["traps"]
+    assert t["MVIT.PATCH_KERNEL"]["yaml_type"] == "str" and t["SOLVER.BASE_LR"]["yaml_type"] == "str"
+    y = tmp_path / "traps.yaml"
+    y.write_text("MVIT:\n  PATCH_KERNEL: %s\nSOLVER:\n  BASE_LR: %s\n"
+                 % (t["MVIT.PATCH_KERNEL"]["yaml_value"], t["SOLVER.BASE_LR"]["yaml_value"]))
+    c2 = config.get_cfg()
+    c2.merge_from_file(str(y))
+    assert plain(c2.MVIT.PATCH_KERNEL) == t["MVIT.PATCH_KERNEL"]["merged"]
+    assert type(c2.MVIT.PATCH_KERNEL).__name__ == t["MVIT.PATCH_KERNEL"]["merged_type"]
+    assert c2.SOLVER.BASE_LR == t["SOLVER.BASE_LR"]["merged"] and isinstance(c2.SOLVER.BASE_LR, float)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/configs/ssv2.yaml"),
+                    reason="reference checkout only exists in the build container")
+def test_reference_yaml_merges_to_the_recorded_tree(golden_dir):
+    """svit_amd.config.get_cfg().merge_from_file(<the reference's own configs/ssv2.yaml>) gives the
+    tree the reference's get_cfg() + merge gave (tests/golden/cfg.json); sections this build does
+    not know (AUG, MIXUP, DATA_LOADER, ...) merge without error."""
+    import json
+    from svit_amd import config
+    ref = json.load(open(os.path.join(golden_dir, "cfg.json")))
+    cfg = config.get_cfg()
+    cfg.merge_from_file("/root/reference/configs/ssv2.yaml")
+    want = config.ssv2_cfg(num_gpus=ref["top_level"]["NUM_GPUS"])
+    for sec in ref["sections"]:
+        for k, v in ref["merged"][sec].items():
+            got = cfg[sec][k]
+            got = list(got) if isinstance(got, tuple) else got
+            assert got == v, (sec, k, got, v)
+            assert want[sec][k] == v
+    assert cfg.NUM_GPUS == 8 and "AUG" in cfg and "MIXUP" in cfg
