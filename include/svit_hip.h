@@ -87,13 +87,18 @@ int svit_scale_cast(const float* src, void* dst, const float* row_scale, int row
 
 /* ------------------------------------------- deferred second-stage reductions ---------- */
 /* svit_layernorm_bwd, svit_pool_ln_bwd(_qkv) and svit_pool_conv_wgrad(_qkv) finish with a
- * "reduce partial rows" launch.  Between svit_reduce_defer(1) and svit_reduce_flush() those
- * launches are queued (host side) and run as ONE launch at the flush -- the engine brackets a
- * transformer block's backward with them.  While deferred, every producer must be given its own
- * workspace region (the rows are read at the flush), and the gradients are final only after
- * the flush.  svit_reduce_defer(0) flushes too.  Not thread-safe (one engine thread). */
+ * "reduce partial rows" launch.  The queue is PER STREAM: between svit_reduce_defer(1, s) and
+ * svit_reduce_flush(s) / svit_reduce_defer(0, s) the reduces launched ON STREAM s are queued
+ * (host side) and run as ONE launch on s -- the engine brackets a transformer block's backward
+ * with them.  Launches on any other stream are unaffected (they reduce at once on their own
+ * stream).  While deferred, every producer must be given its own workspace region (the rows are
+ * read at the flush), and the gradients are final only after the flush.  svit_reduce_defer(1)
+ * drops leftovers of an aborted bracket; svit_reduce_reset(s) is the error path: forget s's queue
+ * and leave deferred mode.  Thread-safe (mutex-guarded map keyed by stream; no other global
+ * mutable state in the library). */
 int svit_reduce_defer(int on, void* stream);
 int svit_reduce_flush(void* stream);
+int svit_reduce_reset(void* stream);
 
 /* ---------------------------------------------------------------- LayerNorm (K3) ------ */
 /* nn.LayerNorm(eps=1e-6): attention.py:501,531; video_model_builder.py:69,233. */

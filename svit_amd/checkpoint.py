@@ -62,6 +62,11 @@ def _to_cpu(obj):
     return obj
 
 
+# torch.amp.GradScaler().state_dict() of a scaler that has not stepped yet
+DEFAULT_SCALER_STATE = {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5,
+                        "growth_interval": 2000, "_growth_tracker": 0}
+
+
 def save_checkpoint(path_to_job, model, optimizer, epoch, cfg, scaler=None):
     """checkpoint.py:124-156.  Tensors are copied off the flat device buffers (independent CPU
     tensors, as the reference writes them)."""
@@ -74,9 +79,10 @@ def save_checkpoint(path_to_job, model, optimizer, epoch, cfg, scaler=None):
         "model_state": OrderedDict((k, _to_cpu(v)) for k, v in ms.state_dict().items()),
         "optimizer_state": _to_cpu(optimizer.state_dict()),
         "cfg": cfg.dump(),
-        # the reference's loader reads this key whenever it is handed a GradScaler; the bf16 path
-        # needs no loss scaling, so the state is empty (= a disabled GradScaler's)
-        "scaler_state": scaler.state_dict() if scaler is not None else {},
+        # the reference's trainer hands its loader an ENABLED GradScaler (TRAIN.MIXED_PRECISION,
+        # train_net.py:501-505; checkpoint.py:381-382), whose load_state_dict refuses an empty
+        # dict: the bf16 path needs no loss scaling, so write a fresh scaler's state
+        "scaler_state": scaler.state_dict() if scaler is not None else dict(DEFAULT_SCALER_STATE),
     }
     path = get_path_to_checkpoint(path_to_job, epoch + 1)
     with open(path, "wb") as f:

@@ -298,20 +298,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(svit_attn_bwd_args
 
 template <int DA>
 int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
-  static bool configured = false;
+  static SvitOnce once_dq, once_kv;
   const size_t lds_dq = 2 * (size_t)(KT * DA * 2 + KT * HD * 2);
   size_t lds_kv = 3 * (size_t)(QT * DA * 2 + QT * HD * 2 + 2 * QT * 4);
   const size_t lds_out = (size_t)128 * (HD + 1) * 4;
   if (lds_kv < lds_out) lds_kv = lds_out;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DA>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DA>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-    if (e != hipSuccess) return (int)e;
-    configured = true;
-  }
+  if (int rc = svit_max_lds_once(once_dq, (const void*)attn_bwd_dq_kernel<DA>, lds_dq)) return rc;
+  if (int rc = svit_max_lds_once(once_kv, (const void*)attn_bwd_dkv_kernel<DA>, lds_kv)) return rc;
   const int nqt = (a.Nq + QT - 1) / QT;
   const int key_blocks = (a.Nk + 127) / 128;
   int splits = a.q_splits;

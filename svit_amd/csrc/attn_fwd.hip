@@ -301,13 +301,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
 template <int DA, int NW, int NS>
 int launch_cfg(const svit_attn_fwd_args& a, hipStream_t st) {
   const size_t lds = NS * (size_t)(KT * DA * 2 + KT * HD * 2);
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<DA, NW, NS>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    configured = true;
-  }
+  static SvitOnce once;
+  if (int rc = svit_max_lds_once(once, (const void*)attn_fwd_kernel<DA, NW, NS>, lds)) return rc;
   dim3 grid((a.Nq + NW * 32 - 1) / (NW * 32), a.B * a.heads);
   hipLaunchKernelGGL((attn_fwd_kernel<DA, NW, NS>), grid, dim3(NW * 64), lds, st, a);
   SVIT_LAUNCH_CHECK();

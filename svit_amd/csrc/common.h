@@ -16,6 +16,24 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define SVIT_ERR_ALIGN (-3)
 #define SVIT_ERR_ARG (-4)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device), safe to call from any
+// host thread (forward runs on the main thread, backward on autograd's device thread): one bit
+// per device in an atomic mask; a lost race only repeats an idempotent call.  Replaces the
+// process-global `static bool configured` flags (no global mutable state).
+struct SvitOnce {
+  unsigned long long mask;   // zero-initialised static storage; accessed through __atomic builtins
+};
+static inline int svit_max_lds_once(SvitOnce& once, const void* fn, size_t bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (__atomic_load_n(&once.mask, __ATOMIC_ACQUIRE) & bit) return 0;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return (int)e;
+  __atomic_fetch_or(&once.mask, bit, __ATOMIC_RELEASE);
+  return 0;
+}
+
 #define SVIT_LAUNCH_CHECK()                       \
   do {                                            \
     hipError_t e__ = hipGetLastError();           \
@@ -116,8 +134,10 @@ struct SvitReduceDst {
   float* ptr[6];
   int end[6];  // exclusive end of each segment within [0, n); unused tail entries = n
 };
-// Defined in misc.hip: launches the reduce now, or -- between svit_reduce_defer(1) and
-// svit_reduce_flush() -- queues it so that all reduces of a transformer block run as ONE launch.
+// Defined in misc.hip: launches the reduce now on `st`, or -- while `st` is in deferred mode
+// (svit_reduce_defer(1, st) ... svit_reduce_defer(0, st)) -- queues it in THAT STREAM's queue so
+// that all reduces of a transformer block run as ONE launch on the stream that produced their
+// partial rows.  A launch on any other stream is never captured by the queue.
 void svit_launch_reduce(const float* partial, int nblocks, int n, SvitReduceDst dst, hipStream_t st);
 
 // Zero-fill as a kernel (16-byte stores): hipMemsetAsync turns into a memset node under stream

@@ -14,6 +14,7 @@
 // (wave-uniform base + lane*16); the four 16-B chunks of a row are XOR-swizzled with
 // ((row>>2)&3) on the per-lane SOURCE address, and the same XOR is applied on the fragment
 // reads -> ds_read_b128 of 16 consecutive rows hits 16 distinct slots of the 256-B bank row.
+#include <atomic>
 #include "gemm_epilogue.h"
 
 namespace {
@@ -131,16 +132,13 @@ int launch_v2(const svit_gemm_args& a, hipStream_t st) {
   const size_t lds_epi = (size_t)WAVES_M * WAVES_N * 16 * (32 * NB + 4) * sizeof(float);
   if (lds < lds_epi) lds = lds_epi;
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM);
-  static bool configured = false;
-  if (!configured) {
-#define SVIT_V2_ATTR(E)                                                                      \
-  hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<RB, NB, WAVES_M, WAVES_N, STAGES, E>,   \
-                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-    SVIT_V2_ATTR(SVIT_EPI_BF16); SVIT_V2_ATTR(SVIT_EPI_GELU); SVIT_V2_ATTR(SVIT_EPI_RESID);
-    SVIT_V2_ATTR(SVIT_EPI_F32); SVIT_V2_ATTR(SVIT_EPI_DGELU);
+  static SvitOnce once[5];
+#define SVIT_V2_ATTR(E)                                                                              \
+  if (int rc = svit_max_lds_once(once[E], (const void*)gemm_nt_v2_kernel<RB, NB, WAVES_M, WAVES_N, STAGES, E>, lds)) \
+    return rc
+  SVIT_V2_ATTR(SVIT_EPI_BF16); SVIT_V2_ATTR(SVIT_EPI_GELU); SVIT_V2_ATTR(SVIT_EPI_RESID);
+  SVIT_V2_ATTR(SVIT_EPI_F32); SVIT_V2_ATTR(SVIT_EPI_DGELU);
 #undef SVIT_V2_ATTR
-    configured = true;
-  }
 #define SVIT_V2_CASE(E)                                                                       \
   case E:                                                                                     \
     hipLaunchKernelGGL((gemm_nt_v2_kernel<RB, NB, WAVES_M, WAVES_N, STAGES, E>), grid, dim3(NT), \
@@ -161,8 +159,8 @@ int launch_v2(const svit_gemm_args& a, hipStream_t st) {
 }
 }  // namespace
 
-static int g_nt_stages = 0;     // tuning knob (svit_debug_set(0, n)); 2..4, 0 = heuristic
-static int g_nt_force_cfg = -1; // tuning knob (svit_debug_set(1, c)); -1 = heuristic
+static std::atomic<int> g_nt_stages{0};     // tuning knob (svit_debug_set(0, n)); 2..4, 0 = heuristic
+static std::atomic<int> g_nt_force_cfg{-1}; // tuning knob (svit_debug_set(1, c)); -1 = heuristic
 extern "C" int svit_debug_set(int key, int val) {
   if (key == 0) g_nt_stages = val;
   else if (key == 1) g_nt_force_cfg = val;
@@ -195,18 +193,19 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
   // fragments, only W streamed through a 4-deep LDS ring: 4x fewer fill bytes per flop) --
   // 0.6-0.9x the speed of these tiles on every shape of the model: one barrier-locked workgroup
   // per CU leaves nothing to overlap its epilogues and barriers with.
+  const int force_cfg = g_nt_force_cfg.load(), force_stages = g_nt_stages.load();
   bool big = a.N % 192 == 0 && (long)((a.M + 127) / 128) * (a.N / 192) >= 256;
-  if (g_nt_force_cfg == 0 && a.N % 192 == 0) big = true;
-  if (g_nt_force_cfg == 2) big = false;
+  if (force_cfg == 0 && a.N % 192 == 0) big = true;
+  if (force_cfg == 2) big = false;
   // pipeline depth (measured, tools/bench_kernels.py ntstages): short K loops prefer 2 stages
   // (less LDS -> more resident workgroups), K >= 2048 wants the 4-deep prefetch
-  const int stages = g_nt_stages ? g_nt_stages : (a.K >= 2048 ? 4 : 2);
+  const int stages = force_stages ? force_stages : (a.K >= 2048 ? 4 : 2);
   // 128x128 blocks (2x2 waves of 64x64): measured ~10 % faster than 128x192 for the wide, short-K
   // GEMMs of the 14x14 stage (M = 13064, N = 1152 / 1536, K = 384: fc1, fc2-dgrad, qkv)
   bool sq = a.N % 128 == 0 && a.N >= 1024 && a.K <= 512 &&
             (long)((a.M + 127) / 128) * (a.N / 128) <= 2048;
-  if (g_nt_force_cfg == 4) sq = a.N % 128 == 0;
-  else if (g_nt_force_cfg >= 0) sq = false;
+  if (force_cfg == 4) sq = a.N % 128 == 0;
+  else if (force_cfg >= 0) sq = false;
   if (sq) {
     if (stages == 2) return launch_v2<2, 2, 2, 2, 2>(a, st);
     if (stages == 3) return launch_v2<2, 2, 2, 2, 3>(a, st);

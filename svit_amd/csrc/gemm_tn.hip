@@ -2,6 +2,7 @@
 //   svit_gemm_tn : dW[N,K] += A[M,N]^T * B[M,K]  (reduction over rows, operands consumed
 //                  through ds_read_b64_tr_b16 transposed LDS reads; fused bias gradient)
 // (the forward / dgrad kernel svit_gemm_nt lives in gemm_nt.hip)
+#include <atomic>
 #include "common.h"
 #include "../../include/svit_hip.h"
 
@@ -242,8 +243,8 @@ extern "C" int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, floa
 }
 
 // cost-model constants of the grouped launch (svit_debug_set keys 2 / 3 for sweeps)
-static double g_tn_step_us = 0.85;      // one 64-row step of a workgroup, 512 resident
-static double g_tn_atomic_tbs = 0.75;   // effective fp32 atomic flush rate, TB/s
+static std::atomic<double> g_tn_step_us{0.85};      // one 64-row step of a workgroup, 512 resident
+static std::atomic<double> g_tn_atomic_tbs{0.75};   // effective fp32 atomic flush rate, TB/s
 extern "C" int svit_debug_set_tn(int step_us_x100, int atomic_tbs_x100) {
   if (step_us_x100 > 0) g_tn_step_us = step_us_x100 * 0.01;
   if (atomic_tbs_x100 > 0) g_tn_atomic_tbs = atomic_tbs_x100 * 0.01;

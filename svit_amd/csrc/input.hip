@@ -23,8 +23,14 @@ __global__ __launch_bounds__(256) void im2col_patch_u8_kernel(
   __shared__ bf16_t img[63][COLS + 4];  // [(c*3+kt)*7+ky][x - x_start], normalised, 0 = padding
   __shared__ bf16_t tab[768];
   const int yo = blockIdx.x % Ho, to = (blockIdx.x / Ho) % To, b = blockIdx.x / (Ho * To);
-  const int v = crops ? crops[b * 3] : b, y0 = crops ? crops[b * 3 + 1] : 0,
-            x0 = crops ? crops[b * 3 + 2] : 0;
+  // the host validates the crop table when it is built (svit_amd/input.py); a table rewritten
+  // on the device later is clamped into the frames here, so no entry can address outside them
+  int v = crops ? crops[b * 3] : b, y0 = crops ? crops[b * 3 + 1] : 0,
+      x0 = crops ? crops[b * 3 + 2] : 0;
+  const int64_t n_videos = frames_bytes / ((int64_t)T * Hs * Ws * 3);
+  v = max(0, min(v, (int)n_videos - 1));
+  y0 = max(0, min(y0, Hs - S));
+  x0 = max(0, min(x0, Ws - S));
   for (int i = threadIdx.x; i < 768; i += 256) tab[i] = lut[i];
   bf16_t* out = cols + (((int64_t)b * To + to) * Ho + yo) * Wo * 448;
   for (int xc0 = 0; xc0 < Wo; xc0 += XO) {

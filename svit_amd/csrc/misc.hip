@@ -1,6 +1,8 @@
 // Memory-bound helpers: casts / transposes of the weight copies, DropPath backward scaling,
 // im2col for the patch-embedding conv, special-token rows, max-pool skip path, and the
 // optimiser tail (global grad norm + clip + AdamW) -- gfx950 only.
+#include <mutex>
+#include <unordered_map>
 #include "common.h"
 #include "../../include/svit_hip.h"
 
@@ -455,8 +457,21 @@ extern "C" int svit_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, 
   return SVIT_OK;
 }
 
-static SvitReduceBatch g_reduce_batch;   // host-side queue (one engine thread per process)
-static bool g_reduce_defer = false;
+// Deferred second-stage reductions, ONE QUEUE PER STREAM (host side, mutex-guarded): a stream
+// enters deferred mode with svit_reduce_defer(1, stream); reduces launched on THAT stream are
+// then queued and run as one launch -- on that same stream, i.e. behind the kernels that wrote
+// their partial rows -- when it leaves the mode.  Work on any other stream (a side stream running
+// weight-gradient kernels next to the chain) is never captured by a queue it did not open: its
+// reduce runs at once on its own stream.  (Round 1 kept one process-global queue that ignored the
+// launching stream; a reduce queued from a side stream was flushed on the main stream with no
+// dependency on the kernel producing its rows.)
+struct ReduceQueue {
+  SvitReduceBatch batch;
+  bool defer = false;
+  ReduceQueue() { batch.count = 0; }
+};
+static std::mutex g_reduce_mu;
+static std::unordered_map<hipStream_t, ReduceQueue> g_reduce_q;
 
 static void reduce_launch(const SvitReduceBatch& b, hipStream_t st) {
   int max_n = 0;
@@ -474,37 +489,68 @@ static void reduce_launch(const SvitReduceBatch& b, hipStream_t st) {
 
 void svit_launch_reduce(const float* partial, int nblocks, int n, SvitReduceDst dst, hipStream_t st) {
   SvitReduceJob job = {partial, nblocks, n, dst};
-  if (g_reduce_defer) {
-    if (g_reduce_batch.count == SVIT_REDUCE_MAX_JOBS) {      // queue full: run what we have
-      reduce_launch(g_reduce_batch, st);
-      g_reduce_batch.count = 0;
+  SvitReduceBatch run;
+  run.count = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_reduce_mu);
+    auto it = g_reduce_q.find(st);
+    if (it != g_reduce_q.end() && it->second.defer) {
+      ReduceQueue& q = it->second;
+      if (q.batch.count == SVIT_REDUCE_MAX_JOBS) {      // queue full: run what we have
+        run = q.batch;
+        q.batch.count = 0;
+      }
+      q.batch.job[q.batch.count++] = job;
+      job.partial = nullptr;                            // queued
     }
-    g_reduce_batch.job[g_reduce_batch.count++] = job;
-    return;
   }
-  SvitReduceBatch one;
-  one.job[0] = job;
-  one.count = 1;
-  reduce_launch(one, st);
+  if (run.count) reduce_launch(run, st);
+  if (job.partial) {
+    SvitReduceBatch one;
+    one.job[0] = job;
+    one.count = 1;
+    reduce_launch(one, st);
+  }
+}
+
+// take the stream's queued jobs (and optionally set its mode) under the lock, launch outside it
+static void reduce_take(hipStream_t st, int set_defer /* -1 = keep */, bool drop, SvitReduceBatch* out) {
+  out->count = 0;
+  std::lock_guard<std::mutex> lk(g_reduce_mu);
+  auto it = g_reduce_q.find(st);
+  if (it == g_reduce_q.end()) {
+    if (set_defer != 1) return;
+    it = g_reduce_q.emplace(st, ReduceQueue()).first;
+  }
+  ReduceQueue& q = it->second;
+  if (!drop) *out = q.batch;
+  q.batch.count = 0;
+  if (set_defer >= 0) q.defer = set_defer != 0;
+  if (!q.defer) g_reduce_q.erase(it);                  // streams come and go (graph capture)
 }
 
 extern "C" int svit_reduce_defer(int on, void* stream) {
-  // leaving deferred mode flushes (see svit_reduce_flush)
-  if (!on && g_reduce_batch.count) {
-    reduce_launch(g_reduce_batch, (hipStream_t)stream);
-    g_reduce_batch.count = 0;
-  }
-  g_reduce_defer = on != 0;
+  // entering deferred mode drops leftovers of an aborted block (their pointers may be stale);
+  // leaving it runs the queue (see svit_reduce_flush)
+  SvitReduceBatch run;
+  reduce_take((hipStream_t)stream, on ? 1 : 0, on != 0, &run);
+  if (run.count) reduce_launch(run, (hipStream_t)stream);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }
 
 extern "C" int svit_reduce_flush(void* stream) {
-  if (g_reduce_batch.count) {
-    reduce_launch(g_reduce_batch, (hipStream_t)stream);
-    g_reduce_batch.count = 0;
-  }
+  SvitReduceBatch run;
+  reduce_take((hipStream_t)stream, -1, false, &run);
+  if (run.count) reduce_launch(run, (hipStream_t)stream);
   SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_reduce_reset(void* stream) {
+  // error path of the host schedule: forget the stream's queued jobs and leave deferred mode
+  SvitReduceBatch run;
+  reduce_take((hipStream_t)stream, 0, true, &run);
   return SVIT_OK;
 }
 

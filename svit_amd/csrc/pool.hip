@@ -685,13 +685,8 @@ static int launch_wgrad(const svit_pool_wgrad_args& a, int Ho, int Wo, hipStream
   if (blocks > 1024) blocks = 1024;
   if (blocks > a.workspace_floats / (27 * HD)) blocks = a.workspace_floats / (27 * HD);
   if (blocks < 1) return SVIT_ERR_ARG;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)pool_wgrad_kernel<S>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, TL::LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    configured = true;
-  }
+  static SvitOnce once;
+  if (int rc = svit_max_lds_once(once, (const void*)pool_wgrad_kernel<S>, TL::LDS_BYTES)) return rc;
   hipLaunchKernelGGL(pool_wgrad_kernel<S>, dim3((unsigned)blocks), dim3(192), TL::LDS_BYTES, st, a,
                      pl.n_tiles, pl.tiles_x, pl.tiles_y, pl.t_chunks, pl.t_len);
   SVIT_LAUNCH_CHECK();
@@ -1164,15 +1159,12 @@ extern "C" int svit_pool_conv_wgrad_qkv(const svit_pool_wgrad_args* a3, void* st
   if (blocks > 1024) blocks = 1024;
   if (blocks > a3[0].workspace_floats / (3 * 27 * HD)) blocks = a3[0].workspace_floats / (3 * 27 * HD);
   if (blocks < 1) return SVIT_ERR_ARG;
-  static bool configured = false;
-  if (!configured) {
+  {
     size_t mx = WgradTile<1>::LDS_BYTES;
     if ((size_t)WgradTile<2>::LDS_BYTES > mx) mx = WgradTile<2>::LDS_BYTES;
     if ((size_t)WgradTile<3>::LDS_BYTES > mx) mx = WgradTile<3>::LDS_BYTES;
-    hipError_t e = hipFuncSetAttribute((const void*)pool_wgrad3_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)mx);
-    if (e != hipSuccess) return (int)e;
-    configured = true;
+    static SvitOnce once;
+    if (int rc = svit_max_lds_once(once, (const void*)pool_wgrad3_kernel, mx)) return rc;
   }
   hipLaunchKernelGGL(pool_wgrad3_kernel, dim3((unsigned)blocks, 3), dim3(192), lds,
                      (hipStream_t)stream, g);
@@ -1219,13 +1211,8 @@ extern "C" int svit_pool_conv_bwd_qkv(const svit_pool_dgrad_args* d3, const svit
     g.nsplit[i] = d3[i].stride_hw == 1 ? 2 : 1;     // 27 taps per token vs <= 12
   }
   g.qkv = w3[0].qkv;
-  static bool configured = false;
-  if (!configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)pool_bwd_small_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
-    if (e != hipSuccess) return (int)e;
-    configured = true;
-  }
+  static SvitOnce once;
+  if (int rc = svit_max_lds_once(once, (const void*)pool_bwd_small_kernel, 112 * 1024)) return rc;
   hipLaunchKernelGGL(pool_bwd_small_kernel, dim3(d3[0].B * d3[0].heads, 3, 8), dim3(192), lds,
                      (hipStream_t)stream, g);
   SVIT_LAUNCH_CHECK();
@@ -1337,13 +1324,8 @@ extern "C" int svit_relpos_q_bwd(const svit_relq_bwd_args* a, void* stream) {
   if (rc) return rc;
   const size_t lds = (size_t)(a->rows_h + a->rows_w + a->rows_t) * HD * sizeof(float);
   if (lds > 150 * 1024) return SVIT_ERR_SHAPE;
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)relq_bwd_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    configured = lds;
-  }
+  static SvitOnce once;      // sized for the largest table set the shape check admits
+  if (int rc = svit_max_lds_once(once, (const void*)relq_bwd_kernel, 150 * 1024)) return rc;
   const int64_t total = (int64_t)a->B * a->heads * (1 + a->qt * a->qh * a->qw + a->n_obj);
   if (!a->workspace) return SVIT_ERR_ARG;
   const int tab_n = (a->rows_h + a->rows_w + a->rows_t) * HD;

@@ -352,7 +352,14 @@ class Engine:
         hip.mark("bwd_norm")
         for blk in reversed(plan.blocks):
             below = st["blocks"][blk.index - 1] if blk.index > 0 else None
-            dx, dx16 = self._block_bwd(blk, st["blocks"][blk.index], dx, dx16, st["n_obj"], below)
+            try:
+                dx, dx16 = self._block_bwd(blk, st["blocks"][blk.index], dx, dx16, st["n_obj"], below)
+            except BaseException:
+                # a failed launch / allocation inside the bracket: the queued second-stage
+                # reductions and weight-gradient GEMMs hold pointers into this step's scratch
+                ops.reduce_reset()
+                self._tn = []
+                raise
             hip.mark("bwd%d" % blk.index)
             ready(1 + (depth - 1 - blk.index))
         # block-0 input: [cls | patches | objects]

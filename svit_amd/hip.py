@@ -112,6 +112,7 @@ _SIGS = {
     "svit_pad_cast_rows": (i32, [vp, vp, i32, i32, i32, vp]),
     "svit_reduce_defer": (i32, [i32, vp]),
     "svit_reduce_flush": (i32, [vp]),
+    "svit_reduce_reset": (i32, [vp]),
     "svit_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, vp]),
     "svit_layernorm_bwd": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i64, i32, vp,
                                  i64, vp]),

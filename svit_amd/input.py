@@ -42,12 +42,13 @@ class U8Clips:
         crops = torch.as_tensor(crops, dtype=torch.int32)
         if crops.dim() != 2 or crops.shape[1] != 3:
             raise ValueError("crops must be int32 [B,3] = (video, y0, x0)")
-        if not crops.is_cuda:                 # host-side range check (the kernel does none)
-            c = crops
-            ok = ((c[:, 0] >= 0) & (c[:, 0] < V) & (c[:, 1] >= 0) & (c[:, 1] + self.size <= Hs) &
-                  (c[:, 2] >= 0) & (c[:, 2] + self.size <= Ws))
-            if not bool(ok.all()):
-                raise ValueError("crop table outside the frames")
+        # range check wherever the table lives (one tiny reduction + one sync at construction; the
+        # kernel additionally clamps, so a table rewritten later through copy_ cannot read outside)
+        c = crops
+        ok = ((c[:, 0] >= 0) & (c[:, 0] < V) & (c[:, 1] >= 0) & (c[:, 1] + self.size <= Hs) &
+              (c[:, 2] >= 0) & (c[:, 2] + self.size <= Ws))
+        if not bool(ok.all()):
+            raise ValueError("crop table outside the frames")
         self.crops = crops.to(frames.device).contiguous()
         self.lut = normalize_lut(mean, std, frames.device) if lut is None else lut
 

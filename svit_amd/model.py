@@ -40,10 +40,13 @@ class Registry:
 MODEL_REGISTRY = Registry("MODEL")
 
 
-def _weight_decayed(name, shape):
-    """slowfast/models/optimizer.py:39-60 with ZERO_WD_1D_PARAM: 1-D tensors and biases are not
-    decayed; everything else (incl. cls_token, object_queries, rel_pos_*) is."""
-    return not (len(shape) == 1 or name.endswith(".bias"))
+def _weight_decayed(name, shape, skip=()):
+    """slowfast/models/optimizer.py:35-52 with ZERO_WD_1D_PARAM: 1-D tensors, biases and the
+    names `model.no_weight_decay()` lists are not decayed; everything else is.  The reference
+    tests `name in skip` on the FULL dotted name, so of the names SViT.no_weight_decay() returns
+    (video_model_builder.py:267-289) only the top-level cls_token / object_queries /
+    pos_embed_temporal ever match -- "rel_pos_h" never equals "blocks.0.attn.rel_pos_h"."""
+    return not (name in skip or len(shape) == 1 or name.endswith(".bias"))
 
 
 def _trunc_normal_(t, std=0.02):
@@ -186,6 +189,15 @@ class SViT(nn.Module):
                           "object_queries", "pos_embed_temporal"])
         return names
 
+    def decay_skip(self):
+        """The skip list `construct_optimizer` really applies (optimizer.py:35-37): it asks
+        `hasattr(model, "no_weight_decay")` of the object build_model returned, which is the DDP
+        wrapper when NUM_GPUS > 1 -- there the attribute does not exist and nothing is skipped."""
+        return frozenset(self.no_weight_decay()) if self.cfg.NUM_GPUS <= 1 else frozenset()
+
+    def weight_decayed(self, name, shape):
+        return _weight_decayed(name, shape, self.decay_skip())
+
     # -- device placement ------------------------------------------------------------------------
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
@@ -204,7 +216,7 @@ class SViT(nn.Module):
                                    "GPU (build_model with cfg.NUM_GPUS >= 1); no CPU fallback")
         hip.load()
         shapes = {n: tuple(p.shape) for n, p in named.items()}
-        flat = FlatParams(shapes, _weight_decayed, dev, arch.readiness_rank)
+        flat = FlatParams(shapes, self.weight_decayed, dev, arch.readiness_rank)
         for n, p in named.items():
             flat.p(n).copy_(p.data)
             p.data = flat.p(n)

@@ -109,6 +109,11 @@ def reduce_defer(on):
     hip.call("svit_reduce_defer", int(on))
 
 
+def reduce_reset():
+    """error path: drop the current stream's queued reductions and leave deferred mode"""
+    hip.call("svit_reduce_reset")
+
+
 def colsum(a, out):
     _chk_dev(a, out)
     hip.call("svit_colsum_bf16", ptr(a), a.stride(0), ptr(out), a.shape[0], a.shape[1])

@@ -85,9 +85,9 @@ class FusedClipAdamW:
         """state index -> parameter name: the reference's two groups (decayed, then 1-D / bias;
         slowfast/models/optimizer.py:39-72), each in named_parameters() order."""
         named = [(n, tuple(p.shape)) for n, p in self.model.named_parameters()]
-        from .model import _weight_decayed
-        dec = [n for n, s in named if _weight_decayed(n, s)]
-        return dec, [n for n, s in named if not _weight_decayed(n, s)]
+        wd = self.model.weight_decayed       # same predicate that laid out the flat buffers
+        dec = [n for n, s in named if wd(n, s)]
+        return dec, [n for n, s in named if not wd(n, s)]
 
     def state_dict(self):
         """The dict torch.optim.AdamW.state_dict() yields for the reference's optimizer (what a
@@ -126,6 +126,12 @@ class FusedClipAdamW:
             ent = state.get(j, state.get(str(j)))
             if ent is None:
                 continue
+            want = self.flat.slots[n][2]
+            for key in ("exp_avg", "exp_avg_sq"):     # copy_ would silently broadcast [96] -> [1,1,96]
+                if tuple(ent[key].shape) != tuple(want):
+                    raise ValueError("optimizer state %d (%s): %s has shape %s, the parameter %s -- the "
+                                     "checkpoint's parameter order / decay groups differ from this model's"
+                                     % (j, n, key, tuple(ent[key].shape), tuple(want)))
             self.flat.view(self.exp_avg, n).copy_(ent["exp_avg"])
             self.flat.view(self.exp_avg_sq, n).copy_(ent["exp_avg_sq"])
             step = max(step, int(ent["step"]))

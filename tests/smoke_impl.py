@@ -66,6 +66,7 @@ def compare_step(num_frames=4, crop=64, batch=2, frames_path=False, verbose=Fals
     named = dict(model.named_parameters())
     gmax = max(float(v.grad.abs().max()) for v in p.values() if v.grad is not None)
     worst, worst_name = 1.0, ""
+    ratio_lo, ratio_hi, ratio_name = 1.0, 1.0, ""
     num = den_a = den_b = 0.0
     for k, v in p.items():
         ref = v.grad if v.grad is not None else torch.zeros_like(v)
@@ -79,17 +80,28 @@ def compare_step(num_frames=4, crop=64, batch=2, frames_path=False, verbose=Fals
         c = cosine(got, ref)
         if c < worst:
             worst, worst_name = c, k
+        # a scale error (a DropPath factor applied twice, mean-vs-sum) leaves the cosine at 1:
+        # the norms must agree too
+        r = float(got.double().norm() / ref.double().norm())
+        if r < ratio_lo or r > ratio_hi:
+            ratio_name = k
+        ratio_lo, ratio_hi = min(ratio_lo, r), max(ratio_hi, r)
         if verbose:
             print("%-40s cos %.5f  |ref| %.3e |got| %.3e" % (k, c, float(ref.norm()), float(got.norm())))
     out["grad_cos_worst"] = worst
     out["grad_cos_worst_name"] = worst_name
     out["grad_cos_global"] = num / ((den_a ** 0.5) * (den_b ** 0.5) + 1e-30)
+    out["grad_norm_ratio_min"], out["grad_norm_ratio_max"] = ratio_lo, ratio_hi
+    out["grad_norm_ratio_name"] = ratio_name
+    out["grad_norm_ratio_global"] = (den_a / den_b) ** 0.5
     return out
 
 
 # stated tolerance of the bf16 HIP path against the fp32 oracle (BASELINE.json north_star;
 # SURVEY.md 8(c)): logits max-abs <= 0.05 and cosine >= 0.999; per-tensor grad cosine >= 0.99.
-TOL = {"logits_maxabs": 0.05, "logits_cos": 0.999, "grad_cos": 0.99, "obj_desc_cos": 0.999}
+# per-tensor gradient norm ratio |got| / |ref| in [0.97, 1.03] (global: [0.99, 1.01]).
+TOL = {"logits_maxabs": 0.05, "logits_cos": 0.999, "grad_cos": 0.99, "obj_desc_cos": 0.999,
+       "grad_norm_ratio": (0.97, 1.03), "grad_norm_ratio_global": (0.99, 1.01)}
 
 
 def check(res):
@@ -98,6 +110,10 @@ def check(res):
     assert res["obj_desc_cos"] >= TOL["obj_desc_cos"], res
     assert res["grad_cos_worst"] >= TOL["grad_cos"], res
     assert res["grad_cos_global"] >= 0.995, res
+    lo, hi = TOL["grad_norm_ratio"]
+    assert lo <= res["grad_norm_ratio_min"] and res["grad_norm_ratio_max"] <= hi, res
+    lo, hi = TOL["grad_norm_ratio_global"]
+    assert lo <= res["grad_norm_ratio_global"] <= hi, res
 
 
 def run():

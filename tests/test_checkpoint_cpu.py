@@ -46,7 +46,15 @@ def test_save_then_load_with_shape_matching(tmp_path):
     assert checkpoint.has_checkpoint(str(tmp_path)) and checkpoint.get_last_checkpoint(str(tmp_path)) == path
     ck = torch.load(path, weights_only=False)
     assert sorted(ck) == ["cfg", "epoch", "model_state", "optimizer_state", "scaler_state"]
-    assert isinstance(ck["cfg"], str) and ck["epoch"] == 2 and ck["scaler_state"] == {}
+    assert isinstance(ck["cfg"], str) and ck["epoch"] == 2
+    # the reference's trainer resumes through an ENABLED GradScaler (train_net.py:501-505,
+    # checkpoint.py:381-382); an empty state would make its load_state_dict raise
+    scaler = torch.amp.GradScaler("cpu", enabled=True)
+    scaler.load_state_dict(ck["scaler_state"])
+    assert scaler.get_scale() == 65536.0 and scaler.get_growth_interval() == 2000
+    assert ck["scaler_state"] == torch.amp.GradScaler("cpu", enabled=True).state_dict()
+    path2 = checkpoint.save_checkpoint(str(tmp_path / "s"), src, opt, 2, cfg, scaler=scaler)
+    assert torch.load(path2, weights_only=False)["scaler_state"] == scaler.state_dict()
     # same architecture: everything loads, optimizer moments restored, epoch returned
     dst = _Tiny(4)
     opt2 = torch.optim.AdamW(dst.parameters(), lr=1e-3)
@@ -80,3 +88,23 @@ def test_parameter_order_is_the_references(golden_dir):
     assert {k: list(v) for k, v in shapes.items()} == layout["shapes"]
     from oracle import svit_ref as R
     assert list(R.param_shapes(R.make_spec(16, 224))) == layout["named_parameters"]
+
+
+def test_zero_decay_pos_cls_follows_the_reference_rule():
+    """optimizer.py:35-52: `name in skip` is an exact match on the dotted name, so of
+    no_weight_decay()'s names only cls_token / object_queries / pos_embed_temporal ever leave the
+    decayed group (single GPU); behind the DDP wrapper (NUM_GPUS > 1) the reference finds no
+    `no_weight_decay` attribute and skips nothing."""
+    from svit_amd.model import SViT
+    cfg = config.ssv2_cfg(4, 64)
+    cfg.MVIT.ZERO_DECAY_POS_CLS = True
+    m = SViT(cfg)
+    shapes = {n: tuple(p.shape) for n, p in m.named_parameters()}
+    zero = {n for n, s in shapes.items() if not m.weight_decayed(n, s)}
+    plain = {n for n, s in shapes.items() if len(s) == 1 or n.endswith(".bias")}
+    assert zero == plain | {"cls_token", "object_queries", "pos_embed_temporal"}
+    assert "blocks.0.attn.rel_pos_h" not in zero
+    cfg.NUM_GPUS = 8
+    assert {n for n, s in shapes.items() if not m.weight_decayed(n, s)} == plain
+    cfg.NUM_GPUS, cfg.MVIT.ZERO_DECAY_POS_CLS = 1, False
+    assert {n for n, s in shapes.items() if not m.weight_decayed(n, s)} == plain

@@ -42,6 +42,7 @@ def _worker(rank, world, port, ok):
     from svit_amd.dp import DataParallel
     from svit_amd.engine import FlatParams
     from svit_amd.model import _weight_decayed
+    torch.set_num_threads(2)
     cfg = config.ssv2_cfg(16, 224)
     plan = arch.build_plan(cfg)
     shapes = arch.param_shapes(plan)
@@ -86,8 +87,11 @@ def _worker(rank, world, port, ok):
 def test_flat_allreduce_gloo_world2():
     world = 2
     port = _free_port()
-    ok = mp.Array("i", [0] * world)
-    procs = [mp.Process(target=_worker, args=(r, world, port, ok)) for r in range(world)]
+    # spawn, not fork: earlier tests of the same pytest process may have started OpenMP threads
+    # (any multi-threaded torch op), and a forked child then deadlocks in its first parallel region
+    ctx = mp.get_context("spawn")
+    ok = ctx.Array("i", [0] * world)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ok)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

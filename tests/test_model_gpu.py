@@ -19,6 +19,8 @@ from tests import smoke_impl as S
     (4, 88, 2, False),     # odd sizes: rel-pos tables interpolated in blocks >= 3
     (4, 64, 3, True),      # T=1 frames path of a 4-frame model (rel_pos_t interpolated to 1 row)
     (8, 224, 1, False),    # BASELINE config 1 (C1)
+    (16, 224, 1, False),   # BASELINE config 2/3: the shape the headline metric is quoted on
+    (16, 224, 2, False),   # ... and with two clips (cross-clip reductions of every weight gradient)
     (32, 224, 1, False),   # BASELINE config 4: long clip (T' = 16, J = 30 / 44 bias columns)
     (16, 312, 1, False),   # BASELINE config 5: 312^2 crop (78x78 patches, interpolated tables)
 ])
@@ -67,6 +69,88 @@ def test_against_reference_golden(name, manifest, golden_dir):
         np.testing.assert_allclose(ex["pred_bboxes"].cpu().numpy(), arrays["eval_pred_bboxes"], atol=3e-2)
 
 
+def _grad_vs_golden(named_grads, digests, arrays, prefix):
+    """HIP gradients against the REFERENCE's own (digest l2 + strided sample or full tensor):
+    per-tensor norm ratio in [0.97, 1.03] and cosine >= 0.99 on what the fixture holds."""
+    gmax = max(digests[prefix + k]["l2"] for k in named_grads)
+    worst_cos, worst_ratio = (1.0, ""), (0.0, "")
+    for k, g in named_grads.items():
+        d = digests[prefix + k]
+        g = g.detach().float().cpu()
+        if d["l2"] < 1e-4 * gmax:      # mathematically ~zero (e.g. norm_k.bias)
+            assert float(g.norm()) < 2e-2 * gmax, (k, float(g.norm()), gmax)
+            continue
+        ratio = float(g.double().norm()) / d["l2"]
+        if abs(ratio - 1) > abs(worst_ratio[0] - 1) or worst_ratio[1] == "":
+            worst_ratio = (ratio, k)
+        if prefix + k in arrays:
+            c = S.cosine(g, torch.from_numpy(arrays[prefix + k]))
+        else:
+            c = S.cosine(P.sample_of(g), torch.from_numpy(arrays["sample:" + prefix + k]))
+        if c < worst_cos[0]:
+            worst_cos = (c, k)
+    print("worst cosine", worst_cos, "worst norm ratio", worst_ratio)
+    assert worst_cos[0] >= 0.985, worst_cos       # 256-element samples: a little noisier than full
+    assert 0.97 <= worst_ratio[0] <= 1.03, worst_ratio
+
+
+def test_headline_config_gradients_vs_reference_golden(manifest, golden_dir):
+    """16x224^2 (the config the metric is quoted on): logits, loss and ALL 405 parameter gradients
+    of the HIP step against the reference's own forward+backward (tests/golden/c2.npz, fp32 CPU)."""
+    case = manifest["cases"]["c2"]
+    cfg, model, spec, sd = S.build_hip_model(16, 224)
+    x, y = P.frames(case["batch"], 16, 224), P.labels(case["batch"])
+    arrays = np.load(os.path.join(golden_dir, "c2.npz"))
+    logits, extra = model([x.cuda()], {})
+    loss = torch.nn.functional.cross_entropy(logits, y.cuda())
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(arrays["logits"])
+    assert float((logits.detach().cpu() - ref).abs().max()) <= S.TOL["logits_maxabs"]
+    assert abs(float(loss.detach()) - float(arrays["loss"])) < 2e-2
+    _grad_vs_golden({k: v.grad for k, v in model.named_parameters()}, case["digests"], arrays, "grad:")
+
+
+@pytest.mark.parametrize("mode", ["l1", "l2"])
+def test_consistency_loss_vs_reference_golden(mode, manifest, golden_dir):
+    """clip forward + the no-grad single-frame pass (train_net.py:105-110) +
+    the frame-clip consistency term, all through the HIP path, against the numbers the reference's
+    own `VideoImageLoss._consistency_loss` (losses.py:127-136) produced: frames obj_desc, the
+    loss value, CE + LAMBDA_CON * consistency, and its 405 gradients."""
+    from svit_amd import losses
+    c = manifest["consistency"]
+    arrays = np.load(os.path.join(golden_dir, "consistency.npz"))
+    cfg, model, spec, sd = S.build_hip_model(4, 64)
+    cfg.TRAIN.FORWARD_VIDEO_FRAMES = True
+    cfg.SVIT.CONSISTENCY = mode
+    B = c["info"]["batch"]
+    x, y = P.frames(B, 4, 64).cuda(), P.labels(B).cuda()
+    logits, extra = model([x], {})
+    with torch.no_grad():
+        fp, fe = model([x.transpose(1, 2).flatten(0, 1).unsqueeze(2)], {})
+    d = c["digests"]["frames_obj_desc"]
+    got = P.digest(fe["obj_desc"].detach().cpu())
+    assert abs(got["l2"] - d["l2"]) / d["l2"] < 2e-2
+    assert S.cosine(P.sample_of(fe["obj_desc"].detach().cpu()),
+                    torch.from_numpy(arrays["sample:frames_obj_desc"])) >= 0.999
+    extra = dict(extra)
+    extra["frames_output"] = {"preds": fp, "extra_preds": fe}
+    fn = losses.VideoImageLoss(cfg, is_video_rank=True)
+    parts = fn(logits, extra, y, {})
+    key = "video_image_desc_%s_loss" % mode
+    assert set(parts) == {"loss_ce", key}
+    info = c["info"][mode]
+    assert abs(float(parts[key].detach()) - info["value"]) / info["value"] < 2e-2
+    total = fn.total(parts)
+    assert abs(float(total.detach()) - info["total"]) < 3e-2
+    model.zero_grad(set_to_none=True)
+    total.backward()
+    torch.cuda.synchronize()
+    _grad_vs_golden({k: v.grad for k, v in model.named_parameters()}, c["digests"], arrays,
+                    mode + ":grad:")
+
+
 def test_droppath_and_dropout_masks(manifest, golden_dir):
     """DropPath per-sample factors and head dropout mask taken from the reference's own run."""
     case = manifest["cases"]["tiny_drop"]
@@ -96,6 +180,37 @@ def test_state_dict_layout_and_interface():
     assert [list(r) for r in cfg.MVIT.POOL_KV_STRIDE][:2] == [[0, 1, 8, 8], [1, 1, 4, 4]]
     with pytest.raises(Exception):
         model([torch.zeros(1, 3, 8, 224, 224).cuda()], {})   # wrong clip length for this cfg
+
+
+def test_zero_decay_pos_cls_layout_and_state_shape_check():
+    """MVIT.ZERO_DECAY_POS_CLS (the default of defaults.py; ssv2.yaml turns it off): the three
+    top-level tokens move to the zero-decay group of the flat layout AND of the optimizer-state
+    order, and a state whose order does not fit is refused instead of broadcast."""
+    from svit_amd import config, optim
+    from svit_amd.model import build_model
+    cfg = config.ssv2_cfg(4, 64)
+    cfg.MVIT.ZERO_DECAY_POS_CLS = True
+    cfg.MVIT.DROPPATH_RATE = 0.0
+    model = build_model(cfg)
+    flat = model.flat
+    for n in ("cls_token", "object_queries", "pos_embed_temporal"):
+        assert flat.slots[n][0] >= flat.n_decay, n
+    assert flat.slots["blocks.0.attn.rel_pos_h"][0] < flat.n_decay
+    opt = optim.construct_optimizer(model, cfg)
+    dec, rest = opt._order()
+    assert rest[:3] == ["cls_token", "pos_embed_temporal", "object_queries"]
+    x, y = P.frames(2, 4, 64), P.labels(2)
+    logits, _ = model([x.cuda()], {})
+    torch.nn.functional.cross_entropy(logits, y.cuda()).backward()
+    opt.step()
+    sd = opt.state_dict()
+    opt.load_state_dict(sd)
+    # the ssv2-recipe order (tokens decayed) must not load into this layout silently
+    cfg2 = config.ssv2_cfg(4, 64)
+    other = optim.construct_optimizer(build_model(cfg2), cfg2)
+    other.step_count = 1
+    with pytest.raises(ValueError):
+        opt.load_state_dict(other.state_dict())
 
 
 def test_fused_optimizer_step_matches_oracle():
