@@ -62,11 +62,18 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(frames, crop, timed_steps=2):
-    """fp32 CPU oracle (oracle/svit_ref.py, pinned against the reference) fwd+bwd at B=1."""
-    from oracle import svit_ref as R
-    threads = min(usable_cores(), 64)
-    torch.set_num_threads(threads)
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_leg(R, frames, crop, autocast, timed_steps):
+    """1 warm-up + `timed_steps` timed fwd+bwd steps of the oracle at B=1 -> (best s, median s)."""
     spec = R.make_spec(num_frames=frames, crop=crop)
     torch.manual_seed(0)
     p = {k: (torch.randn(s) * 0.02).requires_grad_(True) for k, s in R.param_shapes(spec).items()}
@@ -80,15 +87,41 @@ def cpu_baseline(frames, crop, timed_steps=2):
         t0 = time.perf_counter()
         ds = R.sample_drop_scales(spec, 1)
         keep = (torch.rand(1, 1 + frames * 4, spec.final_dim) > 0.5).float() * 2.0
-        logits, _ = R.forward(p, spec, x, training=True, drop_scales=ds, dropout_keep=keep)
-        R.video_loss(logits, y).backward()
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            logits, _ = R.forward(p, spec, x, training=True, drop_scales=ds, dropout_keep=keep)
+            loss = R.video_loss(logits.float(), y)
+        loss.backward()
         for v in p.values():
             v.grad = None
         times.append(time.perf_counter() - t0)
-    best = min(times[1:])
-    return {"value": round(1.0 / best, 4), "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": "fp32 CPU oracle (oracle/svit_ref.py), %dx%d^2, B=1, 1 warm-up + %d timed "
-                      "fwd+bwd steps, best step %.2f s" % (frames, crop, timed_steps, best)}
+    t = sorted(times[1:])
+    return t[0], t[len(t) // 2]
+
+
+def cpu_baseline(frames, crop, timed_steps=3):
+    """SURVEY.md 8(d) protocol: the fp32 CPU oracle (oracle/svit_ref.py, pinned against the
+    reference) fwd+bwd at B=1, DropPath / dropout on, 1 warm-up + 3 timed steps, best and median,
+    for the workload shape (fp32 and bf16-autocast legs) and for C1 (8x224^2 fp32).  `value` is
+    the fp32 leg of the workload shape; about 20-30 s of CPU work in all."""
+    from oracle import svit_ref as R
+    threads = min(usable_cores(), 64)
+    torch.set_num_threads(threads)
+    legs = {}
+    for name, (f, c, ac) in (("%dx%d_fp32" % (frames, crop), (frames, crop, False)),
+                             ("%dx%d_bf16_autocast" % (frames, crop), (frames, crop, True)),
+                             ("8x224_fp32", (8, 224, False))):
+        if name in legs:
+            continue
+        best, med = _cpu_leg(R, f, c, ac, timed_steps)
+        legs[name] = {"best_clips_per_s": round(1.0 / best, 4), "median_clips_per_s": round(1.0 / med, 4),
+                      "best_s": round(best, 3), "median_s": round(med, 3)}
+    head = legs["%dx%d_fp32" % (frames, crop)]
+    return {"value": head["best_clips_per_s"], "unit": "clips/s", "cores": threads, "kind": "port",
+            "cpu": cpu_model_name(), "median": head["median_clips_per_s"], "legs": legs,
+            "sample": "fp32 CPU oracle (oracle/svit_ref.py), %dx%d^2, B=1, DropPath/dropout on, "
+                      "1 warm-up + %d timed fwd+bwd steps, best step %.2f s (median %.2f s); legs: "
+                      "same shape under CPU bf16 autocast, and C1 8x224^2 fp32"
+                      % (frames, crop, timed_steps, head["best_s"], head["median_s"])}
 
 
 def kernel_report(trace, batch):
@@ -128,6 +161,36 @@ def kernel_report(trace, batch):
     return rows, total
 
 
+def self_launch(n):
+    """Start n ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the env, as
+    torch.distributed.run would), wait for all of them, return the worst exit code."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                break            # a rank died: its peers would wait in a collective forever
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+            rc = rc or p.returncode
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,12 +213,16 @@ def main():
                     help="launch every kernel from Python instead of replaying the HIP graphs")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher.  N fresh child processes, one rank
+        # per GPU, started BEFORE this process makes any GPU call (it never does); rank 0 prints
+        # the JSON line on the inherited stdout.
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # rehearsal knobs (not used by the driver): SVIT_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and
     # SVIT_BENCH_BACKEND=gloo replaces RCCL, so the N > 1 code path can be run on a one-GPU box
     share = os.environ.get("SVIT_BENCH_SHARE_GPU") == "1"
@@ -256,6 +323,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     ms_per_step = dt / args.steps * 1e3
+    ranks_seen = dist.get_world_size() if world > 1 else 1
     n_vid = world - args.image_ranks
     clips_per_s = args.batch * n_vid * args.steps / dt
 
@@ -268,7 +336,8 @@ def main():
                                "clip+AdamW%s" % (args.frames, args.crop, args.batch,
                                                  " + no-grad frames pass" if args.frames_pass else ""),
                    "global_batch": args.batch * world, "seq_len": None,
-                   "parallelism": "dp%d" % world,
+                   "parallelism": "dp%d" % world, "ranks_seen": ranks_seen,
+                   "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
                    "launch": launch_note, "input": "uint8 frames" if args.u8 else "fp32 clips"},
         "loss": round(loss_val, 4),
         "step_mfma_frac": round(clips_per_s / max(1, n_vid) * STEP_GFLOP_PER_CLIP * 1e9 /

@@ -22,13 +22,18 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out, graphed=False):
+def _worker(rank, world, port, out, graphed=False, backend="gloo"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":        # the production branch: one GPU per rank, RCCL, ReduceOp.AVG
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import procedural as P
     from oracle import svit_ref as R
     from svit_amd import config, optim
@@ -77,10 +82,11 @@ def _worker(rank, world, port, out, graphed=False):
     dist.destroy_process_group()
 
 
-def _run(world, out, graphed=False):
+def _run(world, out, graphed=False, backend="gloo"):
     port = _free_port()
-    ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, port, out, graphed)) for r in range(world)]
+    ctx = mp.get_context("spawn")      # fresh children, started before this process touches a GPU
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out, graphed, backend))
+             for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -108,6 +114,40 @@ def test_graphed_two_ranks_equal_eager_one_rank(tmp_path):
     assert diff < 2e-3 * one.abs().max().item()
     cos = torch.dot(one.double(), two.double()) / (one.double().norm() * two.double().norm())
     assert cos > 0.999999
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+@pytest.mark.parametrize("graphed", [False, True])
+def test_rccl_two_gpus_equal_one_rank(tmp_path, graphed):
+    """The production exchange (slowfast/models/build.py:67-74 replaced by svit_amd/dp.py):
+    backend nccl = RCCL, one GPU per rank, ReduceOp.AVG, init_process_group(device_id=...),
+    collectives launched between graph segments -- equal to one rank on the merged batch.
+    Skipped on the one-GPU test box; runs wherever two GPUs are visible."""
+    one = _run(1, str(tmp_path / "w1.pt"))
+    two = _run(2, str(tmp_path / "w2r.pt"), graphed=graphed, backend="nccl")
+    assert (one - two).abs().max().item() < 2e-3 * one.abs().max().item()
+    cos = torch.dot(one.double(), two.double()) / (one.double().norm() * two.double().norm())
+    assert cos > 0.999999
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher: bench.py starts the ranks itself (here both on
+    the box's one GPU over gloo -- the rehearsal knobs) and rank 0 prints ONE JSON line."""
+    import json
+    import subprocess
+    env = dict(os.environ, SVIT_BENCH_SHARE_GPU="1", SVIT_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--batch", "1", "--frames", "4", "--crop", "64",
+                        "--no-cpu-baseline", "--no-kernel-trace"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks_seen"] == 2 and out["value"] > 0
+    assert out["config"]["backend"] == "gloo" and out["scaling"] == "weak"
 
 
 # ---- heterogeneous ranks of the published recipe (SURVEY 8(f) rank 2): rank 0 trains clips with
