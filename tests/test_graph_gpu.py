@@ -109,3 +109,34 @@ def test_graphed_step_with_frames_pass_and_consistency():
     plain = GraphedTrainStep(model, lambda p, e, l: torch.nn.functional.cross_entropy(p, l), [x], y)
     loss_plain, _ = plain([x], y)
     assert float(loss) > float(loss_plain)            # the consistency term is really in there
+
+
+def test_overlap_wgrad_is_bit_equal_to_stream_order():
+    """Weight-gradient GEMMs on a side stream next to the dgrad chain (Engine.overlap_wgrad):
+    everything produced by ordered reductions -- the whole dgrad chain, the pooling-conv weight
+    gradients, every LayerNorm gain/bias gradient (two-stage reduce, per-stream deferred queue,
+    include/svit_hip.h) -- must be BIT-identical to the stream-ordered schedule.  (The Linear
+    weight gradients leave the grouped TN GEMM through fp32 atomics and the attention backward
+    may split its query range; with attn_q_splits = 1 only the former are order-dependent.)"""
+    cfg, model, spec, sd = S.build_hip_model(8, 224)
+    eng = model.engine
+    eng.attn_q_splits = 1
+    x, y = P.frames(2, 8, 224).cuda(), P.labels(2).cuda()
+    det = [n for n in sd if ".pool_" in n or "norm" in n.split(".")[-2] or n in
+           ("cls_token", "object_queries", "pos_embed_temporal")]
+    assert len(det) > 100
+
+    def run(overlap):
+        eng.overlap_wgrad = overlap
+        _, _, g = _eager(model, x, y)
+        return {n: model.flat.view(g, n).clone() for n in sd}
+
+    a, b = run(False), run(False)
+    c, d = run(True), run(True)
+    eng.overlap_wgrad = False
+    for n in det:
+        assert torch.equal(a[n], b[n]), ("stream order itself not reproducible", n)
+        assert torch.equal(a[n], c[n]) and torch.equal(a[n], d[n]), ("overlap changed", n)
+    flat_a = torch.cat([a[n].flatten() for n in sd])
+    flat_c = torch.cat([c[n].flatten() for n in sd])
+    assert S.cosine(flat_a, flat_c) > 0.999999
