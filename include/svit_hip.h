@@ -252,10 +252,12 @@ int svit_relpos_scatter(const svit_relq_scatter_args* a, void* stream);
 /* (q*scale)@k^T + rel-pos bias -> softmax -> @v -> + pooled q (all tokens but cls) ->
  * merge heads (attention.py:429-461).
  * qa bf16 [B,h,Nq,DA], ka bf16 [B,h,Nk,DA] (DA = 128 or 160), v bf16 [B,h,Nk,96],
- * ctx bf16 [B,Nq,h*96], lse2 f32 [B,h,Nq] (log2-domain log-sum-exp, saved for backward). */
+ * ctx bf16 [B,Nq,h*96], lse2 f32 [B,h,Nq] (log2-domain log-sum-exp, saved for backward).
+ * bias_cols: how many of the DA - 96 rel-pos columns carry data (kt + kh + kw); the kernel only
+ * multiplies the 16-column k-steps that do.  0 = all of them. */
 typedef struct {
   const void* qa; const void* ka; const void* v; void* ctx; float* lse2;
-  int32_t B, heads, Nq, Nk, DA; float scale;
+  int32_t B, heads, Nq, Nk, DA; float scale; int32_t bias_cols;
 } svit_attn_fwd_args;
 int svit_attn_fwd(const svit_attn_fwd_args* a, void* stream);
 typedef struct {

@@ -227,6 +227,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 }  // namespace attn
 
+
 // Workgroups are dealt to the 8 XCDs round-robin by linear id, and every XCD has its own L2.
 // Remap the linear id so that CONSECUTIVE logical ids land on ONE XCD: all query tiles of a
 // (batch, head) then share that XCD's L2 copy of K/V instead of fetching it up to 8 times over

@@ -321,11 +321,18 @@ int launch_fwd(const svit_attn_fwd_args& a, hipStream_t st) {
 }
 }  // namespace
 
+int svit_attn_fwd_v2(const svit_attn_fwd_args& a, int bias_cols, hipStream_t st);   // attn_fwd2.hip
+
 extern "C" int svit_attn_fwd(const svit_attn_fwd_args* a, void* stream) {
   if (!a || !a->qa || !a->ka || !a->v || !a->ctx || !a->lse2) return SVIT_ERR_ARG;
   if (a->B <= 0 || a->heads <= 0 || a->Nq <= 0 || a->Nk <= 0) return SVIT_ERR_SHAPE;
   if (((uintptr_t)a->qa | (uintptr_t)a->ka | (uintptr_t)a->v | (uintptr_t)a->ctx) & 15)
     return SVIT_ERR_ALIGN;
+  if (a->DA != 128 && a->DA != 160) return SVIT_ERR_SHAPE;
+  if (a->bias_cols < 0 || a->bias_cols > a->DA - 96) return SVIT_ERR_ARG;
+  // SVIT_ATTN_FWD_V=1 selects the round-1 kernel (A/B measurements)
+  static const int version = getenv("SVIT_ATTN_FWD_V") ? atoi(getenv("SVIT_ATTN_FWD_V")) : 2;
+  if (version != 1) return svit_attn_fwd_v2(*a, a->bias_cols, (hipStream_t)stream);
   if (a->DA == 128) return launch_fwd<128>(*a, (hipStream_t)stream);
   if (a->DA == 160) return launch_fwd<160>(*a, (hipStream_t)stream);
   return SVIT_ERR_SHAPE;

@@ -1,0 +1,446 @@
+// Fused pooled attention, forward -- second-generation kernel (round 2) -- gfx950.
+//
+//   S = (q*scale) k^T + rel-pos bias ; P = softmax(S) ; ctx = P v + q (all tokens but cls)
+//   (attention.py:429-461; operands as in attn_fwd.hip: qa = [q | relq/scale], ka = [k | one-hot])
+//
+// What changed against attn_fwd.hip (round-1 anatomy: 4100 cycles per 64-key tile for 32 queries
+// per wave, of which the MFMA floor is 1024 -- DMA issue, exposed softmax and one K fragment read
+// per MFMA made up the rest):
+//   * ONE wave per SIMD with the whole register file (launch_bounds(256, 1)); a wave owns QB
+//     blocks of 32 queries (QB = 2: every K and V fragment read from LDS feeds two MFMAs).
+//   * The loop is software-pipelined across tiles INSIDE the wave's instruction stream: while the
+//     matrix pipe runs S(t+1) = K(t+1) Q^T, the vector pipe exponentiates S(t); while it runs
+//     O += V(t)^T P(t), the vector pipe takes the row maxima of S(t+1) and finishes P(t).  Each
+//     step of the stream is a few MFMAs plus its slice of VALU work, fenced by sched_barrier so
+//     that the compiler keeps the interleave.
+//   * Only the k-steps that carry data are multiplied: KS = 6 (q.k) + ceil(J/16) bias steps
+//     instead of DA/16 (J = kt+kh+kw <= 36 at 16x224^2: 9 steps where round 1 ran 10).
+//   * K/V tiles arrive by LDS-DMA into an NS-deep ring, two tiles ahead; one raw barrier per tile.
+//   * The output leaves through LDS as whole 192-byte rows (16-byte stores), with the residual
+//     pooling add, instead of 8-byte pieces at a row stride.
+#include <cstdlib>
+#include <type_traits>
+#include "attn_common.h"
+#include "../../include/svit_hip.h"
+
+namespace {
+using namespace attn;
+constexpr int KT = 64;  // keys per tile
+
+template <int I> using Int = std::integral_constant<int, I>;
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(Int<B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+// LDS reads by inline asm (invisible to hipcc's waitcnt pass, which would otherwise drain the
+// LDS-DMA pipeline in front of every read); released by counted lgkmcnt waits that carry the
+// destination registers as in/out operands.
+template <int OFF>
+__device__ __forceinline__ void lds_read128(bf16x8_t& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "i"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr(s16x4_t& d, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "i"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lgkm_release(bf16x8_t& f) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lgkm_release(s16x4_t (&f)[6]) {
+  asm volatile("s_waitcnt lgkmcnt(%6)"
+               : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) : "n"(N) : "memory");
+}
+// both halves of a query's row statistics: lane l <-> lane l^32 (VALU, no LDS traffic)
+__device__ __forceinline__ float other_half(float x) {
+  const unsigned u = __float_as_uint(x);
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  // r[0]: lanes 32..63 now hold the low half's value; r[1]: lanes 0..31 hold the high half's
+  return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+#else
+  return __shfl_xor(x, 32, 64);
+#endif
+}
+
+// KS  = k-steps of the contraction that are multiplied (6 + bias steps); the K image holds
+//       NP = ceil(KS/2) panels of 32 columns.
+// QB  = 32-query blocks per wave (1 or 2).   NS = depth of the K/V ring (3 or 4).
+template <int KS, int QB, int NS>
+__global__ __launch_bounds__(256, 1) void attn_fwd2_kernel(svit_attn_fwd_args a) {
+  constexpr int NP = (KS + 1) / 2, KCOLS = NP * 32;
+  constexpr int K_BYTES = KT * KCOLS * 2, V_BYTES = KT * HD * 2, STAGE = K_BYTES + V_BYTES;
+  using KLoad = GldsTile<KT, KCOLS, 4>;
+  using VLoad = GldsTile<KT, HD, 4>;
+  constexpr int PIECES = KLoad::PER_WAVE + VLoad::PER_WAVE;    // DMA instructions per wave, tile
+  constexpr int NK = 2 * KS;                                    // K fragment steps per tile
+  constexpr int WQ = QB * 32;                                   // queries per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int DA = a.DA;
+  const int wgid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int bh = wgid / gridDim.x, b = bh / a.heads, head = bh % a.heads;
+  const int q0 = (wgid % gridDim.x) * (4 * WQ) + wave * WQ;
+  const bf16_t* qa = (const bf16_t*)a.qa + ((size_t)bh * a.Nq) * DA;
+  const bf16_t* ka = (const bf16_t*)a.ka + ((size_t)bh * a.Nk) * DA;
+  const bf16_t* vv = (const bf16_t*)a.v + ((size_t)bh * a.Nk) * HD;
+  const float c = a.scale * 1.4426950408889634f;
+
+  bf16x8_t qf[QB][KS];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int qc = min(q0 + qb * 32 + (lane & 31), a.Nq - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      qf[qb][ks] = *(const bf16x8_t*)(qa + (size_t)qc * DA + ks * 16 + hh * 8);
+  }
+
+  f32x16_t o[QB][3];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = -INFINITY;
+    l_run[qb] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[qb][j][r] = 0.f;
+  }
+
+  // per-lane LDS byte addresses of the fragment reads in stage 0 (image: attn_common.h)
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  unsigned kaddr0[2], vaddr0[2];
+  {
+    const int row = lane & 31, sw = (row >> 2) & 3;
+    kaddr0[0] = lds0 + row * 64 + 16 * ((0 + hh) ^ sw);
+    kaddr0[1] = lds0 + row * 64 + 16 * ((2 + hh) ^ sw);
+    const int cg = (lane >> 4) & 1, i = lane & 15, q = i >> 2, pp = i & 3;
+    const int r0 = 4 * hh, ch = 2 * cg + (pp >> 1);
+    const unsigned vb = lds0 + K_BYTES + 8 * (pp & 1);
+    vaddr0[0] = vb + (r0 + q) * 64 + 16 * (ch ^ ((r0 >> 2) & 3));
+    vaddr0[1] = vb + (r0 + 8 + q) * 64 + 16 * (ch ^ (((r0 + 8) >> 2) & 3));
+  }
+
+  const int nt = (a.Nk + KT - 1) / KT;
+  KLoad kload;
+  VLoad vload;
+  kload.init(DA, wave, lane);
+  vload.init(HD, wave, lane);
+  auto issue = [&](int t) {
+    unsigned char* st = smem + (t % NS) * STAGE;
+    const int k0 = t * KT;
+    kload.issue_auto(ka + (size_t)k0 * DA, DA, a.Nk - k0, st, wave, lane);
+    vload.issue_auto(vv + (size_t)k0 * HD, HD, a.Nk - k0, st + K_BYTES, wave, lane);
+  };
+  // the Q fragments must be in registers before the first LDS-DMA is issued: a later wait for
+  // them would be a vmcnt(0) in the middle of the pipeline
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[qb][ks]));
+  constexpr int AHEAD = NS - 1;                 // tiles in flight beyond the one being consumed
+#pragma unroll
+  for (int t = 0; t < AHEAD; ++t)
+    if (t < nt) issue(t);
+
+  // ---- pieces of the pipelined step -----------------------------------------------------
+  // K row fragment of step i (kb = i / KS, ks = i % KS)
+  auto issue_k = [&](auto I, bf16x8_t& d, const unsigned (&kaddr)[2]) {
+    constexpr int i = decltype(I)::value, kb = i / KS, ks = i % KS;
+    lds_read128<kb * 2048 + (ks >> 1) * KT * 64>(d, kaddr[ks & 1]);
+  };
+  // V^T fragments of key group g (16 keys: kb = g>>1, sp = g&1), 3 panels x (lo, hi)
+  auto issue_v = [&](auto Gi, s16x4_t (&d)[6], const unsigned (&vaddr)[2]) {
+    constexpr int g = decltype(Gi)::value;
+    static_for<0, 3>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      lds_read_tr<g * 16 * 64 + j * KT * 64>(d[2 * j], vaddr[0]);
+      lds_read_tr<g * 16 * 64 + j * KT * 64>(d[2 * j + 1], vaddr[1]);
+    });
+  };
+  // exponentiate half a P fragment: registers 8*sp + 4*half .. +3 of S block (qb, kb) become
+  // elements 4*half .. +3 of the bf16 operand fragment (the scores themselves are only read:
+  // they can stay in the accumulator file)
+  auto exp_unit = [&](const f32x16_t (&s)[QB][2], float (&rs)[QB], bf16x8_t& frag, int qb, int kb,
+                      int sp, int half) {
+    float p[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      p[e] = fast_exp2(__builtin_fmaf(s[qb][kb][8 * sp + 4 * half + e], c, -m_run[qb]));
+      rs[qb] += p[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) frag[4 * half + e] = (__bf16)p[e];
+  };
+  // row maxima of a score tile + the deferred re-basing decision (cdna guide T13): called when
+  // the previous tile's P.V is complete, so O and l carry exactly one scale
+  auto rebase = [&](f32x16_t (&s)[QB][2]) {
+    constexpr float RESCALE_THR = 6.0f;
+    float mx[QB];
+    bool need = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float v = max3(s[qb][0][0], s[qb][1][0], s[qb][0][1]);
+      v = max3(v, s[qb][1][1], s[qb][0][2]);
+#pragma unroll
+      for (int r = 2; r < 15; ++r) v = max3(v, s[qb][1][r], s[qb][0][r + 1]);
+      v = fmaxf(v, s[qb][1][15]);
+      mx[qb] = fmaxf(v, other_half(v)) * c;
+      need = need || (mx[qb] - m_run[qb] > RESCALE_THR);
+    }
+    if (__any(need)) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        const float m_new = fmaxf(m_run[qb], mx[qb]);
+        const float alpha = fast_exp2(m_run[qb] - m_new);
+        l_run[qb] *= alpha;
+        m_run[qb] = m_new;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[qb][j][r] *= alpha;
+      }
+    }
+  };
+  auto mask_tail = [&](f32x16_t (&s)[QB][2], int t) {   // ragged last tile: rows >= Nk hold re-read data
+    const int kbase = t * KT;
+    if (kbase + KT > a.Nk) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kbase + kb * 32 + acc_row(r, lane) >= a.Nk) s[qb][kb][r] = -INFINITY;
+    }
+  };
+
+  // P fragment f (consumption order of the P.V phase): key group g = f / QB, query block f % QB
+  // -> 2 exp units.  Phase 1 (beside the QK^T MFMAs of the next tile) exponentiates the groups
+  // 0..2, phase 2 (beside the P.V MFMAs of groups 0..2) the last group.
+  constexpr int U1 = 6 * QB;         // exp units done in phase 1 (of 8 * QB)
+
+  // One pipelined step: consumes the scores `sc` of tile t (row maxima already folded into
+  // m_run), produces the scores `sn` of tile t + 1 when HAS_NEXT.
+  auto step = [&](auto HasNext, int t, f32x16_t (&sc)[QB][2], f32x16_t (&sn)[QB][2]) {
+    constexpr bool HAS_NEXT = decltype(HasNext)::value;
+    // tile t+1 landed (mine), then everyone's; tile t-1's slot is free for tile t + AHEAD
+    if (HAS_NEXT) {
+      if (t + 2 < nt && AHEAD >= 3) wait_vmcnt<(AHEAD - 2) * PIECES>();   // unreachable for NS 3
+      else if (t + 2 < nt && AHEAD == 2) wait_vmcnt<0>();
+      else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (t + AHEAD < nt) issue(t + AHEAD);
+    const unsigned so_c = (t % NS) * STAGE, so_n = ((t + 1) % NS) * STAGE;
+    const unsigned kaddr[2] = {kaddr0[0] + so_n, kaddr0[1] + so_n};
+    const unsigned vaddr[2] = {vaddr0[0] + so_c, vaddr0[1] + so_c};
+    float rs[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) rs[qb] = 0.f;
+    bf16x8_t pf[4][QB];              // P fragments, [key group][query block]
+    s16x4_t vt[2][6];
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 1: S(t+1) = K(t+1) Q^T on the matrix pipe, exp(S(t)) on the vector pipe -----
+    if constexpr (HAS_NEXT) {
+      bf16x8_t kf[3];
+      issue_k(Int<0>{}, kf[0], kaddr);
+      issue_k(Int<1>{}, kf[1], kaddr);
+      static_for<0, NK>([&](auto I) {
+        constexpr int i = decltype(I)::value, kb = i / KS, ks = i % KS;
+        if constexpr (i + 2 < NK) issue_k(Int<i + 2>{}, kf[(i + 2) % 3], kaddr);
+        if constexpr (i == NK - 2) issue_v(Int<0>{}, vt[0], vaddr);
+        // LDS returns in order: everything older than the last N operations has landed
+        if constexpr (i + 2 < NK) lgkm_release<2>(kf[i % 3]);
+        else if constexpr (i == NK - 2) lgkm_release<7>(kf[i % 3]);
+        else lgkm_release<6>(kf[i % 3]);
+        static_for<0, QB>([&](auto Q) {
+          constexpr int qb = decltype(Q)::value;
+          if constexpr (ks == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sn[qb][kb][r] = 0.f;
+          }
+          sn[qb][kb] = mfma32(kf[i % 3], qf[qb][ks], sn[qb][kb]);
+        });
+        // this step's slice of the exponentials: unit u -> fragment u / 2, half u % 2
+        static_for<0, U1>([&](auto U) {
+          constexpr int u = decltype(U)::value;
+          if constexpr (u * NK / U1 == i) {
+            constexpr int f = u / 2, g = f / QB, qb = f % QB;
+            exp_unit(sc, rs, pf[g][qb], qb, g >> 1, g & 1, u & 1);
+          }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    } else {
+      issue_v(Int<0>{}, vt[0], vaddr);
+      static_for<0, U1>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        constexpr int f = u / 2, g = f / QB, qb = f % QB;
+        exp_unit(sc, rs, pf[g][qb], qb, g >> 1, g & 1, u & 1);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (HAS_NEXT) mask_tail(sn, t + 1);
+    // ---- phase 2: O^T += V(t)^T P(t)^T on the matrix pipe; last exp units on the vector pipe
+    static_for<0, 4>([&](auto Gi) {
+      constexpr int g = decltype(Gi)::value;
+      if constexpr (g + 1 < 4) {
+        issue_v(Int<g + 1>{}, vt[(g + 1) & 1], vaddr);
+        lgkm_release<6>(vt[g & 1]);
+      } else {
+        lgkm_release<0>(vt[g & 1]);
+      }
+      static_for<0, QB>([&](auto Q) {
+        constexpr int qb = decltype(Q)::value;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          o[qb][j] = mfma32(make_bf16x8(vt[g & 1][2 * j], vt[g & 1][2 * j + 1]), pf[g][qb], o[qb][j]);
+      });
+      // the last key group's exponentials, spread over the first three groups' MFMAs
+      static_for<U1, 8 * QB>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        if constexpr ((u - U1) * 3 / (2 * QB) == g) {
+          constexpr int f = u / 2, gg = f / QB, qb = f % QB;
+          exp_unit(sc, rs, pf[gg][qb], qb, gg >> 1, gg & 1, u & 1);
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) l_run[qb] += rs[qb];
+    if (HAS_NEXT) rebase(sn);          // P.V of tile t is complete: O and l carry one scale
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: scores of tile 0 -----------------------------------------------------
+  f32x16_t sa[QB][2], sb[QB][2];
+  {
+    if (nt > 1 && AHEAD >= 2) {
+      if (nt > 2 && AHEAD >= 3) wait_vmcnt<2 * PIECES>();
+      else wait_vmcnt<PIECES>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    const unsigned kaddr[2] = {kaddr0[0], kaddr0[1]};
+    bf16x8_t kf[3];
+    issue_k(Int<0>{}, kf[0], kaddr);
+    issue_k(Int<1>{}, kf[1], kaddr);
+    static_for<0, NK>([&](auto I) {
+      constexpr int i = decltype(I)::value, kb = i / KS, ks = i % KS;
+      if constexpr (i + 2 < NK) issue_k(Int<i + 2>{}, kf[(i + 2) % 3], kaddr);
+      if constexpr (i + 2 < NK) lgkm_release<2>(kf[i % 3]);
+      else if constexpr (i == NK - 2) lgkm_release<1>(kf[i % 3]);
+      else lgkm_release<0>(kf[i % 3]);
+      static_for<0, QB>([&](auto Q) {
+        constexpr int qb = decltype(Q)::value;
+        if constexpr (ks == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sa[qb][kb][r] = 0.f;
+        }
+        sa[qb][kb] = mfma32(kf[i % 3], qf[qb][ks], sa[qb][kb]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    mask_tail(sa, 0);
+    rebase(sa);
+  }
+  // ---- main loop, unrolled by two so that the score tiles keep their registers ------------
+  for (int t = 0;; t += 2) {
+    if (t + 1 < nt) step(std::true_type{}, t, sa, sb);
+    else { step(std::false_type{}, t, sa, sb); break; }
+    if (t + 2 < nt) step(std::true_type{}, t + 1, sb, sa);
+    else { step(std::false_type{}, t + 1, sb, sa); break; }
+  }
+
+  // ---- epilogue: normalise, stage the wave's WQ x 96 tile in LDS, store whole rows ----------
+  __builtin_amdgcn_s_barrier();        // every wave is done with the K/V ring
+  constexpr int OROW = 208;            // bytes per staged row (192 + pad: spreads the banks)
+  unsigned char* ost = smem + wave * (WQ * OROW);
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const float l_tot = l_run[qb] + other_half(l_run[qb]);
+    const float inv = 1.f / l_tot;
+    const int qi = q0 + qb * 32 + (lane & 31);
+    if (hh == 0 && qi < a.Nq) a.lse2[(size_t)bh * a.Nq + qi] = m_run[qb] + log2f(l_tot);
+    unsigned char* orow = ost + (qb * 32 + (lane & 31)) * OROW;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dv = j * 32 + 8 * g + 4 * hh;
+        uint2 pk;
+        pk.x = pack_bf16x2(o[qb][j][4 * g] * inv, o[qb][j][4 * g + 1] * inv);
+        pk.y = pack_bf16x2(o[qb][j][4 * g + 2] * inv, o[qb][j][4 * g + 3] * inv);
+        *(uint2*)(orow + dv * 2) = pk;
+      }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's staging writes have landed
+  // 12 sixteen-byte chunks per row; lane -> (row, chunk) so that a row's 192 bytes are written
+  // by 12 consecutive lanes
+#pragma unroll
+  for (int it = 0; it < WQ * 12 / 64; ++it) {
+    const int id = it * 64 + lane, row = id / 12, ch = id % 12;
+    const int qi = q0 + row;
+    if (qi < a.Nq) {
+      uint4 ov = *(const uint4*)(ost + row * OROW + ch * 16);
+      if (qi > 0) {                   // residual pooling: every token but cls adds its pooled q
+        const uint4 qq = *(const uint4*)(qa + (size_t)qi * DA + ch * 8);
+        ov.x = pack_bf16x2(lo_bf16(ov.x) + lo_bf16(qq.x), hi_bf16(ov.x) + hi_bf16(qq.x));
+        ov.y = pack_bf16x2(lo_bf16(ov.y) + lo_bf16(qq.y), hi_bf16(ov.y) + hi_bf16(qq.y));
+        ov.z = pack_bf16x2(lo_bf16(ov.z) + lo_bf16(qq.z), hi_bf16(ov.z) + hi_bf16(qq.z));
+        ov.w = pack_bf16x2(lo_bf16(ov.w) + lo_bf16(qq.w), hi_bf16(ov.w) + hi_bf16(qq.w));
+      }
+      *(uint4*)((bf16_t*)a.ctx + ((size_t)b * a.Nq + qi) * a.heads * HD + head * HD + ch * 8) = ov;
+    }
+  }
+}
+
+template <int KS, int QB, int NS>
+int launch_cfg(const svit_attn_fwd_args& a, hipStream_t st) {
+  constexpr int NP = (KS + 1) / 2;
+  size_t lds = NS * (size_t)(KT * NP * 32 * 2 + KT * HD * 2);
+  const size_t lds_out = 4 * (size_t)(QB * 32) * 208;
+  if (lds < lds_out) lds = lds_out;
+  static SvitOnce once;
+  if (int rc = svit_max_lds_once(once, (const void*)attn_fwd2_kernel<KS, QB, NS>, lds)) return rc;
+  dim3 grid((a.Nq + QB * 128 - 1) / (QB * 128), a.B * a.heads);
+  hipLaunchKernelGGL((attn_fwd2_kernel<KS, QB, NS>), grid, dim3(256), lds, st, a);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+template <int KS>
+int launch_ks(const svit_attn_fwd_args& a, int qb, hipStream_t st) {
+  return qb == 2 ? launch_cfg<KS, 2, 4>(a, st) : launch_cfg<KS, 1, 4>(a, st);
+}
+}  // namespace
+
+// bias_cols = number of rel-pos columns that carry data (J = kt + kh + kw), 0 = unknown (all of
+// DA - 96).  Returns SVIT_ERR_SHAPE for shapes this kernel does not cover (the caller falls back
+// to the round-1 kernel).
+int svit_attn_fwd_v2(const svit_attn_fwd_args& a, int bias_cols, hipStream_t st) {
+  const int extra = a.DA - HD;
+  if (bias_cols <= 0 || bias_cols > extra) bias_cols = extra;
+  const int ks = 6 + (bias_cols + 15) / 16;
+  // two query blocks per wave while that still gives every CU a workgroup
+  static const int force_qb = getenv("SVIT_ATTN_FWD_QB") ? atoi(getenv("SVIT_ATTN_FWD_QB")) : 0;
+  const long wg2 = (long)((a.Nq + 255) / 256) * a.B * a.heads;
+  // (two query blocks per wave do not fit the 256 + 256 register split without spilling yet:
+  // SVIT_ATTN_FWD_QB=2 selects them for experiments)
+  (void)wg2;
+  const int qb = force_qb ? force_qb : 1;
+  switch (ks) {
+    case 7: return launch_ks<7>(a, qb, st);
+    case 8: return launch_ks<8>(a, qb, st);
+    case 9: return launch_ks<9>(a, qb, st);
+    case 10: return launch_ks<10>(a, qb, st);
+  }
+  return SVIT_ERR_SHAPE;
+}

@@ -270,43 +270,41 @@ struct SvitReduceBatch {
   int count;
 };
 
-__global__ __launch_bounds__(256) void svit_reduce_partials_kernel(SvitReduceBatch batch) {
-  // block (32 columns x 8 row lanes): coalesced 128-byte row segments, 8x4 rows in flight.
-  // blockIdx.z cuts long row ranges into chunks (their sums meet in fp32 atomics), so a job with
-  // ~1000 partial rows is not one serial sweep per column block.
-  __shared__ float red[8][33];
+__global__ __launch_bounds__(1024) void svit_reduce_partials_kernel(SvitReduceBatch batch) {
+  // block (32 columns x 32 row lanes): coalesced 128-byte row segments, 32x4 rows in flight per
+  // iteration, so ~1000 partial rows are 8 iterations deep.  ONE workgroup owns a column block
+  // from the first row to the last and adds in a fixed order: the result is bit-reproducible
+  // (round 1 cut the rows into blockIdx.z chunks that met in fp32 atomics -- every LayerNorm /
+  // pooling-conv parameter gradient then depended on the order the chunks happened to commit).
+  __shared__ float red[32][33];
   const SvitReduceJob& j = batch.job[blockIdx.y];
   const float* __restrict__ partial = j.partial;
   const int n = j.n;
   if ((int)blockIdx.x * 32 >= n) return;
-  const int chunks = min((int)gridDim.z, max(1, j.nblocks / 96));
-  if ((int)blockIdx.z >= chunks) return;
-  const int per = (j.nblocks + chunks - 1) / chunks;
-  const int r0 = blockIdx.z * per, r1 = min(j.nblocks, r0 + per);
+  const int r1 = j.nblocks;
   const int i = blockIdx.x * 32 + threadIdx.x;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < n) {
-    int b = r0 + threadIdx.y;
-    for (; b + 24 < r1; b += 32) {
+    int b = threadIdx.y;
+    for (; b + 96 < r1; b += 128) {
       s0 += partial[(size_t)b * n + i];
-      s1 += partial[(size_t)(b + 8) * n + i];
-      s2 += partial[(size_t)(b + 16) * n + i];
-      s3 += partial[(size_t)(b + 24) * n + i];
+      s1 += partial[(size_t)(b + 32) * n + i];
+      s2 += partial[(size_t)(b + 64) * n + i];
+      s3 += partial[(size_t)(b + 96) * n + i];
     }
-    for (; b < r1; b += 8) s0 += partial[(size_t)b * n + i];
+    for (; b < r1; b += 32) s0 += partial[(size_t)b * n + i];
   }
   red[threadIdx.y][threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (threadIdx.y == 0 && i < n) {
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
+    for (int k = 0; k < 32; ++k) s += red[k][threadIdx.x];
     int k = 0, lo = 0;
 #pragma unroll
     for (int q = 0; q < 5; ++q)
       if (i >= j.dst.end[q]) { k = q + 1; lo = j.dst.end[q]; }
-    if (chunks == 1) j.dst.ptr[k][i - lo] += s;
-    else atomicAdd(j.dst.ptr[k] + (i - lo), s);
+    j.dst.ptr[k][i - lo] += s;
   }
 }
 
@@ -477,13 +475,7 @@ static void reduce_launch(const SvitReduceBatch& b, hipStream_t st) {
   int max_n = 0;
   for (int i = 0; i < b.count; ++i)
     if (b.job[i].n > max_n) max_n = b.job[i].n;
-  int max_rows = 0;
-  for (int i = 0; i < b.count; ++i)
-    if (b.job[i].nblocks > max_rows) max_rows = b.job[i].nblocks;
-  int z = max_rows / 96;
-  if (z < 1) z = 1;
-  if (z > 8) z = 8;
-  hipLaunchKernelGGL(svit_reduce_partials_kernel, dim3((max_n + 31) / 32, b.count, z), dim3(32, 8),
+  hipLaunchKernelGGL(svit_reduce_partials_kernel, dim3((max_n + 31) / 32, b.count), dim3(32, 32),
                      0, st, b);
 }
 

@@ -623,6 +623,21 @@ __device__ __forceinline__ void pool_wgrad_body(const svit_pool_wgrad_args& a, i
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] += g * nt[k / 9] * nh[(k / 3) % 3] * nh[k % 3];
   }
+#ifdef SVIT_DIAG_WGRAD_NO_LDS_COMBINE   // tools/diag: the two row halves meet in global memory
+  {
+    float* prow = prow_base + c * 27;
+    if (r == 0) {
+#pragma unroll
+      for (int k = 0; k < 27; ++k) prow[k] = acc[k];
+    }
+    __threadfence();
+    __syncthreads();
+    if (r == 1) {
+#pragma unroll
+      for (int k = 0; k < 27; ++k) atomicAdd(prow + k, acc[k]);
+    }
+  }
+#else
   __syncthreads();
   float* comb = (float*)smem_w;   // [27][96]
   if (r == 1) {
@@ -635,6 +650,7 @@ __device__ __forceinline__ void pool_wgrad_body(const svit_pool_wgrad_args& a, i
 #pragma unroll
     for (int k = 0; k < 27; ++k) prow[k] = acc[k] + comb[k * HD + c];
   }
+#endif
 }
 
 template <int S>

@@ -300,7 +300,7 @@ class Engine:
                     r32[rows_off[2]:rows_off[2] + need[2]]]
         P = ops.gemm_nt(qa.view(B * h * Nq, DA)[:, :HD], rcat, None, hip.EPI_BF16)
         ops.relpos_gather(P, qa, idx, rows_off, B, h, q_thw, k_thw, n_obj, 1.0 / SCALE)
-        ctx, lse2 = ops.attn_fwd(qa, ka, v, SCALE)
+        ctx, lse2 = ops.attn_fwd(qa, ka, v, SCALE, bias_cols=J)
         pool_idx = None
         if blk.has_proj:
             skip = ops.gemm_nt(xn2d, f.w(pre + "proj.weight"), f.p(pre + "proj.bias"), hip.EPI_F32)

@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (must be imported first: the library binds to torch's HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsvit_hip.so")
+# SVIT_HIP_LIB: a diagnostic build of the same library (tools/diag), never set in production
+LIB_PATH = os.environ.get("SVIT_HIP_LIB") or os.path.join(_HERE, "lib", "libsvit_hip.so")
 _lib = None
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -90,7 +91,8 @@ class RelqScatterArgs(C.Structure):
 
 class AttnFwdArgs(C.Structure):
     _fields_ = [("qa", vp), ("ka", vp), ("v", vp), ("ctx", vp), ("lse2", vp), ("B", i32),
-                ("heads", i32), ("Nq", i32), ("Nk", i32), ("DA", i32), ("scale", f32)]
+                ("heads", i32), ("Nq", i32), ("Nk", i32), ("DA", i32), ("scale", f32),
+                ("bias_cols", i32)]
 
 
 class AttnBwdArgs(C.Structure):

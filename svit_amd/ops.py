@@ -403,8 +403,9 @@ def relpos_scatter(dqa, idx, offs, ldd, B, heads, q_thw, k_thw, n_obj, inv_scale
     return D
 
 
-def attn_fwd(qa, ka, v, scale):
-    """qa [B,h,Nq,DA], ka [B,h,Nk,DA], v [B,h,Nk,96] -> ctx bf16 [B,Nq,h*96], lse2 [B,h,Nq]."""
+def attn_fwd(qa, ka, v, scale, bias_cols=0):
+    """qa [B,h,Nq,DA], ka [B,h,Nk,DA], v [B,h,Nk,96] -> ctx bf16 [B,Nq,h*96], lse2 [B,h,Nq].
+    bias_cols = kt + kh + kw (rel-pos columns that carry data; 0 = all DA - 96)."""
     _chk_dev(qa, ka, v)
     B, heads, Nq, DA = qa.shape
     Nk = ka.shape[2]
@@ -412,7 +413,7 @@ def attn_fwd(qa, ka, v, scale):
     lse2 = torch.empty((B, heads, Nq), device=qa.device, dtype=F32)
     a = hip.AttnFwdArgs()
     a.qa, a.ka, a.v, a.ctx, a.lse2 = ptr(qa), ptr(ka), ptr(v), ptr(ctx), ptr(lse2)
-    a.B, a.heads, a.Nq, a.Nk, a.DA, a.scale = B, heads, Nq, Nk, DA, scale
+    a.B, a.heads, a.Nq, a.Nk, a.DA, a.scale, a.bias_cols = B, heads, Nq, Nk, DA, scale, bias_cols
     hip.call("svit_attn_fwd", C.byref(a), meta=("attn", B, heads, Nq, Nk, DA))
     return ctx, lse2
 

@@ -503,6 +503,34 @@ def test_attention_fwd_eight_wave_path(ops, Nk):
     assert rel_err(lse2, torch.logsumexp(s, dim=-1) * math.log2(math.e)) < 1e-3
 
 
+@pytest.mark.parametrize("B,h,Nq,Nk,DA,J", [
+    (8, 4, 1633, 457, 128, 22),    # blocks 4-13: two query blocks per wave, 8 tiles (ragged), 8 k-steps
+    (8, 4, 1633, 1633, 160, 36),   # block 3: 9 of 10 k-steps, 26 tiles
+    (2, 8, 457, 457, 128, 22),     # small grid: one query block per wave
+    (2, 2, 300, 54, 128, 15),      # frames pass: a single ragged tile, 7 k-steps
+    (2, 2, 300, 201, 160, 29),     # frames pass: 4 tiles, J <= 32 at DA 160 -> 8 k-steps
+    (1, 1, 70, 64, 128, 32),       # exactly one full tile
+    (1, 1, 70, 128, 160, 64),      # two tiles, every bias column in use (10 k-steps)
+    (1, 1, 257, 192, 128, 0),      # three tiles; bias_cols unknown (0 = all)
+    (1, 2, 129, 330, 128, 22),     # six tiles: both halves of the two-tile unrolled loop end the sweep
+])
+def test_attention_fwd_pipelined_kernel(ops, B, h, Nq, Nk, DA, J):
+    """The round-2 forward kernel (csrc/attn_fwd2.hip): software-pipelined tiles, 1 or 2 query
+    blocks per wave, only the k-steps that carry data -- against the fp32 reference, over the
+    tile-count and raggedness cases of its pipeline (1, 2, 3, 4, 6, 8, 26 tiles)."""
+    scale = 96 ** -0.5
+    qa = rnd("pq%d_%d" % (Nq, DA), (B, h, Nq, DA), 1.0, BF16)
+    ka = rnd("pk%d_%d" % (Nk, DA), (B, h, Nk, DA), 1.0, BF16)
+    v = rnd("pv%d" % Nk, (B, h, Nk, 96), 1.0, BF16)
+    if J:
+        qa[..., 96 + J:] = 0      # columns past J carry no data (the pool kernel writes zeros)
+        ka[..., 96 + J:] = 0
+    ctx, lse2 = ops.attn_fwd(qa, ka, v, scale, bias_cols=J)
+    ref, s = _attn_ref(qa.float().cpu(), ka.float().cpu(), v.float().cpu(), scale)
+    assert rel_err(ctx, ref) < 2e-2 and cos(ctx, ref) > 0.9999
+    assert rel_err(lse2, torch.logsumexp(s, dim=-1) * math.log2(math.e)) < 1e-3
+
+
 def test_attention_large_scores(ops):
     """Online-softmax rescale path: one key dominates late in the sweep (forces max jumps)."""
     B, h, Nq, Nk, DA = 1, 1, 64, 200, 128

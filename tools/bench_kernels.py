@@ -102,6 +102,33 @@ def bench_attn():
               (blk, h, Nq, Nk, DA, us, alg / us / 1e6, usb, 2 * alg / usb / 1e6))
 
 
+def bench_attn_fwd():
+    """forward only, per block shape, with the bias-column count the engine passes (J = kt+kh+kw);
+    SVIT_ATTN_FWD_V=1|2 selects the kernel generation, SVIT_ATTN_FWD_QB the query blocks per wave."""
+    print("== attention fwd (version %s) ==" % os.environ.get("SVIT_ATTN_FWD_V", "2"))
+    tot_us = tot_alg = 0.0
+    mult = {0: 1, 1: 1, 2: 1, 3: 1, 4: 10, 14: 1, 15: 1}
+    for blk, Nin, Nq, Nk, Ci, Co, h, DA in BLOCKS:
+        J = 22 if DA == 128 else 36
+        qa, ka, v = rnd(B, h, Nq, DA), rnd(B, h, Nk, DA), rnd(B, h, Nk, 96)
+        qa[..., 96 + J:] = 0
+        ka[..., 96 + J:] = 0
+        scale = 96 ** -0.5
+        us = timeit(lambda: ops.attn_fwd(qa, ka, v, scale, bias_cols=J), iters=50)
+        alg = 2.0 * B * h * Nq * Nk * 192
+        tot_us += us * mult[blk]
+        tot_alg += alg * mult[blk]
+        print("blk%-2d h=%d Nq=%6d Nk=%5d DA=%d J=%d  fwd %8.1f us %7.1f TF (%.3f of 2.5 PF)" %
+              (blk, h, Nq, Nk, DA, J, us, alg / us / 1e6, alg / us / 1e6 / 2500), flush=True)
+    print("step total (16 launches): %.1f us, %.1f TF = %.3f of peak" %
+          (tot_us, tot_alg / tot_us / 1e6, tot_alg / tot_us / 1e6 / 2500))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "attnfwd":
+    hip.load()
+    bench_attn_fwd()
+    sys.exit(0)
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     hip.load()
