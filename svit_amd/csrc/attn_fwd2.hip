@@ -149,23 +149,49 @@ __global__ __launch_bounds__(256, 1) void attn_fwd2_kernel(svit_attn_fwd_args a)
     if (t < nt) issue(t);
 
   // ---- pieces of the pipelined step -----------------------------------------------------
-  // K row fragment of step i (kb = i / KS, ks = i % KS)
-  auto issue_k = [&](auto I, bf16x8_t& d, const unsigned (&kaddr)[2]) {
+  // With ONE wave per SIMD nothing hides an LDS round trip but the wave's own instruction
+  // stream, so every fragment is read a whole phase before the MFMAs that consume it:
+  //   phase 1 of tile t   : S(t+1) = K(t+1) Q^T from kreg (read during the previous phase 2)
+  //                         || exp(S(t)) -> P fragments || V(t)^T fragments -> vreg
+  //   barrier             : tile t+2 has landed for everyone; tile t's slot is free
+  //   phase 2 of tile t   : O^T += V(t)^T P(t)^T from vreg || K(t+2) fragments -> kreg
+  //                         || LDS-DMA of tile t+4 || row maxima of S(t+1), re-basing
+  bf16x8_t kreg[NK];                 // K row fragments of one tile, step i = kb * KS + ks
+  s16x4_t vreg[4][6];                // V^T fragments of one tile, [key group][panel lo/hi]
+  auto read_k = [&](auto I, unsigned so) {
     constexpr int i = decltype(I)::value, kb = i / KS, ks = i % KS;
-    lds_read128<kb * 2048 + (ks >> 1) * KT * 64>(d, kaddr[ks & 1]);
+    lds_read128<kb * 2048 + (ks >> 1) * KT * 64>(kreg[i], kaddr0[ks & 1] + so);
   };
-  // V^T fragments of key group g (16 keys: kb = g>>1, sp = g&1), 3 panels x (lo, hi)
-  auto issue_v = [&](auto Gi, s16x4_t (&d)[6], const unsigned (&vaddr)[2]) {
+  auto read_v = [&](auto Gi, unsigned so) {
     constexpr int g = decltype(Gi)::value;
     static_for<0, 3>([&](auto J) {
       constexpr int j = decltype(J)::value;
-      lds_read_tr<g * 16 * 64 + j * KT * 64>(d[2 * j], vaddr[0]);
-      lds_read_tr<g * 16 * 64 + j * KT * 64>(d[2 * j + 1], vaddr[1]);
+      lds_read_tr<g * 16 * 64 + j * KT * 64>(vreg[g][2 * j], vaddr0[0] + so);
+      lds_read_tr<g * 16 * 64 + j * KT * 64>(vreg[g][2 * j + 1], vaddr0[1] + so);
     });
   };
+  // everything this wave has asked of the LDS has landed; the registers named become visible
+  auto landed_k = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NK; ++i) asm volatile("" : "+v"(kreg[i]));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto landed_v = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) asm volatile("" : "+v"(vreg[g][j]));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto wait_tiles = [&](int in_flight) {   // my LDS-DMA pieces: at most `in_flight` tiles may still travel
+    if (in_flight >= 2) wait_vmcnt<2 * PIECES>();
+    else if (in_flight == 1) wait_vmcnt<PIECES>();
+    else wait_vmcnt<0>();
+  };
   // exponentiate half a P fragment: registers 8*sp + 4*half .. +3 of S block (qb, kb) become
-  // elements 4*half .. +3 of the bf16 operand fragment (the scores themselves are only read:
-  // they can stay in the accumulator file)
+  // elements 4*half .. +3 of the bf16 operand fragment (the scores are only read)
   auto exp_unit = [&](const f32x16_t (&s)[QB][2], float (&rs)[QB], bf16x8_t& frag, int qb, int kb,
                       int sp, int half) {
     float p[4];
@@ -219,88 +245,78 @@ __global__ __launch_bounds__(256, 1) void attn_fwd2_kernel(svit_attn_fwd_args a)
             if (kbase + kb * 32 + acc_row(r, lane) >= a.Nk) s[qb][kb][r] = -INFINITY;
     }
   };
+  // S = K Q^T for the tile whose fragments sit in kreg
+  auto qk_step = [&](auto I, f32x16_t (&sn)[QB][2]) {
+    constexpr int i = decltype(I)::value, kb = i / KS, ks = i % KS;
+    static_for<0, QB>([&](auto Q) {
+      constexpr int qb = decltype(Q)::value;
+      if constexpr (ks == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sn[qb][kb][r] = 0.f;
+      }
+      sn[qb][kb] = mfma32(kreg[i], qf[qb][ks], sn[qb][kb]);
+    });
+  };
 
   // P fragment f (consumption order of the P.V phase): key group g = f / QB, query block f % QB
-  // -> 2 exp units.  Phase 1 (beside the QK^T MFMAs of the next tile) exponentiates the groups
-  // 0..2, phase 2 (beside the P.V MFMAs of groups 0..2) the last group.
+  // -> 2 exp units.  Phase 1 exponentiates the groups 0..2, phase 2 the last group.
   constexpr int U1 = 6 * QB;         // exp units done in phase 1 (of 8 * QB)
+  constexpr int VR = 12;             // phase-1 steps over which the 24 V^T reads are issued
 
   // One pipelined step: consumes the scores `sc` of tile t (row maxima already folded into
-  // m_run), produces the scores `sn` of tile t + 1 when HAS_NEXT.
+  // m_run) and kreg = K(t+1); leaves the scores `sn` of tile t + 1 and kreg = K(t+2).
   auto step = [&](auto HasNext, int t, f32x16_t (&sc)[QB][2], f32x16_t (&sn)[QB][2]) {
     constexpr bool HAS_NEXT = decltype(HasNext)::value;
-    // tile t+1 landed (mine), then everyone's; tile t-1's slot is free for tile t + AHEAD
-    if (HAS_NEXT) {
-      if (t + 2 < nt && AHEAD >= 3) wait_vmcnt<(AHEAD - 2) * PIECES>();   // unreachable for NS 3
-      else if (t + 2 < nt && AHEAD == 2) wait_vmcnt<0>();
-      else wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    if (t + AHEAD < nt) issue(t + AHEAD);
-    const unsigned so_c = (t % NS) * STAGE, so_n = ((t + 1) % NS) * STAGE;
-    const unsigned kaddr[2] = {kaddr0[0] + so_n, kaddr0[1] + so_n};
-    const unsigned vaddr[2] = {vaddr0[0] + so_c, vaddr0[1] + so_c};
+    const unsigned so_c = (t % NS) * STAGE;
     float rs[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) rs[qb] = 0.f;
     bf16x8_t pf[4][QB];              // P fragments, [key group][query block]
-    s16x4_t vt[2][6];
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- phase 1: S(t+1) = K(t+1) Q^T on the matrix pipe, exp(S(t)) on the vector pipe -----
-    if constexpr (HAS_NEXT) {
-      bf16x8_t kf[3];
-      issue_k(Int<0>{}, kf[0], kaddr);
-      issue_k(Int<1>{}, kf[1], kaddr);
-      static_for<0, NK>([&](auto I) {
-        constexpr int i = decltype(I)::value, kb = i / KS, ks = i % KS;
-        if constexpr (i + 2 < NK) issue_k(Int<i + 2>{}, kf[(i + 2) % 3], kaddr);
-        if constexpr (i == NK - 2) issue_v(Int<0>{}, vt[0], vaddr);
-        // LDS returns in order: everything older than the last N operations has landed
-        if constexpr (i + 2 < NK) lgkm_release<2>(kf[i % 3]);
-        else if constexpr (i == NK - 2) lgkm_release<7>(kf[i % 3]);
-        else lgkm_release<6>(kf[i % 3]);
-        static_for<0, QB>([&](auto Q) {
-          constexpr int qb = decltype(Q)::value;
-          if constexpr (ks == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sn[qb][kb][r] = 0.f;
-          }
-          sn[qb][kb] = mfma32(kf[i % 3], qf[qb][ks], sn[qb][kb]);
-        });
-        // this step's slice of the exponentials: unit u -> fragment u / 2, half u % 2
-        static_for<0, U1>([&](auto U) {
-          constexpr int u = decltype(U)::value;
-          if constexpr (u * NK / U1 == i) {
-            constexpr int f = u / 2, g = f / QB, qb = f % QB;
-            exp_unit(sc, rs, pf[g][qb], qb, g >> 1, g & 1, u & 1);
-          }
-        });
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    } else {
-      issue_v(Int<0>{}, vt[0], vaddr);
+    if constexpr (HAS_NEXT) landed_k();
+    // ---- phase 1 ------------------------------------------------------------------------
+    static_for<0, NK>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if constexpr (i < VR) {        // two V^T reads per step: group i / 3, panel i % 3
+        constexpr int g = i / 3, j = i % 3;
+        lds_read_tr<g * 16 * 64 + j * KT * 64>(vreg[g][2 * j], vaddr0[0] + so_c);
+        lds_read_tr<g * 16 * 64 + j * KT * 64>(vreg[g][2 * j + 1], vaddr0[1] + so_c);
+      }
+      if constexpr (HAS_NEXT) qk_step(I, sn);
       static_for<0, U1>([&](auto U) {
         constexpr int u = decltype(U)::value;
-        constexpr int f = u / 2, g = f / QB, qb = f % QB;
-        exp_unit(sc, rs, pf[g][qb], qb, g >> 1, g & 1, u & 1);
+        if constexpr (u * NK / U1 == i) {
+          constexpr int f = u / 2, g = f / QB, qb = f % QB;
+          exp_unit(sc, rs, pf[g][qb], qb, g >> 1, g & 1, u & 1);
+        }
       });
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
     if (HAS_NEXT) mask_tail(sn, t + 1);
-    // ---- phase 2: O^T += V(t)^T P(t)^T on the matrix pipe; last exp units on the vector pipe
+    if constexpr (HAS_NEXT) {
+      // tile t+2 must have landed before its K fragments are read below; tiles up to t+3 are in
+      // flight.  Every wave has read V(t) and K(t+1): tile t's slot takes tile t+4.
+      wait_tiles(t + 3 < nt ? 1 : 0);
+      landed_v();
+      __builtin_amdgcn_s_barrier();
+    } else {
+      landed_v();
+    }
+    // ---- phase 2 ------------------------------------------------------------------------
+    const bool more = HAS_NEXT && t + 2 < nt;
+    const unsigned so_k = ((t + 2) % NS) * STAGE;
     static_for<0, 4>([&](auto Gi) {
       constexpr int g = decltype(Gi)::value;
-      if constexpr (g + 1 < 4) {
-        issue_v(Int<g + 1>{}, vt[(g + 1) & 1], vaddr);
-        lgkm_release<6>(vt[g & 1]);
-      } else {
-        lgkm_release<0>(vt[g & 1]);
+      if constexpr (HAS_NEXT) {
+        if (more) {                  // K(t+2): NK reads over the four groups
+          static_for<g * NK / 4, (g + 1) * NK / 4>([&](auto I) { read_k(I, so_k); });
+        }
+        if (g == 1 && t + 4 < nt) issue(t + 4);
       }
       static_for<0, QB>([&](auto Q) {
         constexpr int qb = decltype(Q)::value;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-          o[qb][j] = mfma32(make_bf16x8(vt[g & 1][2 * j], vt[g & 1][2 * j + 1]), pf[g][qb], o[qb][j]);
+          o[qb][j] = mfma32(make_bf16x8(vreg[g][2 * j], vreg[g][2 * j + 1]), pf[g][qb], o[qb][j]);
       });
       // the last key group's exponentials, spread over the first three groups' MFMAs
       static_for<U1, 8 * QB>([&](auto U) {
@@ -318,38 +334,25 @@ __global__ __launch_bounds__(256, 1) void attn_fwd2_kernel(svit_attn_fwd_args a)
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- prologue: scores of tile 0 -----------------------------------------------------
+  // ---- prologue: S(0), then K(1) into kreg ---------------------------------------------
   f32x16_t sa[QB][2], sb[QB][2];
   {
-    if (nt > 1 && AHEAD >= 2) {
-      if (nt > 2 && AHEAD >= 3) wait_vmcnt<2 * PIECES>();
-      else wait_vmcnt<PIECES>();
-    } else {
-      wait_vmcnt<0>();
-    }
+    wait_tiles(min(nt, AHEAD) - 1);            // tile 0 landed (mine)
     __builtin_amdgcn_s_barrier();
-    const unsigned kaddr[2] = {kaddr0[0], kaddr0[1]};
-    bf16x8_t kf[3];
-    issue_k(Int<0>{}, kf[0], kaddr);
-    issue_k(Int<1>{}, kf[1], kaddr);
+    if (AHEAD < nt) issue(AHEAD);              // tile 3 into the last free slot
+    static_for<0, NK>([&](auto I) { read_k(I, 0u); });
+    landed_k();
     static_for<0, NK>([&](auto I) {
-      constexpr int i = decltype(I)::value, kb = i / KS, ks = i % KS;
-      if constexpr (i + 2 < NK) issue_k(Int<i + 2>{}, kf[(i + 2) % 3], kaddr);
-      if constexpr (i + 2 < NK) lgkm_release<2>(kf[i % 3]);
-      else if constexpr (i == NK - 2) lgkm_release<1>(kf[i % 3]);
-      else lgkm_release<0>(kf[i % 3]);
-      static_for<0, QB>([&](auto Q) {
-        constexpr int qb = decltype(Q)::value;
-        if constexpr (ks == 0) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sa[qb][kb][r] = 0.f;
-        }
-        sa[qb][kb] = mfma32(kf[i % 3], qf[qb][ks], sa[qb][kb]);
-      });
+      qk_step(I, sa);
       __builtin_amdgcn_sched_barrier(0);
     });
     mask_tail(sa, 0);
     rebase(sa);
+    if (nt > 1) {
+      wait_tiles(min(nt, AHEAD + 1) - 2);      // tile 1 landed; tiles 2, 3 may still travel
+      __builtin_amdgcn_s_barrier();
+      static_for<0, NK>([&](auto I) { read_k(I, (unsigned)STAGE); });
+    }
   }
   // ---- main loop, unrolled by two so that the score tiles keep their registers ------------
   for (int t = 0;; t += 2) {

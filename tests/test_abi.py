@@ -53,3 +53,19 @@ def test_product_path_has_no_oracle_import():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_no_inplace_cross_half_packed_fp32_in_the_device_code():
+    """profiles/r02_wgrad_overlap_rootcause.md: `v_pk_*_f32` with destination pair == source pair
+    read across its halves gave wrong results beside the TN GEMM on MI355X.  The build keeps the
+    device assembly and refuses it; the scanner itself is checked on the offending instruction."""
+    from svit_amd import build
+    bad = build.hazardous_packed_f32(
+        "\tv_pk_mul_f32 v[10:11], v[4:5], v[10:11] op_sel:[0,1]\n"
+        "\tv_pk_mul_f32 v[10:11], v[10:11], v[16:17] op_sel_hi:[1,0]\n"
+        "\tv_pk_fma_f32 v[76:77], v[74:75], s[12:13], v[76:77] op_sel_hi:[1,0,0]\n"
+        "\tv_pk_add_f32 v[2:3], v[4:5], v[6:7]\n")
+    assert [ln for ln, _ in bad] == [1, 3]
+    assert "-fno-slp-vectorize" in build.FLAGS
+    build.build()
+    assert build.check_isa()
