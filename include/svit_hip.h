@@ -66,6 +66,9 @@ typedef struct {
   int32_t lda, ldb, lddw, M, N, K;
 } svit_tn_problem;
 int svit_gemm_tn_grouped(const svit_tn_problem* probs, int count, void* stream);
+/* ordered != 0: no split along the reduction rows -- one atomic add per dW element, i.e.
+ * bit-reproducible weight gradients (regression-diff mode; slower). */
+int svit_gemm_tn_grouped_ex(const svit_tn_problem* probs, int count, int ordered, void* stream);
 /* dbias[N] (f32, atomically accumulated) += column sums of bf16 A[M,N]. */
 int svit_colsum_bf16(const void* A, int lda, float* out, int M, int N, void* stream);
 

@@ -77,23 +77,81 @@ __device__ __forceinline__ void lgkm_release(s16x4_t (&f)[6]) {
                : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) : "n"(N) : "memory");
 }
 
+// LDS-DMA of a [ROWS][COLS] bf16 tile into the panel image through a BUFFER descriptor: the
+// per-lane byte offset of every piece is tile-invariant (a VGPR computed once), the tile's base
+// is a scalar offset, so a piece costs `s_mov m0` + `buffer_load_dwordx4 ... lds` and no vector
+// ALU work at all (round 1 spent ~45 VALU instructions per tile on 64-bit piece addresses).  The
+// descriptor's size is the (batch, head)'s whole K or V matrix: rows past the end read zeros, so
+// a ragged last tile needs no address clamping.
+template <int ROWS, int COLS, int NWAVES>
+struct BufTile {
+  static_assert(ROWS % 16 == 0 && COLS % 32 == 0, "panel image geometry");
+  static constexpr int RG = ROWS / 16, INSTRS = RG * (COLS / 32);
+  static constexpr int PER_WAVE = (INSTRS + NWAVES - 1) / NWAVES;
+  unsigned voff[PER_WAVE];
+  __device__ __forceinline__ void init(int ld, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      int n = wave + i * NWAVES;
+      if (n >= INSTRS) n = INSTRS - 1;
+      const int panel = n / RG, rg = n % RG;
+      const int row = rg * 16 + (lane >> 2);
+      const int ch = (lane & 3) ^ ((row >> 2) & 3);
+      voff[i] = (unsigned)(row * ld + panel * 32 + ch * 8) * 2u;
+    }
+  }
+#if __HIP_DEVICE_COMPILE__
+  template <typename RSRC>
+  __device__ __forceinline__ void issue(RSRC rsrc, unsigned soff_bytes, unsigned char* tile, int wave) const {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      int n = wave + i * NWAVES;
+      if (n >= INSTRS) n = INSTRS - 1;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsrc, (__attribute__((address_space(3))) void*)(tile + (n / RG) * ROWS * 64 + (n % RG) * 1024),
+          16, voff[i], soff_bytes, 0, 0);
+    }
+  }
+#endif
+};
+
+template <int N, int G>
+__device__ __forceinline__ void lgkm_release_n(bf16x8_t (&f)[G]) {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+#pragma unroll
+  for (int i = 0; i < G; ++i) asm volatile("" : "+v"(f[i]));
+}
+__device__ __forceinline__ float other_half(float x) {      // lane l <-> lane l ^ 32, VALU only
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+
 // NW waves per workgroup share one K/V stream (NW*32 queries); NS = depth of the K/V ring.
 // <4, 2>: two independent workgroups per CU.  <8, 3>: one 8-wave workgroup per CU streams each
-// K/V tile ONCE for 256 queries and prefetches two tiles ahead.  Cycle stamps of the <4, 2> loop
-// (tools/attn_stamps.py, 6337 x 1633, DA 160): ~4100 cycles per tile = DMA issue 1150 (a wave
-// is held ~140 cycles per 1-KiB piece, wherever in the tile the piece is placed) + QK^T 1030 +
-// softmax 380 + PV 1000 + wait/barrier 450, data landing ~3900 cycles after its first piece.
-template <int DA, int NW, int NS>
+// K/V tile ONCE for 256 queries and prefetches two tiles ahead.
+// KSU = k-steps of the QK^T contraction that carry data: 6 (q.k) + ceil(bias columns / 16); the
+// K image holds ceil(KSU / 2) panels.  Round-2 changes against the round-1 loop (cycle anatomy in
+// DESIGN.md; PMC: 280 VALU instructions per tile and wave for 28 MFMAs):
+//   * row sums of P on the matrix pipe (one extra MFMA per 16 keys against a constant "ones"
+//     fragment) instead of 32 v_add per tile;
+//   * LDS-DMA pieces addressed by buffer descriptor + scalar offset (BufTile): no VALU;
+//   * only the k-steps with data are multiplied (9 of 10 at 16x224^2's 14x14 key grids);
+//   * the output leaves through LDS as whole 192-byte rows with 16-byte stores (was 12 strided
+//     8-byte stores per lane: the store tail was ~3 us of a 24 us launch).
+template <int KSU, int NW, int NS>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit_attn_fwd_args a) {
-  constexpr int KS = DA / 16;                 // k-steps of the QK^T contraction
-  constexpr int K_BYTES = KT * DA * 2, V_BYTES = KT * HD * 2;
+#if __HIP_DEVICE_COMPILE__          // (the buffer-descriptor builtins have no host-side type)
+  constexpr int NP = (KSU + 1) / 2, KCOLS = NP * 32;
+  constexpr int K_BYTES = KT * KCOLS * 2, V_BYTES = KT * HD * 2;
   constexpr int STAGE = K_BYTES + V_BYTES;    // [K tile | V tile] per pipeline stage
-  using KLoad = GldsTile<KT, DA, NW>;
-  using VLoad = GldsTile<KT, HD, NW>;
+  using KLoad = BufTile<KT, KCOLS, NW>;
+  using VLoad = BufTile<KT, HD, NW>;
   constexpr int PIECES = KLoad::PER_WAVE + VLoad::PER_WAVE;   // DMA instructions per wave and tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int DA = a.DA;
   const int wgid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
   const int bh = wgid / gridDim.x, b = bh / a.heads, head = bh % a.heads;
   const int q0 = (wgid % gridDim.x) * (NW * 32) + wave * 32;
@@ -104,30 +162,35 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
   const bf16_t* vv = (const bf16_t*)a.v + ((size_t)bh * a.Nk) * HD;
   const float c = a.scale * 1.4426950408889634f;
 
-  bf16x8_t qf[KS];
+  bf16x8_t qf[KSU];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
+  for (int ks = 0; ks < KSU; ++ks)
     qf[ks] = *(const bf16x8_t*)(qa + (size_t)qc * DA + ks * 16 + hh * 8);
   // pin the register operands before the tile loop: their first use must not sit inside it,
   // or the compiler's wait for them (vmcnt(0)) would drain the LDS-DMA pipeline every tile
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+  for (int ks = 0; ks < KSU; ++ks) asm volatile("" : "+v"(qf[ks]));
 
-  f32x16_t o[3];
+  f32x16_t o[3], lacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
-  // running max kept in the exp2 domain (already multiplied by c); l = partial row sum
-  float m_run = -INFINITY, l_run = 0.f;
+  // A operand of the row-sum MFMA: output row 0 = sum over the 16 keys of the P fragment
+  bf16x8_t onesf;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) onesf[e] = (lane & 31) == 0 ? (__bf16)1.0f : (__bf16)0.0f;
+  float m_run = -INFINITY;      // running max in the exp2 domain (already multiplied by c)
 
   // per-lane LDS byte addresses of the fragment reads (stage 0; everything else is an
   // immediate): K row fragments of k-step ks sit at kaddr[ks&1] + (ks>>1)*KT*64 + kb*2048, the
   // transposed V fragments of key group rbase / panel j at vaddr[0|1] + rbase*64 + j*KT*64
   // (image and swizzle: attn_common.h).
-  constexpr int G = DA == 128 ? 4 : 5;          // fragments per chunk; 2*KS/G chunks per tile
-  constexpr int NC = 2 * KS / G;
-  static_assert(NC * G == 2 * KS, "chunking");
+  constexpr int G = KSU == 8 ? 4 : KSU == 9 ? 6 : KSU == 10 ? 5 : 7;   // fragments per chunk
+  constexpr int NC = 2 * KSU / G;
+  static_assert(NC * G == 2 * KSU, "chunking");
   const unsigned lds0 = (unsigned)(size_t)smem;
   unsigned kaddr0[2], vaddr0[2];
   {
@@ -150,11 +213,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
   VLoad vload;
   kload.init(DA, wave, lane);
   vload.init(HD, wave, lane);
+  // descriptors over this (batch, head)'s K and V: reads past row Nk return zeros
+  const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)ka, 0, a.Nk * DA * 2, 0x00020000);
+  const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vv, 0, a.Nk * HD * 2, 0x00020000);
   auto issue = [&](int t) {
     unsigned char* st = smem + (t % NS) * STAGE;
-    const int k0 = t * KT;
-    kload.issue_auto(ka + (size_t)k0 * DA, DA, a.Nk - k0, st, wave, lane);
-    vload.issue_auto(vv + (size_t)k0 * HD, HD, a.Nk - k0, st + K_BYTES, wave, lane);
+    const unsigned k0 = (unsigned)t * KT;
+    kload.issue(krs, k0 * DA * 2u, st, wave);
+    vload.issue(vrs, k0 * HD * 2u, st + K_BYTES, wave);
   };
   issue(0);
   if (NS == 3 && nt > 1) issue(1);
@@ -185,34 +251,34 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
     f32x16_t s[2];
     bf16x8_t kf[2][G];
     auto issue_k = [&](auto Ci, bf16x8_t (&d)[G]) {
-      constexpr int c = decltype(Ci)::value;
+      constexpr int cc = decltype(Ci)::value;
       static_for<0, G>([&](auto J) {
-        constexpr int j = c * G + decltype(J)::value, kb = j / KS, ks = j % KS;
+        constexpr int j = cc * G + decltype(J)::value, kb = j / KSU, ks = j % KSU;
         lds_read128<kb * 2048 + (ks >> 1) * KT * 64>(d[decltype(J)::value], kaddr[ks & 1]);
       });
     };
     issue_k(Int<0>{}, kf[0]);
     static_for<0, NC>([&](auto Ci) {
-      constexpr int c = decltype(Ci)::value;
-      if constexpr (c + 1 < NC) {
-        issue_k(Int<c + 1>{}, kf[(c + 1) & 1]);
-        lgkm_release<G>(kf[c & 1]);          // chunk c landed; chunk c+1 stays in flight
+      constexpr int cc = decltype(Ci)::value;
+      if constexpr (cc + 1 < NC) {
+        issue_k(Int<cc + 1>{}, kf[(cc + 1) & 1]);
+        lgkm_release_n<G>(kf[cc & 1]);          // chunk cc landed; chunk cc+1 stays in flight
       } else {
-        lgkm_release<0>(kf[c & 1]);
+        lgkm_release_n<0>(kf[cc & 1]);
       }
       static_for<0, G>([&](auto J) {
-        constexpr int j = c * G + decltype(J)::value, kb = j / KS, ks = j % KS;
+        constexpr int j = cc * G + decltype(J)::value, kb = j / KSU, ks = j % KSU;
         if constexpr (ks == 0) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
         }
-        s[kb] = mfma32(kf[c & 1][decltype(J)::value], qf[ks], s[kb]);
+        s[kb] = mfma32(kf[cc & 1][decltype(J)::value], qf[ks], s[kb]);
       });
-      __builtin_amdgcn_sched_barrier(0);   // keep chunk c's MFMAs here: they cover chunk c+1's flight
+      __builtin_amdgcn_sched_barrier(0);   // keep chunk cc's MFMAs here: they cover chunk cc+1's flight
     });
     STAMP(8 + t * 8 + 2);
     const int kbase = t * KT;
-    if (kbase + KT > a.Nk) {  // ragged last tile: rows >= Nk hold re-read data
+    if (kbase + KT > a.Nk) {  // ragged last tile: rows >= Nk are zero-filled by the descriptor
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -224,7 +290,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
     mx = max3(mx, s[1][1], s[0][2]);
 #pragma unroll
     for (int r = 2; r < 15; ++r) mx = max3(mx, s[1][r], s[0][r + 1]);
-    mx = max3(mx, s[1][15], __shfl_xor(max3(mx, s[1][15], mx), 32, 64)) * c;
+    mx = fmaxf(mx, s[1][15]);
+    mx = fmaxf(mx, other_half(mx)) * c;
     // defer-max: only re-base when the max grew by more than 2^RESCALE_THR; until then P is
     // bounded by 2^THR instead of 1, which fp32 accumulation absorbs (cdna guide T13).  The
     // previous tile's P.V is complete at this point, so O and l carry exactly one scale.
@@ -232,25 +299,20 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
     if (!__all(mx - m_run <= RESCALE_THR)) {
       const float m_new = fmaxf(m_run, mx);
       const float alpha = fast_exp2(m_run - m_new);
-      l_run *= alpha;
+      lacc[0] *= alpha;
       m_run = m_new;
 #pragma unroll
       for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[j][r] *= alpha;
     }
-    float rs = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(s[kb][r] * c - m_run);
-        s[kb][r] = p;
-        rs += p;
-      }
-    l_run += rs;
+      for (int r = 0; r < 16; ++r) s[kb][r] = fast_exp2(__builtin_fmaf(s[kb][r], c, -m_run));
     STAMP(8 + t * 8 + 3);
-    // ---- O^T += V^T . P^T: group g+1's fragments are read while group g multiplies -------
+    // ---- O^T += V^T . P^T (and l += 1^T P^T): group g+1's fragments are read while group g
+    // multiplies ---------------------------------------------------------------------------
     __builtin_amdgcn_sched_barrier(0);   // no compiler-issued LDS op may slip between my counted waits
     static_for<0, 4>([&](auto Gi) {
       constexpr int g = decltype(Gi)::value, kb = g >> 1, sp = g & 1;
@@ -264,6 +326,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
 #pragma unroll
       for (int j = 0; j < 3; ++j)
         o[j] = mfma32(make_bf16x8(vt[g & 1][2 * j], vt[g & 1][2 * j + 1]), pf, o[j]);
+      lacc = mfma32(onesf, pf, lacc);
       __builtin_amdgcn_sched_barrier(0);
     });
     STAMP(8 + t * 8 + 4);
@@ -272,52 +335,71 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
   if (stamp_on) { g_attn_stamps[2] = __builtin_readcyclecounter(); g_attn_stamps[3] = wall_clock64(); }
 #endif
 
-  // ---- epilogue: normalise, add the pooled query (residual pooling), merge heads ----------
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.f / l_tot;
-  if (qi < a.Nq) {
-    if (hh == 0) a.lse2[(size_t)bh * a.Nq + qi] = m_run + log2f(l_tot);
-    bf16_t* out = (bf16_t*)a.ctx + ((size_t)b * a.Nq + qi) * a.heads * HD + head * HD;
-    const bf16_t* qres = qa + (size_t)qi * DA;
+  // ---- epilogue: normalise, stage the wave's 32 x 96 tile in LDS, store whole rows with the
+  // pooled query added (residual pooling), merge heads ---------------------------------------
+  const float l_lo = __shfl(lacc[0], lane & 31, 64);   // row 0 of the sum block lives in lanes 0..31
+  const float inv = 1.f / l_lo;
+  if (hh == 0 && qi < a.Nq) a.lse2[(size_t)bh * a.Nq + qi] = m_run + log2f(l_lo);
+  __builtin_amdgcn_s_barrier();        // every wave is done with the K/V ring
+  constexpr int OROW = 208;            // bytes per staged row (192 + pad: spreads the banks)
+  unsigned char* ost = smem + wave * (32 * OROW);
+  {
+    unsigned char* orow = ost + (lane & 31) * OROW;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int dv = j * 32 + 8 * g + 4 * hh;
-        float v0 = o[j][4 * g] * inv, v1 = o[j][4 * g + 1] * inv, v2 = o[j][4 * g + 2] * inv,
-              v3 = o[j][4 * g + 3] * inv;
-        if (qi > 0) {
-          const uint2 qq = *(const uint2*)(qres + dv);
-          v0 += lo_bf16(qq.x); v1 += hi_bf16(qq.x); v2 += lo_bf16(qq.y); v3 += hi_bf16(qq.y);
-        }
         uint2 pk;
-        pk.x = pack_bf16x2(v0, v1);
-        pk.y = pack_bf16x2(v2, v3);
-        *(uint2*)(out + dv) = pk;
+        pk.x = pack_bf16x2(o[j][4 * g] * inv, o[j][4 * g + 1] * inv);
+        pk.y = pack_bf16x2(o[j][4 * g + 2] * inv, o[j][4 * g + 3] * inv);
+        *(uint2*)(orow + dv * 2) = pk;
       }
   }
+  // 12 sixteen-byte chunks per row; lane -> (row, chunk): a row's 192 bytes are written by 12
+  // consecutive lanes (the wave's own staging writes are ordered by the compiler's LDS waits)
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int id = it * 64 + lane, row = id / 12, ch = id % 12;
+    const int q = q0 + row;
+    if (q < a.Nq) {
+      uint4 ov = *(const uint4*)(ost + row * OROW + ch * 16);
+      if (q > 0) {                     // every token but cls adds its pooled q
+        const uint4 qq = *(const uint4*)(qa + (size_t)q * DA + ch * 8);
+        ov.x = pack_bf16x2(lo_bf16(ov.x) + lo_bf16(qq.x), hi_bf16(ov.x) + hi_bf16(qq.x));
+        ov.y = pack_bf16x2(lo_bf16(ov.y) + lo_bf16(qq.y), hi_bf16(ov.y) + hi_bf16(qq.y));
+        ov.z = pack_bf16x2(lo_bf16(ov.z) + lo_bf16(qq.z), hi_bf16(ov.z) + hi_bf16(qq.z));
+        ov.w = pack_bf16x2(lo_bf16(ov.w) + lo_bf16(qq.w), hi_bf16(ov.w) + hi_bf16(qq.w));
+      }
+      *(uint4*)((bf16_t*)a.ctx + ((size_t)b * a.Nq + q) * a.heads * HD + head * HD + ch * 8) = ov;
+    }
+  }
+#endif
 }
 
-template <int DA, int NW, int NS>
+template <int KSU, int NW, int NS>
 int launch_cfg(const svit_attn_fwd_args& a, hipStream_t st) {
-  const size_t lds = NS * (size_t)(KT * DA * 2 + KT * HD * 2);
+  constexpr int NP = (KSU + 1) / 2;
+  size_t lds = NS * (size_t)(KT * NP * 32 * 2 + KT * HD * 2);
+  const size_t lds_out = (size_t)NW * 32 * 208;
+  if (lds < lds_out) lds = lds_out;
   static SvitOnce once;
-  if (int rc = svit_max_lds_once(once, (const void*)attn_fwd_kernel<DA, NW, NS>, lds)) return rc;
+  if (int rc = svit_max_lds_once(once, (const void*)attn_fwd_kernel<KSU, NW, NS>, lds)) return rc;
   dim3 grid((a.Nq + NW * 32 - 1) / (NW * 32), a.B * a.heads);
-  hipLaunchKernelGGL((attn_fwd_kernel<DA, NW, NS>), grid, dim3(NW * 64), lds, st, a);
+  hipLaunchKernelGGL((attn_fwd_kernel<KSU, NW, NS>), grid, dim3(NW * 64), lds, st, a);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }
 
-template <int DA>
+template <int KSU>
 int launch_fwd(const svit_attn_fwd_args& a, hipStream_t st) {
   // 8-wave workgroups once they still cover the chip (one per CU); SVIT_ATTN_FWD_NW forces 4 / 8
   static const int force = getenv("SVIT_ATTN_FWD_NW") ? atoi(getenv("SVIT_ATTN_FWD_NW")) : 0;
   // measured (tools/bench_kernels.py attn): the 8-wave form wins 3-4 % on the long-key blocks
   // (Nk = 1633, DA = 160) and loses on the short ones, where the 8-wave barrier dominates
   const long wg8 = (long)((a.Nq + 255) / 256) * a.B * a.heads;
-  const bool wide = force ? force == 8 : (DA == 160 && wg8 >= 200);
-  return wide ? launch_cfg<DA, 8, 3>(a, st) : launch_cfg<DA, 4, 2>(a, st);
+  const bool wide = force ? force == 8 : (a.DA == 160 && wg8 >= 200);
+  return wide ? launch_cfg<KSU, 8, 3>(a, st) : launch_cfg<KSU, 4, 2>(a, st);
 }
 }  // namespace
 
@@ -330,10 +412,17 @@ extern "C" int svit_attn_fwd(const svit_attn_fwd_args* a, void* stream) {
     return SVIT_ERR_ALIGN;
   if (a->DA != 128 && a->DA != 160) return SVIT_ERR_SHAPE;
   if (a->bias_cols < 0 || a->bias_cols > a->DA - 96) return SVIT_ERR_ARG;
-  // SVIT_ATTN_FWD_V=1 selects the round-1 kernel (A/B measurements)
-  static const int version = getenv("SVIT_ATTN_FWD_V") ? atoi(getenv("SVIT_ATTN_FWD_V")) : 2;
-  if (version != 1) return svit_attn_fwd_v2(*a, a->bias_cols, (hipStream_t)stream);
-  if (a->DA == 128) return launch_fwd<128>(*a, (hipStream_t)stream);
-  if (a->DA == 160) return launch_fwd<160>(*a, (hipStream_t)stream);
+  // SVIT_ATTN_FWD_V=2 selects the one-wave-per-SIMD pipelined kernel of attn_fwd2.hip (kept for
+  // experiments: correct, but a single wave per SIMD only reaches half the VALU issue rate)
+  static const int version = getenv("SVIT_ATTN_FWD_V") ? atoi(getenv("SVIT_ATTN_FWD_V")) : 1;
+  if (version == 2) return svit_attn_fwd_v2(*a, a->bias_cols, (hipStream_t)stream);
+  const int extra = a->DA - 96;
+  const int bias_cols = a->bias_cols > 0 ? a->bias_cols : extra;
+  switch (6 + (bias_cols + 15) / 16) {
+    case 7: return launch_fwd<7>(*a, (hipStream_t)stream);
+    case 8: return launch_fwd<8>(*a, (hipStream_t)stream);
+    case 9: return launch_fwd<9>(*a, (hipStream_t)stream);
+    case 10: return launch_fwd<10>(*a, (hipStream_t)stream);
+  }
   return SVIT_ERR_SHAPE;
 }

@@ -260,7 +260,21 @@ static int tn_check(const svit_tn_problem& p) {
   return SVIT_OK;
 }
 
+static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void* stream);
+
 extern "C" int svit_gemm_tn_grouped(const svit_tn_problem* probs, int count, void* stream) {
+  return tn_grouped(probs, count, 0, stream);
+}
+
+// ordered != 0: no problem is cut along its reduction rows, so every element of every dW
+// receives exactly ONE atomic add -- the weight gradients are bit-reproducible (a debugging /
+// regression-diff mode: few workgroups, several times slower than the split form).
+extern "C" int svit_gemm_tn_grouped_ex(const svit_tn_problem* probs, int count, int ordered,
+                                       void* stream) {
+  return tn_grouped(probs, count, ordered, stream);
+}
+
+static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void* stream) {
   if (!probs || count <= 0) return SVIT_ERR_ARG;
   for (int i = 0; i < count; ++i) {
     const int rc = tn_check(probs[i]);
@@ -292,6 +306,7 @@ extern "C" int svit_gemm_tn_grouped(const svit_tn_problem* probs, int count, voi
                        (double)blocks * (TN_TN * TN_TK * 4.0) / (g_tn_atomic_tbs * 1e6);
       if (t < best) { best = t; best_steps = steps; }
     }
+    if (ordered) best_steps = max_steps;
     int total = 0;
     for (int i = 0; i < g.count; ++i) {
       g.rows_per_split[i] = (int)best_steps * TN_BM;

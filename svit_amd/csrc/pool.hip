@@ -725,7 +725,7 @@ static int launch_wgrad(const svit_pool_wgrad_args& a, int Ho, int Wo, hipStream
 struct PoolBwdSmall {
   svit_pool_dgrad_args d[3];
   const void* qkv;
-  float* dw[3];
+  float* partial;     // [B*heads * 2 (split)][3 (which)][96][27] partial weight gradients
   int nsplit[3];
 };
 
@@ -865,20 +865,27 @@ __device__ __forceinline__ void pool_bwd_small_body(const PoolBwdSmall& g, int w
     red[(tl * 12 + cp) * 54 + 27 + k] = dw1[k];
   }
   __syncthreads();
+  // one partial row per (batch*head, split): plain stores, summed in a fixed order by the
+  // second-stage reduce (round 1 used fp32 atomics here: <= 64 adders per address, any order)
+  float* prow = g.partial + (((size_t)bh * 2 + split) * 3 + which) * (27 * HD);
   for (int o = tid; o < 12 * 54; o += 192) {
     float sum = 0.f;
 #pragma unroll
     for (int l = 0; l < 16; ++l) sum += red[l * 648 + o];
     const int pair = o / 54, k2 = o % 54;
     const int ch = group * 24 + 2 * pair + (k2 >= 27 ? 1 : 0);
-    atomicAdd(g.dw[which] + (size_t)ch * 27 + (k2 % 27), sum);
+    prow[(size_t)ch * 27 + (k2 % 27)] = sum;
   }
 }
 
 __global__ __launch_bounds__(192) void pool_bwd_small_kernel(PoolBwdSmall g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_pbs[];
   const int which = blockIdx.y, group = blockIdx.z >> 1, split = blockIdx.z & 1;
-  if (split >= g.nsplit[which]) return;
+  if (split >= g.nsplit[which]) {     // unsplit tensor: this row segment contributes zeros
+    float* prow = g.partial + (((size_t)blockIdx.x * 2 + split) * 3 + which) * (27 * HD) + group * 24 * 27;
+    for (int o = threadIdx.x; o < 24 * 27; o += 192) prow[o] = 0.f;
+    return;
+  }
   if (g.d[which].stride_hw == 1) pool_bwd_small_body<1>(g, which, blockIdx.x, group, split, smem_pbs);
   else pool_bwd_small_body<2>(g, which, blockIdx.x, group, split, smem_pbs);
 }
@@ -1223,14 +1230,20 @@ extern "C" int svit_pool_conv_bwd_qkv(const svit_pool_dgrad_args* d3, const svit
   PoolBwdSmall g;
   for (int i = 0; i < 3; ++i) {
     g.d[i] = d3[i];
-    g.dw[i] = w3[i].dw;
     g.nsplit[i] = d3[i].stride_hw == 1 ? 2 : 1;     // 27 taps per token vs <= 12
   }
   g.qkv = w3[0].qkv;
+  const int prows = d3[0].B * d3[0].heads * 2;
+  if (!w3[0].workspace || w3[0].workspace_floats < (int64_t)prows * 3 * 27 * HD) return SVIT_ERR_ARG;
+  g.partial = w3[0].workspace;
   static SvitOnce once;
   if (int rc = svit_max_lds_once(once, (const void*)pool_bwd_small_kernel, 112 * 1024)) return rc;
   hipLaunchKernelGGL(pool_bwd_small_kernel, dim3(d3[0].B * d3[0].heads, 3, 8), dim3(192), lds,
                      (hipStream_t)stream, g);
+  SVIT_LAUNCH_CHECK();
+  SvitReduceDst dst = {{w3[0].dw, w3[1].dw, w3[2].dw, w3[2].dw, w3[2].dw, w3[2].dw},
+                       {27 * HD, 2 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD}};
+  svit_launch_reduce(w3[0].workspace, prows, 3 * 27 * HD, dst, (hipStream_t)stream);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }

@@ -183,7 +183,11 @@ class Engine:
         self._side_keep = []
         self._side_active = False
         self.overlap_wgrad = False   # measured: TN beside the chain costs more than it hides
-        self.attn_q_splits = 0      # 0 = heuristic; 1 makes the whole backward bit-reproducible
+        self.attn_q_splits = 0      # 0 = heuristic; 1 = no query split in the dk/dv kernel
+        # regression-diff mode: every reduction that normally meets in fp32 atomics (attention
+        # dk/dv query splits, the row splits of the grouped weight-gradient GEMM) runs unsplit, so
+        # the whole backward is bit-reproducible run to run (several times slower)
+        self.deterministic = False
         self._capture_fork = None   # set by svit_amd/graph.py while it captures: (fn) -> None
         self._capture_join = None
 
@@ -371,7 +375,7 @@ class Engine:
             f.g("pos_embed_temporal").add_(dobj.sum((0, 2)).view(1, Tx, C))
         dtok = ops.scale_cast(dx, gather=(L, 1))       # patch rows of every clip -> bf16 [B*L, C]
         ops.gemm_tn(dtok, st["cols"], f.g("patch_embed.proj.weight").view(C, 441),
-                    dbias=f.g("patch_embed.proj.bias"))
+                    splits=1 if self.deterministic else 0, dbias=f.g("patch_embed.proj.bias"))
         self._flush_tn()
         self._join()
         ready(depth + 1)
@@ -416,7 +420,8 @@ class Engine:
         q, self._tn = self._tn, []
         if not q:
             return
-        self._fork(lambda: ops.gemm_tn_grouped(q), q)
+        det = self.deterministic
+        self._fork(lambda: ops.gemm_tn_grouped(q, ordered=det), q)
 
     def _linear_bwd(self, dy16, x16, wname, bname, need_dx, out=None, accumulate=False,
                     epilogue=hip.EPI_F32, aux=None):
@@ -455,7 +460,7 @@ class Engine:
                                 pre + "attn.proj.bias", True, epilogue=hip.EPI_BF16)
         (qa, preq, mq, rq), (ka, prek, mk, rk), (v, prev, mv, rv) = sv["pools"]
         dqa, dk, dv = ops.attn_bwd(qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE,
-                                   q_splits=self.attn_q_splits)
+                                   q_splits=1 if self.deterministic else self.attn_q_splits)
         # rel-pos backward as GEMMs over the scattered matrix D [tokens, Lpad]
         tabs, mats = sv["tabs"], sv["mats"]
         names = (pre + "attn.rel_pos_h", pre + "attn.rel_pos_w", pre + "attn.rel_pos_t")
@@ -475,7 +480,7 @@ class Engine:
                 self._tn.append((D[:, o:o + rows], qa2[:, :HD], f.g(n), None))
             else:
                 d = torch.zeros_like(t)
-                ops.gemm_tn(D[:, o:o + rows], qa2[:, :HD], d)
+                ops.gemm_tn(D[:, o:o + rows], qa2[:, :HD], d, splits=1 if self.deterministic else 0)
                 f.g(n).add_(m.t() @ d)
         dq_extra = ops.gemm_nt(D, rcat_t, None, hip.EPI_F32)
         Nk = ka.shape[2]

@@ -83,9 +83,10 @@ def gemm_tn(a, b, dw, splits=0, dbias=None):
     return dw
 
 
-def gemm_tn_grouped(problems):
+def gemm_tn_grouped(problems, ordered=False):
     """problems: [(a[M,N], b[M,K'], dw[N,K] f32, dbias or None)], each as for gemm_tn; all are
-    accumulated by one launch (per group of 8)."""
+    accumulated by one launch (per group of 8).  ordered: no split along the reduction rows
+    (bit-reproducible weight gradients, slower)."""
     n = len(problems)
     if n == 0:
         return
@@ -101,7 +102,10 @@ def gemm_tn_grouped(problems):
         t.A, t.B, t.dW, t.dbias = ptr(a), ptr(b), ptr(dw), ptr(dbias)
         t.lda, t.ldb, t.lddw, t.M, t.N, t.K = a.stride(0), b.stride(0), dw.stride(-2), M, N, K
         flop += 2.0 * M * N * K
-    hip.call("svit_gemm_tn_grouped", arr, n, meta=("flop", flop))
+    if ordered:
+        hip.call("svit_gemm_tn_grouped_ex", arr, n, 1, meta=("flop", flop))
+    else:
+        hip.call("svit_gemm_tn_grouped", arr, n, meta=("flop", flop))
 
 
 def reduce_defer(on):

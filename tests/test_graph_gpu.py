@@ -112,31 +112,41 @@ def test_graphed_step_with_frames_pass_and_consistency():
 
 
 def test_overlap_wgrad_is_bit_equal_to_stream_order():
-    """Weight-gradient GEMMs on a side stream next to the dgrad chain (Engine.overlap_wgrad):
-    everything produced by ordered reductions -- the whole dgrad chain, the pooling-conv weight
-    gradients, every LayerNorm gain/bias gradient (two-stage reduce, per-stream deferred queue,
-    include/svit_hip.h) -- must be BIT-identical to the stream-ordered schedule.  (The Linear
-    weight gradients leave the grouped TN GEMM through fp32 atomics and the attention backward
-    may split its query range; with attn_q_splits = 1 only the former are order-dependent.)"""
+    """Weight-gradient GEMMs on a side stream next to the dgrad chain (Engine.overlap_wgrad) must
+    give what the stream-ordered schedule gives.  In `Engine.deterministic` mode (no reduction
+    meets in fp32 atomics: unsplit attention dk/dv, unsplit weight-gradient GEMMs, ordered
+    two-stage reductions with per-stream deferred queues) ALL 405 gradients are bit-reproducible,
+    so the comparison is exact: stream order twice (the mode itself), then overlapped twice.
+    Round 1 saw the pooling-conv weight gradient change here
+    (profiles/r02_wgrad_overlap_rootcause.md)."""
     cfg, model, spec, sd = S.build_hip_model(8, 224)
     eng = model.engine
-    eng.attn_q_splits = 1
+    eng.deterministic = True
     x, y = P.frames(2, 8, 224).cuda(), P.labels(2).cuda()
-    det = [n for n in sd if ".pool_" in n or ("." in n and "norm" in n.split(".")[-2]) or n in
-           ("cls_token", "object_queries", "pos_embed_temporal")]
-    assert len(det) > 100
 
     def run(overlap):
         eng.overlap_wgrad = overlap
         _, _, g = _eager(model, x, y)
-        return {n: model.flat.view(g, n).clone() for n in sd}
+        return g
 
     a, b = run(False), run(False)
     c, d = run(True), run(True)
     eng.overlap_wgrad = False
-    for n in det:
-        assert torch.equal(a[n], b[n]), ("stream order itself not reproducible", n)
-        assert torch.equal(a[n], c[n]) and torch.equal(a[n], d[n]), ("overlap changed", n)
-    flat_a = torch.cat([a[n].flatten() for n in sd])
-    flat_c = torch.cat([c[n].flatten() for n in sd])
-    assert S.cosine(flat_a, flat_c) > 0.999999
+    eng.deterministic = False
+
+    def first_diff(u, v):
+        bad = (u != v).nonzero()
+        if len(bad) == 0:
+            return None
+        i = int(bad[0])
+        for n, (off, numel, _) in model.flat.slots.items():
+            if off <= i < off + numel:
+                return n, len(bad)
+        return "padding", len(bad)
+
+    assert first_diff(a, b) is None, ("stream order itself not reproducible", first_diff(a, b))
+    assert first_diff(a, c) is None, ("overlap changed the gradients", first_diff(a, c))
+    assert first_diff(a, d) is None, ("overlap changed the gradients", first_diff(a, d))
+    # and the default (split, atomics) mode agrees with the deterministic one to rounding
+    e = run(False)
+    assert S.cosine(a, e) > 0.999999
