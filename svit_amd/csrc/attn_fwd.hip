@@ -151,6 +151,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+#ifdef SVIT_ATTN_STAMPS
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) g_attn_stamps[4] = __builtin_readcyclecounter();
+#endif
   const int DA = a.DA;
   const int wgid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
   const int bh = wgid / gridDim.x, b = bh / a.heads, head = bh % a.heads;
@@ -161,15 +164,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
   const bf16_t* ka = (const bf16_t*)a.ka + ((size_t)bh * a.Nk) * DA;
   const bf16_t* vv = (const bf16_t*)a.v + ((size_t)bh * a.Nk) * HD;
   const float c = a.scale * 1.4426950408889634f;
-
-  bf16x8_t qf[KSU];
-#pragma unroll
-  for (int ks = 0; ks < KSU; ++ks)
-    qf[ks] = *(const bf16x8_t*)(qa + (size_t)qc * DA + ks * 16 + hh * 8);
-  // pin the register operands before the tile loop: their first use must not sit inside it,
-  // or the compiler's wait for them (vmcnt(0)) would drain the LDS-DMA pipeline every tile
-#pragma unroll
-  for (int ks = 0; ks < KSU; ++ks) asm volatile("" : "+v"(qf[ks]));
 
   f32x16_t o[3], lacc;
 #pragma unroll
@@ -222,8 +216,20 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
     kload.issue(krs, k0 * DA * 2u, st, wave);
     vload.issue(vrs, k0 * HD * 2u, st + K_BYTES, wave);
   };
-  issue(0);
+  issue(0);                        // the first tile(s) travel while the Q fragments are fetched
   if (NS == 3 && nt > 1) issue(1);
+  bf16x8_t qf[KSU];
+#pragma unroll
+  for (int ks = 0; ks < KSU; ++ks)
+    qf[ks] = *(const bf16x8_t*)(qa + (size_t)qc * DA + ks * 16 + hh * 8);
+  // pin the register operands before the tile loop: their first use must not sit inside it,
+  // or the compiler's wait for them (vmcnt(0)) would drain the LDS-DMA pipeline every tile
+  // (here that wait also covers the tiles issued above, which tile 0 needs anyway)
+#pragma unroll
+  for (int ks = 0; ks < KSU; ++ks) asm volatile("" : "+v"(qf[ks]));
+  // residual-pooling operand of the epilogue (the pooled q rows, in the row-major chunk order
+  // of the output stores): fetched during the LAST tile so that its latency is not exposed
+  uint4 qres[6];
   for (int t = 0; t < nt; ++t) {
     // this wave's share of tile t has landed (NS == 3: tile t+1's pieces may stay in flight)
     if (NS == 3 && t + 1 < nt) wait_vmcnt<PIECES>();
@@ -232,6 +238,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
     __builtin_amdgcn_s_barrier();    // everyone's share has; everyone is done with tile t-1
     STAMP(8 + t * 8 + 0);
     if (t + NS - 1 < nt) issue(t + NS - 1);    // into tile t-1's slot; travels while tiles are consumed
+    if (t == nt - 1) {               // no LDS-DMA is in flight any more: plain loads are safe here
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {
+        const int id = it * 64 + lane, row = id / 12, ch = id % 12;
+        const int q = min(q0 + row, a.Nq - 1);
+        qres[it] = *(const uint4*)(qa + (size_t)q * DA + ch * 8);
+      }
+    }
     STAMP(8 + t * 8 + 1);
     const unsigned so = (t % NS) * STAGE;
     const unsigned kaddr[2] = {kaddr0[0] + so, kaddr0[1] + so};
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
     if (q < a.Nq) {
       uint4 ov = *(const uint4*)(ost + row * OROW + ch * 16);
       if (q > 0) {                     // every token but cls adds its pooled q
-        const uint4 qq = *(const uint4*)(qa + (size_t)q * DA + ch * 8);
+        const uint4 qq = qres[it];
         ov.x = pack_bf16x2(lo_bf16(ov.x) + lo_bf16(qq.x), hi_bf16(ov.x) + hi_bf16(qq.x));
         ov.y = pack_bf16x2(lo_bf16(ov.y) + lo_bf16(qq.y), hi_bf16(ov.y) + hi_bf16(qq.y));
         ov.z = pack_bf16x2(lo_bf16(ov.z) + lo_bf16(qq.z), hi_bf16(ov.z) + hi_bf16(qq.z));
@@ -374,6 +388,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
       *(uint4*)((bf16_t*)a.ctx + ((size_t)b * a.Nq + q) * a.heads * HD + head * HD + ch * 8) = ov;
     }
   }
+#ifdef SVIT_ATTN_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  if (stamp_on) g_attn_stamps[5] = __builtin_readcyclecounter();
+#endif
 #endif
 }
 

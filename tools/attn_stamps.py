@@ -21,20 +21,23 @@ def main():
     out = os.path.join(ROOT, "gpurun_out", "libattn_stamps.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17",
-                           "-ffast-math", "-fno-finite-math-only", "-DSVIT_ATTN_STAMPS", "-shared",
-                           os.path.join(ROOT, "svit_amd", "csrc", "attn_fwd.hip"), "-o", out])
+                           "-ffast-math", "-fno-finite-math-only", "-fno-slp-vectorize", "-DSVIT_ATTN_STAMPS", "-shared",
+                           os.path.join(ROOT, "svit_amd", "csrc", "attn_fwd.hip"),
+                           os.path.join(ROOT, "svit_amd", "csrc", "attn_fwd2.hip"), "-o", out])
     lib = ctypes.CDLL(out)
 
     class Args(ctypes.Structure):
         _fields_ = [(n, ctypes.c_void_p) for n in ("qa", "ka", "v", "ctx", "lse2")] + \
-                   [(n, ctypes.c_int32) for n in ("B", "heads", "Nq", "Nk", "DA")] + [("scale", ctypes.c_float)]
+                   [(n, ctypes.c_int32) for n in ("B", "heads", "Nq", "Nk", "DA")] + [("scale", ctypes.c_float),
+                                                                            ("bias_cols", ctypes.c_int32)]
     dev = "cuda"
     qa = (torch.randn(B, h, Nq, DA, device=dev) * 0.5).bfloat16()
     ka = (torch.randn(B, h, Nk, DA, device=dev) * 0.5).bfloat16()
     v = torch.randn(B, h, Nk, 96, device=dev).bfloat16()
     ctx = torch.empty(B, Nq, h * 96, device=dev, dtype=torch.bfloat16)
     lse = torch.empty(B, h, Nq, device=dev)
-    a = Args(qa.data_ptr(), ka.data_ptr(), v.data_ptr(), ctx.data_ptr(), lse.data_ptr(), B, h, Nq, Nk, DA, 96 ** -0.5)
+    a = Args(qa.data_ptr(), ka.data_ptr(), v.data_ptr(), ctx.data_ptr(), lse.data_ptr(), B, h, Nq, Nk, DA, 96 ** -0.5,
+             22 if DA == 128 else 36)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
         rc = lib.svit_attn_fwd(ctypes.byref(a), st)
@@ -48,6 +51,8 @@ def main():
     cyc, wall = s[2] - s[0], (s[3] - s[1]) / 100e6
     print("shape Nq=%d Nk=%d DA=%d h=%d: loop %d cycles in %.2f us -> %.2f GHz, %d tiles, %.0f cycles/tile"
           % (Nq, Nk, DA, h, cyc, wall * 1e6, cyc / wall / 1e9, nt, cyc / nt))
+    print("prologue (entry -> loop) %d cycles, epilogue (loop end -> stores retired) %d cycles"
+          % (s[0] - s[4], s[5] - s[2]))
     names = ["vmcnt wait", "barrier", "dma issue", "QK^T", "softmax", "PV"]
     rows = []
     for t in range(nt):
