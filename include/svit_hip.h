@@ -192,6 +192,15 @@ int svit_pool_conv_wgrad(const svit_pool_wgrad_args* a, void* stream);
  * chain, so three side by side cost the time of one (attention.py:263-304 runs them serially).
  * The two-stage reductions use args[0].workspace (>= 1024 * 3 * 27 * 96 floats for wgrad). */
 int svit_pool_ln_fwd_qkv(const svit_pool_args* args3, void* stream);
+/* Round 2: LDS-tiled stride-1 stencils.  svit_pool_weight_sel turns a list of depthwise weights
+ * (fp32 [96][27] each, at src_base + src_off[i]) into "selector" tables dst[i][27][96] (uint32:
+ * bf16(w) in the half of the dword that matches the channel's position in a packed bf16 pair) --
+ * the SCALAR operands of the tiled kernels (run once per step for all blocks).  The *_sel entry
+ * points take the three tables of a block; tensors with stride 1 then read every input element
+ * once into an LDS halo ring instead of 27 times through the texture path. */
+int svit_pool_weight_sel(const float* src_base, const int64_t* src_off, uint32_t* dst, int n_tables,
+                         void* stream);
+int svit_pool_ln_fwd_qkv_sel(const svit_pool_args* args3, const uint32_t* const* sel3, void* stream);
 int svit_pool_ln_bwd_qkv(const svit_pool_ln_bwd_args* args3, void* stream);
 int svit_pool_conv_dgrad_qkv(const svit_pool_dgrad_args* args3, void* stream);
 int svit_pool_conv_wgrad_qkv(const svit_pool_wgrad_args* args3, void* stream);
@@ -201,6 +210,8 @@ int svit_pool_conv_wgrad_qkv(const svit_pool_wgrad_args* args3, void* stream);
  * dgrad3[i] / wgrad3[i] describe the same `which` = i (same dpre, stride, dims). */
 int svit_pool_conv_bwd_qkv(const svit_pool_dgrad_args* dgrad3, const svit_pool_wgrad_args* wgrad3,
                            void* stream);
+int svit_pool_conv_bwd_qkv_sel(const svit_pool_dgrad_args* dgrad3, const svit_pool_wgrad_args* wgrad3,
+                               const uint32_t* const* sel3, void* stream);
 
 /* ------------------------------------------- decomposed rel-pos bias, query side (K9/K10) */
 /* cal_rel_pos_spatial / cal_rel_pos_temporal (attention.py:84-183) restated as

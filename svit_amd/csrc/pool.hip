@@ -88,6 +88,54 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ conv_w, f
 }
 
 // ---------------------------------------------------------------------------------------
+// LayerNorm(96) over the 4 lanes of a token + stores: out (LN result, + one-hot key
+// coordinates in mode 1), pre (bf16 pre-LN value, saved for backward), mean / rstd.  All 256
+// threads of the workgroup call it (the quad shuffles need the whole quad).
+__device__ __forceinline__ void pool_ln_finish(const svit_pool_args& a, float (&acc)[24], bool live,
+                                               int tok, bool is_patch, int py, int px, int pt,
+                                               int bh, int Nout, int Ho, int Wo) {
+  const int sub = threadIdx.x & 3, c0 = sub * 24;
+  // the saved pre-LN value is the bf16-rounded one: normalise exactly what backward will see
+#pragma unroll
+  for (int i = 0; i < 24; ++i) acc[i] = bf16_to_f32(f32_to_bf16(acc[i]));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 24; ++i) sum += acc[i];
+  const float mean = quad_sum(sum) * (1.f / HD);
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 24; ++i) sq += (acc[i] - mean) * (acc[i] - mean);
+  const float rstd = rsqrtf(quad_sum(sq) * (1.f / HD) + a.eps);
+  if (!live) return;
+  const size_t orow = (size_t)bh * Nout + tok;
+  if (sub == 0 && a.mean) { a.mean[orow] = mean; a.rstd[orow] = rstd; }
+  bf16_t* outp = (bf16_t*)a.out + orow * a.ld_out + c0;
+  bf16_t* prep = a.pre ? (bf16_t*)a.pre + orow * HD + c0 : nullptr;   // NULL: nothing saved
+#pragma unroll
+  for (int v = 0; v < 3; ++v) {
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      o[e] = (acc[v * 8 + e] - mean) * rstd * a.gamma[c0 + v * 8 + e] + a.beta[c0 + v * 8 + e];
+    *(uint4*)(outp + v * 8) = pack8(o);
+    if (prep) *(uint4*)(prep + v * 8) = pack8(&acc[v * 8]);
+  }
+  if (a.mode == 1) {  // one-hot key coordinates [y | kh+x | kh+kw+t], zeros elsewhere
+    const int extra = a.ld_out - HD, per = extra / 4;
+    bf16_t* ex = (bf16_t*)a.out + orow * a.ld_out + HD + sub * per;
+    for (int v = 0; v < per; v += 8) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = sub * per + v + e;
+        o[e] = (is_patch && (j == py || j == Ho + px || j == Ho + Wo + pt)) ? 1.f : 0.f;
+      }
+      *(uint4*)(ex + v) = pack8(o);
+    }
+  }
+}
+
+
 __device__ __forceinline__ void pool_ln_fwd_body(const svit_pool_args& a, const float* w_lds,
                                                  const float* g_lds, int tb) {
   const int s = a.stride_hw;
@@ -154,44 +202,200 @@ __device__ __forceinline__ void pool_ln_fwd_body(const svit_pool_args& a, const 
       }
     }
   }
-  // the saved pre-LN value is the bf16-rounded one: normalise exactly what backward will see
+  pool_ln_finish(a, acc, live, tok, is_patch, py, px, pt, bh, Nout, Ho, Wo);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Stride-1 depthwise 3x3x3 stencil, LDS-tiled (round 2).  The streaming kernels above fetch every
+// tap from global memory: 81 sixteen-byte loads per lane and token, each input element 27 times
+// through the texture path (rocprofv3 round 1: 3.2x the algorithmic read traffic, 0.21 of the HBM
+// roofline).  Here a workgroup owns a TY x TX patch of output positions of one (batch, head,
+// tensor) and walks t: the halo of three consecutive input planes lives in an LDS ring (one new
+// plane per step, fetched ONCE with coalesced 16-byte loads while the previous plane is being
+// computed), so global memory sees each element ~1.7 times and the 27 taps are LDS reads.
+//   * Wave w owns the channels [24w, 24w+24) of every token of the patch, lane = token.  The
+//     weights of a wave are therefore wave-uniform: they are read as SCALAR operands
+//     (s_load_dwordx8 from a per-tensor "selector" table, see svit_pool_weight_sel) and cost no
+//     LDS bandwidth and no vector registers; LDS carries only the 3 x 16 input bytes per tap.
+//   * Token rows are 208 bytes apart in LDS (13 sixteen-byte slots, odd): the 16 lanes of a
+//     ds_read_b128 group are 16 consecutive tokens and hit 16 distinct slots of the bank row.
+//   * LayerNorm(96) spans the four waves: two tiny exchanges (sum, then squared deviations)
+//     through LDS per plane.
+//   * FLIP selects the transposed stencil (conv dgrad of a stride-1 conv = correlation with the
+//     flipped kernel), DGRAD the epilogue: bf16 rows of dqkv instead of LayerNorm + out/pre.
+constexpr int TL_ROW = 208;       // LDS bytes per token row (192 + 16 pad)
+
+struct PoolTilePlan {
+  int tiled;          // 1: this tensor runs the tiled body
+  int tiles_x, tiles_y, tch, tlen, n_wgs, n_special;
+};
+
+template <int TX, int TY, bool DGRAD>
+__device__ __forceinline__ void pool_tiled_body(
+    const bf16_t* __restrict__ in_base, size_t in_tok_stride /* elements */, int in_first /* token index of patch 0 */,
+    const uint32_t* __restrict__ sel /* [27][96] selector dwords */, int T, int H, int W, int wg,
+    const PoolTilePlan& pl, unsigned char* ring, float* xch /* [2][4][64] */,
+    const svit_pool_args* fa, const svit_pool_dgrad_args* da, int bh) {
+  constexpr int HX = TX + 2, HY = TY + 2, HTOK = HX * HY, PLANE_B = HTOK * TL_ROW;
+  constexpr int CH = HTOK * 12, PER = (CH + 255) / 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tc = wg % pl.tch, txi = (wg / pl.tch) % pl.tiles_x, tyi = wg / (pl.tch * pl.tiles_x);
+  const int y0 = tyi * TY, x0 = txi * TX;
+  const int t0 = tc * pl.tlen, t1 = min(T, t0 + pl.tlen);
+  uint4 sreg[PER];
+  auto fetch = [&](int tp) {        // global -> registers (zero outside the volume)
 #pragma unroll
-  for (int i = 0; i < 24; ++i) acc[i] = bf16_to_f32(f32_to_bf16(acc[i]));
-  float sum = 0.f;
+    for (int u = 0; u < PER; ++u) {
+      const int q = tid + u * 256;
+      const int tok = q / 12, cc = q % 12, hy = tok / HX, hx = tok % HX;
+      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      sreg[u] = make_uint4(0, 0, 0, 0);
+      if (q < CH && tp >= 0 && tp < T && y >= 0 && y < H && x >= 0 && x < W)
+        sreg[u] = *(const uint4*)(in_base + (size_t)(in_first + (tp * H + y) * W + x) * in_tok_stride + cc * 8);
+    }
+  };
+  auto store = [&](int tp) {        // registers -> ring slot (tp + 1) % 3
+    unsigned char* dst = ring + ((tp + 1) % 3) * PLANE_B;
 #pragma unroll
-  for (int i = 0; i < 24; ++i) sum += acc[i];
-  const float mean = quad_sum(sum) * (1.f / HD);
-  float sq = 0.f;
+    for (int u = 0; u < PER; ++u) {
+      const int q = tid + u * 256;
+      if (q < CH) *(uint4*)(dst + (q / 12) * TL_ROW + (q % 12) * 16) = sreg[u];
+    }
+  };
+  // lane -> output position of the patch (lanes past TX*TY idle on position 0)
+  const int lt = lane < TX * TY ? lane : 0;
+  const int ty = lt / TX, tx = lt % TX;
+  const bool live = lane < TX * TY && y0 + ty < H && x0 + tx < W;
+  const unsigned ldsoff = (unsigned)((ty * HX + tx) * TL_ROW + wave * 48);
+  const uint32_t* wsel = sel + wave * 24;           // this wave's 24 channels of every tap
+
+  __syncthreads();                 // the ring is free (previous work item of this workgroup)
+  fetch(t0 - 1); store(t0 - 1);
+  fetch(t0);     store(t0);
+  fetch(t0 + 1);
+  for (int t = t0; t < t1; ++t) {
+    store(t + 1);
+    __syncthreads();
+    if (t + 1 < t1) fetch(t + 2);  // travels while this plane is computed
+    float acc[24];
 #pragma unroll
-  for (int i = 0; i < 24; ++i) sq += (acc[i] - mean) * (acc[i] - mean);
-  const float rstd = rsqrtf(quad_sum(sq) * (1.f / HD) + a.eps);
-  if (!live) return;
-  const size_t orow = (size_t)bh * Nout + tok;
-  if (sub == 0 && a.mean) { a.mean[orow] = mean; a.rstd[orow] = rstd; }
-  bf16_t* outp = (bf16_t*)a.out + orow * a.ld_out + c0;
-  bf16_t* prep = a.pre ? (bf16_t*)a.pre + orow * HD + c0 : nullptr;   // NULL: nothing saved
+    for (int i = 0; i < 24; ++i) acc[i] = 0.f;
+    // one t-plane (9 taps, 27 LDS reads in flight) at a time: fully unrolled the scheduler hoists
+    // all 81 reads and spills
+#pragma unroll 1
+    for (int kt = 0; kt < 3; ++kt) {
+      const unsigned char* pl_base = ring + ((t + kt) % 3) * PLANE_B + ldsoff;
 #pragma unroll
-  for (int v = 0; v < 3; ++v) {
-    float o[8];
+      for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      o[e] = (acc[v * 8 + e] - mean) * rstd * a.gamma[c0 + v * 8 + e] + a.beta[c0 + v * 8 + e];
-    *(uint4*)(outp + v * 8) = pack8(o);
-    if (prep) *(uint4*)(prep + v * 8) = pack8(&acc[v * 8]);
-  }
-  if (a.mode == 1) {  // one-hot key coordinates [y | kh+x | kh+kw+t], zeros elsewhere
-    const int extra = a.ld_out - HD, per = extra / 4;
-    bf16_t* ex = (bf16_t*)a.out + orow * a.ld_out + HD + sub * per;
-    for (int v = 0; v < per; v += 8) {
-      float o[8];
+        for (int kx = 0; kx < 3; ++kx) {
+          const int tap = (kt * 3 + ky) * 3 + kx;
+          const uint32_t* wt = wsel + (DGRAD ? 26 - tap : tap) * HD;   // wave-uniform: scalar loads
+          const unsigned char* p = pl_base + (ky * HX + kx) * TL_ROW;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int j = sub * per + v + e;
-        o[e] = (is_patch && (j == py || j == Ho + px || j == Ho + Wo + pt)) ? 1.f : 0.f;
+          for (int u = 0; u < 3; ++u) {
+            const uint4 v = *(const uint4*)(p + u * 16);
+            acc[u * 8 + 0] = dot2_sel(v.x, wt[u * 8 + 0], acc[u * 8 + 0]);
+            acc[u * 8 + 1] = dot2_sel(v.x, wt[u * 8 + 1], acc[u * 8 + 1]);
+            acc[u * 8 + 2] = dot2_sel(v.y, wt[u * 8 + 2], acc[u * 8 + 2]);
+            acc[u * 8 + 3] = dot2_sel(v.y, wt[u * 8 + 3], acc[u * 8 + 3]);
+            acc[u * 8 + 4] = dot2_sel(v.z, wt[u * 8 + 4], acc[u * 8 + 4]);
+            acc[u * 8 + 5] = dot2_sel(v.z, wt[u * 8 + 5], acc[u * 8 + 5]);
+            acc[u * 8 + 6] = dot2_sel(v.w, wt[u * 8 + 6], acc[u * 8 + 6]);
+            acc[u * 8 + 7] = dot2_sel(v.w, wt[u * 8 + 7], acc[u * 8 + 7]);
+          }
+        }
+    }
+    const int y = y0 + ty, x = x0 + tx;
+    if constexpr (DGRAD) {
+      if (live) {
+        const int b = bh / da->heads, head = bh % da->heads;
+        const int N = 1 + T * H * W + da->n_obj;
+        const size_t ts = (size_t)3 * da->heads * HD;
+        bf16_t* o = (bf16_t*)da->dqkv + ((size_t)b * N + 1 + (t * H + y) * W + x) * ts +
+                    ((size_t)da->which * da->heads + head) * HD + wave * 24;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) *(uint4*)(o + v * 8) = pack8(&acc[v * 8]);
       }
-      *(uint4*)(ex + v) = pack8(o);
+    } else {
+      // LayerNorm over the 96 channels of the token = over the four waves
+#pragma unroll
+      for (int i = 0; i < 24; ++i) acc[i] = bf16_to_f32(f32_to_bf16(acc[i]));   // what backward sees
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 24; ++i) sum += acc[i];
+      xch[wave * 64 + lane] = sum;
+      __syncthreads();
+      const float mean = ((xch[lane] + xch[64 + lane]) + (xch[128 + lane] + xch[192 + lane])) * (1.f / HD);
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 24; ++i) sq += (acc[i] - mean) * (acc[i] - mean);
+      xch[256 + wave * 64 + lane] = sq;
+      __syncthreads();
+      const float var = ((xch[256 + lane] + xch[320 + lane]) + (xch[384 + lane] + xch[448 + lane])) * (1.f / HD);
+      const float rstd = rsqrtf(var + fa->eps);
+      if (live) {
+        const int Lo = T * H * W, Nout = 1 + Lo + fa->n_obj;
+        const int tok = 1 + (t * H + y) * W + x, c0 = wave * 24;
+        const size_t orow = (size_t)bh * Nout + tok;
+        if (wave == 0 && fa->mean) { fa->mean[orow] = mean; fa->rstd[orow] = rstd; }
+        bf16_t* outp = (bf16_t*)fa->out + orow * fa->ld_out + c0;
+        bf16_t* prep = fa->pre ? (bf16_t*)fa->pre + orow * HD + c0 : nullptr;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+          float o8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            o8[e] = (acc[v * 8 + e] - mean) * rstd * fa->gamma[c0 + v * 8 + e] + fa->beta[c0 + v * 8 + e];
+          *(uint4*)(outp + v * 8) = pack8(o8);
+          if (prep) *(uint4*)(prep + v * 8) = pack8(&acc[v * 8]);
+        }
+        if (fa->mode == 1) {   // one-hot key coordinates [y | kh+x | kh+kw+t], zeros elsewhere
+          const int extra = fa->ld_out - HD, per = extra / 4;
+          bf16_t* ex = (bf16_t*)fa->out + orow * fa->ld_out + HD + wave * per;
+          for (int v = 0; v < per; v += 8) {
+            float o8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int j = wave * per + v + e;
+              o8[e] = (j == y || j == H + x || j == H + W + t) ? 1.f : 0.f;
+            }
+            *(uint4*)(ex + v) = pack8(o8);
+          }
+        }
+      }
+    }
+    __syncthreads();               // ring slot of plane t-1 (and xch) are overwritten next step
+  }
+}
+
+// cls and object tokens of a tiled forward tensor: out = LN(x) / LN(x * g(w)) (the closed form of
+// the cube branch).  Token list = [0, Lo+1 .. Lo+n_obj], 64 per workgroup.
+__device__ __forceinline__ void pool_ln_special_body(const svit_pool_args& a, const float* g_lds, int blk) {
+  const int L = a.T * a.H * a.W, Lo = L;          // stride 1: Lo == L
+  const int N = 1 + L + a.n_obj, Nout = N;
+  const int bh = blockIdx.y, b = bh / a.heads, head = bh % a.heads;
+  const int idx = blk * 64 + (threadIdx.x >> 2);
+  const int sub = threadIdx.x & 3, c0 = sub * 24;
+  const bool live = idx <= a.n_obj;
+  const int tok = idx == 0 ? 0 : Lo + idx;
+  const size_t tok_stride = (size_t)3 * a.heads * HD;
+  const bf16_t* base = (const bf16_t*)a.qkv + (size_t)b * N * tok_stride + ((size_t)a.which * a.heads + head) * HD + c0;
+  float acc[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) acc[i] = 0.f;
+  if (live) {
+    const bf16_t* p = base + (size_t)tok * tok_stride;       // tok == source index at stride 1
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      float f[8];
+      unpack8(*(const uint4*)(p + v * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[v * 8 + e] = (tok == 0) ? f[e] : f[e] * g_lds[c0 + v * 8 + e];
     }
   }
+  pool_ln_finish(a, acc, live, tok, false, 0, 0, 0, bh, Nout, a.H, a.W);
 }
 
 // Workgroups are persistent over token blocks (blockIdx.x strides by gridDim.x): the conv weights
@@ -207,15 +411,52 @@ __global__ __launch_bounds__(256) void pool_ln_fwd_kernel(svit_pool_args a) {
 // q, k and v of one block in one launch (blockIdx.z = which): the three stencils differ only in
 // stride, and at the 14x14 / 7x7 stages each of them is a few-microsecond latency chain, so
 // running them side by side costs the time of the longest one.
-struct PoolFwd3 { svit_pool_args p[3]; };
+struct PoolFwd3 { svit_pool_args p[3]; PoolTilePlan plan[3]; const uint32_t* sel[3]; };
 __global__ __launch_bounds__(256) void pool_ln_fwd3_kernel(PoolFwd3 g) {
-  __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];
+  __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];   // streaming body: selector weights
   __shared__ __attribute__((aligned(16))) float g_lds[HD];
+  extern __shared__ __attribute__((aligned(16))) unsigned char pool_dyn[];   // tiled body: ring + exchange
   const svit_pool_args& a = g.p[blockIdx.z];
+  const PoolTilePlan& pl = g.plan[blockIdx.z];
+  if (pl.tiled) {
+    const int wg = blockIdx.x;
+    if (wg >= pl.n_wgs + pl.n_special) return;
+    if (wg >= pl.n_wgs) {                       // cls / object tokens
+      load_weights(a.conv_w, w_lds, g_lds, a.stride_hw);
+      pool_ln_special_body(a, g_lds, wg - pl.n_wgs);
+      return;
+    }
+    const int bh = blockIdx.y, b = bh / a.heads, head = bh % a.heads;
+    const int N = 1 + a.T * a.H * a.W + a.n_obj;
+    const size_t ts = (size_t)3 * a.heads * HD;
+    const bf16_t* base = (const bf16_t*)a.qkv + (size_t)b * N * ts + ((size_t)a.which * a.heads + head) * HD;
+    float* xch = (float*)pool_dyn;
+    unsigned char* ring = pool_dyn + 512 * sizeof(float);
+    if (a.W > 7)
+      pool_tiled_body<14, 4, false>(base, ts, 1, g.sel[blockIdx.z], a.T, a.H, a.W, wg, pl, ring, xch, &a, nullptr, bh);
+    else
+      pool_tiled_body<7, 7, false>(base, ts, 1, g.sel[blockIdx.z], a.T, a.H, a.W, wg, pl, ring, xch, &a, nullptr, bh);
+    return;
+  }
   const int Nout = 1 + a.T * pooled(a.H, a.stride_hw) * pooled(a.W, a.stride_hw) + a.n_obj;
   if ((int)blockIdx.x * 64 >= Nout) return;
   load_weights(a.conv_w, w_lds, g_lds, a.stride_hw);
   for (int tb = blockIdx.x; tb * 64 < Nout; tb += gridDim.x) pool_ln_fwd_body(a, w_lds, g_lds, tb);
+}
+
+// selector table of a depthwise weight: dst[tap][c] = bf16(w[c][tap]) in the half of the dword that
+// matches c's position in a packed bf16 pair (see dot2_sel) -- the scalar operand of the tiled
+// stencils.  One launch converts a list of [96][27] fp32 weights (src_off: element offsets into
+// src_base) -- the engine runs it once per step for all blocks next to the bf16 weight mirror.
+__global__ void pool_weight_sel_kernel(const float* __restrict__ src_base, const int64_t* __restrict__ src_off,
+                                       uint32_t* __restrict__ dst, int n) {
+  const int t = blockIdx.y;
+  if (t >= n) return;
+  const float* w = src_base + src_off[t];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 27 * HD; i += gridDim.x * blockDim.x) {
+    const int tap = i / HD, c = i % HD;
+    dst[(size_t)t * 27 * HD + i] = (uint32_t)f32_to_bf16(w[c * 27 + tap]) << (16 * (c & 1));
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -473,11 +714,55 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(svit_pool_dgrad_args a)
   __shared__ __attribute__((aligned(16))) float g_lds[HD];
   pool_dgrad_loop<S>(a, w_lds, g_lds);
 }
-struct PoolDgrad3 { svit_pool_dgrad_args p[3]; };
+// cls and object rows of a tiled dgrad tensor: dx[cls] = dpre[cls], dx[obj] = dpre[obj] * g(w)
+__device__ __forceinline__ void pool_dgrad_special_body(const svit_pool_dgrad_args& a, const float* g_lds, int blk) {
+  const int L = a.T * a.H * a.W, N = 1 + L + a.n_obj;     // stride 1: Nout == N
+  const int bh = blockIdx.y, b = bh / a.heads, head = bh % a.heads;
+  const int idx = blk * 64 + (threadIdx.x >> 2);
+  const int sub = threadIdx.x & 3, c0 = sub * 24;
+  if (idx > a.n_obj) return;
+  const int tok = idx == 0 ? 0 : L + idx;
+  const bf16_t* dp = (const bf16_t*)a.dpre + ((size_t)bh * N + tok) * HD + c0;
+  const size_t ts = (size_t)3 * a.heads * HD;
+  bf16_t* o = (bf16_t*)a.dqkv + ((size_t)b * N + tok) * ts + ((size_t)a.which * a.heads + head) * HD + c0;
+#pragma unroll
+  for (int v = 0; v < 3; ++v) {
+    float f[8];
+    unpack8(*(const uint4*)(dp + v * 8), f);
+    if (tok != 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] *= g_lds[c0 + v * 8 + e];
+    }
+    *(uint4*)(o + v * 8) = pack8(f);
+  }
+}
+
+struct PoolDgrad3 { svit_pool_dgrad_args p[3]; PoolTilePlan plan[3]; const uint32_t* sel[3]; };
 __global__ __launch_bounds__(256) void pool_dgrad3_kernel(PoolDgrad3 g) {
   __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];
   __shared__ __attribute__((aligned(16))) float g_lds[HD];
+  extern __shared__ __attribute__((aligned(16))) unsigned char pool_dyn[];
   const svit_pool_dgrad_args& a = g.p[blockIdx.z];
+  const PoolTilePlan& pl = g.plan[blockIdx.z];
+  if (pl.tiled) {
+    const int wg = blockIdx.x;
+    if (wg >= pl.n_wgs + pl.n_special) return;
+    if (wg >= pl.n_wgs) {
+      load_weights(a.conv_w, w_lds, g_lds, a.stride_hw);
+      pool_dgrad_special_body(a, g_lds, wg - pl.n_wgs);
+      return;
+    }
+    const int bh = blockIdx.y;
+    const int N = 1 + a.T * a.H * a.W + a.n_obj;
+    const bf16_t* base = (const bf16_t*)a.dpre + (size_t)bh * N * HD;
+    float* xch = (float*)pool_dyn;
+    unsigned char* ring = pool_dyn + 512 * sizeof(float);
+    if (a.W > 7)
+      pool_tiled_body<14, 4, true>(base, HD, 1, g.sel[blockIdx.z], a.T, a.H, a.W, wg, pl, ring, xch, nullptr, &a, bh);
+    else
+      pool_tiled_body<7, 7, true>(base, HD, 1, g.sel[blockIdx.z], a.T, a.H, a.W, wg, pl, ring, xch, nullptr, &a, bh);
+    return;
+  }
   if (a.stride_hw == 1) pool_dgrad_loop<1>(a, w_lds, g_lds);
   else if (a.stride_hw == 2) pool_dgrad_loop<2>(a, w_lds, g_lds);
   else pool_dgrad_loop<3>(a, w_lds, g_lds);
@@ -1085,22 +1370,72 @@ static int check_pool_fwd(const svit_pool_args* a) {
   return SVIT_OK;
 }
 
-extern "C" int svit_pool_ln_fwd_qkv(const svit_pool_args* a3, void* stream) {
+// plan of the LDS-tiled stride-1 stencil for one tensor (see pool_tiled_body)
+static PoolTilePlan plan_tiled(int T, int H, int W, int n_obj, int bh) {
+  PoolTilePlan pl;
+  const int TX = W > 7 ? 14 : 7, TY = W > 7 ? 4 : 7;
+  pl.tiled = 1;
+  pl.tiles_x = (W + TX - 1) / TX;
+  pl.tiles_y = (H + TY - 1) / TY;
+  int tch = 1;           // cut the t walk while the (y, x) tiling alone leaves CUs idle
+  while (tch * 2 <= T && (long)pl.tiles_x * pl.tiles_y * tch * bh < 384 && T / (tch * 2) >= 1) tch *= 2;
+  pl.tch = tch;
+  pl.tlen = (T + tch - 1) / tch;
+  pl.n_wgs = pl.tiles_x * pl.tiles_y * tch;
+  pl.n_special = (1 + n_obj + 63) / 64;
+  return pl;
+}
+static size_t tiled_lds_bytes(int W) {
+  const int htok = W > 7 ? 6 * 16 : 9 * 9;
+  return 512 * sizeof(float) + 3 * (size_t)htok * TL_ROW;
+}
+
+static int pool_ln_fwd_qkv_impl(const svit_pool_args* a3, const uint32_t* const* sel3, void* stream) {
   if (!a3) return SVIT_ERR_ARG;
   PoolFwd3 g;
-  int max_nout = 0;
+  unsigned gx = 1;
+  size_t lds = 0;
   for (int i = 0; i < 3; ++i) {
     const int rc = check_pool_fwd(&a3[i]);
     if (rc) return rc;
     if (a3[i].B != a3[0].B || a3[i].heads != a3[0].heads) return SVIT_ERR_SHAPE;
     g.p[i] = a3[i];
+    g.sel[i] = sel3 ? sel3[i] : nullptr;
+    g.plan[i].tiled = 0;
     const int s = a3[i].stride_hw;
     const int nout = 1 + a3[i].T * ((a3[i].H - 1) / s + 1) * ((a3[i].W - 1) / s + 1) + a3[i].n_obj;
-    if (nout > max_nout) max_nout = nout;
+    unsigned x = persistent_x((nout + 63) / 64, a3[0].B * a3[0].heads * 3);
+    if (s == 1 && g.sel[i]) {
+      g.plan[i] = plan_tiled(a3[i].T, a3[i].H, a3[i].W, a3[i].n_obj, a3[i].B * a3[i].heads);
+      x = (unsigned)(g.plan[i].n_wgs + g.plan[i].n_special);
+      const size_t need = tiled_lds_bytes(a3[i].W);
+      if (need > lds) lds = need;
+    }
+    if (x > gx) gx = x;
   }
-  hipLaunchKernelGGL(pool_ln_fwd3_kernel,
-                     dim3(persistent_x((max_nout + 63) / 64, a3[0].B * a3[0].heads * 3),
-                          a3[0].B * a3[0].heads, 3), dim3(256), 0, (hipStream_t)stream, g);
+  static SvitOnce once;
+  if (int rc = svit_max_lds_once(once, (const void*)pool_ln_fwd3_kernel, 64 * 1024)) return rc;
+  hipLaunchKernelGGL(pool_ln_fwd3_kernel, dim3(gx, a3[0].B * a3[0].heads, 3), dim3(256), lds,
+                     (hipStream_t)stream, g);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_pool_ln_fwd_qkv(const svit_pool_args* a3, void* stream) {
+  return pool_ln_fwd_qkv_impl(a3, nullptr, stream);
+}
+// the same with the selector tables of the three depthwise weights (svit_pool_weight_sel): tensors
+// with stride 1 run the LDS-tiled stencil
+extern "C" int svit_pool_ln_fwd_qkv_sel(const svit_pool_args* a3, const uint32_t* const* sel3, void* stream) {
+  if (!sel3) return SVIT_ERR_ARG;
+  return pool_ln_fwd_qkv_impl(a3, sel3, stream);
+}
+
+extern "C" int svit_pool_weight_sel(const float* src_base, const int64_t* src_off, uint32_t* dst,
+                                    int n_tables, void* stream) {
+  if (!src_base || !src_off || !dst || n_tables <= 0) return SVIT_ERR_ARG;
+  hipLaunchKernelGGL(pool_weight_sel_kernel, dim3(4, n_tables), dim3(256), 0, (hipStream_t)stream,
+                     src_base, src_off, dst, n_tables);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }
@@ -1139,9 +1474,12 @@ extern "C" int svit_pool_ln_bwd_qkv(const svit_pool_ln_bwd_args* a3, void* strea
   return SVIT_OK;
 }
 
-extern "C" int svit_pool_conv_dgrad_qkv(const svit_pool_dgrad_args* a3, void* stream) {
+static int pool_conv_dgrad_qkv_impl(const svit_pool_dgrad_args* a3, const uint32_t* const* sel3, void* stream) {
   if (!a3) return SVIT_ERR_ARG;
   PoolDgrad3 g;
+  const int N = 1 + a3[0].T * a3[0].H * a3[0].W + a3[0].n_obj;
+  unsigned gx = persistent_x((N + 63) / 64, a3[0].B * a3[0].heads * 3);
+  size_t lds = 0;
   for (int i = 0; i < 3; ++i) {
     const svit_pool_dgrad_args* a = &a3[i];
     if (!a->dpre || !a->conv_w || !a->dqkv || a->which < 0 || a->which > 2) return SVIT_ERR_ARG;
@@ -1151,13 +1489,26 @@ extern "C" int svit_pool_conv_dgrad_qkv(const svit_pool_dgrad_args* a3, void* st
         a->W != a3[0].W || a->n_obj != a3[0].n_obj)
       return SVIT_ERR_SHAPE;
     g.p[i] = *a;
+    g.sel[i] = sel3 ? sel3[i] : nullptr;
+    g.plan[i].tiled = 0;
+    if (a->stride_hw == 1 && g.sel[i]) {
+      g.plan[i] = plan_tiled(a->T, a->H, a->W, a->n_obj, a->B * a->heads);
+      const unsigned x = (unsigned)(g.plan[i].n_wgs + g.plan[i].n_special);
+      if (x > gx) gx = x;
+      const size_t need = tiled_lds_bytes(a->W);
+      if (need > lds) lds = need;
+    }
   }
-  const int N = 1 + a3[0].T * a3[0].H * a3[0].W + a3[0].n_obj;
-  hipLaunchKernelGGL(pool_dgrad3_kernel,
-                     dim3(persistent_x((N + 63) / 64, a3[0].B * a3[0].heads * 3),
-                          a3[0].B * a3[0].heads, 3), dim3(256), 0, (hipStream_t)stream, g);
+  static SvitOnce once;
+  if (int rc = svit_max_lds_once(once, (const void*)pool_dgrad3_kernel, 64 * 1024)) return rc;
+  hipLaunchKernelGGL(pool_dgrad3_kernel, dim3(gx, a3[0].B * a3[0].heads, 3), dim3(256), lds,
+                     (hipStream_t)stream, g);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
+}
+
+extern "C" int svit_pool_conv_dgrad_qkv(const svit_pool_dgrad_args* a3, void* stream) {
+  return pool_conv_dgrad_qkv_impl(a3, nullptr, stream);
 }
 
 extern "C" int svit_pool_conv_wgrad_qkv(const svit_pool_wgrad_args* a3, void* stream) {
@@ -1199,8 +1550,19 @@ extern "C" int svit_pool_conv_wgrad_qkv(const svit_pool_wgrad_args* a3, void* st
   return SVIT_OK;
 }
 
+static int pool_conv_bwd_qkv_impl(const svit_pool_dgrad_args* d3, const svit_pool_wgrad_args* w3,
+                                  const uint32_t* const* sel3, void* stream);
 extern "C" int svit_pool_conv_bwd_qkv(const svit_pool_dgrad_args* d3, const svit_pool_wgrad_args* w3,
                                       void* stream) {
+  return pool_conv_bwd_qkv_impl(d3, w3, nullptr, stream);
+}
+extern "C" int svit_pool_conv_bwd_qkv_sel(const svit_pool_dgrad_args* d3, const svit_pool_wgrad_args* w3,
+                                          const uint32_t* const* sel3, void* stream) {
+  if (!sel3) return SVIT_ERR_ARG;
+  return pool_conv_bwd_qkv_impl(d3, w3, sel3, stream);
+}
+static int pool_conv_bwd_qkv_impl(const svit_pool_dgrad_args* d3, const svit_pool_wgrad_args* w3,
+                                  const uint32_t* const* sel3, void* stream) {
   if (!d3 || !w3) return SVIT_ERR_ARG;
   bool small = true;
   size_t lds = 16 * 648 * sizeof(float);
@@ -1222,8 +1584,8 @@ extern "C" int svit_pool_conv_bwd_qkv(const svit_pool_dgrad_args* d3, const svit
   // 126 us) and loses from 14x14 on (155 vs 108 us: two channels per thread do not amortise
   // the tap addressing the way the streaming dgrad's 24 channels per lane do)
   if (lds > 112 * 1024 || N > 1024) small = false;
-  if (!small) {   // large planes: the streaming kernels
-    int rc = svit_pool_conv_dgrad_qkv(d3, stream);
+  if (!small) {   // large planes: the streaming / tiled kernels
+    int rc = pool_conv_dgrad_qkv_impl(d3, sel3, stream);
     if (rc) return rc;
     return svit_pool_conv_wgrad_qkv(w3, stream);
   }

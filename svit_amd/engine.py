@@ -75,6 +75,14 @@ class FlatParams:
                 for a, o, r in zip("hwt", offs, rows):
                     table += [self.slots[pre + "attn.rel_pos_" + a][0], toff + o, r, HD, lpad]
                 toff += _align(HD * lpad)
+        # selector tables of the depthwise pooling weights (scalar operands of the LDS-tiled
+        # stencils, csrc/pool.hip): [block * 3 + (q, k, v)][27][96] uint32, refreshed with the mirror
+        pool_names = [n for n in names if ".attn.pool_" in n and n.endswith(".weight")]
+        pool_names.sort(key=lambda n: (int(n.split(".")[1]), "qkv".index(n.split(".")[3][-1])))
+        self.pool_sel_index = {n: i for i, n in enumerate(pool_names)}
+        self.pool_sel = torch.zeros((max(1, len(pool_names)), 27 * 96), device=device, dtype=torch.int32)
+        self.pool_sel_off = torch.tensor([self.slots[n][0] for n in pool_names] or [0], dtype=torch.int64,
+                                         device=device)
         self.wT16 = torch.zeros(max(toff, 8), device=device, dtype=BF16)
         self.t_table = torch.tensor(table, dtype=torch.int64, device=device)
         self.n_t = len(table) // 5
@@ -124,8 +132,14 @@ class FlatParams:
         lpad = (total + 95) // 96 * 96
         return (self.w16[offs[0]:offs[0] + lpad * HD].view(lpad, HD), (0, rows[0], rows[0] + rows[1]))
 
+    def sels(self, pre):
+        """the three selector tables of a block's pool_q / pool_k / pool_v weights"""
+        return [self.pool_sel[self.pool_sel_index[pre + "attn.pool_%s.weight" % r]] for r in "qkv"]
+
     def refresh_low_precision(self):
         ops.cast_bf16(self.data, self.w16[:self.total])
+        if self.pool_sel_index:
+            ops.pool_weight_sel(self.data, self.pool_sel_off, self.pool_sel)
         if self.n_t:
             ops.transpose_cast_batched(self.data, self.wT16, self.t_table, self.n_t, 256)
 
@@ -289,7 +303,7 @@ class Engine:
             qkv, [f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
             [f.p(pre + "attn.norm_%s.weight" % r) for r in "qkv"],
             [f.p(pre + "attn.norm_%s.bias" % r) for r in "qkv"],
-            B, h, thw, n_obj, (sq, skv, skv), (DA, DA, HD), (0, 1, 0), save=save)
+            B, h, thw, n_obj, (sq, skv, skv), (DA, DA, HD), (0, 1, 0), save=save, sels=f.sels(pre))
         qa, ka, v = pools[0][0], pools[1][0], pools[2][0]
         idx, mats, mcat, need = self._rel(blk, q_thw, k_thw)
         # rel-pos query side: P = q . Rcat^T on the MFMA GEMM, then a 2-byte gather per (q, j)
@@ -501,7 +515,7 @@ class Engine:
         ops.pool_conv_bwd_qkv(dpres, [f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
                               dqkv, sv["qkv"],
                               [f.g(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
-                              B, h, thw, n_obj, strides, ws=self._rws("wgrad"))
+                              B, h, thw, n_obj, strides, ws=self._rws("wgrad"), sels=f.sels(pre))
         # (bf16 unless the dim-change projection accumulates into it below)
         dxn = self._linear_bwd(dqkv, sv["xn"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", True,
                                epilogue=hip.EPI_F32 if blk.has_proj else hip.EPI_BF16)

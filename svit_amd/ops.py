@@ -255,14 +255,33 @@ def pool_ln_fwd(qkv, which, conv_w, gamma, beta, B, heads, thw, n_obj, stride_hw
     return res
 
 
+def pool_weight_sel(src_flat, offsets, dst):
+    """selector tables (uint32 [n, 27, 96]) of n depthwise weights living at `offsets` (int64
+    element offsets) of the fp32 buffer `src_flat` -- scalar operands of the tiled stencils."""
+    _chk_dev(src_flat, offsets, dst)
+    hip.call("svit_pool_weight_sel", ptr(src_flat), ptr(offsets), ptr(dst), offsets.numel())
+    return dst
+
+
+def _sel_ptrs(sels):
+    arr = (C.c_void_p * 3)()
+    for i in range(3):
+        arr[i] = ptr(sels[i])
+    return arr
+
+
 def pool_ln_fwd_qkv(qkv, conv_ws, gammas, betas, B, heads, thw, n_obj, strides, ld_outs, modes,
-                    eps=1e-6, save=True):
+                    eps=1e-6, save=True, sels=None):
     """q, k, v pooling + LayerNorm in one launch -> [(out, pre, mean, rstd)] * 3 (the last three
-    are None with save=False: no-grad passes keep nothing for a backward)."""
+    are None with save=False: no-grad passes keep nothing for a backward).  sels: the three
+    selector tables (pool_weight_sel) -- stride-1 tensors then run the LDS-tiled stencil."""
     arr = (hip.PoolArgs * 3)()
     res = [_pool_fwd_args(arr[i], qkv, i, conv_ws[i], gammas[i], betas[i], B, heads, thw, n_obj,
                           strides[i], ld_outs[i], modes[i], eps, save) for i in range(3)]
-    hip.call("svit_pool_ln_fwd_qkv", arr)
+    if sels is None:
+        hip.call("svit_pool_ln_fwd_qkv", arr)
+    else:
+        hip.call("svit_pool_ln_fwd_qkv_sel", arr, _sel_ptrs(sels))
     return res
 
 
@@ -336,14 +355,18 @@ def pool_conv_wgrad_qkv(dpres, qkv, dws, B, heads, thw, n_obj, strides, ws=None)
     hip.call("svit_pool_conv_wgrad_qkv", arr)
 
 
-def pool_conv_bwd_qkv(dpres, conv_ws, dqkv, qkv, dws, B, heads, thw, n_obj, strides, ws=None):
-    """conv dgrad + conv wgrad of q, k, v: one fused kernel for small planes, else two launches."""
+def pool_conv_bwd_qkv(dpres, conv_ws, dqkv, qkv, dws, B, heads, thw, n_obj, strides, ws=None, sels=None):
+    """conv dgrad + conv wgrad of q, k, v: one fused kernel for small planes, else two launches
+    (with sels, the stride-1 dgrads run the LDS-tiled stencil)."""
     da = (hip.PoolDgradArgs * 3)()
     wa = (hip.PoolWgradArgs * 3)()
     for i in range(3):
         _pool_dgrad_args(da[i], dpres[i], conv_ws[i], dqkv, i, B, heads, thw, n_obj, strides[i])
         _pool_wgrad_args(wa[i], dpres[i], qkv, i, dws[i], B, heads, thw, n_obj, strides[i], ws)
-    hip.call("svit_pool_conv_bwd_qkv", da, wa)
+    if sels is None:
+        hip.call("svit_pool_conv_bwd_qkv", da, wa)
+    else:
+        hip.call("svit_pool_conv_bwd_qkv_sel", da, wa, _sel_ptrs(sels))
 
 
 def relpos_q_fwd(qa, tabs, idx, B, heads, q_thw, k_thw, n_obj, inv_scale):

@@ -282,6 +282,45 @@ def test_pool_ln_fwd_bwd(ops, stride, thw):
     assert cos(dw, wc.grad.reshape(96, 27)) > 0.9995 and rel_err(dw, wc.grad.reshape(96, 27)) < 3e-2
 
 
+@pytest.mark.parametrize("sq,skv,thw", [(1, 1, (2, 8, 8)), (1, 2, (3, 7, 7)), (2, 1, (2, 16, 16)),
+                                         (1, 8, (2, 30, 30)), (1, 1, (1, 14, 14)), (1, 1, (5, 5, 9))])
+def test_pool_tiled_stride1_equals_streaming(ops, sq, skv, thw):
+    """Round-2 LDS-tiled stride-1 stencils (halo ring in LDS, scalar weight operands; forward with
+    the LayerNorm spanning four waves, and the conv dgrad with the flipped kernel) against the
+    streaming kernels they replace: the forward is BIT-identical (same taps in the same order),
+    the dgrad equal to fp32 rounding.  Covers partial tiles, the 7x7 tile, two x tiles, a t walk
+    cut in chunks, T = 1 and non-square planes."""
+    B, h, O = 2, 2, 3
+    qkv = _qkv(B, h, thw, O, "t%d%d%d" % (sq, skv, thw[1]))
+    ws = [rnd("tw%d" % i, (96, 27), 0.3) for i in range(3)]
+    gs = [rnd("tg%d" % i, (96,), 0.2) + 1.0 for i in range(3)]
+    bs = [rnd("tb%d" % i, (96,), 0.1) for i in range(3)]
+    strides, lds, modes = (sq, skv, skv), (128, 128, 96), (0, 1, 0)
+    if thw[0] + ops.pooled(thw[1], skv) + ops.pooled(thw[2], skv) > 32:
+        lds = (160, 160, 96)
+    wflat = torch.cat([w.flatten() for w in ws]).contiguous()
+    offs = torch.tensor([0, 96 * 27, 2 * 96 * 27], dtype=torch.int64, device=DEV)
+    sel = ops.pool_weight_sel(wflat, offs, torch.zeros((3, 27 * 96), dtype=torch.int32, device=DEV))
+    sels = [sel[i] for i in range(3)]
+    ref = ops.pool_ln_fwd_qkv(qkv, ws, gs, bs, B, h, thw, O, strides, lds, modes)
+    got = ops.pool_ln_fwd_qkv(qkv, ws, gs, bs, B, h, thw, O, strides, lds, modes, sels=sels)
+    for i in range(3):
+        cols = slice(0, 96) if modes[i] == 0 else slice(None)
+        assert torch.equal(got[i][0][..., cols], ref[i][0][..., cols]), i
+        assert torch.equal(got[i][1], ref[i][1]) and torch.equal(got[i][2], ref[i][2]), i
+        assert torch.equal(got[i][3], ref[i][3]), i
+    # backward: dgrad tiled vs streaming
+    dpres = [rnd("td%d%d" % (i, thw[1]), tuple(ref[i][1].shape), 1.0, BF16) for i in range(3)]
+    dws_a = [torch.zeros(96, 27, device=DEV) for _ in range(3)]
+    dws_b = [torch.zeros(96, 27, device=DEV) for _ in range(3)]
+    dq_a, dq_b = torch.zeros_like(qkv), torch.zeros_like(qkv)
+    ops.pool_conv_bwd_qkv(dpres, ws, dq_a, qkv, dws_a, B, h, thw, O, strides)
+    ops.pool_conv_bwd_qkv(dpres, ws, dq_b, qkv, dws_b, B, h, thw, O, strides, sels=sels)
+    assert cos(dq_b, dq_a) > 0.99999 and rel_err(dq_b, dq_a) < 1e-2
+    for a_, b_ in zip(dws_a, dws_b):
+        assert cos(b_, a_) > 0.99999
+
+
 @pytest.mark.parametrize("sq,skv,thw", [(1, 2, (2, 8, 8)), (2, 1, (3, 7, 7)), (1, 8, (2, 16, 16)),
                                          (2, 4, (2, 12, 12))])
 def test_pool_qkv_fused_equals_single(ops, sq, skv, thw):

@@ -376,3 +376,43 @@ def bench_pool_fwd3():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "poolfwd":
     bench_pool_fwd3()
+
+
+def bench_pool_tiled():
+    """q/k/v pooling forward and conv dgrad(+wgrad): streaming kernels vs the LDS-tiled stride-1
+    stencils (us), per block shape of the 16x224^2 step (x multiplicity)."""
+    print("== pool: streaming | tiled (stride-1 tensors) ==")
+    cfgs = [(0, 1, (8, 56, 56), 1, 8, 1), (1, 2, (8, 56, 56), 2, 4, 1), (2, 2, (8, 28, 28), 1, 4, 1),
+            (3, 4, (8, 28, 28), 2, 2, 1), (4, 4, (8, 14, 14), 1, 2, 10), (14, 8, (8, 14, 14), 2, 1, 1),
+            (15, 8, (8, 7, 7), 1, 1, 1)]
+    n_obj = 64
+    tot = [0.0, 0.0, 0.0, 0.0]
+    for blk, h, thw, sq, skv, mult in cfgs:
+        N = 1 + thw[0] * thw[1] * thw[2] + n_obj
+        qkv = rnd(B, N, 3, h, 96)
+        ws = [torch.randn(96, 27, device=DEV) * 0.2 for _ in range(3)]
+        g = [torch.ones(96, device=DEV) for _ in range(3)]
+        b = [torch.zeros(96, device=DEV) for _ in range(3)]
+        wflat = torch.cat([w.flatten() for w in ws]).contiguous()
+        offs = torch.tensor([0, 2592, 5184], dtype=torch.int64, device=DEV)
+        sel = ops.pool_weight_sel(wflat, offs, torch.zeros((3, 2592), dtype=torch.int32, device=DEV))
+        sels = [sel[i] for i in range(3)]
+        J = 2 * ops.pooled(thw[1], skv) + thw[0]
+        da = 128 if J <= 32 else 160
+        strides, lds, modes = (sq, skv, skv), (da, da, 96), (0, 1, 0)
+        f0 = timeit(lambda: ops.pool_ln_fwd_qkv(qkv, ws, g, b, B, h, thw, n_obj, strides, lds, modes))
+        f1 = timeit(lambda: ops.pool_ln_fwd_qkv(qkv, ws, g, b, B, h, thw, n_obj, strides, lds, modes, sels=sels))
+        dpres = [rnd(B, h, 1 + thw[0] * ops.pooled(thw[1], s) * ops.pooled(thw[2], s) + n_obj, 96) for s in strides]
+        dqkv = torch.empty_like(qkv)
+        dws = [torch.zeros(96, 27, device=DEV) for _ in range(3)]
+        b0 = timeit(lambda: ops.pool_conv_bwd_qkv(dpres, ws, dqkv, qkv, dws, B, h, thw, n_obj, strides))
+        b1 = timeit(lambda: ops.pool_conv_bwd_qkv(dpres, ws, dqkv, qkv, dws, B, h, thw, n_obj, strides, sels=sels))
+        for i, v in enumerate((f0, f1, b0, b1)):
+            tot[i] += v * mult
+        print("blk%-2d h=%d N=%6d sq=%d skv=%d  fwd %6.1f | %6.1f   conv bwd %6.1f | %6.1f" %
+              (blk, h, N, sq, skv, f0, f1, b0, b1), flush=True)
+    print("step totals (16 blocks): fwd %.0f | %.0f us, conv bwd %.0f | %.0f us" % tuple(tot))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "pooltiled":
+    bench_pool_tiled()
