@@ -136,6 +136,12 @@ class FlatParams:
         """the three selector tables of a block's pool_q / pool_k / pool_v weights"""
         return [self.pool_sel[self.pool_sel_index[pre + "attn.pool_%s.weight" % r]] for r in "qkv"]
 
+    # The LDS-tiled stride-1 stencil (csrc/pool.hip::pool_tiled_body) only pays on the largest
+    # planes (measured, tools/bench_kernels.py pooltiled: 56x56 forward 111 -> 83 us; 28x28 and
+    # below the same or slower: those launches are bound by per-workgroup latency chains, not by
+    # the 27x re-reads -- DESIGN.md section 5)
+    TILED_MIN_PLANE = 2048
+
     def refresh_low_precision(self):
         ops.cast_bf16(self.data, self.w16[:self.total])
         if self.pool_sel_index:
@@ -303,7 +309,8 @@ class Engine:
             qkv, [f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
             [f.p(pre + "attn.norm_%s.weight" % r) for r in "qkv"],
             [f.p(pre + "attn.norm_%s.bias" % r) for r in "qkv"],
-            B, h, thw, n_obj, (sq, skv, skv), (DA, DA, HD), (0, 1, 0), save=save, sels=f.sels(pre))
+            B, h, thw, n_obj, (sq, skv, skv), (DA, DA, HD), (0, 1, 0), save=save,
+            sels=f.sels(pre) if thw[1] * thw[2] >= f.TILED_MIN_PLANE else None)
         qa, ka, v = pools[0][0], pools[1][0], pools[2][0]
         idx, mats, mcat, need = self._rel(blk, q_thw, k_thw)
         # rel-pos query side: P = q . Rcat^T on the MFMA GEMM, then a 2-byte gather per (q, j)
@@ -515,7 +522,7 @@ class Engine:
         ops.pool_conv_bwd_qkv(dpres, [f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
                               dqkv, sv["qkv"],
                               [f.g(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
-                              B, h, thw, n_obj, strides, ws=self._rws("wgrad"), sels=f.sels(pre))
+                              B, h, thw, n_obj, strides, ws=self._rws("wgrad"))
         # (bf16 unless the dim-change projection accumulates into it below)
         dxn = self._linear_bwd(dqkv, sv["xn"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", True,
                                epilogue=hip.EPI_F32 if blk.has_proj else hip.EPI_BF16)
