@@ -138,11 +138,13 @@ def kernel_report(trace, batch):
         if last is None:
             last = e0
         ms = e0.elapsed_time(e1)
-        a = agg.setdefault(name, {"ms": 0.0, "calls": 0, "flop": 0.0})
+        a = agg.setdefault(name, {"ms": 0.0, "calls": 0, "flop": 0.0, "bytes": 0.0})
         a["ms"] += ms
         a["calls"] += 1
         if meta and meta[0] == "mnk":
             a["flop"] += 2.0 * meta[1] * meta[2] * meta[3]
+            if len(meta) > 5:
+                a["bytes"] += meta[5]
         elif meta and meta[0] == "flop":
             a["flop"] += meta[1]
         elif meta and meta[0] == "attn":
@@ -156,6 +158,8 @@ def kernel_report(trace, batch):
              "share": round(a["ms"] / total, 4)}
         if a["flop"] > 0:
             r["tflops"] = round(a["flop"] / (a["ms"] * 1e-3) / 1e12, 2)
+        if a["bytes"] > 0:
+            r["gbs"] = round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)
         rows.append(r)
     kernel_report.phases = phases
     return rows, total
@@ -365,27 +369,42 @@ def main():
         out["kernel_ms_total"] = round(total, 3)
         top = rows[0]
         # the north-star kernel is the fused attention; report the dominant kernel's roofline and
-        # always the attention forward's
+        # always the attention forward's and backward's
         attn = next(r for r in rows if r["kernel"] == "svit_attn_fwd")
+        attn_b = next((r for r in rows if r["kernel"] == "svit_attn_bwd"), None)
         dom = top if "tflops" in top else attn
-        out["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"],
-                           "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                           "avg_launch_ms": round(dom["ms"] / dom["calls"], 4)}
+        frac_mfma = dom["tflops"] / MFMA_PEAK_TFLOPS
+        frac_hbm = dom.get("gbs", 0.0) / HBM_PEAK_GBS
+        if frac_hbm > frac_mfma:     # K <= 384 GEMMs sit under the ridge: priced against HBM
+            out["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["gbs"],
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4)}
+        else:
+            out["roofline"] = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"],
+                               "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
+        out["roofline"].update({"frac_mfma": round(frac_mfma, 4), "frac_hbm": round(frac_hbm, 4),
+                                "traffic": None, "avg_launch_ms": round(dom["ms"] / dom["calls"], 4),
+                                "algorithmic": "2*M*N*K flop and operand+output+epilogue-slab bytes "
+                                               "per call, summed over the step's %d calls" % dom["calls"]})
         # memory-side bytes per launch: PMC counters cannot be read from inside this process, so
-        # the committed rocprofv3 --pmc summary of the same build is quoted (null if absent)
+        # the committed rocprofv3 --pmc summary is quoted together with the git head it was taken at
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             t = pmc["bytes_per_launch"][dom["kernel"]]
             out["roofline"]["traffic"] = t["fetch"] + t["write"]
             out["roofline"]["traffic_unit"] = "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE)"
             out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json"
+            out["roofline"]["traffic_head"] = pmc.get("git_head")
         except (OSError, KeyError, ValueError):
             pass
         out["roofline_attn_fwd"] = {"bound": "mfma", "achieved": attn["tflops"],
                                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": round(attn["tflops"] / MFMA_PEAK_TFLOPS, 4),
                                     "avg_launch_ms": round(attn["ms"] / attn["calls"], 4)}
+        if attn_b is not None:
+            out["roofline_attn_bwd"] = {"bound": "mfma", "achieved": attn_b["tflops"],
+                                        "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": round(attn_b["tflops"] / MFMA_PEAK_TFLOPS, 4),
+                                        "avg_launch_ms": round(attn_b["ms"] / attn_b["calls"], 4)}
     elif world > 1 and not args.no_kernel_trace:
         step(args.warmup + args.steps, eager=True)  # keep ranks in lock-step with rank 0's traced step
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -67,7 +67,17 @@ def gemm_nt(a, w, bias=None, epilogue=hip.EPI_BF16, out=None, out2=None, aux=Non
     g.epilogue, g.accumulate = epilogue, int(accumulate)
     if remap is not None:
         g.remap_L, g.remap_N, g.remap_off = remap
-    hip.call("svit_gemm_nt", C.byref(g), meta=("mnk", M, N, K, epilogue))
+    # algorithmic HBM bytes of the call (operands once, outputs once; residual / saved-derivative
+    # slabs the epilogue reads): what bench.py prices against the 8 TB/s roof
+    osz = out.element_size()
+    nbytes = 2 * M * K + 2 * N * K + M * N * osz
+    if out2 is not None:
+        nbytes += 2 * M * N
+    if aux is not None:
+        nbytes += M * N * aux.element_size()
+    if accumulate:
+        nbytes += M * N * osz
+    hip.call("svit_gemm_nt", C.byref(g), meta=("mnk", M, N, K, epilogue, nbytes))
     return (out, out2) if epilogue == hip.EPI_GELU else out
 
 

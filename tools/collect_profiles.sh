@@ -9,6 +9,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcN
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmcNw -- python bench.py --steps 1 --warmup 1 --eager --no-cpu-baseline --no-kernel-trace > gpurun_out/pmcNw.log 2>&1
 F=$(ls gpurun_out/pmcNf/*/*counter_collection.csv | head -1); W=$(ls gpurun_out/pmcNw/*/*counter_collection.csv | head -1)
 python tools/pmc_summary.py $F $W > gpurun_out/rNN_pmc_traffic.txt
+cp profiles/pmc_traffic.json gpurun_out/pmc_traffic_prev.json 2>/dev/null || true
+python tools/pmc_to_json.py gpurun_out/rNN_pmc_traffic.txt "${GIT_HEAD:-unknown}" > /dev/null && cp profiles/pmc_traffic.json gpurun_out/pmc_traffic.json
 K=$(ls gpurun_out/profN/*/*kernel_trace.csv | head -1)
 python tools/trace_gaps.py $K 3000 > gpurun_out/rNN_device_busy.txt
 python tools/trace_gaps.py $K --blocks > gpurun_out/rNN_backward_by_block.txt 2>&1 || true

@@ -30,7 +30,7 @@ agg = {}
 for name, e0, e1, meta in tr:
     if name != "svit_gemm_nt":
         continue
-    key = tuple(meta[1:])
+    key = tuple(meta[1:5])
     a = agg.setdefault(key, [0.0, 0])
     a[0] += e0.elapsed_time(e1) * 1e3
     a[1] += 1
