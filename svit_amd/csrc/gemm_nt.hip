@@ -19,23 +19,33 @@
 
 namespace {
 
-constexpr int BK2 = 32;
+// LDS byte offset of the 16-B chunk `ch` of tile row `r`.  BK = 32: rows of 64 B, chunk XOR
+// ((r>>2)&3).  BK = 64: rows of 128 B (a whole 128-B cache line per row and K-step: a 64-B row
+// uses half of every line it touches), two tile rows (r, r+8) share a 256-B bank row, chunk XOR
+// (r&7) -> the 16 rows of a ds_read_b128 lane group land on 16 distinct 16-B bank slots.
+template <int BK>
+__device__ __forceinline__ int nt_lds_off(int r, int ch) {
+  if constexpr (BK == 32) return r * 64 + 16 * (ch ^ ((r >> 2) & 3));
+  else return (r >> 4) * 2048 + (r & 7) * 256 + ((r >> 3) & 1) * 128 + 16 * (ch ^ (r & 7));
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int RB, int NB, int WAVES_M, int WAVES_N, int STAGES, int EPI>
+template <int RB, int NB, int WAVES_M, int WAVES_N, int STAGES, int EPI, int BK2>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N > 4 ? 1 : 2)) void
 gemm_nt_v2_kernel(svit_gemm_args p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = 32 * RB * WAVES_M, WN = 32 * NB, BN = WN * WAVES_N;
   // rows per stage, padded so that every wave issues the same number of loads per stage (the
   // counted vmcnt must be the same immediate for all waves); pad rows re-read a valid W row
-  constexpr int ROWS = (BM + BN + NT / 4 - 1) / (NT / 4) * (NT / 4);
-  constexpr int STAGE_BYTES = ROWS * 64;
-  constexpr int PER = ROWS * 4 / NT;         // global_load_lds per thread per stage
+  constexpr int CPR = BK2 / 8;                // 16-B chunks per tile row
+  constexpr int RPR = NT / CPR;               // rows one round of loads (NT x 16 B) covers
+  constexpr int ROWS = (BM + BN + RPR - 1) / RPR * RPR;
+  constexpr int STAGE_BYTES = ROWS * BK2 * 2;
+  constexpr int PER = ROWS * CPR / NT;        // global_load_lds per thread per stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -50,8 +60,15 @@ gemm_nt_v2_kernel(svit_gemm_args p) {
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int q = tid + i * NT;              // LDS position q*16 bytes within a stage
-    const int row = q >> 2, slot = q & 3;
-    const int ch = slot ^ ((row >> 2) & 3);
+    int row, ch;
+    if constexpr (BK2 == 32) {
+      row = q >> 2;
+      ch = (q & 3) ^ ((row >> 2) & 3);
+    } else {
+      const int line = q >> 4;
+      row = (line >> 3) * 16 + ((q >> 3) & 1) * 8 + (line & 7);
+      ch = (q & 7) ^ (row & 7);
+    }
     if (row < BM) {
       const int gr = min(m0 + row, p.M - 1);
       src[i] = (const bf16_t*)p.A + (size_t)gr * p.lda + ch * 8;
@@ -103,12 +120,12 @@ gemm_nt_v2_kernel(svit_gemm_args p) {
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         const int r = a_row + i * 32;
-        af[ks][i] = *(const bf16x8_t*)(st + r * 64 + 16 * (ch ^ ((r >> 2) & 3)));
+        af[ks][i] = *(const bf16x8_t*)(st + nt_lds_off<BK2>(r, ch));
       }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const int r = w_row + j * 32;
-        wf[ks][j] = *(const bf16x8_t*)(st + r * 64 + 16 * (ch ^ ((r >> 2) & 3)));
+        wf[ks][j] = *(const bf16x8_t*)(st + nt_lds_off<BK2>(r, ch));
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -124,24 +141,25 @@ gemm_nt_v2_kernel(svit_gemm_args p) {
   nt_epilogue<RB, NB, EPI>(p, acc, smem, m0, n0, wm, wn, lane, wave);
 }
 
-template <int RB, int NB, int WAVES_M, int WAVES_N, int STAGES>
+template <int RB, int NB, int WAVES_M, int WAVES_N, int STAGES, int BK2 = 32>
 int launch_v2(const svit_gemm_args& a, hipStream_t st) {
   constexpr int BM = 32 * RB * WAVES_M, BN = 32 * NB * WAVES_N;
   constexpr int NT = WAVES_M * WAVES_N * 64;
-  size_t lds = (size_t)STAGES * ((BM + BN + NT / 4 - 1) / (NT / 4) * (NT / 4)) * 64;
+  constexpr int RPR = NT / (BK2 / 8);
+  size_t lds = (size_t)STAGES * ((BM + BN + RPR - 1) / RPR * RPR) * BK2 * 2;
   const size_t lds_epi = (size_t)WAVES_M * WAVES_N * 16 * (32 * NB + 4) * sizeof(float);
   if (lds < lds_epi) lds = lds_epi;
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM);
   static SvitOnce once[5];
 #define SVIT_V2_ATTR(E)                                                                              \
-  if (int rc = svit_max_lds_once(once[E], (const void*)gemm_nt_v2_kernel<RB, NB, WAVES_M, WAVES_N, STAGES, E>, lds)) \
+  if (int rc = svit_max_lds_once(once[E], (const void*)gemm_nt_v2_kernel<RB, NB, WAVES_M, WAVES_N, STAGES, E, BK2>, lds)) \
     return rc
   SVIT_V2_ATTR(SVIT_EPI_BF16); SVIT_V2_ATTR(SVIT_EPI_GELU); SVIT_V2_ATTR(SVIT_EPI_RESID);
   SVIT_V2_ATTR(SVIT_EPI_F32); SVIT_V2_ATTR(SVIT_EPI_DGELU);
 #undef SVIT_V2_ATTR
 #define SVIT_V2_CASE(E)                                                                       \
   case E:                                                                                     \
-    hipLaunchKernelGGL((gemm_nt_v2_kernel<RB, NB, WAVES_M, WAVES_N, STAGES, E>), grid, dim3(NT), \
+    hipLaunchKernelGGL((gemm_nt_v2_kernel<RB, NB, WAVES_M, WAVES_N, STAGES, E, BK2>), grid, dim3(NT), \
                        lds, st, a);                                                           \
     break;
   switch (a.epilogue) {
@@ -161,9 +179,11 @@ int launch_v2(const svit_gemm_args& a, hipStream_t st) {
 
 static std::atomic<int> g_nt_stages{0};     // tuning knob (svit_debug_set(0, n)); 2..4, 0 = heuristic
 static std::atomic<int> g_nt_force_cfg{-1}; // tuning knob (svit_debug_set(1, c)); -1 = heuristic
+static std::atomic<int> g_nt_force_bk{0};   // tuning knob (svit_debug_set(2, bk)); 32 / 64, 0 = heuristic
 extern "C" int svit_debug_set(int key, int val) {
   if (key == 0) g_nt_stages = val;
   else if (key == 1) g_nt_force_cfg = val;
+  else if (key == 2) g_nt_force_bk = val;
   else return SVIT_ERR_ARG;
   return SVIT_OK;
 }
@@ -206,17 +226,27 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
             (long)((a.M + 127) / 128) * (a.N / 128) <= 2048;
   if (force_cfg == 4) sq = a.N % 128 == 0;
   else if (force_cfg >= 0) sq = false;
-  if (sq) {
-    if (stages == 2) return launch_v2<2, 2, 2, 2, 2>(a, st);
-    if (stages == 3) return launch_v2<2, 2, 2, 2, 3>(a, st);
-    return launch_v2<2, 2, 2, 2, 4>(a, st);
-  }
-  if (big) {
-    if (stages == 2) return launch_v2<2, 3, 2, 2, 2>(a, st);
-    if (stages == 3) return launch_v2<2, 3, 2, 2, 3>(a, st);
-    return launch_v2<2, 3, 2, 2, 4>(a, st);
-  }
-  if (stages == 2) return launch_v2<1, 3, 4, 1, 2>(a, st);
-  if (stages == 3) return launch_v2<1, 3, 4, 1, 3>(a, st);
-  return launch_v2<1, 3, 4, 1, 4>(a, st);
+  // K-step of 64 (whole 128-B lines per tile row; half as many barriers): measured 5-14 % faster
+  // for the narrow-output, long-K GEMMs (fc2, proj, qkv dgrad: N <= 768, K >= 384) as 128x96
+  // blocks at depth 2, and slower elsewhere -- the 2x LDS per stage costs a resident workgroup
+  // (tools/bench_kernels.py ntstages, profiles/r02_nt_tile_sweep.txt)
+  const int force_bk = g_nt_force_bk.load();
+  bool bk64 = a.K % 64 == 0 && a.N <= 768 && a.K >= 384;
+  if (force_bk) bk64 = force_bk == 64 && a.K % 64 == 0;
+  else if (bk64 && force_cfg < 0 && !force_stages) return launch_v2<1, 3, 4, 1, 2, 64>(a, st);
+#define SVIT_NT_PICK(RB, NB, WM, WN)                                           \
+  do {                                                                         \
+    if (bk64) {                                                                \
+      if (stages == 2) return launch_v2<RB, NB, WM, WN, 2, 64>(a, st);         \
+      if (stages == 3) return launch_v2<RB, NB, WM, WN, 3, 64>(a, st);         \
+      return launch_v2<RB, NB, WM, WN, 4, 64>(a, st);                          \
+    }                                                                          \
+    if (stages == 2) return launch_v2<RB, NB, WM, WN, 2, 32>(a, st);           \
+    if (stages == 3) return launch_v2<RB, NB, WM, WN, 3, 32>(a, st);           \
+    return launch_v2<RB, NB, WM, WN, 4, 32>(a, st);                            \
+  } while (0)
+  if (sq) SVIT_NT_PICK(2, 2, 2, 2);
+  if (big) SVIT_NT_PICK(2, 3, 2, 2);
+  SVIT_NT_PICK(1, 3, 4, 1);
+#undef SVIT_NT_PICK
 }

@@ -75,6 +75,30 @@ def test_gemm_nt_epilogues(ops, M, K, N):
     assert rel_err(out, (ref - bias) * dsaved.float()) < 1.5e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(700, 384, 128), (1333, 1152, 384), (2049, 768, 192), (515, 384, 2304)])
+def test_gemm_nt_tile_variants(ops, M, N, K):
+    """every (tile, pipeline depth, K-step) variant the heuristic can pick gives the same product"""
+    import ctypes as C
+    from svit_amd import hip
+    lib = hip.load()
+    lib.svit_debug_set.restype, lib.svit_debug_set.argtypes = C.c_int32, [C.c_int32, C.c_int32]
+    a = rnd("va%d" % M, (M, K), 1.0, BF16)
+    w = rnd("vw%d" % N, (N, K), 0.2, BF16)
+    bias = rnd("vb%d" % N, (N,), 0.5)
+    ref = a.float() @ w.float().t() + bias
+    try:
+        for cfg in (0, 2, 4):
+            if (cfg == 0 and N % 192) or (cfg == 4 and N % 128):
+                continue
+            for st in (2, 3, 4):
+                for bk in (32, 64):
+                    lib.svit_debug_set(0, st), lib.svit_debug_set(1, cfg), lib.svit_debug_set(2, bk)
+                    out = ops.gemm_nt(a, w, bias, hip.EPI_F32)
+                    assert rel_err(out, ref) < 1e-3, (cfg, st, bk)
+    finally:
+        lib.svit_debug_set(0, 0), lib.svit_debug_set(1, -1), lib.svit_debug_set(2, 0)
+
+
 def test_gemm_nt_row_remap(ops):
     from svit_amd import hip
     B, L, N, K = 3, 50, 96, 448

@@ -213,12 +213,17 @@ def bench_nt_stages():
             if cfg == 4 and N % 128:
                 continue
             for st in (2, 3, 4):
-                lib.svit_debug_set(0, st)
-                lib.svit_debug_set(1, cfg)
-                us = timeit(lambda: ops.gemm_nt(a, w, bias, hip.EPI_BF16, out=out), iters=10)
-                res.append("c%ds%d:%.1f" % (cfg, st, us))
+                for bk in (32, 64):
+                    if bk == 64 and K % 64:
+                        continue
+                    lib.svit_debug_set(0, st)
+                    lib.svit_debug_set(1, cfg)
+                    lib.svit_debug_set(2, bk)
+                    us = timeit(lambda: ops.gemm_nt(a, w, bias, hip.EPI_BF16, out=out), iters=10)
+                    res.append("c%ds%dk%d:%.1f" % (cfg, st, bk, us))
         lib.svit_debug_set(0, 0)
         lib.svit_debug_set(1, -1)
+        lib.svit_debug_set(2, 0)
         print("M=%6d N=%4d K=%4d  " % (M, N, K), " ".join(res))
 
 
