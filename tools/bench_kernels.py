@@ -199,7 +199,7 @@ def bench_nt_stages():
     lib = hip.load()
     lib.svit_debug_set.restype, lib.svit_debug_set.argtypes = C.c_int32, [C.c_int32, C.c_int32]
     print("== gemm_nt: us for (stages, cfg) ==")
-    shapes = [(13064, 1152, 384), (13064, 1536, 384), (13064, 384, 1536), (13064, 384, 384),
+    shapes = [(13064, 1152, 384), (13064, 1536, 384), (13064, 384, 1536), (13064, 384, 384), (50696, 192, 768),
               (13064, 384, 1152), (3656, 768, 3072), (3656, 3072, 768), (3656, 2304, 768),
               (50696, 576, 192), (50696, 192, 576), (201224, 288, 96), (201224, 96, 384)]
     for (M, N, K) in shapes:
@@ -221,6 +221,11 @@ def bench_nt_stages():
                     lib.svit_debug_set(2, bk)
                     us = timeit(lambda: ops.gemm_nt(a, w, bias, hip.EPI_BF16, out=out), iters=10)
                     res.append("c%ds%dk%d:%.1f" % (cfg, st, bk, us))
+            if K % 64 == 0:
+                lib.svit_debug_set(0, 0), lib.svit_debug_set(2, 0), lib.svit_debug_set(3, 1)
+                us = timeit(lambda: ops.gemm_nt(a, w, bias, hip.EPI_BF16, out=out), iters=10)
+                lib.svit_debug_set(3, 0)
+                res.append("c%dREG:%.1f" % (cfg, us))
         lib.svit_debug_set(0, 0)
         lib.svit_debug_set(1, -1)
         lib.svit_debug_set(2, 0)

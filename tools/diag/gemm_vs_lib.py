@@ -22,13 +22,18 @@ def timeit(fn, iters=30):
     return s.elapsed_time(e) / iters * 1e3
 
 
-for M, N, K in SHAPES:
-    a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
-    w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * 0.05
-    b = torch.zeros(N, device="cuda", dtype=torch.float32)
-    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    t_mine = timeit(lambda: ops.gemm_nt(a, w, b, hip.EPI_BF16, out=out))
-    t_lib = timeit(lambda: torch.mm(a, w.t(), out=out))
-    fl = 2.0 * M * N * K
-    print(f"M {M:6d} N {N:5d} K {K:5d}  svit {t_mine:7.1f} us {fl/t_mine*1e-6:6.0f} TF   "
-          f"library {t_lib:7.1f} us {fl/t_lib*1e-6:6.0f} TF", flush=True)
+def main():
+  for M, N, K in SHAPES:
+      a = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+      w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * 0.05
+      b = torch.zeros(N, device="cuda", dtype=torch.float32)
+      out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+      t_mine = timeit(lambda: ops.gemm_nt(a, w, b, hip.EPI_BF16, out=out))
+      t_lib = timeit(lambda: torch.mm(a, w.t(), out=out))
+      fl = 2.0 * M * N * K
+      print(f"M {M:6d} N {N:5d} K {K:5d}  svit {t_mine:7.1f} us {fl/t_mine*1e-6:6.0f} TF   "
+            f"library {t_lib:7.1f} us {fl/t_lib*1e-6:6.0f} TF", flush=True)
+
+
+if __name__ == "__main__":
+  main()
