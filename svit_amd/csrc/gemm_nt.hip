@@ -141,135 +141,6 @@ gemm_nt_v2_kernel(svit_gemm_args p) {
   nt_epilogue<RB, NB, EPI>(p, acc, smem, m0, n0, wm, wn, lane, wave);
 }
 
-// Register-staged variant (K-step 64): A / W tiles go HBM/L2 -> VGPR (global_load_dwordx4, 8
-// lanes per 128-B row) -> LDS (ds_write_b128 into the same XOR image), two LDS stages.  The loads
-// of tile kt+2 are issued right after tile kt+1 has been written to LDS, i.e. a whole K-step of
-// MFMAs ahead of their use; the LDS writes sit between the two halves of the K-step's MFMAs.
-template <int RB, int NB, int WAVES_M, int WAVES_N, int EPI>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_nt_v3_kernel(svit_gemm_args p) {
-  constexpr int BK = 64;
-  constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr int BM = 32 * RB * WAVES_M, WN = 32 * NB, BN = WN * WAVES_N;
-  constexpr int RPR = NT / 8;
-  constexpr int ROWS = (BM + BN + RPR - 1) / RPR * RPR;
-  constexpr int STAGE_BYTES = ROWS * BK * 2;
-  constexpr int PER = ROWS * 8 / NT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
-  const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
-  const int m0 = (wgid / gridDim.x) * BM, n0 = (wgid % gridDim.x) * BN;
-
-  const bf16_t* src[PER];
-  int dst[PER];
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int row = (tid >> 3) + i * RPR, ch = tid & 7;
-    if (row < BM) src[i] = (const bf16_t*)p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + ch * 8;
-    else src[i] = (const bf16_t*)p.W + (size_t)min(n0 + row - BM, p.N - 1) * p.ldw + ch * 8;
-    dst[i] = nt_lds_off<BK>(row, ch);
-  }
-  bf16x8_t stg[PER];   // (a native vector type: an array of HIP uint4 structs went to scratch)
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) stg[i] = *(const bf16x8_t*)(src[i] + kt * BK);
-  };
-  auto lwrite = [&](int stage) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) *(bf16x8_t*)(smem + stage * STAGE_BYTES + dst[i]) = stg[i];
-  };
-
-  f32x16_t acc[RB][NB];
-#pragma unroll
-  for (int i = 0; i < RB; ++i)
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = p.K / BK;
-  // loads / LDS writes are unconditional (the tile index is clamped): the staging registers must
-  // not sit behind control flow, or the compiler demotes the array to scratch memory
-  gload(0);
-  lwrite(0);
-  gload(min(1, nk - 1));
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  const int a_row = wm * 32 * RB + (lane & 31);
-  const int w_row = BM + wn * WN + (lane & 31);
-  for (int kt = 0; kt < nk; ++kt) {
-    const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
-    bf16x8_t af[BK / 16][RB], wf[BK / 16][NB];
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int ch = 2 * ks + (lane >> 5);
-#pragma unroll
-      for (int i = 0; i < RB; ++i) af[ks][i] = *(const bf16x8_t*)(st + nt_lds_off<BK>(a_row + i * 32, ch));
-#pragma unroll
-      for (int j = 0; j < NB; ++j) wf[ks][j] = *(const bf16x8_t*)(st + nt_lds_off<BK>(w_row + j * 32, ch));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < RB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) acc[i][j] = mfma32(af[ks][i], wf[ks][j], acc[i][j]);
-    __builtin_amdgcn_sched_barrier(0);
-    lwrite((kt + 1) & 1);                // the compiler's vmcnt wait for tile kt+1 lands here
-    gload(min(kt + 2, nk - 1));          // (past the end: a harmless re-read / re-write)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 2; ks < 4; ++ks)
-#pragma unroll
-      for (int i = 0; i < RB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) acc[i][j] = mfma32(af[ks][i], wf[ks][j], acc[i][j]);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-  nt_epilogue<RB, NB, EPI>(p, acc, smem, m0, n0, wm, wn, lane, wave);
-}
-
-template <int RB, int NB, int WAVES_M, int WAVES_N>
-int launch_v3(const svit_gemm_args& a, hipStream_t st) {
-  constexpr int BM = 32 * RB * WAVES_M, BN = 32 * NB * WAVES_N;
-  constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr int RPR = NT / 8;
-  size_t lds = (size_t)2 * ((BM + BN + RPR - 1) / RPR * RPR) * 128;
-  const size_t lds_epi = (size_t)WAVES_M * WAVES_N * 16 * (32 * NB + 4) * sizeof(float);
-  if (lds < lds_epi) lds = lds_epi;
-  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM);
-  static SvitOnce once[5];
-#define SVIT_V3_ATTR(E)                                                                              \
-  if (int rc = svit_max_lds_once(once[E], (const void*)gemm_nt_v3_kernel<RB, NB, WAVES_M, WAVES_N, E>, lds)) \
-    return rc
-  SVIT_V3_ATTR(SVIT_EPI_BF16); SVIT_V3_ATTR(SVIT_EPI_GELU); SVIT_V3_ATTR(SVIT_EPI_RESID);
-  SVIT_V3_ATTR(SVIT_EPI_F32); SVIT_V3_ATTR(SVIT_EPI_DGELU);
-#undef SVIT_V3_ATTR
-#define SVIT_V3_CASE(E)                                                                          \
-  case E:                                                                                        \
-    hipLaunchKernelGGL((gemm_nt_v3_kernel<RB, NB, WAVES_M, WAVES_N, E>), grid, dim3(NT), lds, st, a); \
-    break;
-  switch (a.epilogue) {
-    SVIT_V3_CASE(SVIT_EPI_BF16)
-    SVIT_V3_CASE(SVIT_EPI_GELU)
-    SVIT_V3_CASE(SVIT_EPI_RESID)
-    SVIT_V3_CASE(SVIT_EPI_F32)
-    SVIT_V3_CASE(SVIT_EPI_DGELU)
-    default:
-      return SVIT_ERR_ARG;
-  }
-#undef SVIT_V3_CASE
-  SVIT_LAUNCH_CHECK();
-  return SVIT_OK;
-}
-
 template <int RB, int NB, int WAVES_M, int WAVES_N, int STAGES, int BK2 = 32>
 int launch_v2(const svit_gemm_args& a, hipStream_t st) {
   constexpr int BM = 32 * RB * WAVES_M, BN = 32 * NB * WAVES_N;
@@ -308,13 +179,11 @@ int launch_v2(const svit_gemm_args& a, hipStream_t st) {
 
 static std::atomic<int> g_nt_stages{0};     // tuning knob (svit_debug_set(0, n)); 2..4, 0 = heuristic
 static std::atomic<int> g_nt_force_cfg{-1}; // tuning knob (svit_debug_set(1, c)); -1 = heuristic
-static std::atomic<int> g_nt_impl{0};       // tuning knob (svit_debug_set(3, i)); 1 = register-staged
 static std::atomic<int> g_nt_force_bk{0};   // tuning knob (svit_debug_set(2, bk)); 32 / 64, 0 = heuristic
 extern "C" int svit_debug_set(int key, int val) {
   if (key == 0) g_nt_stages = val;
   else if (key == 1) g_nt_force_cfg = val;
   else if (key == 2) g_nt_force_bk = val;
-  else if (key == 3) g_nt_impl = val;
   else return SVIT_ERR_ARG;
   return SVIT_OK;
 }
@@ -340,7 +209,13 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
   // variant lands within 10 % of the others: the bound is the per-CU LDS fill rate (~40 GB/s
   // per CU, ~10 TB/s chip-wide for the mix of L2 and Infinity-Cache hits), not the pipeline
   // depth, the fragment-read scheduling or the tile shape.  Also measured and rejected: a
-  // row-stationary form for K <= 384 (8-wave workgroups, A rows held in registers as MFMA
+  // register-staged form (global_load_dwordx4 -> VGPR -> ds_write_b128, K-step 64, loads a whole
+  // K-step ahead; commit "experiment: register-staged NT GEMM variant", profiles/
+  // r02_nt_tile_sweep.txt column REG): 5-10 % slower than LDS-DMA on every shape -- the bound is
+  // the CU's vector-memory path itself (SQ counters, profiles/r02_nt_pmc_13064x384x1536.txt: waves
+  // spend 51 % of their cycles stalled at instruction issue with the MFMA pipe 28 % busy; ~35
+  // cycles per 1-KiB load instruction per CU = 29 B/clk/CU = 56 GB/s/CU), not how the bytes reach
+  // LDS.  Also measured and rejected: a row-stationary form for K <= 384 (8-wave workgroups, A rows held in registers as MFMA
   // fragments, only W streamed through a 4-deep LDS ring: 4x fewer fill bytes per flop) --
   // 0.6-0.9x the speed of these tiles on every shape of the model: one barrier-locked workgroup
   // per CU leaves nothing to overlap its epilogues and barriers with.
@@ -357,11 +232,6 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
             (long)((a.M + 127) / 128) * (a.N / 128) <= 2048;
   if (force_cfg == 4) sq = a.N % 128 == 0;
   else if (force_cfg >= 0) sq = false;
-  if (g_nt_impl.load() == 1 && a.K % 64 == 0) {
-    if (force_cfg == 0 && a.N % 192 == 0) return launch_v3<2, 3, 2, 2>(a, st);
-    if (force_cfg == 4 && a.N % 128 == 0) return launch_v3<2, 2, 2, 2>(a, st);
-    return launch_v3<1, 3, 4, 1>(a, st);
-  }
   // K-step of 64 (whole 128-B lines per tile row; half as many barriers): measured 5-14 % faster
   // for the narrow-output, long-K GEMMs (fc2, proj, qkv dgrad: N <= 768, K >= 384) as 128x96
   // blocks at depth 2, and slower elsewhere -- the 2x LDS per stage costs a resident workgroup

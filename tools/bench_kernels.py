@@ -221,11 +221,6 @@ def bench_nt_stages():
                     lib.svit_debug_set(2, bk)
                     us = timeit(lambda: ops.gemm_nt(a, w, bias, hip.EPI_BF16, out=out), iters=10)
                     res.append("c%ds%dk%d:%.1f" % (cfg, st, bk, us))
-            if K % 64 == 0:
-                lib.svit_debug_set(0, 0), lib.svit_debug_set(2, 0), lib.svit_debug_set(3, 1)
-                us = timeit(lambda: ops.gemm_nt(a, w, bias, hip.EPI_BF16, out=out), iters=10)
-                lib.svit_debug_set(3, 0)
-                res.append("c%dREG:%.1f" % (cfg, us))
         lib.svit_debug_set(0, 0)
         lib.svit_debug_set(1, -1)
         lib.svit_debug_set(2, 0)
