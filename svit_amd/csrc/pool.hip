@@ -5,7 +5,6 @@
 // channels-last: 4 lanes own one output token (24 channels each, 16-byte bf16 vector loads),
 // the 27-tap stencil reads the qkv GEMM output in place, the object-token branch is the closed
 // form obj*g(w), and LayerNorm(96) is fused (4-lane shuffle reduce).
-#include <atomic>
 #include "common.h"
 #include "../../include/svit_hip.h"
 
@@ -260,28 +259,26 @@ __device__ __forceinline__ void pool_tiled_body(
   const int tc = wg % pl.tch, txi = (wg / pl.tch) % pl.tiles_x, tyi = wg / (pl.tch * pl.tiles_x);
   const int y0 = tyi * TY, x0 = txi * TX;
   const int t0 = tc * pl.tlen, t1 = min(T, t0 + pl.tlen);
-  uint4 sreg[PER], sreg_a[PER], sreg_b[PER];
-  auto fetch_to = [&](int tp, uint4 (&r)[PER]) {   // global -> registers (zero outside the volume)
+  uint4 sreg[PER];
+  auto fetch = [&](int tp) {        // global -> registers (zero outside the volume)
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int q = tid + u * 256;
       const int tok = q / 12, cc = q % 12, hy = tok / HX, hx = tok % HX;
       const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-      r[u] = make_uint4(0, 0, 0, 0);
+      sreg[u] = make_uint4(0, 0, 0, 0);
       if (q < CH && tp >= 0 && tp < T && y >= 0 && y < H && x >= 0 && x < W)
-        r[u] = *(const uint4*)(in_base + (size_t)(in_first + (tp * H + y) * W + x) * in_tok_stride + cc * 8);
+        sreg[u] = *(const uint4*)(in_base + (size_t)(in_first + (tp * H + y) * W + x) * in_tok_stride + cc * 8);
     }
   };
-  auto store_from = [&](int tp, const uint4 (&r)[PER]) {   // registers -> ring slot (tp + 1) % 3
+  auto store = [&](int tp) {        // registers -> ring slot (tp + 1) % 3
     unsigned char* dst = ring + ((tp + 1) % 3) * PLANE_B;
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int q = tid + u * 256;
-      if (q < CH) *(uint4*)(dst + (q / 12) * TL_ROW + (q % 12) * 16) = r[u];
+      if (q < CH) *(uint4*)(dst + (q / 12) * TL_ROW + (q % 12) * 16) = sreg[u];
     }
   };
-  auto fetch = [&](int tp) { fetch_to(tp, sreg); };
-  auto store = [&](int tp) { store_from(tp, sreg); };
   // lane -> output position of the patch (lanes past TX*TY idle on position 0)
   const int vl = b128_group_order(lane);
   const int lt = vl < TX * TY ? vl : 0;
@@ -291,9 +288,9 @@ __device__ __forceinline__ void pool_tiled_body(
   const float* wsel = w_lds + wave * 24;            // this wave's 24 channels of every tap
 
   __syncthreads();                 // the ring is free (previous work item of this workgroup)
-  // the three planes of the first output plane travel together (one memory round trip, not three)
-  fetch_to(t0 - 1, sreg_a); fetch_to(t0, sreg_b); fetch(t0 + 1);
-  store_from(t0 - 1, sreg_a); store_from(t0, sreg_b);
+  fetch(t0 - 1); store(t0 - 1);
+  fetch(t0);     store(t0);
+  fetch(t0 + 1);
   for (int t = t0; t < t1; ++t) {
     store(t + 1);
     __syncthreads();
@@ -417,238 +414,6 @@ __device__ __forceinline__ void pool_ln_special_body(const svit_pool_args& a, co
   pool_ln_finish(a, acc, live, tok, false, 0, 0, 0, bh, Nout, a.H, a.W);
 }
 
-// ---------------------------------------------------------------------------------------
-// "Channel-lane" 3x3x3 depthwise stencil (round 2), strides 1 and 2.
-// The streaming kernels push every input element 27 times through the CU's vector-memory path
-// (measured bound: ~56 GB/s per CU); the first LDS-tiled form (pool_tiled_body: lane = token,
-// wave = 24 channels) read its wave-uniform weights from LDS for every tap -- two thirds of its
-// LDS traffic -- and ran at the LDS rate.  Here the roles are swapped:
-//   * a lane owns 8 CHANNELS (one 16-byte chunk of a token row) and keeps the selector weights of
-//     all 27 taps of those channels in 216 VGPRs for the life of the workgroup; 12 lanes of a
-//     16-lane row make one token, a wave works on 4 output tokens per pass (two x-adjacent pairs);
-//   * the input halo block of the workgroup's (t, y, x) output tile arrives ONCE, by LDS-DMA
-//     through a buffer descriptor (out-of-volume lanes carry an out-of-range offset and read
-//     zeros -- no staging registers, no border code), token rows 192 B apart, no padding;
-//   * a tap is ONE ds_read_b128 + 8 v_dot2c per lane; nothing else is read from LDS.
-//   * bank layout: within a ds_read_b128 lane group ({0-3,12-15,20-27} / {4-11,16-19,28-31}) the
-//     active lanes belong to two x-adjacent output tokens whose rows are s*192 B apart; the odd
-//     token's lanes take a rotated set of chunks (cl_chunk) so that the 12 reads land on 12
-//     distinct 16-byte bank slots; the 4 idle lanes of a row mirror an active lane (broadcast).
-//   * LayerNorm(96) = a rotate-reduce over the 16-lane DPP row, twice.
-constexpr int CL_HX = 16;            // x extent of the halo block in LDS (tokens)
-constexpr int CL_PITCH = 192;        // bytes per token row
-constexpr int CL_MAXTOK = 336;       // 63 KB: two workgroups per CU
-struct PoolClPlan {
-  int on, s, to_t, to_y, to_x, nt, ny, nx, ht, hy, n_wgs, n_special;
-  unsigned m_hy, m_npx, m_toy;       // floor(n / d) = (n * m) >> 16 for the small n used here
-};
-
-__device__ __forceinline__ int cl_chunk(int l12, int odd, int s) {
-  if (!odd) return l12;
-  if (s == 1) return l12 < 4 ? l12 + 4 : (l12 < 8 ? l12 - 4 : l12);
-  return l12 < 4 ? l12 + 8 : l12 - 4;
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_row(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float row16_sum(float v) {   // all 16 lanes of a DPP row get the sum
-  v += dpp_row<0x128>(v);   // row_ror:8
-  v += dpp_row<0x124>(v);   // row_ror:4
-  v += dpp_row<0x122>(v);   // row_ror:2
-  v += dpp_row<0x121>(v);   // row_ror:1
-  return v;
-}
-__device__ __forceinline__ void load_gain(const float* __restrict__ conv_w, float* g_lds, int stride_hw) {
-  float nt[3], nh[3], ipt, iph;
-  obj_counts(1, nt, &ipt);
-  obj_counts(stride_hw, nh, &iph);
-  for (int c = threadIdx.x; c < HD; c += blockDim.x) {
-    float g = 0.f;
-    for (int kt = 0; kt < 3; ++kt)
-      for (int ky = 0; ky < 3; ++ky)
-        for (int kx = 0; kx < 3; ++kx)
-          g += conv_w[c * 27 + (kt * 3 + ky) * 3 + kx] * nt[kt] * nh[ky] * nh[kx];
-    g_lds[c] = g * ipt * iph * iph;
-  }
-  __syncthreads();
-}
-
-template <bool DGRAD>
-__device__ __forceinline__ void pool_cl_body(
-    const bf16_t* __restrict__ in_base, unsigned in_bytes, unsigned in_tok_stride /* elements */, int in_first,
-    const uint32_t* __restrict__ sel, int T, int H, int W, int wg, const PoolClPlan& pl,
-    unsigned char* tile, const float* gb_lds /* gamma[96] | beta[96] */,
-    const svit_pool_args* fa, const svit_pool_dgrad_args* da, int bh) {
-#if __HIP_DEVICE_COMPILE__
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int s = pl.s, HY = pl.hy;
-  const int txi = wg % pl.nx, tyi = (wg / pl.nx) % pl.ny, tci = wg / (pl.nx * pl.ny);
-  const int to0 = tci * pl.to_t, yo0 = tyi * pl.to_y, xo0 = txi * pl.to_x;
-  const int ti0 = to0 - 1, yi0 = yo0 * s - 1, xi0 = xo0 * s - 1;
-  const int npieces = pl.ht * HY * (CL_HX * 12 / 64);
-  // ---- halo block -> LDS (1-KiB pieces, wave-interleaved)
-  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in_base, 0, in_bytes, 0x00020000);
-  for (int n = wave; n < npieces; n += 4) {
-    const int q = n * 64 + lane;
-    const int tok = q / 12, cc = q - tok * 12;
-    const int xx = tok & (CL_HX - 1), r = tok / CL_HX;
-    const int tt = (int)(((unsigned)r * pl.m_hy) >> 16), yy = r - tt * HY;
-    const int t = ti0 + tt, y = yi0 + yy, x = xi0 + xx;
-    const bool ok = t >= 0 && t < T && y >= 0 && y < H && x >= 0 && x < W;
-    const unsigned voff = ok ? ((unsigned)(in_first + (t * H + y) * W + x) * in_tok_stride + cc * 8) * 2u
-                             : 0x80000000u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + n * 1024),
-                                             16, voff, 0, 0, 0);
-    // (measured: an out-of-range lane of an LDS-DMA leaves its 16 bytes of LDS untouched rather
-    // than zero-filling them -- stale data of the previous workgroup -- so zero them by hand)
-    if (!ok) *(uint4*)(tile + q * 16) = make_uint4(0, 0, 0, 0);
-  }
-  // ---- this lane's 8 channels of every tap
-  const int lane16 = lane & 15, slot = lane >> 4;
-  const bool active = lane16 < 12;
-  const int chunk = cl_chunk(active ? lane16 : lane16 - 12, slot & 1, s);
-  uint32_t w[27][8];
-#pragma unroll
-  for (int tap = 0; tap < 27; ++tap) {
-    const uint32_t* wp = sel + (DGRAD ? 26 - tap : tap) * HD + chunk * 8;
-    const uint4 w0 = *(const uint4*)wp, w1 = *(const uint4*)(wp + 4);
-    w[tap][0] = w0.x; w[tap][1] = w0.y; w[tap][2] = w0.z; w[tap][3] = w0.w;
-    w[tap][4] = w1.x; w[tap][5] = w1.y; w[tap][6] = w1.z; w[tap][7] = w1.w;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  const int Ho = DGRAD ? H : (H - 1) / s + 1, Wo = DGRAD ? W : (W - 1) / s + 1;
-  const int npx = (pl.to_x + 1) >> 1, npairs = pl.to_t * pl.to_y * npx;
-  const unsigned plane_b = (unsigned)HY * CL_HX * CL_PITCH;
-  for (int pp = wave; pp * 2 < npairs; pp += 4) {
-    const int p = pp * 2 + (lane >> 5);
-    const int r2 = (int)(((unsigned)p * pl.m_npx) >> 16), xp = p - r2 * npx;
-    const int tl = (int)(((unsigned)r2 * pl.m_toy) >> 16), yl = r2 - tl * pl.to_y;
-    const int xl = xp * 2 + (slot & 1);
-    const int to = to0 + tl, yo = yo0 + yl, xo = xo0 + xl;
-    const bool inside = p < npairs && xl < pl.to_x && to < T && yo < Ho && xo < Wo;
-    const unsigned base = inside ? (unsigned)(((tl * HY + yl * s) * CL_HX + xl * s) * CL_PITCH + chunk * 16)
-                                 : (unsigned)(chunk * 16);
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
-      const unsigned char* pk = tile + base + kt * plane_b;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const uint4 d = *(const uint4*)(pk + (ky * CL_HX + kx) * CL_PITCH);
-          const uint32_t* wt = w[(kt * 3 + ky) * 3 + kx];
-          acc[0] = dot2_sel(d.x, wt[0], acc[0]); acc[1] = dot2_sel(d.x, wt[1], acc[1]);
-          acc[2] = dot2_sel(d.y, wt[2], acc[2]); acc[3] = dot2_sel(d.y, wt[3], acc[3]);
-          acc[4] = dot2_sel(d.z, wt[4], acc[4]); acc[5] = dot2_sel(d.z, wt[5], acc[5]);
-          acc[6] = dot2_sel(d.w, wt[6], acc[6]); acc[7] = dot2_sel(d.w, wt[7], acc[7]);
-        }
-    }
-    const bool live = inside && active;
-    if constexpr (DGRAD) {
-      if (live) {
-        const int b = bh / da->heads, head = bh % da->heads;
-        const int N = 1 + T * H * W + da->n_obj;
-        const size_t ts = (size_t)3 * da->heads * HD;
-        bf16_t* o = (bf16_t*)da->dqkv + ((size_t)b * N + 1 + (to * H + yo) * W + xo) * ts +
-                    ((size_t)da->which * da->heads + head) * HD + chunk * 8;
-        *(uint4*)o = pack8(acc);
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = active ? bf16_to_f32(f32_to_bf16(acc[e])) : 0.f;   // what backward sees
-      float sum = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sum += acc[e];
-      const float mean = row16_sum(sum) * (1.f / HD);
-      float sq = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sq += (acc[e] - mean) * (acc[e] - mean);
-      if (!active) sq = 0.f;
-      const float rstd = rsqrtf(row16_sum(sq) * (1.f / HD) + fa->eps);
-      if (live) {
-        const int Nout = 1 + T * Ho * Wo + fa->n_obj;
-        const size_t orow = (size_t)bh * Nout + 1 + (to * Ho + yo) * Wo + xo;
-        if (lane16 == 0 && fa->mean) { fa->mean[orow] = mean; fa->rstd[orow] = rstd; }
-        const float4 g0 = *(const float4*)(gb_lds + chunk * 8), g1 = *(const float4*)(gb_lds + chunk * 8 + 4);
-        const float4 b0 = *(const float4*)(gb_lds + HD + chunk * 8), b1 = *(const float4*)(gb_lds + HD + chunk * 8 + 4);
-        const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        float o8[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o8[e] = (acc[e] - mean) * rstd * gm[e] + bt[e];
-        *(uint4*)((bf16_t*)fa->out + orow * fa->ld_out + chunk * 8) = pack8(o8);
-        if (fa->pre) *(uint4*)((bf16_t*)fa->pre + orow * HD + chunk * 8) = pack8(acc);
-        if (fa->mode == 1 && lane16 * 8 < fa->ld_out - HD) {   // one-hot key coordinates [y | kh+x | kh+kw+t]
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int j = lane16 * 8 + e;
-            o8[e] = (j == yo || j == Ho + xo || j == Ho + Wo + to) ? 1.f : 0.f;
-          }
-          *(uint4*)((bf16_t*)fa->out + orow * fa->ld_out + HD + lane16 * 8) = pack8(o8);
-        }
-      }
-    }
-  }
-#endif
-}
-
-// cls and object tokens of a channel-lane forward tensor (any stride): out = LN(x) / LN(x * g(w))
-__device__ __forceinline__ void pool_cl_special_fwd(const svit_pool_args& a, const float* g_lds, int blk) {
-  const int s = a.stride_hw, Ho = pooled(a.H, s), Wo = pooled(a.W, s);
-  const int L = a.T * a.H * a.W, Lo = a.T * Ho * Wo;
-  const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
-  const int bh = blockIdx.y, b = bh / a.heads, head = bh % a.heads;
-  const int idx = blk * 64 + (threadIdx.x >> 2);
-  const int sub = threadIdx.x & 3, c0 = sub * 24;
-  const bool live = idx <= a.n_obj;
-  const int tok = idx == 0 ? 0 : Lo + idx, src = idx == 0 ? 0 : L + idx;
-  const size_t tok_stride = (size_t)3 * a.heads * HD;
-  const bf16_t* base = (const bf16_t*)a.qkv + (size_t)b * N * tok_stride + ((size_t)a.which * a.heads + head) * HD + c0;
-  float acc[24];
-#pragma unroll
-  for (int i = 0; i < 24; ++i) acc[i] = 0.f;
-  if (live) {
-    const bf16_t* p = base + (size_t)src * tok_stride;
-#pragma unroll
-    for (int v = 0; v < 3; ++v) {
-      float f[8];
-      unpack8(*(const uint4*)(p + v * 8), f);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[v * 8 + e] = (tok == 0) ? f[e] : f[e] * g_lds[c0 + v * 8 + e];
-    }
-  }
-  pool_ln_finish(a, acc, live, tok, false, 0, 0, 0, bh, Nout, Ho, Wo);
-}
-
-struct PoolClFwd { svit_pool_args p[3]; PoolClPlan plan[3]; const uint32_t* sel[3]; };
-__global__ __launch_bounds__(256, 2) void pool_cl_fwd_kernel(PoolClFwd g) {
-  __shared__ __attribute__((aligned(16))) float g_lds[HD];
-  extern __shared__ __attribute__((aligned(16))) unsigned char pool_dyn[];   // [gamma | beta][halo block]
-  const svit_pool_args& a = g.p[blockIdx.z];
-  const PoolClPlan& pl = g.plan[blockIdx.z];
-  const int wg = blockIdx.x;
-  if (!pl.on || wg >= pl.n_wgs + pl.n_special) return;
-  if (wg >= pl.n_wgs) {
-    load_gain(a.conv_w, g_lds, a.stride_hw);
-    pool_cl_special_fwd(a, g_lds, wg - pl.n_wgs);
-    return;
-  }
-  float* gb = (float*)pool_dyn;
-  if (threadIdx.x < 2 * HD) gb[threadIdx.x] = threadIdx.x < HD ? a.gamma[threadIdx.x] : a.beta[threadIdx.x - HD];
-  const int bh = blockIdx.y, b = bh / a.heads, head = bh % a.heads;
-  const int N = 1 + a.T * a.H * a.W + a.n_obj;
-  const size_t ts = (size_t)3 * a.heads * HD;
-  const bf16_t* base = (const bf16_t*)a.qkv + (size_t)b * N * ts + ((size_t)a.which * a.heads + head) * HD;
-  pool_cl_body<false>(base, (unsigned)((size_t)N * ts * 2), (unsigned)ts, 1, g.sel[blockIdx.z], a.T, a.H, a.W, wg, pl,
-                      pool_dyn + 2 * HD * sizeof(float), gb, &a, nullptr, bh);
-}
-
 // Workgroups are persistent over token blocks (blockIdx.x strides by gridDim.x): the conv weights
 // go to LDS once per workgroup instead of once per 64 tokens.
 __global__ __launch_bounds__(256) void pool_ln_fwd_kernel(svit_pool_args a) {
@@ -669,7 +434,6 @@ __global__ __launch_bounds__(256) void pool_ln_fwd3_kernel(PoolFwd3 g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pool_dyn[];   // tiled body: ring + exchange
   const svit_pool_args& a = g.p[blockIdx.z];
   const PoolTilePlan& pl = g.plan[blockIdx.z];
-  if (pl.tiled == 2) return;                    // this tensor runs in the channel-lane launch
   if (pl.tiled) {
     const int wg = blockIdx.x;
     if (wg >= pl.n_wgs + pl.n_special) return;
@@ -1624,54 +1388,6 @@ static int check_pool_fwd(const svit_pool_args* a) {
   return SVIT_OK;
 }
 
-static std::atomic<long> g_pool_tiled_wgs{384};   // tuning knob (svit_pool_debug_set(0, n))
-static std::atomic<long> g_pool_cl{1};             // svit_pool_debug_set(1, 0 / 1): channel-lane stencils off / on
-static std::atomic<long> g_pool_cl_wgs{512};       // svit_pool_debug_set(2, n): workgroups the planner asks for
-extern "C" int svit_pool_debug_set(int key, long val) {
-  if (key == 0) g_pool_tiled_wgs = val;
-  else if (key == 1) g_pool_cl = val;
-  else if (key == 2) g_pool_cl_wgs = val;
-  else return SVIT_ERR_ARG;
-  return SVIT_OK;
-}
-static unsigned magic16(int d) { return (unsigned)((65536 + d - 1) / d); }
-// output tile of the channel-lane stencil: as many outputs per staged input token as the LDS
-// budget allows, while the launch still has a couple of workgroups per CU
-static PoolClPlan plan_cl(int T, int H, int W, int s, int bh, int n_obj) {
-  PoolClPlan pl;
-  const int Ho = (H - 1) / s + 1, Wo = (W - 1) / s + 1;
-  const int max_x = s == 1 ? 14 : 7;
-  pl.on = 1;
-  pl.s = s;
-  pl.nx = (Wo + max_x - 1) / max_x;
-  pl.to_x = (Wo + pl.nx - 1) / pl.nx;
-  const long want = g_pool_cl_wgs.load();
-  double best = -1.0;
-  pl.to_t = pl.to_y = 1;
-  for (int tt = 1; tt <= T && tt <= 8; tt *= 2)
-    for (int ty = 1; ty <= Ho && ty <= 8; ++ty) {
-      const int ht = tt + 2, hy = s * (ty - 1) + 3;
-      if (ht * hy * CL_HX > CL_MAXTOK) continue;
-      const long n = (long)((T + tt - 1) / tt) * ((Ho + ty - 1) / ty) * pl.nx * bh;
-      // useful outputs per staged token (partial tiles at the border count as what they cover)
-      const double cover = (double)T * Ho / ((double)((T + tt - 1) / tt) * ((Ho + ty - 1) / ty) * ht * hy);
-      const double score = (n >= want ? 1000.0 : 0.0) + cover + (n < want ? 1e-6 * (double)n : 0.0);
-      if (score > best) { best = score; pl.to_t = tt; pl.to_y = ty; }
-    }
-  pl.ht = pl.to_t + 2;
-  pl.hy = s * (pl.to_y - 1) + 3;
-  pl.nt = (T + pl.to_t - 1) / pl.to_t;
-  pl.ny = (Ho + pl.to_y - 1) / pl.to_y;
-  pl.n_wgs = pl.nt * pl.ny * pl.nx;
-  pl.n_special = (1 + n_obj + 63) / 64;
-  pl.m_hy = magic16(pl.hy);
-  pl.m_npx = magic16((pl.to_x + 1) / 2);
-  pl.m_toy = magic16(pl.to_y);
-  return pl;
-}
-static size_t cl_lds_bytes(const PoolClPlan& pl) {
-  return 2 * HD * sizeof(float) + (size_t)pl.ht * pl.hy * CL_HX * CL_PITCH;
-}
 // plan of the LDS-tiled stride-1 stencil for one tensor (see pool_tiled_body)
 static PoolTilePlan plan_tiled(int T, int H, int W, int n_obj, int bh) {
   PoolTilePlan pl;
@@ -1680,8 +1396,7 @@ static PoolTilePlan plan_tiled(int T, int H, int W, int n_obj, int bh) {
   pl.tiles_x = (W + TX - 1) / TX;
   pl.tiles_y = (H + TY - 1) / TY;
   int tch = 1;           // cut the t walk while the (y, x) tiling alone leaves CUs idle
-  const long want = g_pool_tiled_wgs.load();
-  while (tch * 2 <= T && (long)pl.tiles_x * pl.tiles_y * tch * bh < want && T / (tch * 2) >= 1) tch *= 2;
+  while (tch * 2 <= T && (long)pl.tiles_x * pl.tiles_y * tch * bh < 384 && T / (tch * 2) >= 1) tch *= 2;
   pl.tch = tch;
   pl.tlen = (T + tch - 1) / tch;
   pl.n_wgs = pl.tiles_x * pl.tiles_y * tch;
@@ -1696,11 +1411,8 @@ static size_t tiled_lds_bytes(int W) {
 static int pool_ln_fwd_qkv_impl(const svit_pool_args* a3, const uint32_t* const* sel3, void* stream) {
   if (!a3) return SVIT_ERR_ARG;
   PoolFwd3 g;
-  PoolClFwd c;
-  unsigned gx = 1, cx = 1;
-  size_t lds = 0, clds = 0;
-  bool any_cl = false, any_stream = false;
-  const bool use_cl = g_pool_cl.load() != 0;
+  unsigned gx = 1;
+  size_t lds = 0;
   for (int i = 0; i < 3; ++i) {
     const int rc = check_pool_fwd(&a3[i]);
     if (rc) return rc;
@@ -1708,21 +1420,7 @@ static int pool_ln_fwd_qkv_impl(const svit_pool_args* a3, const uint32_t* const*
     g.p[i] = a3[i];
     g.sel[i] = sel3 ? sel3[i] : nullptr;
     g.plan[i].tiled = 0;
-    c.p[i] = a3[i];
-    c.sel[i] = g.sel[i];
-    c.plan[i].on = 0;
     const int s = a3[i].stride_hw;
-    if (use_cl && g.sel[i] && s <= 2) {    // channel-lane stencil (its own launch)
-      c.plan[i] = plan_cl(a3[i].T, a3[i].H, a3[i].W, s, a3[i].B * a3[i].heads, a3[i].n_obj);
-      const unsigned x = (unsigned)(c.plan[i].n_wgs + c.plan[i].n_special);
-      if (x > cx) cx = x;
-      const size_t need = cl_lds_bytes(c.plan[i]);
-      if (need > clds) clds = need;
-      g.plan[i].tiled = 2;                 // skipped by the streaming launch
-      any_cl = true;
-      continue;
-    }
-    any_stream = true;
     const int nout = 1 + a3[i].T * ((a3[i].H - 1) / s + 1) * ((a3[i].W - 1) / s + 1) + a3[i].n_obj;
     unsigned x = persistent_x((nout + 63) / 64, a3[0].B * a3[0].heads * 3);
     if (s == 1 && g.sel[i]) {
@@ -1733,20 +1431,11 @@ static int pool_ln_fwd_qkv_impl(const svit_pool_args* a3, const uint32_t* const*
     }
     if (x > gx) gx = x;
   }
-  if (any_cl) {
-    static SvitOnce once_cl;
-    if (int rc = svit_max_lds_once(once_cl, (const void*)pool_cl_fwd_kernel, 66 * 1024)) return rc;
-    hipLaunchKernelGGL(pool_cl_fwd_kernel, dim3(cx, a3[0].B * a3[0].heads, 3), dim3(256), clds,
-                       (hipStream_t)stream, c);
-    SVIT_LAUNCH_CHECK();
-  }
-  if (any_stream) {
-    static SvitOnce once;
-    if (int rc = svit_max_lds_once(once, (const void*)pool_ln_fwd3_kernel, 64 * 1024)) return rc;
-    hipLaunchKernelGGL(pool_ln_fwd3_kernel, dim3(gx, a3[0].B * a3[0].heads, 3), dim3(256), lds,
-                       (hipStream_t)stream, g);
-    SVIT_LAUNCH_CHECK();
-  }
+  static SvitOnce once;
+  if (int rc = svit_max_lds_once(once, (const void*)pool_ln_fwd3_kernel, 64 * 1024)) return rc;
+  hipLaunchKernelGGL(pool_ln_fwd3_kernel, dim3(gx, a3[0].B * a3[0].heads, 3), dim3(256), lds,
+                     (hipStream_t)stream, g);
+  SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }
 
