@@ -13,6 +13,7 @@
 //                  (transposed through LDS first -- row-per-lane atomics are ~17x slower).
 // No N x N matrix is ever stored.  The residual-pooling path (ctx += q) contributes dctx to dq
 // outside these kernels (svit_pool_ln_bwd's d_res input).
+#include <atomic>
 #include "attn_common.h"
 #include "../../include/svit_hip.h"
 
@@ -157,28 +158,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
 }
 
 // ---------------------------------------------------------------------------------------
-// dkv kernel.  Q / dO tiles (32 queries) and the (lse2, delta) pairs arrive by LDS-DMA into a
-// three-stage ring; key on the lane; dK^T / dV^T accumulate in registers over the sweep.
-template <int DA>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(svit_attn_bwd_args a,
-                                                              int tiles_per_split) {
+// dkv kernel.  Q / dO tiles and the (lse2, delta) pairs arrive by LDS-DMA into a three-stage
+// ring; key on the lane; dK^T / dV^T accumulate in registers over the sweep.
+// NH = 1: 4 waves, 32-query tiles.  NH = 2 (round 2): 8 waves -- the four key groups twice, the
+// two halves working on the two 32-query halves of a 64-query tile -- so that a CU that holds
+// ONE workgroup (the split heuristic aims at one per CU: every extra split costs a full fp32
+// atomic flush) still runs two waves per SIMD: one half's exp / convert / LDS waits hide behind
+// the other's MFMAs.  The halves' dK / dV meet in LDS before the (unchanged) row stores.
+template <int DA, int NH>
+__global__ __launch_bounds__(256 * NH, NH == 2 ? 1 : 2) void attn_bwd_dkv_kernel(svit_attn_bwd_args a,
+                                                                                 int tiles_per_split) {
   constexpr int KS = DA / 16;
-  constexpr int Q_BYTES = QT * DA * 2, O_BYTES = QT * HD * 2;
-  constexpr int STAGE = Q_BYTES + O_BYTES + 2 * QT * 4;   // [Q | dO | (lse2, delta) pairs]
+  constexpr int QR = QT * NH;                             // query rows per ring stage
+  constexpr int Q_BYTES = QR * DA * 2, O_BYTES = QR * HD * 2;
+  constexpr int STAGE = Q_BYTES + O_BYTES + 2 * QR * 4;   // [Q | dO | (lse2, delta) pairs]
   constexpr int NSTAGE = 3;
   constexpr int OUT_LD = HD + 1;                          // padded fp32 transpose buffer
-  using QLoad = GldsTile<QT, DA, 4>;
-  using OLoad = GldsTile<QT, HD, 4>;
+  constexpr int NTHR = 256 * NH;
+  using QLoad = GldsTile<QR, DA, 4 * NH>;
+  using OLoad = GldsTile<QR, HD, 4 * NH>;
   constexpr int PER_TILE = QLoad::PER_WAVE + OLoad::PER_WAVE + 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int kg = wave & 3, qh = wave >> 2;                // key group, query half
   // all key tiles / query splits of one (batch, head) on one XCD: they stream the same Q / dO
   const int wgid = xcd_remap((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y * gridDim.z);
   const int bx = wgid % gridDim.x, by = (wgid / gridDim.x) % gridDim.y;
   const int bh = wgid / (gridDim.x * gridDim.y), b = bh / a.heads, head = bh % a.heads;
   const int key0 = bx * 128;
-  const int ki = key0 + wave * 32 + (lane & 31);
+  const int ki = key0 + kg * 32 + (lane & 31);
   const int kc = min(ki, a.Nk - 1);
   const bf16_t* qa = (const bf16_t*)a.qa + ((size_t)bh * a.Nq) * DA;
   const bf16_t* ka = (const bf16_t*)a.ka + ((size_t)bh * a.Nk) * DA;
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(svit_attn_bwd_args
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[j][r] = 0.f; dv[j][r] = 0.f; }
 
-  const int nqt = (a.Nq + QT - 1) / QT;
+  const int nqt = (a.Nq + QR - 1) / QR;
   const int t_begin = by * tiles_per_split;
   const int t_end = min(nqt, t_begin + tiles_per_split);
   QLoad qload;
@@ -214,14 +223,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(svit_attn_bwd_args
   oload.init((size_t)a.heads * HD, wave, lane);
   auto issue = [&](int t) {
     unsigned char* st = smem + ((t - t_begin) % NSTAGE) * STAGE;
-    const int q0 = t * QT;
+    const int q0 = t * QR;
     qload.issue_auto(qa + (size_t)q0 * DA, DA, a.Nq - q0, st, wave, lane);
     oload.issue_auto(dob + (size_t)q0 * a.heads * HD, (size_t)a.heads * HD, a.Nq - q0, st + Q_BYTES, wave, lane);
-    // 32 (lse2, delta) pairs = 64 floats = one dword LDS-DMA (rows past Nq re-read the last pair)
-    const int qrow = min(q0 + (lane >> 1), a.Nq - 1);
+    // 32 (lse2, delta) pairs = 64 floats = one dword LDS-DMA (rows past Nq re-read the last pair);
+    // with two halves the even waves fetch the first 32 pairs, the odd waves the second 32
+    const int part = NH == 2 ? (wave & 1) : 0;
+    const int qrow = min(q0 + part * 32 + (lane >> 1), a.Nq - 1);
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void*)(ld_g + (size_t)qrow * 2 + (lane & 1)),
-        (__attribute__((address_space(3))) void*)(st + Q_BYTES + O_BYTES), 4, 0, 0);
+        (__attribute__((address_space(3))) void*)(st + Q_BYTES + O_BYTES + part * 256), 4, 0, 0);
   };
   if (t_begin < t_end) issue(t_begin);
   if (t_begin + 1 < t_end) issue(t_begin + 1);
@@ -232,16 +243,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(svit_attn_bwd_args
     if (t + 2 < t_end) issue(t + 2);             // into the stage consumed two steps ago
     const unsigned char* q_cur = smem + ((t - t_begin) % NSTAGE) * STAGE;
     const unsigned char* o_cur = q_cur + Q_BYTES;
-    const float* ld_s = (const float*)(o_cur + O_BYTES);
-    const int q0 = t * QT;
+    const float* ld_s = (const float*)(o_cur + O_BYTES) + qh * 64;
+    const int q0 = t * QR + qh * QT;             // first query of this half's 32 rows
+    const int r0 = qh * QT;                      // their row offset inside the staged tile
 
     f32x16_t s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) s = mfma32(row_frag<QT>(q_cur, 0, ks, lane), kf[ks], s);
+    for (int ks = 0; ks < KS; ++ks) s = mfma32(row_frag<QR>(q_cur, r0, ks, lane), kf[ks], s);
 #pragma unroll
-    for (int ks = 0; ks < 6; ++ks) dp = mfma32(row_frag<QT>(o_cur, 0, ks, lane), vf[ks], dp);
+    for (int ks = 0; ks < 6; ++ks) dp = mfma32(row_frag<QR>(o_cur, r0, ks, lane), vf[ks], dp);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       // rows 8g + 4hh + e, e = 0..3: four consecutive (lse2, delta) pairs
@@ -261,34 +273,48 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(svit_attn_bwd_args
       const bf16x8_t pf = acc_to_frag(s, sp);
       const bf16x8_t dsf = acc_to_frag(dp, sp);
       bf16x8_t ot[3], qt[3];
-      tr_frags_asm<QT, 3>(o_cur, sp * 16, lane, ot);
+      tr_frags_asm<QR, 3>(o_cur, r0 + sp * 16, lane, ot);
 #pragma unroll
       for (int j = 0; j < 3; ++j) dv[j] = mfma32(ot[j], pf, dv[j]);
-      tr_frags_asm<QT, 3>(q_cur, sp * 16, lane, qt);
+      tr_frags_asm<QR, 3>(q_cur, r0 + sp * 16, lane, qt);
 #pragma unroll
       for (int j = 0; j < 3; ++j) dk[j] = mfma32(qt[j], dsf, dk[j]);
     }
   }
-  // ---- transpose through LDS so that every atomic wave-instruction adds whole rows ----------
+  // ---- transpose through LDS so that every atomic wave-instruction adds whole rows; with two
+  // ---- query halves the second half adds its accumulators to the first half's in the buffer
   float* obuf = (float*)smem;  // [128 keys][OUT_LD]
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     __syncthreads();
+    if (qh == 0) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+      for (int j = 0; j < 3; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        obuf[(wave * 32 + (lane & 31)) * OUT_LD + j * 32 + acc_row(r, lane)] =
-            pass == 0 ? dk[j][r] : dv[j][r];
+        for (int r = 0; r < 16; ++r)
+          obuf[(kg * 32 + (lane & 31)) * OUT_LD + j * 32 + acc_row(r, lane)] =
+              pass == 0 ? dk[j][r] : dv[j][r];
+    }
+    if (NH == 2) {
+      __syncthreads();
+      if (qh == 1) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            obuf[(kg * 32 + (lane & 31)) * OUT_LD + j * 32 + acc_row(r, lane)] +=
+                pass == 0 ? dk[j][r] : dv[j][r];
+      }
+    }
     __syncthreads();
     float* dst = (pass == 0 ? a.dk : a.dv) + ((size_t)bh * a.Nk) * HD;
     if (gridDim.y == 1) {   // this block owns its keys outright: plain coalesced row stores
-      for (int i = tid; i < 128 * HD; i += 256) {
+      for (int i = tid; i < 128 * HD; i += NTHR) {
         const int kr = i / HD, d = i % HD;
         if (key0 + kr < a.Nk) dst[(size_t)(key0 + kr) * HD + d] = obuf[kr * OUT_LD + d];
       }
     } else {
-      for (int i = tid; i < 128 * HD; i += 256) {
+      for (int i = tid; i < 128 * HD; i += NTHR) {
         const int kr = i / HD, d = i % HD;
         if (key0 + kr < a.Nk) atomicAdd(dst + (size_t)(key0 + kr) * HD + d, obuf[kr * OUT_LD + d]);
       }
@@ -296,24 +322,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(svit_attn_bwd_args
   }
 }
 
+static std::atomic<int> g_dkv_halves{0};   // tuning knob (svit_attn_debug_set(0, n)): 1 / 2, 0 = heuristic
+
 template <int DA>
 int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
-  static SvitOnce once_dq, once_kv;
+  static SvitOnce once_dq, once_kv, once_kv2;
   const size_t lds_dq = 2 * (size_t)(KT * DA * 2 + KT * HD * 2);
-  size_t lds_kv = 3 * (size_t)(QT * DA * 2 + QT * HD * 2 + 2 * QT * 4);
   const size_t lds_out = (size_t)128 * (HD + 1) * 4;
+  size_t lds_kv = 3 * (size_t)(QT * DA * 2 + QT * HD * 2 + 2 * QT * 4);
+  size_t lds_kv2 = 3 * (size_t)(2 * QT * DA * 2 + 2 * QT * HD * 2 + 4 * QT * 4);
   if (lds_kv < lds_out) lds_kv = lds_out;
+  if (lds_kv2 < lds_out) lds_kv2 = lds_out;
   if (int rc = svit_max_lds_once(once_dq, (const void*)attn_bwd_dq_kernel<DA>, lds_dq)) return rc;
-  if (int rc = svit_max_lds_once(once_kv, (const void*)attn_bwd_dkv_kernel<DA>, lds_kv)) return rc;
-  const int nqt = (a.Nq + QT - 1) / QT;
+  if (int rc = svit_max_lds_once(once_kv, (const void*)attn_bwd_dkv_kernel<DA, 1>, lds_kv)) return rc;
+  if (int rc = svit_max_lds_once(once_kv2, (const void*)attn_bwd_dkv_kernel<DA, 2>, lds_kv2)) return rc;
   const int key_blocks = (a.Nk + 127) / 128;
+  const int base = key_blocks * a.B * a.heads;
+  // two query halves (8 waves) where the launch leaves one 4-wave workgroup per CU anyway: the
+  // short-key blocks (measured, tools/bench_kernels.py attn, profiles/r02_attn_bwd_dkv_halves.txt:
+  // -8..-16 % of the whole backward at Nk = 457; +6..13 % at Nk = 1633 / DA = 160, whose 8-wave
+  // form sits at the 256-VGPR limit with a 100 KB ring)
+  int halves = g_dkv_halves.load();
+  if (halves != 1 && halves != 2) halves = (DA == 128 && base <= 256) ? 2 : 1;
+  const int nqt = (a.Nq + QT * halves - 1) / (QT * halves);
   int splits = a.q_splits;
   if (splits <= 0) {
     // every split adds a full [128 keys x 192] fp32 tile per block with atomics (~1.3 TB/s
     // chip-wide), so split the query range only as far as needed to fill the chip
     // (measured, tools/bench_kernels.py attnsplits: ~1 block per CU is the sweet spot), and
     // keep >= 4 query tiles per block to amortise the epilogue
-    const int base = key_blocks * a.B * a.heads;
     splits = (256 + base - 1) / base;
     if (splits > nqt / 4) splits = nqt / 4;
   }
@@ -325,12 +362,22 @@ int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
   hipLaunchKernelGGL(attn_bwd_dq_kernel<DA>, dim3((a.Nq + 127) / 128, a.B * a.heads), dim3(256),
                      lds_dq, st, a, splits > 1 ? 1 : 0);
   SVIT_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<DA>, dim3(key_blocks, splits, a.B * a.heads), dim3(256),
-                     lds_kv, st, a, tiles_per_split);
+  if (halves == 2)
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DA, 2>), dim3(key_blocks, splits, a.B * a.heads), dim3(512),
+                       lds_kv2, st, a, tiles_per_split);
+  else
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DA, 1>), dim3(key_blocks, splits, a.B * a.heads), dim3(256),
+                       lds_kv, st, a, tiles_per_split);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }
 }  // namespace
+
+extern "C" int svit_attn_debug_set(int key, int val) {
+  if (key == 0) g_dkv_halves = val;
+  else return SVIT_ERR_ARG;
+  return SVIT_OK;
+}
 
 extern "C" int svit_attn_bwd(const svit_attn_bwd_args* a, void* stream) {
   if (!a || !a->qa || !a->ka || !a->v || !a->ctx || !a->dctx || !a->lse2 || !a->delta || !a->dqa ||

@@ -550,11 +550,20 @@ def test_attention_fwd_bwd(ops, Nq, Nk, DA, h):
     o_only = ref - torch.cat([torch.zeros(B, 1, h * 96),
                               qr[:, :, 1:, :96].transpose(1, 2).reshape(B, Nq - 1, h * 96)], 1)
     o_only.backward(dctx.float().cpu())
-    for splits in (0, 1, 3):
-        dqa, dk, dv = ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=splits)
-        assert cos(dqa, qr.grad) > 0.999 and rel_err(dqa, qr.grad) < 4e-2
-        assert cos(dk, kr.grad[..., :96]) > 0.999 and rel_err(dk, kr.grad[..., :96]) < 4e-2
-        assert cos(dv, vr.grad) > 0.999 and rel_err(dv, vr.grad) < 4e-2
+    import ctypes as C
+    from svit_amd import hip
+    lib = hip.load()
+    lib.svit_attn_debug_set.restype, lib.svit_attn_debug_set.argtypes = C.c_int32, [C.c_int32, C.c_int32]
+    try:
+        for halves in (1, 2):      # dkv kernel: 4 waves / 8 waves (two query halves per tile)
+            lib.svit_attn_debug_set(0, halves)
+            for splits in (0, 1, 3):
+                dqa, dk, dv = ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=splits)
+                assert cos(dqa, qr.grad) > 0.999 and rel_err(dqa, qr.grad) < 4e-2
+                assert cos(dk, kr.grad[..., :96]) > 0.999 and rel_err(dk, kr.grad[..., :96]) < 4e-2, (halves, splits)
+                assert cos(dv, vr.grad) > 0.999 and rel_err(dv, vr.grad) < 4e-2, (halves, splits)
+    finally:
+        lib.svit_attn_debug_set(0, 0)
 
 
 @pytest.mark.parametrize("Nk", [64, 128, 130, 457])

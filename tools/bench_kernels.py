@@ -97,9 +97,17 @@ def bench_attn():
         alg = 2.0 * B * h * Nq * Nk * 192
         ctx, lse2 = ops.attn_fwd(qa, ka, v, scale)
         dctx = rnd(B, Nq, h * 96)
+        import ctypes as C
+        lib = hip.load()
+        lib.svit_attn_debug_set.restype, lib.svit_attn_debug_set.argtypes = C.c_int32, [C.c_int32, C.c_int32]
+        lib.svit_attn_debug_set(0, 1)
+        usb1 = timeit(lambda: ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, scale), iters=10)
+        lib.svit_attn_debug_set(0, 2)
+        usb2 = timeit(lambda: ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, scale), iters=10)
+        lib.svit_attn_debug_set(0, 0)
         usb = timeit(lambda: ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, scale), iters=10)
-        print("blk%-2d h=%d Nq=%6d Nk=%5d DA=%d  fwd %8.1f us %7.1f TF | bwd %8.1f us %7.1f TF" %
-              (blk, h, Nq, Nk, DA, us, alg / us / 1e6, usb, 2 * alg / usb / 1e6))
+        print("blk%-2d h=%d Nq=%6d Nk=%5d DA=%d  fwd %8.1f us %7.1f TF | bwd %8.1f us %7.1f TF  (dkv 4 waves %.1f, 8 waves %.1f)" %
+              (blk, h, Nq, Nk, DA, us, alg / us / 1e6, usb, 2 * alg / usb / 1e6, usb1, usb2))
 
 
 def bench_attn_fwd():
