@@ -9,42 +9,58 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------
-// TN kernel: out tile 128(n) x 96(k), 4 waves, each wave one 32-row n-block x 96 k columns.
-// Both operands are [rows=m][cols] in LDS and read transposed (ds_read_b64_tr_b16).
+// TN kernel.  Both operands are [rows=m][cols] in LDS and read transposed (ds_read_b64_tr_b16).
+//   TnCfg<1, 4, 1, 64>: out tile 128(n) x 96(k), 4 waves of 32 x 96, 64 reduction rows per step.
+//   TnCfg<2, 2, 2, 32> (round 2): out tile 128 x 192, 2 x 2 waves of 64 x 96, 32 rows per step --
+//     the same 12 MFMAs per wave and step from 20 KB of staged operands instead of 28 KB
+//     (rocprofv3 round 2: the grouped launch fetched 687 MB against ~320 MB of operands and the
+//     CU's vector-memory path, not the matrix pipe, sets the pace), and 10 transposed LDS reads
+//     per 6 MFMAs instead of 8 per 3.
 // ---------------------------------------------------------------------------------------
-constexpr int TN_BM = 64;        // reduction rows per step
-constexpr int TN_TN = 128, TN_TK = 96;
-constexpr int TN_ROWA = TN_TN * 2 + 64;  // 320 B: the 4 rows of a tr block hit disjoint banks
-constexpr int TN_ROWB = TN_TK * 2;       // 192 B: conflict-free as is
+template <int RB_, int WN_, int WK_, int BM_>
+struct TnCfg {
+  static constexpr int RB = RB_, WN = WN_, WK = WK_, BM = BM_;
+  static constexpr int TN = 32 * RB * WN, TK = 96 * WK;
+  static constexpr int ROWA = TN * 2 + 64;                      // 320 B: the 4 rows of a tr block hit disjoint banks
+  static constexpr int ROWB = TK * 2 + ((TK * 2) % 256 == 128 ? 64 : 0);   // 192 B as is; 384 -> 448
+  static constexpr int STAGE = BM * (ROWA + ROWB);
+};
+using TnSmall = TnCfg<1, 4, 1, 64>;
+using TnBig = TnCfg<2, 2, 2, 32>;
+constexpr int TN_LDS_BYTES = 2 * (TnSmall::STAGE > TnBig::STAGE ? TnSmall::STAGE : TnBig::STAGE);
 
-typedef unsigned char tn_lds_t[2][TN_BM * (TN_ROWA + TN_ROWB)];
-
-// One workgroup's share: rows [m_begin, m_end) of the reduction for the 128x96 tile at (n0, k0).
-__device__ __forceinline__ void tn_tile(tn_lds_t& lds, const bf16_t* __restrict__ A, int lda,
+// One workgroup's share: rows [m_begin, m_end) of the reduction for the TN x TK tile at (n0, k0).
+template <class C>
+__device__ __forceinline__ void tn_tile(unsigned char* lds, const bf16_t* __restrict__ A, int lda,
                                         const bf16_t* __restrict__ B, int ldb,
                                         float* __restrict__ dW, int lddw, int N, int K, int n0,
                                         int k0, int m_begin, int m_end,
                                         float* __restrict__ dbias, bool bias_tile) {
+  constexpr int RB = C::RB, TN_BM = C::BM, TN_TN = C::TN, TN_TK = C::TK, TN_ROWA = C::ROWA, TN_ROWB = C::ROWB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave / C::WK, wk = wave % C::WK;
   if (m_begin >= m_end) return;
 
-  constexpr int A_CH = TN_TN / 8, B_CH = TN_TK / 8;        // 16 / 12 chunks per row
-  constexpr int A_PER = TN_BM * A_CH / 256, B_PER = TN_BM * B_CH / 256;  // 4 / 3
-  uint4 ra[A_PER], rb[B_PER];
+  constexpr int A_CH = TN_TN / 8, B_CH = TN_TK / 8;        // 16-byte chunks per row
+  constexpr int A_PER = TN_BM * A_CH / 256, B_PER = TN_BM * B_CH / 256;
+  static_assert(A_PER * 256 == TN_BM * A_CH && B_PER * 256 == TN_BM * B_CH, "staging must divide evenly");
+  static_assert(A_CH == 16, "the fused bias gradient assumes 16 chunks per A row");
+  bf16x8_t ra[A_PER], rb[B_PER];
+  const bf16x8_t zero8 = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
   auto load_tiles = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int c = tid + i * 256, r = c / A_CH, cc = c % A_CH;
       const int gm = mb + r, gn = n0 + cc * 8;
-      ra[i] = make_uint4(0, 0, 0, 0);
-      if (gm < m_end && gn < N) ra[i] = *(const uint4*)(A + (size_t)gm * lda + gn);
+      ra[i] = zero8;
+      if (gm < m_end && gn < N) ra[i] = *(const bf16x8_t*)(A + (size_t)gm * lda + gn);
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       const int c = tid + i * 256, r = c / B_CH, cc = c % B_CH;
       const int gm = mb + r, gk = k0 + cc * 8;
-      rb[i] = make_uint4(0, 0, 0, 0);
-      if (gm < m_end && gk < K) rb[i] = *(const uint4*)(B + (size_t)gm * ldb + gk);
+      rb[i] = zero8;
+      if (gm < m_end && gk < K) rb[i] = *(const bf16x8_t*)(B + (size_t)gm * ldb + gk);
     }
   };
   // fused bias gradient: column sums of A (= dY) ride along on the k-tile-0 blocks; a thread
@@ -52,36 +68,39 @@ __device__ __forceinline__ void tn_tile(tn_lds_t& lds, const bf16_t* __restrict_
   const bool do_bias = (dbias != nullptr) && bias_tile;
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto store_tiles = [&](int buf) {
-    unsigned char* la = lds[buf];
-    unsigned char* lb = lds[buf] + TN_BM * TN_ROWA;
+    unsigned char* la = lds + buf * C::STAGE;
+    unsigned char* lb = la + TN_BM * TN_ROWA;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int c = tid + i * 256;
-      *(uint4*)(la + (c / A_CH) * TN_ROWA + (c % A_CH) * 16) = ra[i];
+      *(bf16x8_t*)(la + (c / A_CH) * TN_ROWA + (c % A_CH) * 16) = ra[i];
       if (do_bias) {
-        bsum[0] += lo_bf16(ra[i].x); bsum[1] += hi_bf16(ra[i].x);
-        bsum[2] += lo_bf16(ra[i].y); bsum[3] += hi_bf16(ra[i].y);
-        bsum[4] += lo_bf16(ra[i].z); bsum[5] += hi_bf16(ra[i].z);
-        bsum[6] += lo_bf16(ra[i].w); bsum[7] += hi_bf16(ra[i].w);
+        const uint4 u = __builtin_bit_cast(uint4, ra[i]);
+        bsum[0] += lo_bf16(u.x); bsum[1] += hi_bf16(u.x);
+        bsum[2] += lo_bf16(u.y); bsum[3] += hi_bf16(u.y);
+        bsum[4] += lo_bf16(u.z); bsum[5] += hi_bf16(u.z);
+        bsum[6] += lo_bf16(u.w); bsum[7] += hi_bf16(u.w);
       }
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       const int c = tid + i * 256;
-      *(uint4*)(lb + (c / B_CH) * TN_ROWB + (c % B_CH) * 16) = rb[i];
+      *(bf16x8_t*)(lb + (c / B_CH) * TN_ROWB + (c % B_CH) * 16) = rb[i];
     }
   };
 
-  f32x16_t acc[3];
+  f32x16_t acc[RB][3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
+  for (int i = 0; i < RB; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // transposed-read addressing: lane -> (half hh, column group cg, in-group i -> (q,p))
   const int hh = lane >> 5, cg = (lane >> 4) & 1, ii = lane & 15, q = ii >> 2, pp = ii & 3;
-  const int a_off = (8 * hh + q) * TN_ROWA + (wave * 32 + 16 * cg + 4 * pp) * 2;
-  const int b_off = (8 * hh + q) * TN_ROWB + (16 * cg + 4 * pp) * 2;
+  const int a_off = (8 * hh + q) * TN_ROWA + (wn * 32 * RB + 16 * cg + 4 * pp) * 2;
+  const int b_off = (8 * hh + q) * TN_ROWB + (wk * 96 + 16 * cg + 4 * pp) * 2;
 
   const int nsteps = (m_end - m_begin + TN_BM - 1) / TN_BM;
   load_tiles(m_begin);
@@ -90,34 +109,40 @@ __device__ __forceinline__ void tn_tile(tn_lds_t& lds, const bf16_t* __restrict_
   for (int s = 0; s < nsteps; ++s) {
     const int cur = s & 1;
     if (s + 1 < nsteps) load_tiles(m_begin + (s + 1) * TN_BM);
-    const unsigned char* la = lds[cur] + a_off;
-    const unsigned char* lb = lds[cur] + TN_BM * TN_ROWA + b_off;
+    const unsigned char* la = lds + cur * C::STAGE + a_off;
+    const unsigned char* lb = lds + cur * C::STAGE + TN_BM * TN_ROWA + b_off;
 #pragma unroll
     for (int ks = 0; ks < TN_BM / 16; ++ks) {
-      const bf16x8_t af = make_bf16x8(lds_read_tr16(la + (ks * 16) * TN_ROWA),
-                                      lds_read_tr16(la + (ks * 16 + 4) * TN_ROWA));
+      bf16x8_t af[RB];
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+        af[i] = make_bf16x8(lds_read_tr16(la + (ks * 16) * TN_ROWA + i * 64),
+                            lds_read_tr16(la + (ks * 16 + 4) * TN_ROWA + i * 64));
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const bf16x8_t bfr = make_bf16x8(lds_read_tr16(lb + (ks * 16) * TN_ROWB + j * 64),
                                          lds_read_tr16(lb + (ks * 16 + 4) * TN_ROWB + j * 64));
-        acc[j] = mfma32(af, bfr, acc[j]);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) acc[i][j] = mfma32(af[i], bfr, acc[i][j]);
       }
     }
     if (s + 1 < nsteps) store_tiles(cur ^ 1);
     __syncthreads();
   }
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int col = k0 + j * 32 + (lane & 31);
-    if (col >= K) continue;
+  for (int i = 0; i < RB; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = n0 + wave * 32 + acc_row(r, lane);
-      if (row < N) atomicAdd(dW + (size_t)row * lddw + col, acc[j][r]);
+    for (int j = 0; j < 3; ++j) {
+      const int col = k0 + wk * 96 + j * 32 + (lane & 31);
+      if (col >= K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = n0 + wn * 32 * RB + i * 32 + acc_row(r, lane);
+        if (row < N) atomicAdd(dW + (size_t)row * lddw + col, acc[i][j][r]);
+      }
     }
-  }
   if (do_bias) {  // 16 threads share a column chunk: reduce through LDS, one atomic per column
-    float* red = (float*)&lds[0][0];  // [16][128]
+    float* red = (float*)lds;  // [16][128]
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[(tid / A_CH) * TN_TN + (tid % A_CH) * 8 + e] = bsum[e];
     __syncthreads();
@@ -130,14 +155,16 @@ __device__ __forceinline__ void tn_tile(tn_lds_t& lds, const bf16_t* __restrict_
   }
 }
 
+constexpr int TN_BM = TnSmall::BM, TN_TN = TnSmall::TN, TN_TK = TnSmall::TK;   // the single-GEMM entry point
+
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ A, int lda,
                                                       const bf16_t* __restrict__ B, int ldb,
                                                       float* __restrict__ dW, int lddw, int M,
                                                       int N, int K, int rows_per_split,
                                                       float* __restrict__ dbias) {
-  __shared__ __attribute__((aligned(16))) tn_lds_t lds;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[TN_LDS_BYTES];
   const int m_begin = blockIdx.z * rows_per_split;
-  tn_tile(lds, A, lda, B, ldb, dW, lddw, N, K, blockIdx.x * TN_TN, blockIdx.y * TN_TK, m_begin,
+  tn_tile<TnSmall>(lds, A, lda, B, ldb, dW, lddw, N, K, blockIdx.x * TN_TN, blockIdx.y * TN_TK, m_begin,
           min(M, m_begin + rows_per_split), dbias, blockIdx.y == 0);
 }
 
@@ -151,11 +178,12 @@ struct TnGroup {
   int tiles_n[SVIT_TN_GROUP_MAX];
   int tiles[SVIT_TN_GROUP_MAX];
   int rows_per_split[SVIT_TN_GROUP_MAX];
+  int big[SVIT_TN_GROUP_MAX];          // 1: 128 x 192 tiles (TnBig), 0: 128 x 96 (TnSmall)
   int count;
 };
 
 __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup g) {
-  __shared__ __attribute__((aligned(16))) tn_lds_t lds;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[TN_LDS_BYTES];
   // Logical ids are (problem, split)-major, tile-minor: the tiles of one split walk the SAME
   // rows in lock-step and re-read each other's A / B column panels (A once per k-tile, B once
   // per n-tile).  Consecutive logical ids are therefore placed on ONE XCD, so those re-reads
@@ -173,9 +201,14 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup g) {
   const int tile = local % g.tiles[pi], split = local / g.tiles[pi];
   const int tn = tile % g.tiles_n[pi], tk = tile / g.tiles_n[pi];
   const int m_begin = split * g.rows_per_split[pi];
-  tn_tile(lds, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.dW, p.lddw, p.N, p.K,
-          tn * TN_TN, tk * TN_TK, m_begin, min(p.M, m_begin + g.rows_per_split[pi]), p.dbias,
-          tk == 0);
+  if (g.big[pi])
+    tn_tile<TnBig>(lds, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.dW, p.lddw, p.N, p.K,
+                   tn * TnBig::TN, tk * TnBig::TK, m_begin, min(p.M, m_begin + g.rows_per_split[pi]),
+                   p.dbias, tk == 0);
+  else
+    tn_tile<TnSmall>(lds, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.dW, p.lddw, p.N, p.K,
+                     tn * TnSmall::TN, tk * TnSmall::TK, m_begin, min(p.M, m_begin + g.rows_per_split[pi]),
+                     p.dbias, tk == 0);
 }
 
 __global__ void colsum_kernel(const bf16_t* __restrict__ A, int lda, float* __restrict__ out,
@@ -245,6 +278,12 @@ extern "C" int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, floa
 // cost-model constants of the grouped launch (svit_debug_set keys 2 / 3 for sweeps)
 static std::atomic<double> g_tn_step_us{0.85};      // one 64-row step of a workgroup, 512 resident
 static std::atomic<double> g_tn_atomic_tbs{0.75};   // effective fp32 atomic flush rate, TB/s
+static std::atomic<int> g_tn_big{1};                // 0: 128x96 tiles only, 1: heuristic, 2: 128x192 everywhere
+extern "C" int svit_debug_set_tn_tile(int mode) {
+  if (mode < 0 || mode > 2) return SVIT_ERR_ARG;
+  g_tn_big = mode;
+  return SVIT_OK;
+}
 extern "C" int svit_debug_set_tn(int step_us_x100, int atomic_tbs_x100) {
   if (step_us_x100 > 0) g_tn_step_us = step_us_x100 * 0.01;
   if (atomic_tbs_x100 > 0) g_tn_atomic_tbs = atomic_tbs_x100 * 0.01;
@@ -284,32 +323,48 @@ static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void
     TnGroup g;
     g.count = count - base < SVIT_TN_GROUP_MAX ? count - base : SVIT_TN_GROUP_MAX;
     long max_steps = 1;
+    const int big_mode = g_tn_big.load();
+    int bm[SVIT_TN_GROUP_MAX];
+    double tile_bytes[SVIT_TN_GROUP_MAX];
     for (int i = 0; i < g.count; ++i) {
       g.p[i] = probs[base + i];
-      g.tiles_n[i] = (g.p[i].N + TN_TN - 1) / TN_TN;
-      g.tiles[i] = g.tiles_n[i] * ((g.p[i].K + TN_TK - 1) / TN_TK);
-      const long st = (g.p[i].M + TN_BM - 1) / TN_BM;
+      // 128 x 192 tiles where they are fully used (K a multiple of 192) AND the reduction is short
+      // (measured, tools/bench_kernels.py tngroup, profiles/r02_tn_tile_modes.txt: -7 % on the
+      // M = 3656 groups of blocks 14-15; +4..9 % on the M >= 13064 groups, where the doubled fp32
+      // tile a workgroup flushes with atomics outweighs the smaller operand traffic)
+      g.big[i] = big_mode == 1 ? (g.p[i].K % TnBig::TK == 0 && g.p[i].N >= 128 && g.p[i].M <= 4096)
+                               : (big_mode == 2);
+      const int tn = g.big[i] ? TnBig::TN : TnSmall::TN, tk = g.big[i] ? TnBig::TK : TnSmall::TK;
+      bm[i] = g.big[i] ? TnBig::BM : TnSmall::BM;
+      tile_bytes[i] = (double)tn * tk * 4.0;
+      g.tiles_n[i] = (g.p[i].N + tn - 1) / tn;
+      g.tiles[i] = g.tiles_n[i] * ((g.p[i].K + tk - 1) / tk);
+      const long st = (g.p[i].M + bm[i] - 1) / bm[i];
       if (st > max_steps) max_steps = st;
     }
-    // Every problem is cut into chunks of `steps` 64-row steps, so all workgroups run equally
-    // long.  Same fitted model as svit_gemm_tn: 0.85 us per step with 512 resident workgroups,
-    // plus the atomic flush of one 128x96 fp32 tile per workgroup at ~0.75 TB/s.
+    // Every problem is cut into chunks of `steps` steps (64 reduction rows on 128 x 96 tiles, 32 on
+    // 128 x 192: the same 12 MFMAs per wave), so all workgroups run about equally long.  Same
+    // fitted model as svit_gemm_tn: 0.85 us per step with 512 resident workgroups, plus the atomic
+    // flush of one fp32 tile per workgroup at ~0.75 TB/s.
     double best = 1e30;
     long best_steps = max_steps;
     for (long steps = 2; steps <= max_steps; steps += (steps < 32 ? 1 : steps / 16)) {
       long blocks = 0;
+      double flush = 0.0;
       for (int i = 0; i < g.count; ++i) {
-        const long st = (g.p[i].M + TN_BM - 1) / TN_BM;
-        blocks += (long)g.tiles[i] * ((st + steps - 1) / steps);
+        const long st = (g.p[i].M + bm[i] - 1) / bm[i];
+        const long nb = (long)g.tiles[i] * ((st + steps - 1) / steps);
+        blocks += nb;
+        flush += (double)nb * tile_bytes[i];
       }
       const double t = (double)((blocks + 511) / 512) * steps * g_tn_step_us +
-                       (double)blocks * (TN_TN * TN_TK * 4.0) / (g_tn_atomic_tbs * 1e6);
+                       flush / (g_tn_atomic_tbs * 1e6);
       if (t < best) { best = t; best_steps = steps; }
     }
     if (ordered) best_steps = max_steps;
     int total = 0;
     for (int i = 0; i < g.count; ++i) {
-      g.rows_per_split[i] = (int)best_steps * TN_BM;
+      g.rows_per_split[i] = (int)best_steps * bm[i];
       const int splits = (g.p[i].M + g.rows_per_split[i] - 1) / g.rows_per_split[i];
       g.first_block[i] = total;
       total += g.tiles[i] * splits;

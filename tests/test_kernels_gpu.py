@@ -127,10 +127,24 @@ def test_gemm_tn(ops, M, N, K, splits):
     assert rel_err(db, a.float().sum(0) + 1.0) < 2e-4
 
 
+@pytest.mark.parametrize("tile_mode", [1, 0, 2])
 @pytest.mark.parametrize("count", [1, 5, 11])
-def test_gemm_tn_grouped(ops, count):
+def test_gemm_tn_grouped(ops, count, tile_mode):
     """several wgrads per launch (incl. strided column slices, K tail inside a padded ldb, no
-    bias) == the same GEMMs one by one"""
+    bias) == the same GEMMs one by one; tile_mode: 1 = the heuristic (128x192 tiles where K is a
+    multiple of 192), 0 = 128x96 everywhere, 2 = 128x192 everywhere (partial tiles masked)"""
+    import ctypes as C
+    from svit_amd import hip
+    lib = hip.load()
+    lib.svit_debug_set_tn_tile.restype, lib.svit_debug_set_tn_tile.argtypes = C.c_int32, [C.c_int32]
+    lib.svit_debug_set_tn_tile(tile_mode)
+    try:
+        _tn_grouped_case(ops, count)
+    finally:
+        lib.svit_debug_set_tn_tile(1)
+
+
+def _tn_grouped_case(ops, count):
     shapes = [(1000, 288, 96), (4100, 384, 1536), (70, 96, 441), (13064, 384, 384), (333, 40, 96),
               (64, 3072, 768), (2000, 1152, 384), (5000, 96, 96), (129, 128, 96), (8000, 64, 96),
               (700, 768, 768)][:count]

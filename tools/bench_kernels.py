@@ -272,19 +272,23 @@ def bench_tn_group():
             probs.append((M, Co, Ci))
         probs += [(B * h * Nq, 40, 96)] * 3
         groups[blk] = [(rnd(m, n), rnd(m, k), torch.zeros(n, k, device=DEV), None) for m, n, k in probs]
-    settings = [(85, 75), (60, 75), (120, 75), (85, 40), (85, 130), (60, 130), (120, 40), (40, 130), (170, 75)]
-    print("blk   " + "  ".join("%3d/%3d" % s for s in settings))
+    lib.svit_debug_set_tn_tile.restype, lib.svit_debug_set_tn_tile.argtypes = C.c_int32, [C.c_int32]
+    settings = [(85, 75, 0), (85, 75, 1), (60, 75, 1), (120, 75, 1), (85, 40, 1), (85, 130, 1), (60, 130, 1),
+                (40, 130, 1), (170, 75, 1), (85, 75, 2)]
+    print("blk   " + "  ".join("%3d/%3d/%d" % s for s in settings) + "   (step_us x100 / atomic TB/s x100 / tile mode)")
     tot = [0.0] * len(settings)
     for blk, g in groups.items():
         row = []
-        for i, (su, at) in enumerate(settings):
+        for i, (su, at, tm) in enumerate(settings):
             lib.svit_debug_set_tn(su, at)
+            lib.svit_debug_set_tn_tile(tm)
             us = timeit(lambda: ops.gemm_tn_grouped(g), iters=10)
             row.append(us)
             tot[i] += us * (10 if blk == 4 else 1)
-        print("blk%-2d " % blk + "  ".join("%7.1f" % u for u in row))
-    print("step  " + "  ".join("%7.0f" % u for u in tot))
+        print("blk%-2d " % blk + "  ".join("%9.1f" % u for u in row))
+    print("step  " + "  ".join("%9.0f" % u for u in tot))
     lib.svit_debug_set_tn(85, 75)
+    lib.svit_debug_set_tn_tile(1)
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tngroup":
