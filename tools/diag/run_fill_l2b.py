@@ -1,0 +1,21 @@
+"""Diagnostic: L2-resident LDS fill rate with ONE and TWO co-resident workgroups per CU (2 stages x 28 KiB each)."""
+import ctypes as C, os, torch
+lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfill_rate.so"))
+lib.fill_rate2.argtypes = [C.c_int] * 3 + [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+K = 1536
+cyc = torch.zeros(1, dtype=torch.int64, device="cuda")
+sink = torch.zeros(4, device="cuda")
+for wgs_per_cu, ksteps in ((1, 4), (2, 2), (1, 2), (2, 1)):
+    wgs = 256 * wgs_per_cu
+    rows = 224 * wgs
+    A = torch.randn(rows, K, device="cuda").bfloat16()
+    for mode in (0, 1):
+        reps = 600
+        for _ in range(2):
+            rc = lib.fill_rate2(mode, 128, 2, A.data_ptr(), K, rows, ksteps, reps, wgs, cyc.data_ptr(), sink.data_ptr(), 0, 0)
+            torch.cuda.synchronize()
+        assert rc == 0
+        c = int(cyc.item())
+        b = reps * ksteps * 28672
+        print("%d WG/CU  %d K-steps re-read (%4.1f MB per XCD)  %-9s 2 stages: %6.1f B/clk per WG  %6.1f per CU" %
+              (wgs_per_cu, ksteps, wgs / 8 * ksteps * 28672 / 1e6, "LDS-DMA" if mode == 0 else "registers", b / c, wgs_per_cu * b / c), flush=True)
