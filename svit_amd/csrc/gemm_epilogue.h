@@ -7,10 +7,16 @@
 // private LDS region so that global traffic is row-contiguous and vectorised (16 B fp32 / 8 B
 // bf16 per lane) instead of 2-byte column-strided accesses.  Needs
 // n_waves * 16 * (32*NB + 4) * 4 bytes of LDS at `smem`; all waves of the block must call it.
-template <int RB, int NB, int EPI>
+struct NtNoPrefetch { __device__ __forceinline__ void operator()() const {} };
+
+// `prefetch` is called exactly once, at the earliest point after which this function issues no
+// further global LOAD (loads return in order, so a later load would wait for whatever the
+// prefetch put in flight): the persistent GEMM starts the next tile's first LDS-DMA there, so
+// that it travels while this tile's rows are staged and stored.
+template <int RB, int NB, int EPI, class PF = NtNoPrefetch>
 __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&acc)[RB][NB],
                                             unsigned char* smem, int m0, int n0, int wm, int wn,
-                                            int lane, int wave) {
+                                            int lane, int wave, PF prefetch = PF()) {
   constexpr int WN = 32 * NB;
   constexpr int EP_LD = WN + 4;
   constexpr int NIT = 2 * NB;
@@ -47,7 +53,27 @@ __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&
       }
     }
   };
+  // the bias of this lane's NIT column groups is the same for every 16-row slab: load it once
+  float4 bias_r[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int col = n0 + wn * WN + ((lane + 64 * it) % (8 * NB)) * 4;
+    bias_r[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && col < p.N) bias_r[it] = *(const float4*)(p.bias + col);
+  }
+  // DropPath row scale (EPI_RESID): a wave's 32*RB rows span at most two samples when a sample
+  // has at least that many rows -- two loads up front instead of one per row in the store loop
+  float rs_lo = 1.f, rs_hi = 1.f;
+  int rs_boundary = 0x7fffffff;
+  const bool rs_fast = EPI == SVIT_EPI_RESID && p.row_scale && p.rows_per_sample >= 32 * RB;
+  if (rs_fast) {
+    const int r_first = min(m0 + wm * 32 * RB, p.M - 1), r_last = min(r_first + 32 * RB - 1, p.M - 1);
+    rs_lo = p.row_scale[r_first / p.rows_per_sample];
+    rs_hi = p.row_scale[r_last / p.rows_per_sample];
+    rs_boundary = (r_first / p.rows_per_sample + 1) * p.rows_per_sample;
+  }
   if (use_aux) fetch_aux(0, aux_cur);
+  if (!use_aux || 2 * RB == 1) prefetch();
 #pragma unroll
   for (int ih = 0; ih < 2 * RB; ++ih) {
     const int i = ih >> 1, half = ih & 1;
@@ -58,6 +84,7 @@ __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&
         stg[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] =
             acc[i][j][half * 8 + rr];
     if (use_aux && ih + 1 < 2 * RB) fetch_aux(ih + 1, aux_nxt);
+    if (use_aux && 2 * RB > 1 && ih + 2 == 2 * RB) prefetch();   // the last slab's loads are out
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -67,8 +94,8 @@ __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&
       const int col = n0 + wn * WN + c4 * 4;
       if (row >= p.M || col >= p.N) continue;
       float4 v = *(const float4*)(stg + rl * EP_LD + c4 * 4);
-      if (p.bias) {
-        const float4 b = *(const float4*)(p.bias + col);
+      {
+        const float4 b = bias_r[it];
         v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
       }
       if constexpr (EPI == SVIT_EPI_BF16) {
@@ -90,7 +117,8 @@ __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&
         o.x = pack_bf16x2(a0, a1); o.y = pack_bf16x2(a2, a3);
         *(uint2*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = o;
       } else if constexpr (EPI == SVIT_EPI_RESID) {
-        const float s = p.row_scale ? p.row_scale[row / p.rows_per_sample] : 1.f;
+        const float s = rs_fast ? (row < rs_boundary ? rs_lo : rs_hi)
+                                : (p.row_scale ? p.row_scale[row / p.rows_per_sample] : 1.f);
         const float4 res = aux_cur[it];
         float4 o;
         o.x = res.x + s * v.x; o.y = res.y + s * v.y; o.z = res.z + s * v.z; o.w = res.w + s * v.w;
