@@ -7,16 +7,10 @@
 // private LDS region so that global traffic is row-contiguous and vectorised (16 B fp32 / 8 B
 // bf16 per lane) instead of 2-byte column-strided accesses.  Needs
 // n_waves * 16 * (32*NB + 4) * 4 bytes of LDS at `smem`; all waves of the block must call it.
-struct NtNoPrefetch { __device__ __forceinline__ void operator()() const {} };
-
-// `prefetch` is called exactly once, at the earliest point after which this function issues no
-// further global LOAD (loads return in order, so a later load would wait for whatever the
-// prefetch put in flight): the persistent GEMM starts the next tile's first LDS-DMA there, so
-// that it travels while this tile's rows are staged and stored.
-template <int RB, int NB, int EPI, class PF = NtNoPrefetch>
+template <int RB, int NB, int EPI>
 __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&acc)[RB][NB],
                                             unsigned char* smem, int m0, int n0, int wm, int wn,
-                                            int lane, int wave, PF prefetch = PF()) {
+                                            int lane, int wave) {
   constexpr int WN = 32 * NB;
   constexpr int EP_LD = WN + 4;
   constexpr int NIT = 2 * NB;
@@ -73,7 +67,6 @@ __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&
     rs_boundary = (r_first / p.rows_per_sample + 1) * p.rows_per_sample;
   }
   if (use_aux) fetch_aux(0, aux_cur);
-  if (!use_aux || 2 * RB == 1) prefetch();
 #pragma unroll
   for (int ih = 0; ih < 2 * RB; ++ih) {
     const int i = ih >> 1, half = ih & 1;
@@ -84,7 +77,6 @@ __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&
         stg[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] =
             acc[i][j][half * 8 + rr];
     if (use_aux && ih + 1 < 2 * RB) fetch_aux(ih + 1, aux_nxt);
-    if (use_aux && 2 * RB > 1 && ih + 2 == 2 * RB) prefetch();   // the last slab's loads are out
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {

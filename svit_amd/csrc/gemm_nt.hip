@@ -141,145 +141,6 @@ gemm_nt_v2_kernel(svit_gemm_args p) {
   nt_epilogue<RB, NB, EPI>(p, acc, smem, m0, n0, wm, wn, lane, wave);
 }
 
-// Persistent form of the two-stage kernel (round 2).  Time-versus-K of this GEMM (profiles/
-// r02_nt_time_vs_k.txt) shows 7-17 us per launch that do not scale with K: every tile pays the
-// first K-step's memory round trip and its row stores one after the other, and most of the step's
-// GEMMs have K <= 384.  Here a workgroup walks tiles v, v + G, ... of the same XCD-aware order and
-// starts the next tile's first LDS-DMA (into stage 0) from inside the epilogue of the current one
-// (which stages its rows in stage 1), so that round trip and the stores overlap.
-template <int RB, int NB, int WAVES_M, int WAVES_N, int EPI, int BK2>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_nt_p_kernel(svit_gemm_args p, int tiles_n, int ntiles) {
-  constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr int BM = 32 * RB * WAVES_M, WN = 32 * NB, BN = WN * WAVES_N;
-  constexpr int CPR = BK2 / 8, RPR = NT / CPR;
-  constexpr int ROWS = (BM + BN + RPR - 1) / RPR * RPR;
-  constexpr int STAGE_BYTES = ROWS * BK2 * 2;
-  constexpr int PER = ROWS * CPR / NT;
-  // LDS: [stage 0 | stage 1 or the epilogue's row staging, whichever is larger]
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int xq = ntiles >> 3, xr = ntiles & 7;
-  auto tile_origin = [&](int v, int& m0, int& n0) {
-    const int xcd = v & 7;
-    const int wgid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (v >> 3);
-    m0 = (wgid / tiles_n) * BM;
-    n0 = (wgid % tiles_n) * BN;
-  };
-  const bf16_t* src[PER];
-  auto make_src = [&](int m0, int n0) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int q = tid + i * NT;
-      int row, ch;
-      if constexpr (BK2 == 32) {
-        row = q >> 2;
-        ch = (q & 3) ^ ((row >> 2) & 3);
-      } else {
-        const int line = q >> 4;
-        row = (line >> 3) * 16 + ((q >> 3) & 1) * 8 + (line & 7);
-        ch = (q & 7) ^ (row & 7);
-      }
-      if (row < BM) src[i] = (const bf16_t*)p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + ch * 8;
-      else src[i] = (const bf16_t*)p.W + (size_t)min(n0 + row - BM, p.N - 1) * p.ldw + ch * 8;
-    }
-  };
-  auto issue = [&](int kt, int stage) {
-    unsigned char* base = smem + stage * STAGE_BYTES + wave * 1024;
-#pragma unroll
-    for (int i = 0; i < PER; ++i)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(src[i] + kt * BK2),
-          (__attribute__((address_space(3))) void*)(base + i * (NT * 16)), 16, 0, 0);
-  };
-  const int nk = p.K / BK2;
-  const int a_row = wm * 32 * RB + (lane & 31);
-  const int w_row = BM + wn * WN + (lane & 31);
-  int m0, n0;
-  int v = blockIdx.x;
-  tile_origin(v, m0, n0);
-  make_src(m0, n0);
-  issue(0, 0);
-  for (; v < ntiles; v += gridDim.x) {
-    f32x16_t acc[RB][NB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-#pragma unroll
-      for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int kt = 0; kt < nk; ++kt) {
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-      const unsigned char* st = smem + (kt & 1) * STAGE_BYTES;
-      bf16x8_t af[BK2 / 16][RB], wf[BK2 / 16][NB];
-#pragma unroll
-      for (int ks = 0; ks < BK2 / 16; ++ks) {
-        const int ch = 2 * ks + (lane >> 5);
-#pragma unroll
-        for (int i = 0; i < RB; ++i) af[ks][i] = *(const bf16x8_t*)(st + nt_lds_off<BK2>(a_row + i * 32, ch));
-#pragma unroll
-        for (int j = 0; j < NB; ++j) wf[ks][j] = *(const bf16x8_t*)(st + nt_lds_off<BK2>(w_row + j * 32, ch));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ks = 0; ks < BK2 / 16; ++ks)
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-#pragma unroll
-          for (int j = 0; j < NB; ++j) acc[i][j] = mfma32(af[ks][i], wf[ks][j], acc[i][j]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();   // all LDS reads of the last K-steps done: stage 0 / stage 1 are free
-    const int vn = v + gridDim.x, m0c = m0, n0c = n0;
-    auto prefetch = [&]() {
-      if (vn < ntiles) {
-        tile_origin(vn, m0, n0);
-        make_src(m0, n0);
-        issue(0, 0);
-      }
-    };
-    nt_epilogue<RB, NB, EPI>(p, acc, smem + STAGE_BYTES, m0c, n0c, wm, wn, lane, wave, prefetch);
-  }
-}
-
-template <int RB, int NB, int WAVES_M, int WAVES_N, int BK2>
-int launch_p(const svit_gemm_args& a, hipStream_t st) {
-  constexpr int BM = 32 * RB * WAVES_M, BN = 32 * NB * WAVES_N;
-  constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr int RPR = NT / (BK2 / 8);
-  const size_t stage = (size_t)((BM + BN + RPR - 1) / RPR * RPR) * BK2 * 2;
-  const size_t epi = (size_t)WAVES_M * WAVES_N * 16 * (32 * NB + 4) * sizeof(float);
-  const size_t lds = stage + (stage > epi ? stage : epi);
-  const int tiles_n = (a.N + BN - 1) / BN, ntiles = tiles_n * ((a.M + BM - 1) / BM);
-  const int grid = ntiles < 512 ? ntiles : 512;        // two workgroups per CU, resident for the whole launch
-  static SvitOnce once[5];
-#define SVIT_P_ATTR(E)                                                                              \
-  if (int rc = svit_max_lds_once(once[E], (const void*)gemm_nt_p_kernel<RB, NB, WAVES_M, WAVES_N, E, BK2>, lds)) \
-    return rc
-  SVIT_P_ATTR(SVIT_EPI_BF16); SVIT_P_ATTR(SVIT_EPI_GELU); SVIT_P_ATTR(SVIT_EPI_RESID);
-  SVIT_P_ATTR(SVIT_EPI_F32); SVIT_P_ATTR(SVIT_EPI_DGELU);
-#undef SVIT_P_ATTR
-#define SVIT_P_CASE(E)                                                                          \
-  case E:                                                                                       \
-    hipLaunchKernelGGL((gemm_nt_p_kernel<RB, NB, WAVES_M, WAVES_N, E, BK2>), dim3(grid), dim3(NT), lds, st, a, \
-                       tiles_n, ntiles);                                                        \
-    break;
-  switch (a.epilogue) {
-    SVIT_P_CASE(SVIT_EPI_BF16)
-    SVIT_P_CASE(SVIT_EPI_GELU)
-    SVIT_P_CASE(SVIT_EPI_RESID)
-    SVIT_P_CASE(SVIT_EPI_F32)
-    SVIT_P_CASE(SVIT_EPI_DGELU)
-    default:
-      return SVIT_ERR_ARG;
-  }
-#undef SVIT_P_CASE
-  SVIT_LAUNCH_CHECK();
-  return SVIT_OK;
-}
-
 template <int RB, int NB, int WAVES_M, int WAVES_N, int STAGES, int BK2 = 32>
 int launch_v2(const svit_gemm_args& a, hipStream_t st) {
   constexpr int BM = 32 * RB * WAVES_M, BN = 32 * NB * WAVES_N;
@@ -318,13 +179,11 @@ int launch_v2(const svit_gemm_args& a, hipStream_t st) {
 
 static std::atomic<int> g_nt_stages{0};     // tuning knob (svit_debug_set(0, n)); 2..4, 0 = heuristic
 static std::atomic<int> g_nt_force_cfg{-1}; // tuning knob (svit_debug_set(1, c)); -1 = heuristic
-static std::atomic<int> g_nt_persist{1};    // tuning knob (svit_debug_set(3, v)): 0 = one tile per workgroup, 1 = heuristic, 2 = always
 static std::atomic<int> g_nt_force_bk{0};   // tuning knob (svit_debug_set(2, bk)); 32 / 64, 0 = heuristic
 extern "C" int svit_debug_set(int key, int val) {
   if (key == 0) g_nt_stages = val;
   else if (key == 1) g_nt_force_cfg = val;
   else if (key == 2) g_nt_force_bk = val;
-  else if (key == 3) g_nt_persist = val;
   else return SVIT_ERR_ARG;
   return SVIT_OK;
 }
@@ -350,6 +209,12 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
   // variant lands within 10 % of the others: the bound is the per-CU LDS fill rate (~40 GB/s
   // per CU, ~10 TB/s chip-wide for the mix of L2 and Infinity-Cache hits), not the pipeline
   // depth, the fragment-read scheduling or the tile shape.  Also measured and rejected: a
+  // persistent form (a workgroup walks several tiles and issues the next tile's first LDS-DMA from
+  // inside the epilogue of the current one; commit "experiment: persistent NT GEMM", profiles/
+  // r02_nt_persistent_tiles.txt): -10..-17 % on the many-tile K = 384 shapes of the 56x56 stage,
+  // +5..10 % wherever the epilogue writes two outputs or fp32 rows -- the next tile's first
+  // s_waitcnt vmcnt(0) also waits for this tile's stores, which a finishing workgroup never does.
+  // Net zero over the step; not kept.
   // register-staged form (global_load_dwordx4 -> VGPR -> ds_write_b128, K-step 64, loads a whole
   // K-step ahead; commit "experiment: register-staged NT GEMM variant", profiles/
   // r02_nt_tile_sweep.txt column REG): 5-10 % slower than LDS-DMA on every shape -- the bound is
@@ -380,17 +245,7 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
   const int force_bk = g_nt_force_bk.load();
   bool bk64 = a.K % 64 == 0 && a.N <= 768 && a.K >= 384;
   if (force_bk) bk64 = force_bk == 64 && a.K % 64 == 0;
-  // persistent two-stage form: when a launch has more tiles than resident workgroups (512)
-  const int persist = g_nt_persist.load();
-  auto want_p = [&](int bm, int bn) {
-    if (stages != 2 || persist == 0) return false;
-    const long nt = (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn);
-    return persist == 2 || nt > 512;
-  };
-  if (bk64 && force_cfg < 0 && !force_stages) {
-    if (want_p(128, 96)) return launch_p<1, 3, 4, 1, 64>(a, st);
-    return launch_v2<1, 3, 4, 1, 2, 64>(a, st);
-  }
+  if (bk64 && force_cfg < 0 && !force_stages) return launch_v2<1, 3, 4, 1, 2, 64>(a, st);
 #define SVIT_NT_PICK(RB, NB, WM, WN)                                           \
   do {                                                                         \
     if (bk64) {                                                                \
@@ -402,20 +257,8 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
     if (stages == 3) return launch_v2<RB, NB, WM, WN, 3, 32>(a, st);           \
     return launch_v2<RB, NB, WM, WN, 4, 32>(a, st);                            \
   } while (0)
-  // (the 64-row wave tiles at K-step 64 would need more than 256 VGPRs with the epilogue's hoisted
-  // bias: the persistent form exists for them at K-step 32 only)
-  if (sq) {
-    if (!bk64 && want_p(128, 128)) return launch_p<2, 2, 2, 2, 32>(a, st);
-    SVIT_NT_PICK(2, 2, 2, 2);
-  }
-  if (big) {
-    if (!bk64 && want_p(128, 192)) return launch_p<2, 3, 2, 2, 32>(a, st);
-    SVIT_NT_PICK(2, 3, 2, 2);
-  }
-  if (want_p(128, 96)) {
-    if (bk64) return launch_p<1, 3, 4, 1, 64>(a, st);
-    return launch_p<1, 3, 4, 1, 32>(a, st);
-  }
+  if (sq) SVIT_NT_PICK(2, 2, 2, 2);
+  if (big) SVIT_NT_PICK(2, 3, 2, 2);
   SVIT_NT_PICK(1, 3, 4, 1);
 #undef SVIT_NT_PICK
 }

@@ -97,23 +97,8 @@ def test_gemm_nt_tile_variants(ops, M, N, K):
                     lib.svit_debug_set(0, st), lib.svit_debug_set(1, cfg), lib.svit_debug_set(2, bk)
                     out = ops.gemm_nt(a, w, bias, hip.EPI_F32)
                     assert rel_err(out, ref) < 1e-3, (cfg, st, bk)
-            # persistent two-stage form (workgroups walk several tiles, next tile prefetched from
-            # inside the epilogue): forced on, every epilogue
-            lib.svit_debug_set(0, 0), lib.svit_debug_set(2, 0), lib.svit_debug_set(3, 2)
-            out = ops.gemm_nt(a, w, bias, hip.EPI_F32)
-            assert rel_err(out, ref) < 1e-3, (cfg, "persistent")
-            outb = ops.gemm_nt(a, w, bias, hip.EPI_BF16)
-            assert rel_err(outb, ref) < 1.5e-2, (cfg, "persistent bf16")
-            resid = rnd("vr%d" % M, (M, N), 1.0)
-            rows_per = (M + 2) // 3
-            scale = torch.tensor([1.0, 0.0, 1.6667], device=DEV)
-            outr = ops.gemm_nt(a, w, bias, hip.EPI_RESID, aux=resid, row_scale=scale, rows_per_sample=rows_per)
-            rs = scale[torch.arange(M, device=DEV) // rows_per][:, None]
-            assert rel_err(outr, resid + rs * ref) < 1e-3, (cfg, "persistent resid")
-            lib.svit_debug_set(3, 1)
     finally:
         lib.svit_debug_set(0, 0), lib.svit_debug_set(1, -1), lib.svit_debug_set(2, 0)
-        lib.svit_debug_set(3, 1)
 
 
 def test_gemm_nt_row_remap(ops):

@@ -6,7 +6,6 @@ from gemm_vs_lib import timeit  # noqa
 import ctypes as C
 lib = hip.load()
 lib.svit_debug_set.restype, lib.svit_debug_set.argtypes = C.c_int32, [C.c_int32, C.c_int32]
-lib.svit_debug_set(3, int(os.environ.get("NT_PERSIST", "1")))
 M = int(os.environ.get("NT_M", "13064"))
 for N in (384, 1152, 1536) if M < 100000 else (96, 288, 384, 576):
     for epi, name in ((hip.EPI_BF16, "bf16"), (hip.EPI_GELU, "gelu"), (hip.EPI_RESID, "resid"), (hip.EPI_F32, "f32")):
