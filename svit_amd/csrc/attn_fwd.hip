@@ -421,8 +421,6 @@ int launch_fwd(const svit_attn_fwd_args& a, hipStream_t st) {
 }
 }  // namespace
 
-int svit_attn_fwd_v2(const svit_attn_fwd_args& a, int bias_cols, hipStream_t st);   // attn_fwd2.hip
-
 extern "C" int svit_attn_fwd(const svit_attn_fwd_args* a, void* stream) {
   if (!a || !a->qa || !a->ka || !a->v || !a->ctx || !a->lse2) return SVIT_ERR_ARG;
   if (a->B <= 0 || a->heads <= 0 || a->Nq <= 0 || a->Nk <= 0) return SVIT_ERR_SHAPE;
@@ -430,10 +428,8 @@ extern "C" int svit_attn_fwd(const svit_attn_fwd_args* a, void* stream) {
     return SVIT_ERR_ALIGN;
   if (a->DA != 128 && a->DA != 160) return SVIT_ERR_SHAPE;
   if (a->bias_cols < 0 || a->bias_cols > a->DA - 96) return SVIT_ERR_ARG;
-  // SVIT_ATTN_FWD_V=2 selects the one-wave-per-SIMD pipelined kernel of attn_fwd2.hip (kept for
-  // experiments: correct, but a single wave per SIMD only reaches half the VALU issue rate)
-  static const int version = getenv("SVIT_ATTN_FWD_V") ? atoi(getenv("SVIT_ATTN_FWD_V")) : 1;
-  if (version == 2) return svit_attn_fwd_v2(*a, a->bias_cols, (hipStream_t)stream);
+  // (a one-wave-per-SIMD software-pipelined form was built and measured 27-36 % slower -- a single
+  // wave per SIMD reaches half the VALU issue rate; it lives on as tools/diag/attn_fwd2_experiment.hip)
   const int extra = a->DA - 96;
   const int bias_cols = a->bias_cols > 0 ? a->bias_cols : extra;
   switch (6 + (bias_cols + 15) / 16) {

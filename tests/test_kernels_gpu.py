@@ -608,9 +608,9 @@ def test_attention_fwd_eight_wave_path(ops, Nk):
     (1, 2, 129, 330, 128, 22),     # six tiles: both halves of the two-tile unrolled loop end the sweep
 ])
 def test_attention_fwd_pipelined_kernel(ops, B, h, Nq, Nk, DA, J):
-    """The round-2 forward kernel (csrc/attn_fwd2.hip): software-pipelined tiles, 1 or 2 query
-    blocks per wave, only the k-steps that carry data -- against the fp32 reference, over the
-    tile-count and raggedness cases of its pipeline (1, 2, 3, 4, 6, 8, 26 tiles)."""
+    """The round-2 forward kernel (csrc/attn_fwd.hip: buffer-descriptor LDS-DMA, row sums on the
+    matrix pipe, only the k-steps that carry data) against the fp32 reference, over the tile-count,
+    raggedness and bias-column cases of its pipeline (1, 2, 3, 4, 6, 8, 26 tiles; 7-10 k-steps)."""
     scale = 96 ** -0.5
     qa = rnd("pq%d_%d" % (Nq, DA), (B, h, Nq, DA), 1.0, BF16)
     ka = rnd("pk%d_%d" % (Nk, DA), (B, h, Nk, DA), 1.0, BF16)

@@ -22,8 +22,7 @@ def main():
     os.makedirs(os.path.dirname(out), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17",
                            "-ffast-math", "-fno-finite-math-only", "-fno-slp-vectorize", "-DSVIT_ATTN_STAMPS", "-shared",
-                           os.path.join(ROOT, "svit_amd", "csrc", "attn_fwd.hip"),
-                           os.path.join(ROOT, "svit_amd", "csrc", "attn_fwd2.hip"), "-o", out])
+                           os.path.join(ROOT, "svit_amd", "csrc", "attn_fwd.hip"), "-o", out])
     lib = ctypes.CDLL(out)
 
     class Args(ctypes.Structure):

@@ -112,8 +112,8 @@ def bench_attn():
 
 def bench_attn_fwd():
     """forward only, per block shape, with the bias-column count the engine passes (J = kt+kh+kw);
-    SVIT_ATTN_FWD_V=1|2 selects the kernel generation, SVIT_ATTN_FWD_QB the query blocks per wave."""
-    print("== attention fwd (version %s) ==" % os.environ.get("SVIT_ATTN_FWD_V", "2"))
+    the `attnfwd` mode of this tool."""
+    print("== attention fwd ==")
     tot_us = tot_alg = 0.0
     mult = {0: 1, 1: 1, 2: 1, 3: 1, 4: 10, 14: 1, 15: 1}
     for blk, Nin, Nq, Nk, Ci, Co, h, DA in BLOCKS:

@@ -20,7 +20,7 @@
 //     pooling add, instead of 8-byte pieces at a row stride.
 #include <cstdlib>
 #include <type_traits>
-#include "attn_common.h"
+#include "../../svit_amd/csrc/attn_common.h"   // (build: hipcc -I../../svit_amd/csrc, see tools/diag/README.md)
 #include "../../include/svit_hip.h"
 
 namespace {
