@@ -197,7 +197,9 @@ int svit_pool_ln_fwd_qkv(const svit_pool_args* args3, void* stream);
  * bf16(w) in the half of the dword that matches the channel's position in a packed bf16 pair) --
  * the SCALAR operands of the tiled kernels (run once per step for all blocks).  The *_sel entry
  * points take the three tables of a block; tensors with stride 1 then read every input element
- * once into an LDS halo ring instead of 27 times through the texture path. */
+ * once into an LDS halo ring instead of 27 times through the texture path.  (End of round 2: the
+ * tiled kernels build their LDS weight image from conv_w themselves and only consult WHETHER a
+ * table is given; the tables' contents are what the channel-lane experiment consumed) */
 int svit_pool_weight_sel(const float* src_base, const int64_t* src_off, uint32_t* dst, int n_tables,
                          void* stream);
 int svit_pool_ln_fwd_qkv_sel(const svit_pool_args* args3, const uint32_t* const* sel3, void* stream);

@@ -300,13 +300,8 @@ __device__ __forceinline__ void pool_tiled_body(
     for (int i = 0; i < 24; ++i) acc[i] = 0.f;
     // one t-plane (9 taps, 27 LDS reads in flight) at a time: fully unrolled the scheduler hoists
     // all 81 reads and spills
-#ifdef SVIT_DIAG_POOL_ONE_TAP
-#pragma unroll 1
-    for (int kt = 1; kt < 2; ++kt) {
-#else
 #pragma unroll 1
     for (int kt = 0; kt < 3; ++kt) {
-#endif
       const unsigned char* pl_base = ring + ((t + kt) % 3) * PLANE_B + ldsoff;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
@@ -360,12 +355,8 @@ __device__ __forceinline__ void pool_tiled_body(
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             o8[e] = (acc[v * 8 + e] - mean) * rstd * fa->gamma[c0 + v * 8 + e] + fa->beta[c0 + v * 8 + e];
-#ifdef SVIT_DIAG_POOL_NO_STORE
-          if (o8[0] == 12345.678f) *(uint4*)(outp + v * 8) = pack8(o8);
-#else
           *(uint4*)(outp + v * 8) = pack8(o8);
           if (prep) *(uint4*)(prep + v * 8) = pack8(&acc[v * 8]);
-#endif
         }
         if (fa->mode == 1) {   // one-hot key coordinates [y | kh+x | kh+kw+t], zeros elsewhere
           const int extra = fa->ld_out - HD, per = extra / 4;
@@ -926,21 +917,6 @@ __device__ __forceinline__ void pool_wgrad_body(const svit_pool_wgrad_args& a, i
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] += g * nt[k / 9] * nh[(k / 3) % 3] * nh[k % 3];
   }
-#ifdef SVIT_DIAG_WGRAD_NO_LDS_COMBINE   // tools/diag: the two row halves meet in global memory
-  {
-    float* prow = prow_base + c * 27;
-    if (r == 0) {
-#pragma unroll
-      for (int k = 0; k < 27; ++k) prow[k] = acc[k];
-    }
-    __threadfence();
-    __syncthreads();
-    if (r == 1) {
-#pragma unroll
-      for (int k = 0; k < 27; ++k) atomicAdd(prow + k, acc[k]);
-    }
-  }
-#else
   __syncthreads();
   float* comb = (float*)smem_w;   // [27][96]
   if (r == 1) {
@@ -953,7 +929,6 @@ __device__ __forceinline__ void pool_wgrad_body(const svit_pool_wgrad_args& a, i
 #pragma unroll
     for (int k = 0; k < 27; ++k) prow[k] = acc[k] + comb[k * HD + c];
   }
-#endif
 }
 
 template <int S>

@@ -1,5 +1,6 @@
 """single-tensor pooling wgrad (stride 2 and 1) beside the TN GEMM, with the library named by
-SVIT_HIP_LIB (normal build vs the SVIT_DIAG_WGRAD_NO_LDS_COMBINE build)."""
+SVIT_HIP_LIB (normal build vs a build whose two row halves met in global memory instead of LDS --
+the diagnostic macro that produced it was removed from pool.hip after the root cause was found)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
