@@ -7,10 +7,101 @@
 // private LDS region so that global traffic is row-contiguous and vectorised (16 B fp32 / 8 B
 // bf16 per lane) instead of 2-byte column-strided accesses.  Needs
 // n_waves * 16 * (32*NB + 4) * 4 bytes of LDS at `smem`; all waves of the block must call it.
+// bf16-output epilogues (plain, GELU, GELU-backward) with 8 columns = one 16-byte store per lane
+// (the 4-column form below issues twice as many 8-byte stores; the stage-1 GEMMs write 150-310 MB
+// per launch and are bound by exactly that).  Needs 16-byte aligned rows: ldo / ldo2 / ldaux % 8.
+template <int RB, int NB, int EPI>
+__device__ __forceinline__ void nt_epilogue_wide(const svit_gemm_args& p, f32x16_t (&acc)[RB][NB],
+                                                 unsigned char* smem, int m0, int n0, int wm, int wn,
+                                                 int lane, int wave) {
+  constexpr int WN = 32 * NB, EP_LD = WN + 4, GPR = 4 * NB;     // 8-column groups per row
+  float* stg = (float*)smem + wave * (16 * EP_LD);
+  uint4 aux_cur[NB], aux_nxt[NB];
+  auto fetch_aux = [&](int ih, uint4 (&dst)[NB]) {
+    const int i = ih >> 1, half = ih & 1;
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      const int idx = lane + 64 * it, rl = idx / GPR, c8 = idx % GPR;
+      const int row = m0 + wm * 32 * RB + i * 32 + half * 16 + rl, col = n0 + wn * WN + c8 * 8;
+      dst[it] = make_uint4(0, 0, 0, 0);
+      if (row < p.M && col < p.N) dst[it] = *(const uint4*)((const bf16_t*)p.aux + (size_t)row * p.ldaux + col);
+    }
+  };
+  float4 bias_r[NB][2];
+#pragma unroll
+  for (int it = 0; it < NB; ++it) {
+    const int col = n0 + wn * WN + ((lane + 64 * it) % GPR) * 8;
+    bias_r[it][0] = bias_r[it][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && col < p.N) {
+      bias_r[it][0] = *(const float4*)(p.bias + col);
+      bias_r[it][1] = *(const float4*)(p.bias + col + 4);
+    }
+  }
+  if (EPI == SVIT_EPI_DGELU) fetch_aux(0, aux_cur);
+#pragma unroll
+  for (int ih = 0; ih < 2 * RB; ++ih) {
+    const int i = ih >> 1, half = ih & 1;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr)
+        stg[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] =
+            acc[i][j][half * 8 + rr];
+    if (EPI == SVIT_EPI_DGELU && ih + 1 < 2 * RB) fetch_aux(ih + 1, aux_nxt);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      const int idx = lane + 64 * it, rl = idx / GPR, c8 = idx % GPR;
+      const int row = m0 + wm * 32 * RB + i * 32 + half * 16 + rl, col = n0 + wn * WN + c8 * 8;
+      if (row >= p.M || col >= p.N) continue;
+      const float4 v0 = *(const float4*)(stg + rl * EP_LD + c8 * 8), v1 = *(const float4*)(stg + rl * EP_LD + c8 * 8 + 4);
+      const float4 b0 = bias_r[it][0], b1 = bias_r[it][1];
+      float v[8] = {v0.x + b0.x, v0.y + b0.y, v0.z + b0.z, v0.w + b0.w, v1.x + b1.x, v1.y + b1.y, v1.z + b1.z, v1.w + b1.w};
+      uint4 o;
+      if constexpr (EPI == SVIT_EPI_BF16) {
+        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+        o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+      } else if constexpr (EPI == SVIT_EPI_GELU) {
+        float a[8], d[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gelu_fwd_grad(v[e], &a[e], &d[e]);
+        if (p.out2) {
+          uint4 o2;
+          o2.x = pack_bf16x2(d[0], d[1]); o2.y = pack_bf16x2(d[2], d[3]);
+          o2.z = pack_bf16x2(d[4], d[5]); o2.w = pack_bf16x2(d[6], d[7]);
+          *(uint4*)((bf16_t*)p.out2 + (size_t)row * p.ldo2 + col) = o2;
+        }
+        o.x = pack_bf16x2(a[0], a[1]); o.y = pack_bf16x2(a[2], a[3]);
+        o.z = pack_bf16x2(a[4], a[5]); o.w = pack_bf16x2(a[6], a[7]);
+      } else {   // SVIT_EPI_DGELU: acc * saved gelu'(h)
+        const uint4 h = aux_cur[it];
+        o.x = pack_bf16x2(v[0] * lo_bf16(h.x), v[1] * hi_bf16(h.x));
+        o.y = pack_bf16x2(v[2] * lo_bf16(h.y), v[3] * hi_bf16(h.y));
+        o.z = pack_bf16x2(v[4] * lo_bf16(h.z), v[5] * hi_bf16(h.z));
+        o.w = pack_bf16x2(v[6] * lo_bf16(h.w), v[7] * hi_bf16(h.w));
+      }
+      *(uint4*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = o;
+    }
+    if (EPI == SVIT_EPI_DGELU) {
+#pragma unroll
+      for (int it = 0; it < NB; ++it) aux_cur[it] = aux_nxt[it];
+    }
+    if (ih + 1 < 2 * RB) __syncthreads();
+  }
+}
+
 template <int RB, int NB, int EPI>
 __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&acc)[RB][NB],
                                             unsigned char* smem, int m0, int n0, int wm, int wn,
                                             int lane, int wave) {
+  if constexpr (EPI == SVIT_EPI_BF16 || EPI == SVIT_EPI_GELU || EPI == SVIT_EPI_DGELU) {
+    const bool rows16 = (p.ldo % 8 == 0) && (EPI != SVIT_EPI_GELU || !p.out2 || p.ldo2 % 8 == 0) &&
+                        (EPI != SVIT_EPI_DGELU || p.ldaux % 8 == 0);
+    if (rows16) {     // (uniform over the launch)
+      nt_epilogue_wide<RB, NB, EPI>(p, acc, smem, m0, n0, wm, wn, lane, wave);
+      return;
+    }
+  }
   constexpr int WN = 32 * NB;
   constexpr int EP_LD = WN + 4;
   constexpr int NIT = 2 * NB;
