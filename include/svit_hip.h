@@ -156,6 +156,9 @@ typedef struct {
   int32_t stride_hw;               /* spatial stride s (temporal stride is 1)          */
   int32_t mode;                    /* 0 = plain (q, v), 1 = keys (+one-hot)            */
   float eps;
+  float out_scale;                 /* columns 0..95 of out = LN(pooled) * out_scale (0 = 1): the keys
+                                    * carry scale * log2(e) so that qa . ka^T is the score in the
+                                    * log2 domain (svit_attn_fwd)                          */
 } svit_pool_args;
 int svit_pool_ln_fwd(const svit_pool_args* a, void* stream);
 
@@ -269,6 +272,12 @@ int svit_relpos_scatter(const svit_relq_scatter_args* a, void* stream);
  * merge heads (attention.py:429-461).
  * qa bf16 [B,h,Nq,DA], ka bf16 [B,h,Nk,DA] (DA = 128 or 160), v bf16 [B,h,Nk,96],
  * ctx bf16 [B,Nq,h*96], lse2 f32 [B,h,Nq] (log2-domain log-sum-exp, saved for backward).
+ * Operand convention (round 3): qa . ka^T IS the attention score in the log2 domain --
+ *   ka[:, 0:96]  = scale * log2(e) * LN(pool(k))   (svit_pool_args.out_scale of the key tensor),
+ *   ka[:, 96+j]  = one-hot key coordinates [y | kh + x | kh + kw + t],
+ *   qa[:, 0:96]  = LN(pool(q)), qa[:, 96+j] = log2(e) * (q . R_j) (svit_relpos_gather's inv_scale
+ *   = log2 e) -- so the kernels exponentiate with exp2 and no multiply.  `scale` is only used to
+ *   express dk with respect to the UN-scaled pooled keys: dk = scale * sum_q P (dP - delta) q.
  * bias_cols: how many of the DA - 96 rel-pos columns carry data (kt + kh + kw); the kernel only
  * multiplies the 16-column k-steps that do.  0 = all of them. */
 typedef struct {
@@ -278,10 +287,11 @@ typedef struct {
 int svit_attn_fwd(const svit_attn_fwd_args* a, void* stream);
 typedef struct {
   const void* qa; const void* ka; const void* v; const void* ctx; const void* dctx;
-  const float* lse2; float* delta;  /* delta: f32 [B,h,Nq,2] scratch ((lse2, rowsum(dO*O)) pairs) */
+  const float* lse2; float* delta;  /* delta: f32 [B,h,2,Nq] scratch (-lse2/c and -rowsum(dO*O) planes) */
   void* dqa;                        /* bf16 [B,h,Nq,DA]                                  */
   float* dk; float* dv;             /* f32 [B,h,Nk,96], OVERWRITTEN (cleared inside when split) */
   int32_t B, heads, Nq, Nk, DA, q_splits; float scale;
+  int32_t bias_cols;                /* as in svit_attn_fwd_args: kt + kh + kw, 0 = all DA - 96 */
 } svit_attn_bwd_args;
 int svit_attn_bwd(const svit_attn_bwd_args* a, void* stream);
 

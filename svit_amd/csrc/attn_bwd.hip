@@ -2,17 +2,32 @@
 //
 // Two launches (both on the caller's stream):
 //   1. dq kernel : first delta[q] = sum_c dctx[q,c] * (ctx[q,c] - q_pooled[q,c]) (rowsum(dO*O)),
-//                  kept in a register and stored as (lse2, delta) pairs in the caller's scratch
-//                  for launch 2; then per 32-query wave, sweep K/V tiles: S^T, P^T = exp2(c*S - lse2),
-//                  dP^T = V dO^T, dS^T = P^T (dP^T - delta) * scale, dQa^T += Ka^T dS^T.
+//                  kept in a register and stored as (-lse2, -delta) planes in the caller's scratch
+//                  for launch 2; then per 32-query wave, sweep K/V tiles: S^T, P^T = exp2(S - lse2)
+//                  (S = qa . ka^T is the score in the log2 domain: the keys carry scale * log2 e),
+//                  dP^T = V dO^T, dS^T = P^T (dP^T - delta), dQa^T += Ka^T dS^T (x ln 2 at the end).
 //                  Query on the lane => P/dS reach the next MFMA as B operands in registers.
-//   2. dkv kernel: per 32-key wave (128 keys per block), sweep 32-query tiles of a query
+//   2. dkv kernel: per 32-key wave (128 keys per block), sweep 64-query stages of a query
 //                  chunk: S, P, dP, dS with the KEY on the lane; dV^T += dO^T P, dK^T += Q^T dS
 //                  accumulate in registers over the whole sweep; chunks of the query range run
 //                  in different blocks and meet in fp32 atomics shaped as whole 384-byte rows
 //                  (transposed through LDS first -- row-per-lane atomics are ~17x slower).
 // No N x N matrix is ever stored.  The residual-pooling path (ctx += q) contributes dctx to dq
 // outside these kernels (svit_pool_ln_bwd's d_res input).
+//
+// Round 3: every LDS fragment read is issued by hand (attn_common.h RowStream / TrStream), four
+// fragments ahead of the MFMA that consumes it.  The round-2 kernels left the reads to hipcc, which
+// (a) waited lgkmcnt(0) in front of almost every MFMA and (b) in the dkv kernel put an
+// `s_waitcnt vmcnt(0)` in front of the plain LDS loads of the (lse2, delta) pairs, i.e. drained the
+// LDS-DMA ring in the middle of every tile.  Also new: only the k-steps of the QK^T contraction that
+// carry data are multiplied (bias_cols, as in the forward); the per-row constants enter as the
+// initial accumulators of the S and dP chains (-lse2 and -delta: in the dkv kernel read from LDS
+// straight into the accumulator registers, in the dq kernel two constant register blocks at DA = 128)
+// so that P and dS cost two VALU operations per element instead of five (one v_exp, one v_mul: the
+// score arrives in the log2 domain, attn_fwd.hip); ln 2 / `scale` are applied once to the finished
+// dQ / dK tiles; the LDS-DMA pieces are
+// addressed by buffer descriptor + scalar offset (no per-piece address arithmetic); the dkv kernel
+// consumes 64 queries per barrier (was 32); dQa leaves through LDS as whole rows in 16-byte stores.
 #include <atomic>
 #include "attn_common.h"
 #include "../../include/svit_hip.h"
@@ -20,19 +35,38 @@
 namespace {
 using namespace attn;
 constexpr int KT = 64;   // keys per tile (dq kernel)
-constexpr int QT = 32;   // queries per tile (dkv kernel)
+constexpr int QR = 64;   // queries per stage (dkv kernel)
+constexpr float LN2 = 0.6931471805599453f;
+
+// per-lane LDS byte offsets of the fragment reads inside a 64-row panel image (attn_common.h):
+// row fragments of k-step ks of the 32-row block at row0 sit at rowa[ks&1] + row0*64 + (ks>>1)*4096,
+// the transposed fragment (lo, hi) of the 16 rows at rbase / panel p at tra[0|1] + rbase*64 + p*4096.
+struct FragAddr {
+  unsigned rowa[2], tra[2];
+  __device__ __forceinline__ void init(unsigned base, int lane) {
+    const int hh = lane >> 5, row = lane & 31, sw = (row >> 2) & 3;
+    rowa[0] = base + row * 64 + 16 * ((0 + hh) ^ sw);
+    rowa[1] = base + row * 64 + 16 * ((2 + hh) ^ sw);
+    const int cg = (lane >> 4) & 1, i = lane & 15, q = i >> 2, pp = i & 3;
+    const int r0 = 4 * hh, ch = 2 * cg + (pp >> 1);
+    const unsigned tb = base + 8 * (pp & 1);
+    tra[0] = tb + (r0 + q) * 64 + 16 * (ch ^ ((r0 >> 2) & 3));
+    tra[1] = tb + (r0 + 8 + q) * 64 + 16 * (ch ^ (((r0 + 8) >> 2) & 3));
+  }
+};
 
 // ---------------------------------------------------------------------------------------
 // dq kernel.  K/V tiles travel HBM -> LDS by LDS-DMA (no staging registers), two stages, one
-// raw barrier per tile behind a counted vmcnt; 2 blocks per CU (2 waves per SIMD) so one
-// wave's exp/convert VALU work overlaps the other's MFMAs.
-template <int DA>
+// raw barrier per tile behind the wave's vmcnt wait; 2 blocks per CU (2 waves per SIMD) so one
+// wave's exp/convert VALU work overlaps the other's MFMAs.  KSU = k-steps of the S contraction
+// that carry data (6 + ceil(bias columns / 16)).
+template <int DA, int KSU>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args a, int zero_dkv) {
-  constexpr int KS = DA / 16, NP = DA / 32;
+#if __HIP_DEVICE_COMPILE__
+  constexpr int NP = DA / 32;
   constexpr int K_BYTES = KT * DA * 2, V_BYTES = KT * HD * 2, STAGE = K_BYTES + V_BYTES;
-  using KLoad = GldsTile<KT, DA, 4>;
-  using VLoad = GldsTile<KT, HD, 4>;
-  constexpr int PER_TILE = KLoad::PER_WAVE + VLoad::PER_WAVE;
+  using KLoad = BufTile<KT, DA, 4>;
+  using VLoad = BufTile<KT, HD, 4>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   if (zero_dkv) {   // the dkv launch that follows accumulates with atomics: clear dk / dv here
@@ -47,23 +81,38 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
   const int wgid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
   const int bh = wgid / gridDim.x, b = bh / a.heads, head = bh % a.heads;
   const int qtile = wgid % gridDim.x;
-  const int qi = qtile * 128 + wave * 32 + (lane & 31);
+  const int q0 = qtile * 128 + wave * 32;
+  const int qi = q0 + (lane & 31);
   const int qc = min(qi, a.Nq - 1);
   const bf16_t* qa = (const bf16_t*)a.qa + ((size_t)bh * a.Nq) * DA;
   const bf16_t* ka = (const bf16_t*)a.ka + ((size_t)bh * a.Nk) * DA;
   const bf16_t* vv = (const bf16_t*)a.v + ((size_t)bh * a.Nk) * HD;
   const bf16_t* dor = (const bf16_t*)a.dctx + ((size_t)b * a.Nq + qc) * a.heads * HD + head * HD;
-  const float c = a.scale * 1.4426950408889634f;
   const float lse = a.lse2[(size_t)bh * a.Nq + qc];
 
-  bf16x8_t qf[KS], dof[6];
+  const int nt = (a.Nk + KT - 1) / KT;
+  KLoad kload;
+  VLoad vload;
+  kload.init(DA, wave, lane);
+  vload.init(HD, wave, lane);
+  const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)ka, 0, a.Nk * DA * 2, 0x00020000);
+  const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vv, 0, a.Nk * HD * 2, 0x00020000);
+  auto issue = [&](int t) {
+    unsigned char* st = smem + (t & 1) * STAGE;
+    const unsigned k0 = (unsigned)t * KT;
+    kload.issue_auto(krs, k0 * DA * 2u, DA, a.Nk - (int)k0, st, wave, lane);
+    vload.issue_auto(vrs, k0 * HD * 2u, HD, a.Nk - (int)k0, st + K_BYTES, wave, lane);
+  };
+  issue(0);                          // travels while the register operands are fetched
+
+  bf16x8_t qf[KSU], dof[6];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(qa + (size_t)qc * DA + ks * 16 + hh * 8);
+  for (int ks = 0; ks < KSU; ++ks) qf[ks] = *(const bf16x8_t*)(qa + (size_t)qc * DA + ks * 16 + hh * 8);
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks) dof[ks] = *(const bf16x8_t*)(dor + ks * 16 + hh * 8);
   // delta = rowsum(dO . O) with O = ctx - q (residual pooling adds q to every token but cls):
-  // folded in here (was a separate pre-pass); each half-wave lane holds 48 of the 96 channels.
-  // The (lse2, delta) pair is also what the dkv kernel streams, so it is written back once.
+  // each half-wave lane holds 48 of the 96 channels.  (-lse2, -delta) are what the dkv kernel
+  // loads as the initial accumulators of its S and dP chains, so they are written in that form.
   float dlt;
   {
     const bf16_t* orow = (const bf16_t*)a.ctx + ((size_t)b * a.Nq + qc) * a.heads * HD + head * HD;
@@ -80,13 +129,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
       part += lo_bf16(d.w) * (lo_bf16(o.w) - lo_bf16(q.w)) + hi_bf16(d.w) * (hi_bf16(o.w) - hi_bf16(q.w));
     }
     dlt = part + __shfl_xor(part, 32, 64);
-    if (hh == 0 && qi < a.Nq) ((float2*)a.delta)[(size_t)bh * a.Nq + qi] = make_float2(lse, dlt);
+    if (hh == 0 && qi < a.Nq) {
+      float* sc = a.delta + (size_t)bh * a.Nq * 2;
+      sc[qi] = -lse;
+      sc[a.Nq + qi] = -dlt;
+    }
   }
 
   // Pin the register operands NOW: their first use must not sit inside the tile loop, or the
   // compiler's wait for them (vmcnt(0)) would drain the LDS-DMA pipeline every iteration.
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+  for (int ks = 0; ks < KSU; ++ks) asm volatile("" : "+v"(qf[ks]));
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks) asm volatile("" : "+v"(dof[ks]));
   float lse_p = lse, dlt_p = dlt;
@@ -98,86 +151,116 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[j][r] = 0.f;
 
-  const int nt = (a.Nk + KT - 1) / KT;
-  KLoad kload;
-  VLoad vload;
-  kload.init(DA, wave, lane);
-  vload.init(HD, wave, lane);
-  auto issue = [&](int t) {
-    unsigned char* st = smem + (t & 1) * STAGE;
-    const int k0 = t * KT;
-    kload.issue_auto(ka + (size_t)k0 * DA, DA, a.Nk - k0, st, wave, lane);
-    vload.issue_auto(vv + (size_t)k0 * HD, HD, a.Nk - k0, st + K_BYTES, wave, lane);
-  };
-  issue(0);
+  FragAddr fa;
+  fa.init((unsigned)(size_t)smem, lane);
+  // initial accumulators of the S and dP chains: -lse2 and -delta of this lane's query in all 16
+  // registers where the register budget allows it (DA = 128), zeros otherwise
+  constexpr bool CINIT = DA == 128;
+  f32x16_t s_init, dp_init;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { s_init[r] = CINIT ? -lse_p : 0.f; dp_init[r] = CINIT ? -dlt_p : 0.f; }
+
   for (int t = 0; t < nt; ++t) {
     wait_vmcnt<0>();                 // this wave's share of tile t has landed
     __builtin_amdgcn_s_barrier();    // everyone's share has; everyone is done with tile t-1
     if (t + 1 < nt) issue(t + 1);    // travels while tile t is consumed
-    const unsigned char* k_cur = smem + (t & 1) * STAGE;
-    const unsigned char* v_cur = k_cur + K_BYTES;
+    const unsigned so = (t & 1) * STAGE;
+    const unsigned ra[2] = {fa.rowa[0] + so, fa.rowa[1] + so};
+    const unsigned ta[2] = {fa.tra[0] + so, fa.tra[1] + so};
     const int kbase = t * KT;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    static_for<0, 2>([&](auto KB) {
+      constexpr int kb = decltype(KB)::value;
       f32x16_t s, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) s = mfma32(row_frag<KT>(k_cur, kb * 32, ks, lane), qf[ks], s);
-#pragma unroll
-      for (int ks = 0; ks < 6; ++ks) dp = mfma32(row_frag<KT>(v_cur, kb * 32, ks, lane), dof[ks], dp);
-      if (kbase + KT > a.Nk) {   // ragged last tile: rows past Nk hold re-read data
+      // ---- S^T (KSU k-steps of K rows) and dP^T (6 k-steps of V rows) ------------------------
+      RowStream<KSU + 6, 4> rs;
+      auto rd = [&](auto J, bf16x8_t& d) {
+        constexpr int j = decltype(J)::value;
+        if constexpr (j < KSU) lds_read128<kb * 2048 + (j >> 1) * 4096>(d, ra[j & 1]);
+        else lds_read128<K_BYTES + kb * 2048 + ((j - KSU) >> 1) * 4096>(d, ra[(j - KSU) & 1]);
+      };
+      rs.prologue(rd);
+      rs.run(rd, [&](auto J, const bf16x8_t& f) {
+        constexpr int j = decltype(J)::value;
+        if constexpr (j < KSU) s = mfma32(f, qf[j], j == 0 ? s_init : s);
+        else dp = mfma32(f, dof[j - KSU], j == KSU ? dp_init : dp);
+      });
+      // ---- K^T fragments of the dQ product: the first ones travel under the VALU section -----
+      TrStream<2 * NP, 3> ts;
+      auto rdt = [&](auto J, s16x4_t& lo, s16x4_t& hi) {
+        constexpr int j = decltype(J)::value, sp = j / NP, p = j % NP;
+        lds_read_tr<(kb * 32 + sp * 16) * 64 + p * 4096>(lo, ta[0]);
+        lds_read_tr<(kb * 32 + sp * 16) * 64 + p * 4096>(hi, ta[1]);
+      };
+      ts.prologue(rdt);
+      if (kbase + KT > a.Nk) {   // ragged last tile (uniform branch): rows past Nk hold re-read data
+        asm volatile("; ragged key rows" ::: "memory");
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (kbase + kb * 32 + acc_row(r, lane) >= a.Nk) s[r] = -INFINITY;
       }
+      if constexpr (CINIT) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r] * c - lse_p) * (dp[r] - dlt_p) * a.scale;
+        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r]) * dp[r];
+      } else {
 #pragma unroll
-      for (int sp = 0; sp < 2; ++sp) {
-        const bf16x8_t dsf = acc_to_frag(s, sp);
-        bf16x8_t kt[NP];
-        tr_frags_asm<KT, NP>(k_cur, kb * 32 + sp * 16, lane, kt);
-#pragma unroll
-        for (int j = 0; j < NP; ++j) dq[j] = mfma32(kt[j], dsf, dq[j]);
+        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r] - lse_p) * (dp[r] - dlt_p);
       }
-    }
+      const bf16x8_t dsf0 = acc_to_frag(s, 0), dsf1 = acc_to_frag(s, 1);
+      ts.run(rdt, [&](auto J, const bf16x8_t& f) {
+        constexpr int j = decltype(J)::value, sp = j / NP, p = j % NP;
+        dq[p] = mfma32(f, sp == 0 ? dsf0 : dsf1, dq[p]);
+      });
+    });
   }
-  if (qi < a.Nq) {
-    bf16_t* out = (bf16_t*)a.dqa + ((size_t)bh * a.Nq + qi) * DA;
+
+  // ---- epilogue: x ln 2, stage the wave's 32 x DA tile in LDS, store whole rows --------------
+  __builtin_amdgcn_s_barrier();        // every wave is done with the K/V ring
+  constexpr int OROW = DA * 2 + 16;    // bytes per staged row (pad spreads the banks)
+  unsigned char* ost = smem + wave * (32 * OROW);
+  {
+    unsigned char* orow = ost + (lane & 31) * OROW;
 #pragma unroll
     for (int j = 0; j < NP; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         uint2 pk;
-        pk.x = pack_bf16x2(dq[j][4 * g], dq[j][4 * g + 1]);
-        pk.y = pack_bf16x2(dq[j][4 * g + 2], dq[j][4 * g + 3]);
-        *(uint2*)(out + j * 32 + 8 * g + 4 * hh) = pk;
+        pk.x = pack_bf16x2(dq[j][4 * g] * LN2, dq[j][4 * g + 1] * LN2);
+        pk.y = pack_bf16x2(dq[j][4 * g + 2] * LN2, dq[j][4 * g + 3] * LN2);
+        *(uint2*)(orow + (j * 32 + 8 * g + 4 * hh) * 2) = pk;
       }
   }
+  constexpr int CPR = DA / 8;          // 16-byte chunks per row
+  bf16_t* out = (bf16_t*)a.dqa + ((size_t)bh * a.Nq) * DA;
+#pragma unroll
+  for (int it = 0; it < CPR / 2; ++it) {
+    const int id = it * 64 + lane, row = id / CPR, ch = id % CPR;
+    if (q0 + row < a.Nq)
+      *(uint4*)(out + (size_t)(q0 + row) * DA + ch * 8) = *(const uint4*)(ost + row * OROW + ch * 16);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
-// dkv kernel.  Q / dO tiles and the (lse2, delta) pairs arrive by LDS-DMA into a three-stage
-// ring; key on the lane; dK^T / dV^T accumulate in registers over the sweep.
-// NH = 1: 4 waves, 32-query tiles.  NH = 2 (round 2): 8 waves -- the four key groups twice, the
-// two halves working on the two 32-query halves of a 64-query tile -- so that a CU that holds
-// ONE workgroup (the split heuristic aims at one per CU: every extra split costs a full fp32
-// atomic flush) still runs two waves per SIMD: one half's exp / convert / LDS waits hide behind
-// the other's MFMAs.  The halves' dK / dV meet in LDS before the (unchanged) row stores.
-template <int DA, int NH>
+// dkv kernel.  Q / dO stages of 64 queries and their (-lse2, -delta) rows arrive by LDS-DMA into
+// a ring; key on the lane; dK^T / dV^T accumulate in registers over the sweep.
+// NH = 1: 4 waves, each works through both 32-query halves of a stage, two-stage ring, two
+// workgroups per CU.  NH = 2: 8 waves -- the four key groups twice, the halves working on the two
+// 32-query halves of a stage -- so that a CU that holds ONE workgroup (the split heuristic aims at
+// one per CU: every extra split costs a full fp32 atomic flush) still runs two waves per SIMD;
+// three-stage ring.  The halves' dK / dV meet in LDS before the row stores.
+template <int DA, int KSU, int NH>
 __global__ __launch_bounds__(256 * NH, NH == 2 ? 1 : 2) void attn_bwd_dkv_kernel(svit_attn_bwd_args a,
                                                                                  int tiles_per_split) {
-  constexpr int KS = DA / 16;
-  constexpr int QR = QT * NH;                             // query rows per ring stage
+#if __HIP_DEVICE_COMPILE__
   constexpr int Q_BYTES = QR * DA * 2, O_BYTES = QR * HD * 2;
-  constexpr int STAGE = Q_BYTES + O_BYTES + 2 * QR * 4;   // [Q | dO | (lse2, delta) pairs]
-  constexpr int NSTAGE = 3;
+  constexpr int STAGE = Q_BYTES + O_BYTES + 2 * QR * 4;   // [Q | dO | -lse2 | -delta]
+  constexpr int NSTAGE = NH == 2 ? 3 : 2;
   constexpr int OUT_LD = HD + 1;                          // padded fp32 transpose buffer
   constexpr int NTHR = 256 * NH;
-  using QLoad = GldsTile<QR, DA, 4 * NH>;
-  using OLoad = GldsTile<QR, HD, 4 * NH>;
-  constexpr int PER_TILE = QLoad::PER_WAVE + OLoad::PER_WAVE + 1;
+  constexpr int DR = DA == 160 ? 3 : 4, DT = DA == 160 ? 2 : 3;   // read-ahead depths (register budget)
+  using QLoad = BufTile<QR, DA, 4 * NH>;
+  using OLoad = BufTile<QR, HD, 4 * NH>;
+  constexpr int PER_STAGE = QLoad::PER_WAVE + OLoad::PER_WAVE + 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int kg = wave & 3, qh = wave >> 2;                // key group, query half
@@ -193,18 +276,42 @@ __global__ __launch_bounds__(256 * NH, NH == 2 ? 1 : 2) void attn_bwd_dkv_kernel
   const bf16_t* ka = (const bf16_t*)a.ka + ((size_t)bh * a.Nk) * DA;
   const bf16_t* vv = (const bf16_t*)a.v + ((size_t)bh * a.Nk) * HD;
   const bf16_t* dob = (const bf16_t*)a.dctx + ((size_t)b * a.Nq) * a.heads * HD + head * HD;
-  const float* ld_g = a.delta + (size_t)bh * a.Nq * 2;    // (lse2, delta) pairs
-  const float c = a.scale * 1.4426950408889634f;
+  const float* sc_g = a.delta + (size_t)bh * a.Nq * 2;    // [-lse2 | -delta] planes
+  const int ldo = a.heads * HD;
 
-  bf16x8_t kf[KS], vf[6];
+  const int nqt = (a.Nq + QR - 1) / QR;
+  const int t_begin = by * tiles_per_split;
+  const int t_end = min(nqt, t_begin + tiles_per_split);
+  QLoad qload;
+  OLoad oload;
+  qload.init(DA, wave, lane);
+  oload.init(ldo, wave, lane);
+  const auto qrs = __builtin_amdgcn_make_buffer_rsrc((void*)qa, 0, a.Nq * DA * 2, 0x00020000);
+  const auto ors = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, (a.Nq * ldo - head * HD) * 2, 0x00020000);
+  auto issue = [&](int t) {
+    unsigned char* st = smem + ((t - t_begin) % NSTAGE) * STAGE;
+    const int q0 = t * QR;
+    qload.issue_auto(qrs, (unsigned)q0 * DA * 2u, DA, a.Nq - q0, st, wave, lane);
+    oload.issue_auto(ors, (unsigned)q0 * ldo * 2u, ldo, a.Nq - q0, st + Q_BYTES, wave, lane);
+    // 64 floats of one plane = one dword LDS-DMA (rows past Nq re-read the last row): even waves
+    // fetch -lse2, odd waves -delta
+    const int part = wave & 1;
+    const int qrow = min(q0 + lane, a.Nq - 1);
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(sc_g + (size_t)part * a.Nq + qrow),
+        (__attribute__((address_space(3))) void*)(st + Q_BYTES + O_BYTES + part * 256), 4, 0, 0);
+  };
+  if (t_begin < t_end) issue(t_begin);
+  if (NSTAGE == 3 && t_begin + 1 < t_end) issue(t_begin + 1);
+
+  bf16x8_t kf[KSU], vf[6];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8_t*)(ka + (size_t)kc * DA + ks * 16 + hh * 8);
+  for (int ks = 0; ks < KSU; ++ks) kf[ks] = *(const bf16x8_t*)(ka + (size_t)kc * DA + ks * 16 + hh * 8);
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks) vf[ks] = *(const bf16x8_t*)(vv + (size_t)kc * HD + ks * 16 + hh * 8);
-
   // pin the register operands before the tile loop (see the dq kernel)
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(kf[ks]));
+  for (int ks = 0; ks < KSU; ++ks) asm volatile("" : "+v"(kf[ks]));
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks) asm volatile("" : "+v"(vf[ks]));
 
@@ -214,73 +321,85 @@ __global__ __launch_bounds__(256 * NH, NH == 2 ? 1 : 2) void attn_bwd_dkv_kernel
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[j][r] = 0.f; dv[j][r] = 0.f; }
 
-  const int nqt = (a.Nq + QR - 1) / QR;
-  const int t_begin = by * tiles_per_split;
-  const int t_end = min(nqt, t_begin + tiles_per_split);
-  QLoad qload;
-  OLoad oload;
-  qload.init(DA, wave, lane);
-  oload.init((size_t)a.heads * HD, wave, lane);
-  auto issue = [&](int t) {
-    unsigned char* st = smem + ((t - t_begin) % NSTAGE) * STAGE;
-    const int q0 = t * QR;
-    qload.issue_auto(qa + (size_t)q0 * DA, DA, a.Nq - q0, st, wave, lane);
-    oload.issue_auto(dob + (size_t)q0 * a.heads * HD, (size_t)a.heads * HD, a.Nq - q0, st + Q_BYTES, wave, lane);
-    // 32 (lse2, delta) pairs = 64 floats = one dword LDS-DMA (rows past Nq re-read the last pair);
-    // with two halves the even waves fetch the first 32 pairs, the odd waves the second 32
-    const int part = NH == 2 ? (wave & 1) : 0;
-    const int qrow = min(q0 + part * 32 + (lane >> 1), a.Nq - 1);
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(ld_g + (size_t)qrow * 2 + (lane & 1)),
-        (__attribute__((address_space(3))) void*)(st + Q_BYTES + O_BYTES + part * 256), 4, 0, 0);
-  };
-  if (t_begin < t_end) issue(t_begin);
-  if (t_begin + 1 < t_end) issue(t_begin + 1);
+  // NH = 2: this wave's query half is fixed -- its offset lives in the base addresses.  NH = 1: both
+  // halves are unrolled and their offsets are instruction immediates.
+  FragAddr fa;
+  fa.init((unsigned)(size_t)smem + (NH == 2 ? qh * 2048 : 0), lane);
+  const unsigned cba = (unsigned)(size_t)smem + Q_BYTES + O_BYTES + 16 * hh + (NH == 2 ? qh * 128 : 0);   // row 4*hh of the planes
+
   for (int t = t_begin; t < t_end; ++t) {
-    if (t + 1 < t_end) wait_vmcnt<PER_TILE>();   // all but the youngest tile's loads are done
+    if (NSTAGE == 3 && t + 1 < t_end) wait_vmcnt<PER_STAGE>();   // all but the youngest stage's loads are done
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (t + 2 < t_end) issue(t + 2);             // into the stage consumed two steps ago
-    const unsigned char* q_cur = smem + ((t - t_begin) % NSTAGE) * STAGE;
-    const unsigned char* o_cur = q_cur + Q_BYTES;
-    const float* ld_s = (const float*)(o_cur + O_BYTES) + qh * 64;
-    const int q0 = t * QR + qh * QT;             // first query of this half's 32 rows
-    const int r0 = qh * QT;                      // their row offset inside the staged tile
-
-    f32x16_t s, dp;
+    if (t + NSTAGE - 1 < t_end) issue(t + NSTAGE - 1);           // into the stage consumed last
+    const unsigned so = ((t - t_begin) % NSTAGE) * STAGE;
+    const unsigned ra[2] = {fa.rowa[0] + so, fa.rowa[1] + so};
+    const unsigned ta[2] = {fa.tra[0] + so, fa.tra[1] + so};
+    const unsigned ca = cba + so;
+    static_for<0, (NH == 2 ? 1 : 2)>([&](auto HF) {
+      constexpr int HB = NH == 2 ? 0 : decltype(HF)::value * 2048;   // 32 rows of 64 bytes per panel
+      constexpr int HC = NH == 2 ? 0 : decltype(HF)::value * 128;
+      const int q0 = t * QR + (NH == 2 ? qh : decltype(HF)::value) * 32;   // first query of this half's 32 rows
+      // ---- initial accumulators: rows 8g + 4hh + e of the -lse2 and -delta planes -------------
+      f32x4_t cl[4], cd[4];
+      static_for<0, 4>([&](auto G) {
+        constexpr int g = decltype(G)::value;
+        lds_read128f<HC + g * 32>(cl[g], ca);
+        lds_read128f<HC + 256 + g * 32>(cd[g], ca);
+      });
+      // ---- S (KSU k-steps of Q rows) and dP (6 k-steps of dO rows) ----------------------------
+      RowStream<KSU + 6, DR> rs;
+      auto rd = [&](auto J, bf16x8_t& d) {
+        constexpr int j = decltype(J)::value;
+        if constexpr (j < KSU) lds_read128<HB + (j >> 1) * 4096>(d, ra[j & 1]);
+        else lds_read128<HB + Q_BYTES + ((j - KSU) >> 1) * 4096>(d, ra[(j - KSU) & 1]);
+      };
+      rs.prologue(rd);
+      // the DR prologue reads are younger than the eight constant reads: lgkmcnt(DR) = constants landed
+      asm volatile("s_waitcnt lgkmcnt(%8)"
+                   : "+v"(cl[0]), "+v"(cl[1]), "+v"(cl[2]), "+v"(cl[3]), "+v"(cd[0]), "+v"(cd[1]),
+                     "+v"(cd[2]), "+v"(cd[3]) : "n"(DR) : "memory");
+      f32x16_t s, dp;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) s = mfma32(row_frag<QR>(q_cur, r0, ks, lane), kf[ks], s);
+        for (int e = 0; e < 4; ++e) { s[4 * g + e] = cl[g][e]; dp[4 * g + e] = cd[g][e]; }
+      rs.run(rd, [&](auto J, const bf16x8_t& f) {
+        constexpr int j = decltype(J)::value;
+        if constexpr (j < KSU) s = mfma32(f, kf[j], s);
+        else dp = mfma32(f, vf[j - KSU], dp);
+      });
+      // ---- dO^T / Q^T fragments of the dV / dK products: the first travel under the VALU section
+      TrStream<12, DT> ts;
+      auto rdt = [&](auto J, s16x4_t& lo, s16x4_t& hi) {
+        constexpr int j = decltype(J)::value, sp = j / 6, w = (j % 6) / 3, p = j % 3;
+        lds_read_tr<HB + (w == 0 ? Q_BYTES : 0) + sp * 16 * 64 + p * 4096>(lo, ta[0]);
+        lds_read_tr<HB + (w == 0 ? Q_BYTES : 0) + sp * 16 * 64 + p * 4096>(hi, ta[1]);
+      };
+      ts.prologue(rdt);
 #pragma unroll
-    for (int ks = 0; ks < 6; ++ks) dp = mfma32(row_frag<QR>(o_cur, r0, ks, lane), vf[ks], dp);
+      for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r]);
+      if (q0 + 32 > a.Nq) {      // ragged last stage (uniform branch): re-read rows past Nq count nothing
+        asm volatile("; ragged query rows" ::: "memory");   // keeps this a branch (no per-element selects)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      // rows 8g + 4hh + e, e = 0..3: four consecutive (lse2, delta) pairs
-      const float4 p01 = *(const float4*)(ld_s + 2 * (8 * g + 4 * hh));
-      const float4 p23 = *(const float4*)(ld_s + 2 * (8 * g + 4 * hh) + 4);
-      const float lv[4] = {p01.x, p01.z, p23.x, p23.z}, dl[4] = {p01.y, p01.w, p23.y, p23.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float p = fast_exp2(s[4 * g + e] * c - lv[e]);
-        if (q0 + QT > a.Nq && q0 + 8 * g + 4 * hh + e >= a.Nq) p = 0.f;   // re-read rows past Nq
-        s[4 * g + e] = p;
-        dp[4 * g + e] = p * (dp[4 * g + e] - dl[e]) * a.scale;
+        for (int r = 0; r < 16; ++r)
+          if (q0 + acc_row(r, lane) >= a.Nq) s[r] = 0.f;
       }
-    }
 #pragma unroll
-    for (int sp = 0; sp < 2; ++sp) {
-      const bf16x8_t pf = acc_to_frag(s, sp);
-      const bf16x8_t dsf = acc_to_frag(dp, sp);
-      bf16x8_t ot[3], qt[3];
-      tr_frags_asm<QR, 3>(o_cur, r0 + sp * 16, lane, ot);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) dv[j] = mfma32(ot[j], pf, dv[j]);
-      tr_frags_asm<QR, 3>(q_cur, r0 + sp * 16, lane, qt);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) dk[j] = mfma32(qt[j], dsf, dk[j]);
-    }
+      for (int r = 0; r < 16; ++r) dp[r] = s[r] * dp[r];
+      const bf16x8_t pf0 = acc_to_frag(s, 0), pf1 = acc_to_frag(s, 1);
+      const bf16x8_t df0 = acc_to_frag(dp, 0), df1 = acc_to_frag(dp, 1);
+      ts.run(rdt, [&](auto J, const bf16x8_t& f) {
+        constexpr int j = decltype(J)::value, sp = j / 6, w = (j % 6) / 3, p = j % 3;
+        if constexpr (w == 0) dv[p] = mfma32(f, sp == 0 ? pf0 : pf1, dv[p]);
+        else dk[p] = mfma32(f, sp == 0 ? df0 : df1, dk[p]);
+      });
+    });
   }
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[j][r] *= a.scale;
   // ---- transpose through LDS so that every atomic wave-instruction adds whole rows; with two
   // ---- query halves the second half adds its accumulators to the first half's in the buffer
   float* obuf = (float*)smem;  // [128 keys][OUT_LD]
@@ -320,53 +439,54 @@ __global__ __launch_bounds__(256 * NH, NH == 2 ? 1 : 2) void attn_bwd_dkv_kernel
       }
     }
   }
+#endif
 }
 
 static std::atomic<int> g_dkv_halves{0};   // tuning knob (svit_attn_debug_set(0, n)): 1 / 2, 0 = heuristic
 
-template <int DA>
+template <int DA, int KSU>
 int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
   static SvitOnce once_dq, once_kv, once_kv2;
-  const size_t lds_dq = 2 * (size_t)(KT * DA * 2 + KT * HD * 2);
   const size_t lds_out = (size_t)128 * (HD + 1) * 4;
-  size_t lds_kv = 3 * (size_t)(QT * DA * 2 + QT * HD * 2 + 2 * QT * 4);
-  size_t lds_kv2 = 3 * (size_t)(2 * QT * DA * 2 + 2 * QT * HD * 2 + 4 * QT * 4);
+  size_t lds_dq = 2 * (size_t)(KT * DA * 2 + KT * HD * 2);
+  const size_t lds_dq_out = (size_t)4 * 32 * (DA * 2 + 16);
+  if (lds_dq < lds_dq_out) lds_dq = lds_dq_out;
+  const size_t stage = (size_t)(QR * DA * 2 + QR * HD * 2 + 2 * QR * 4);
+  size_t lds_kv = 2 * stage, lds_kv2 = 3 * stage;
   if (lds_kv < lds_out) lds_kv = lds_out;
   if (lds_kv2 < lds_out) lds_kv2 = lds_out;
-  if (int rc = svit_max_lds_once(once_dq, (const void*)attn_bwd_dq_kernel<DA>, lds_dq)) return rc;
-  if (int rc = svit_max_lds_once(once_kv, (const void*)attn_bwd_dkv_kernel<DA, 1>, lds_kv)) return rc;
-  if (int rc = svit_max_lds_once(once_kv2, (const void*)attn_bwd_dkv_kernel<DA, 2>, lds_kv2)) return rc;
+  if (int rc = svit_max_lds_once(once_dq, (const void*)attn_bwd_dq_kernel<DA, KSU>, lds_dq)) return rc;
+  if (int rc = svit_max_lds_once(once_kv, (const void*)attn_bwd_dkv_kernel<DA, KSU, 1>, lds_kv)) return rc;
+  if (int rc = svit_max_lds_once(once_kv2, (const void*)attn_bwd_dkv_kernel<DA, KSU, 2>, lds_kv2)) return rc;
   const int key_blocks = (a.Nk + 127) / 128;
   const int base = key_blocks * a.B * a.heads;
   // two query halves (8 waves) where the launch leaves one 4-wave workgroup per CU anyway: the
-  // short-key blocks (measured, tools/bench_kernels.py attn, profiles/r02_attn_bwd_dkv_halves.txt:
-  // -8..-16 % of the whole backward at Nk = 457; +6..13 % at Nk = 1633 / DA = 160, whose 8-wave
-  // form sits at the 256-VGPR limit with a 100 KB ring)
+  // short-key blocks (tools/bench_kernels.py attn)
   int halves = g_dkv_halves.load();
   if (halves != 1 && halves != 2) halves = (DA == 128 && base <= 256) ? 2 : 1;
-  const int nqt = (a.Nq + QT * halves - 1) / (QT * halves);
+  const int nqt = (a.Nq + QR - 1) / QR;
   int splits = a.q_splits;
   if (splits <= 0) {
     // every split adds a full [128 keys x 192] fp32 tile per block with atomics (~1.3 TB/s
     // chip-wide), so split the query range only as far as needed to fill the chip
     // (measured, tools/bench_kernels.py attnsplits: ~1 block per CU is the sweet spot), and
-    // keep >= 4 query tiles per block to amortise the epilogue
+    // keep >= 2 query stages per block to amortise the epilogue
     splits = (256 + base - 1) / base;
-    if (splits > nqt / 4) splits = nqt / 4;
+    if (splits > nqt / 2) splits = nqt / 2;
   }
   if (splits > nqt) splits = nqt;
   if (splits < 1) splits = 1;
   int tiles_per_split = (nqt + splits - 1) / splits;
   splits = (nqt + tiles_per_split - 1) / tiles_per_split;
   if (((uintptr_t)a.dk | (uintptr_t)a.dv) & 15) return SVIT_ERR_ALIGN;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<DA>, dim3((a.Nq + 127) / 128, a.B * a.heads), dim3(256),
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DA, KSU>), dim3((a.Nq + 127) / 128, a.B * a.heads), dim3(256),
                      lds_dq, st, a, splits > 1 ? 1 : 0);
   SVIT_LAUNCH_CHECK();
   if (halves == 2)
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DA, 2>), dim3(key_blocks, splits, a.B * a.heads), dim3(512),
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DA, KSU, 2>), dim3(key_blocks, splits, a.B * a.heads), dim3(512),
                        lds_kv2, st, a, tiles_per_split);
   else
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DA, 1>), dim3(key_blocks, splits, a.B * a.heads), dim3(256),
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DA, KSU, 1>), dim3(key_blocks, splits, a.B * a.heads), dim3(256),
                        lds_kv, st, a, tiles_per_split);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
@@ -385,7 +505,13 @@ extern "C" int svit_attn_bwd(const svit_attn_bwd_args* a, void* stream) {
     return SVIT_ERR_ARG;
   if (a->B <= 0 || a->heads <= 0 || a->Nq <= 0 || a->Nk <= 0) return SVIT_ERR_SHAPE;
   if (a->B * a->heads > 65535) return SVIT_ERR_SHAPE;
-  if (a->DA == 128) return launch_bwd<128>(*a, (hipStream_t)stream);
-  if (a->DA == 160) return launch_bwd<160>(*a, (hipStream_t)stream);
-  return SVIT_ERR_SHAPE;
+  if (a->DA != 128 && a->DA != 160) return SVIT_ERR_SHAPE;
+  if (a->bias_cols < 0 || a->bias_cols > a->DA - 96) return SVIT_ERR_ARG;
+  if (((uintptr_t)a->qa | (uintptr_t)a->ka | (uintptr_t)a->v | (uintptr_t)a->dctx | (uintptr_t)a->dqa) & 15)
+    return SVIT_ERR_ALIGN;
+  const int bias_cols = a->bias_cols > 0 ? a->bias_cols : a->DA - 96;
+  const int ksu = 6 + (bias_cols + 15) / 16;
+  hipStream_t st = (hipStream_t)stream;
+  if (a->DA == 128) return ksu <= 7 ? launch_bwd<128, 7>(*a, st) : launch_bwd<128, 8>(*a, st);
+  return ksu <= 9 ? launch_bwd<160, 9>(*a, st) : launch_bwd<160, 10>(*a, st);
 }

@@ -11,6 +11,7 @@
 // ds_read_b64_tr_b16 transposed read (per 32-lane half: 4 consecutive rows x the 4 chunks of
 // one panel) does too.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace attn {
@@ -219,6 +220,152 @@ __device__ __forceinline__ void tr_frags_asm(const unsigned char* tile, int rbas
   if constexpr (NP >= 4) out[3] = make_bf16x8(l3, h3);
   if constexpr (NP >= 5) out[4] = make_bf16x8(l4, h4);
 }
+
+// ---- explicitly pipelined LDS fragment reads (shared by the forward and backward kernels) -----
+// Left to itself hipcc emits `ds_read_b128 ; s_waitcnt lgkmcnt(0) ; v_mfma` per k-step -- every
+// MFMA waits out the full LDS latency of its own operand -- and, worse, puts an `s_waitcnt
+// vmcnt(0)` in front of compiler-visible LDS reads that follow an LDS-DMA, which drains the K/V
+// ring every tile.  The reads are therefore issued by hand through inline asm (invisible to the
+// waitcnt pass), a few fragments AHEAD of the MFMAs that consume them, and released by a counted
+// `s_waitcnt lgkmcnt(N)` that carries the fragment registers as in/out operands so that no consumer
+// can be scheduled above it.  LDS operations return in order, so "at most N outstanding" =
+// everything older than the last N has landed.
+template <int I> using Int = std::integral_constant<int, I>;
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(Int<B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read128(bf16x8_t& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "i"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read128f(f32x4_t& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "i"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr(s16x4_t& d, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "i"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lgkm_release1(bf16x8_t& f) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lgkm_release2(s16x4_t& lo, s16x4_t& hi) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo), "+v"(hi) : "n"(N) : "memory");
+}
+
+// A stream of NR row fragments (one ds_read_b128 each) feeding NR MFMAs, read D fragments ahead
+// through a ring of D + 1 register sets.  rd(Int<j>, frag&) issues read j, mm(Int<j>, frag) is MFMA
+// j.  prologue() may be issued early (e.g. before a VALU section); nothing else may issue LDS
+// operations between prologue() and the end of run() -- the waits count every LDS operation.
+template <int NR, int D>
+struct RowStream {
+  static_assert(D >= 1 && D <= NR, "lookahead");
+  bf16x8_t ring[D + 1];
+  template <typename RD>
+  __device__ __forceinline__ void prologue(RD&& rd) {
+    static_for<0, D>([&](auto J) { rd(J, ring[decltype(J)::value % (D + 1)]); });
+  }
+  template <typename RD, typename MM>
+  __device__ __forceinline__ void run(RD&& rd, MM&& mm) {
+    static_for<0, NR>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      if constexpr (j + D < NR) rd(Int<j + D>{}, ring[(j + D) % (D + 1)]);
+      lgkm_release1<(j + D < NR) ? D : NR - 1 - j>(ring[j % (D + 1)]);
+      mm(J, ring[j % (D + 1)]);
+      __builtin_amdgcn_sched_barrier(0);   // MFMA j stays here: it covers the flight of the reads behind it
+    });
+  }
+};
+// The same for transposed fragments (two ds_read_b64_tr_b16 each).
+template <int NR, int D>
+struct TrStream {
+  static_assert(D >= 1 && D <= NR, "lookahead");
+  s16x4_t lo[D + 1], hi[D + 1];
+  template <typename RD>
+  __device__ __forceinline__ void prologue(RD&& rd) {
+    static_for<0, D>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      rd(J, lo[j % (D + 1)], hi[j % (D + 1)]);
+    });
+  }
+  template <typename RD, typename MM>
+  __device__ __forceinline__ void run(RD&& rd, MM&& mm) {
+    static_for<0, NR>([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      if constexpr (j + D < NR) rd(Int<j + D>{}, lo[(j + D) % (D + 1)], hi[(j + D) % (D + 1)]);
+      lgkm_release2<2 * ((j + D < NR) ? D : NR - 1 - j)>(lo[j % (D + 1)], hi[j % (D + 1)]);
+      mm(J, make_bf16x8(lo[j % (D + 1)], hi[j % (D + 1)]));
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+};
+
+// LDS-DMA of a [ROWS][COLS] bf16 tile into the panel image through a BUFFER descriptor: the
+// per-lane byte offset of every piece is tile-invariant (a VGPR computed once), the tile's base
+// is a scalar offset, so a piece costs `s_mov m0` + `buffer_load_dwordx4 ... lds` and no vector
+// ALU work at all.  Only for tiles whose ROWS rows all exist: the scalar offset takes no part in
+// the descriptor's range check, so rows past the end of the matrix would read whatever follows it.
+// A ragged last tile goes through issue_clamped(): per-lane offsets with the row clamped to the
+// last valid one (callers mask those rows arithmetically).
+template <int ROWS, int COLS, int NWAVES>
+struct BufTile {
+  static_assert(ROWS % 16 == 0 && COLS % 32 == 0, "panel image geometry");
+  static constexpr int RG = ROWS / 16, INSTRS = RG * (COLS / 32);
+  static constexpr int PER_WAVE = (INSTRS + NWAVES - 1) / NWAVES;
+  unsigned voff[PER_WAVE];
+  __device__ __forceinline__ void init(int ld, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      int n = wave + i * NWAVES;
+      if (n >= INSTRS) n = INSTRS - 1;
+      const int panel = n / RG, rg = n % RG;
+      const int row = rg * 16 + (lane >> 2);
+      const int ch = (lane & 3) ^ ((row >> 2) & 3);
+      voff[i] = (unsigned)(row * ld + panel * 32 + ch * 8) * 2u;
+    }
+  }
+#if __HIP_DEVICE_COMPILE__
+  template <typename RSRC>
+  __device__ __forceinline__ void issue(RSRC rsrc, unsigned soff_bytes, unsigned char* tile, int wave) const {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      int n = wave + i * NWAVES;
+      if (n >= INSTRS) n = INSTRS - 1;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsrc, (__attribute__((address_space(3))) void*)(tile + (n / RG) * ROWS * 64 + (n % RG) * 1024),
+          16, voff[i], soff_bytes, 0, 0);
+    }
+  }
+  template <typename RSRC>
+  __device__ static __forceinline__ void issue_clamped(RSRC rsrc, unsigned soff_bytes, int ld, int valid_rows,
+                                                       unsigned char* tile, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      int n = wave + i * NWAVES;
+      if (n >= INSTRS) n = INSTRS - 1;
+      const int panel = n / RG, rg = n % RG;
+      const int row = rg * 16 + (lane >> 2);
+      const int ch = (lane & 3) ^ ((row >> 2) & 3);
+      const int grow = min(row, valid_rows - 1);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsrc, (__attribute__((address_space(3))) void*)(tile + (n / RG) * ROWS * 64 + (n % RG) * 1024),
+          16, (unsigned)(grow * ld + panel * 32 + ch * 8) * 2u, soff_bytes, 0, 0);
+    }
+  }
+  template <typename RSRC>
+  __device__ __forceinline__ void issue_auto(RSRC rsrc, unsigned soff_bytes, int ld, int valid_rows,
+                                             unsigned char* tile, int wave, int lane) const {
+    if (valid_rows >= ROWS) issue(rsrc, soff_bytes, tile, wave);
+    else issue_clamped(rsrc, soff_bytes, ld, valid_rows, tile, wave, lane);
+  }
+#endif
+};
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {

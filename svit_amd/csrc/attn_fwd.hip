@@ -2,10 +2,11 @@
 //
 //   S = (q*scale) k^T + rel-pos bias ; P = softmax(S) ; ctx = P v + q (all tokens but cls)
 //
-// The decomposed relative-position bias rides inside the QK^T MFMA: the query operand is
-// augmented to qa = [q | relq/scale] and the key operand to ka = [k | one-hot(y,x,t)], so
-// qa.ka^T * scale = scale*q.k + rel_h[y] + rel_w[x] + rel_t[t]; cls/object rows/cols carry
-// zeros there.  Head dim of the contraction DA = 128 or 160, value dim 96.
+// The decomposed relative-position bias rides inside the QK^T MFMA, and the product comes out in
+// the log2 domain: the query operand is augmented to qa = [q | log2e * relq] and the key operand to
+// ka = [scale * log2e * k | one-hot(y,x,t)] (the pooling kernel writes the keys pre-multiplied), so
+// qa.ka^T = log2e * (scale*q.k + rel_h[y] + rel_w[x] + rel_t[t]); cls/object rows/cols carry zeros
+// in the bias columns.  Head dim of the contraction DA = 128 or 160, value dim 96.
 //
 // Work split: block = 4 waves x 32 queries; K/V tiles of 64 keys arrive by LDS-DMA
 // (global_load_lds) in a two-stage, swizzled LDS panel image (attn_common.h), one raw barrier
@@ -15,7 +16,6 @@
 // exchange, and the exponentiated tile feeds the PV MFMA as its B operand without leaving
 // registers.  O^T accumulates as 3 x (32 dv x 32 query) blocks.
 #include <cstdlib>
-#include <type_traits>
 #include "attn_common.h"
 #include "../../include/svit_hip.h"
 
@@ -38,89 +38,6 @@ namespace {
 using namespace attn;
 constexpr int KT = 64;  // keys per tile
 
-// ---- explicitly pipelined LDS fragment reads -------------------------------------------------
-// Left to itself hipcc emits `ds_read_b128 ; s_waitcnt lgkmcnt(0) ; v_mfma` per k-step -- every
-// MFMA waits out the full LDS latency of its own operand (measured: the QK^T phase ran at a
-// third of the MFMA rate).  The reads are therefore issued by hand, one chunk of G fragments
-// AHEAD of the MFMAs that consume the previous chunk, through inline asm (invisible to the
-// waitcnt pass), and released by a counted `s_waitcnt lgkmcnt(N)` that carries the fragment
-// registers as in/out operands so that no consumer can be scheduled above it.  LDS operations
-// return in order, so "at most N outstanding" = everything older than the last N has landed.
-template <int I> using Int = std::integral_constant<int, I>;
-template <int B, int E, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (B < E) {
-    f(Int<B>{});
-    static_for<B + 1, E>(f);
-  }
-}
-template <int OFF>
-__device__ __forceinline__ void lds_read128(bf16x8_t& d, unsigned addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "i"(OFF) : "memory");
-}
-template <int OFF>
-__device__ __forceinline__ void lds_read_tr(s16x4_t& d, unsigned addr) {
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "i"(OFF) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void lgkm_release(bf16x8_t (&f)[4]) {
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(N) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void lgkm_release(bf16x8_t (&f)[5]) {
-  asm volatile("s_waitcnt lgkmcnt(%5)"
-               : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]) : "n"(N) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void lgkm_release(s16x4_t (&f)[6]) {
-  asm volatile("s_waitcnt lgkmcnt(%6)"
-               : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]) : "n"(N) : "memory");
-}
-
-// LDS-DMA of a [ROWS][COLS] bf16 tile into the panel image through a BUFFER descriptor: the
-// per-lane byte offset of every piece is tile-invariant (a VGPR computed once), the tile's base
-// is a scalar offset, so a piece costs `s_mov m0` + `buffer_load_dwordx4 ... lds` and no vector
-// ALU work at all (round 1 spent ~45 VALU instructions per tile on 64-bit piece addresses).  The
-// descriptor's size is the (batch, head)'s whole K or V matrix: rows past the end read zeros, so
-// a ragged last tile needs no address clamping.
-template <int ROWS, int COLS, int NWAVES>
-struct BufTile {
-  static_assert(ROWS % 16 == 0 && COLS % 32 == 0, "panel image geometry");
-  static constexpr int RG = ROWS / 16, INSTRS = RG * (COLS / 32);
-  static constexpr int PER_WAVE = (INSTRS + NWAVES - 1) / NWAVES;
-  unsigned voff[PER_WAVE];
-  __device__ __forceinline__ void init(int ld, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-      int n = wave + i * NWAVES;
-      if (n >= INSTRS) n = INSTRS - 1;
-      const int panel = n / RG, rg = n % RG;
-      const int row = rg * 16 + (lane >> 2);
-      const int ch = (lane & 3) ^ ((row >> 2) & 3);
-      voff[i] = (unsigned)(row * ld + panel * 32 + ch * 8) * 2u;
-    }
-  }
-#if __HIP_DEVICE_COMPILE__
-  template <typename RSRC>
-  __device__ __forceinline__ void issue(RSRC rsrc, unsigned soff_bytes, unsigned char* tile, int wave) const {
-#pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-      int n = wave + i * NWAVES;
-      if (n >= INSTRS) n = INSTRS - 1;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsrc, (__attribute__((address_space(3))) void*)(tile + (n / RG) * ROWS * 64 + (n % RG) * 1024),
-          16, voff[i], soff_bytes, 0, 0);
-    }
-  }
-#endif
-};
-
-template <int N, int G>
-__device__ __forceinline__ void lgkm_release_n(bf16x8_t (&f)[G]) {
-  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-#pragma unroll
-  for (int i = 0; i < G; ++i) asm volatile("" : "+v"(f[i]));
-}
 __device__ __forceinline__ float other_half(float x) {      // lane l <-> lane l ^ 32, VALU only
   const unsigned u = __float_as_uint(x);
   const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
@@ -131,14 +48,21 @@ __device__ __forceinline__ float other_half(float x) {      // lane l <-> lane l
 // <4, 2>: two independent workgroups per CU.  <8, 3>: one 8-wave workgroup per CU streams each
 // K/V tile ONCE for 256 queries and prefetches two tiles ahead.
 // KSU = k-steps of the QK^T contraction that carry data: 6 (q.k) + ceil(bias columns / 16); the
-// K image holds ceil(KSU / 2) panels.  Round-2 changes against the round-1 loop (cycle anatomy in
-// DESIGN.md; PMC: 280 VALU instructions per tile and wave for 28 MFMAs):
-//   * row sums of P on the matrix pipe (one extra MFMA per 16 keys against a constant "ones"
-//     fragment) instead of 32 v_add per tile;
-//   * LDS-DMA pieces addressed by buffer descriptor + scalar offset (BufTile): no VALU;
-//   * only the k-steps with data are multiplied (9 of 10 at 16x224^2's 14x14 key grids);
-//   * the output leaves through LDS as whole 192-byte rows with 16-byte stores (was 12 strided
-//     8-byte stores per lane: the store tail was ~3 us of a 24 us launch).
+// K image holds ceil(KSU / 2) panels.
+// Round 3 (the loop's VALU work went from ~110 to ~75 instructions per tile and wave):
+//   * the score leaves the MFMA in the log2 domain (the pooling kernel writes the keys multiplied
+//     by scale * log2 e) and already relative to the running maximum (-m enters as the initial
+//     accumulator of the QK^T chain: a block of 16 registers rewritten only when the maximum is
+//     re-based), so a probability costs ONE v_exp_f32 -- no multiply, no subtract;
+//   * every fragment read goes through the RowStream / TrStream ring (attn_common.h) four / three
+//     fragments ahead of its MFMA (was: chunks of 4-7 fragments, twice the registers);
+//   * a ragged last tile with at most 32 valid keys multiplies half a tile (Nk = 457: 7.5 tiles
+//     instead of 8), and is fetched through clamped addresses (nothing relies on what an LDS-DMA
+//     does past the end of a buffer);
+//   * the residual-pooling rows are fetched after the loop (24 registers less inside it).
+// Kept from round 2: row sums of P on the matrix pipe (one extra MFMA per 16 keys against a
+// constant "ones" fragment), LDS-DMA pieces addressed by buffer descriptor + scalar offset, only
+// the k-steps with data multiplied, output through LDS as whole 192-byte rows with 16-byte stores.
 template <int KSU, int NW, int NS>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit_attn_fwd_args a) {
 #if __HIP_DEVICE_COMPILE__          // (the buffer-descriptor builtins have no host-side type)
@@ -163,11 +87,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
   const bf16_t* qa = (const bf16_t*)a.qa + ((size_t)bh * a.Nq) * DA;
   const bf16_t* ka = (const bf16_t*)a.ka + ((size_t)bh * a.Nk) * DA;
   const bf16_t* vv = (const bf16_t*)a.v + ((size_t)bh * a.Nk) * HD;
-  const float c = a.scale * 1.4426950408889634f;
 
-  f32x16_t o[3], lacc;
+  f32x16_t o[3], lacc, negm;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+  for (int r = 0; r < 16; ++r) { lacc[r] = 0.f; negm[r] = 0.f; }
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -176,15 +99,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
   bf16x8_t onesf;
 #pragma unroll
   for (int e = 0; e < 8; ++e) onesf[e] = (lane & 31) == 0 ? (__bf16)1.0f : (__bf16)0.0f;
-  float m_run = -INFINITY;      // running max in the exp2 domain (already multiplied by c)
+  float m_run = 0.f;            // running max (log2 domain); negm holds -m_run in all 16 registers
 
   // per-lane LDS byte addresses of the fragment reads (stage 0; everything else is an
   // immediate): K row fragments of k-step ks sit at kaddr[ks&1] + (ks>>1)*KT*64 + kb*2048, the
   // transposed V fragments of key group rbase / panel j at vaddr[0|1] + rbase*64 + j*KT*64
   // (image and swizzle: attn_common.h).
-  constexpr int G = KSU == 8 ? 4 : KSU == 9 ? 6 : KSU == 10 ? 5 : 7;   // fragments per chunk
-  constexpr int NC = 2 * KSU / G;
-  static_assert(NC * G == 2 * KSU, "chunking");
   const unsigned lds0 = (unsigned)(size_t)smem;
   unsigned kaddr0[2], vaddr0[2];
   {
@@ -207,14 +127,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
   VLoad vload;
   kload.init(DA, wave, lane);
   vload.init(HD, wave, lane);
-  // descriptors over this (batch, head)'s K and V: reads past row Nk return zeros
+  // descriptors over this (batch, head)'s K and V; the ragged last tile re-reads the last valid
+  // row through clamped per-lane offsets (those keys are masked to -inf below)
   const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)ka, 0, a.Nk * DA * 2, 0x00020000);
   const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vv, 0, a.Nk * HD * 2, 0x00020000);
   auto issue = [&](int t) {
     unsigned char* st = smem + (t % NS) * STAGE;
     const unsigned k0 = (unsigned)t * KT;
-    kload.issue(krs, k0 * DA * 2u, st, wave);
-    vload.issue(vrs, k0 * HD * 2u, st + K_BYTES, wave);
+    kload.issue_auto(krs, k0 * DA * 2u, DA, a.Nk - (int)k0, st, wave, lane);
+    vload.issue_auto(vrs, k0 * HD * 2u, HD, a.Nk - (int)k0, st + K_BYTES, wave, lane);
   };
   issue(0);                        // the first tile(s) travel while the Q fragments are fetched
   if (NS == 3 && nt > 1) issue(1);
@@ -227,10 +148,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
   // (here that wait also covers the tiles issued above, which tile 0 needs anyway)
 #pragma unroll
   for (int ks = 0; ks < KSU; ++ks) asm volatile("" : "+v"(qf[ks]));
-  // residual-pooling operand of the epilogue (the pooled q rows, in the row-major chunk order
-  // of the output stores): fetched during the LAST tile so that its latency is not exposed
-  uint4 qres[6];
-  for (int t = 0; t < nt; ++t) {
+
+  // One K/V tile.  HALF: a ragged last tile with at most 32 valid keys -- only key block 0 is
+  // multiplied (QK^T, softmax and P.V of 32 keys).
+  auto tile = [&](int t, auto HalfTag) {
+    constexpr bool HALF = decltype(HalfTag)::value == 1;
+    constexpr int NKB = HALF ? 1 : 2;
     // this wave's share of tile t has landed (NS == 3: tile t+1's pieces may stay in flight)
     if (NS == 3 && t + 1 < nt) wait_vmcnt<PIECES>();
     else wait_vmcnt<0>();
@@ -238,119 +161,114 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
     __builtin_amdgcn_s_barrier();    // everyone's share has; everyone is done with tile t-1
     STAMP(8 + t * 8 + 0);
     if (t + NS - 1 < nt) issue(t + NS - 1);    // into tile t-1's slot; travels while tiles are consumed
-    if (t == nt - 1) {               // no LDS-DMA is in flight any more: plain loads are safe here
-#pragma unroll
-      for (int it = 0; it < 6; ++it) {
-        const int id = it * 64 + lane, row = id / 12, ch = id % 12;
-        const int q = min(q0 + row, a.Nq - 1);
-        qres[it] = *(const uint4*)(qa + (size_t)q * DA + ch * 8);
-      }
-    }
     STAMP(8 + t * 8 + 1);
     const unsigned so = (t % NS) * STAGE;
     const unsigned kaddr[2] = {kaddr0[0] + so, kaddr0[1] + so};
     const unsigned vaddr[2] = {vaddr0[0] + so, vaddr0[1] + so};
-    // V^T fragments of key group g (16 keys: kb = g>>1, sp = g&1), 3 panels x (lo, hi)
-    s16x4_t vt[2][6];
-    auto issue_v = [&](auto Gi, s16x4_t (&d)[6]) {
-      constexpr int g = decltype(Gi)::value;
-      static_for<0, 3>([&](auto J) {
-        constexpr int j = decltype(J)::value;
-        lds_read_tr<g * 16 * 64 + j * KT * 64>(d[2 * j], vaddr[0]);
-        lds_read_tr<g * 16 * 64 + j * KT * 64>(d[2 * j + 1], vaddr[1]);
-      });
+    // V^T fragments: item i = 3 * g + j is key group g (16 keys), value panel j
+    TrStream<6 * NKB, 3> vs;
+    auto rdv = [&](auto J, s16x4_t& lo, s16x4_t& hi) {
+      constexpr int i = decltype(J)::value, g = i / 3, j = i % 3;
+      lds_read_tr<g * 16 * 64 + j * KT * 64>(lo, vaddr[0]);
+      lds_read_tr<g * 16 * 64 + j * KT * 64>(hi, vaddr[1]);
     };
-    issue_v(Int<0>{}, vt[0]);        // lands under the whole QK^T + softmax phase
-    // ---- S^T = ka . qa^T for the two 32-key blocks of the tile --------------------------
+    vs.prologue(rdv);                // lands under the whole QK^T + softmax phase
+    // ---- S^T = ka . qa^T - m for the 32-key blocks of the tile ---------------------------
     f32x16_t s[2];
-    bf16x8_t kf[2][G];
-    auto issue_k = [&](auto Ci, bf16x8_t (&d)[G]) {
-      constexpr int cc = decltype(Ci)::value;
-      static_for<0, G>([&](auto J) {
-        constexpr int j = cc * G + decltype(J)::value, kb = j / KSU, ks = j % KSU;
-        lds_read128<kb * 2048 + (ks >> 1) * KT * 64>(d[decltype(J)::value], kaddr[ks & 1]);
-      });
+    RowStream<KSU * NKB, 4> ks_;
+    auto rdk = [&](auto J, bf16x8_t& d) {
+      constexpr int j = decltype(J)::value, kb = j / KSU, ks = j % KSU;
+      lds_read128<kb * 2048 + (ks >> 1) * KT * 64>(d, kaddr[ks & 1]);
     };
-    issue_k(Int<0>{}, kf[0]);
-    static_for<0, NC>([&](auto Ci) {
-      constexpr int cc = decltype(Ci)::value;
-      if constexpr (cc + 1 < NC) {
-        issue_k(Int<cc + 1>{}, kf[(cc + 1) & 1]);
-        lgkm_release_n<G>(kf[cc & 1]);          // chunk cc landed; chunk cc+1 stays in flight
-      } else {
-        lgkm_release_n<0>(kf[cc & 1]);
-      }
-      static_for<0, G>([&](auto J) {
-        constexpr int j = cc * G + decltype(J)::value, kb = j / KSU, ks = j % KSU;
-        if constexpr (ks == 0) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-        }
-        s[kb] = mfma32(kf[cc & 1][decltype(J)::value], qf[ks], s[kb]);
-      });
-      __builtin_amdgcn_sched_barrier(0);   // keep chunk cc's MFMAs here: they cover chunk cc+1's flight
+    ks_.prologue(rdk);
+    ks_.run(rdk, [&](auto J, const bf16x8_t& f) {
+      constexpr int j = decltype(J)::value, kb = j / KSU, ks = j % KSU;
+      s[kb] = mfma32(f, qf[ks], ks == 0 ? negm : s[kb]);
     });
     STAMP(8 + t * 8 + 2);
     const int kbase = t * KT;
-    if (kbase + KT > a.Nk) {  // ragged last tile: rows >= Nk are zero-filled by the descriptor
+    if (kbase + KT > a.Nk) {  // ragged last tile (uniform branch): rows >= Nk hold re-read data
+      asm volatile("; ragged key rows" ::: "memory");
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (kbase + kb * 32 + acc_row(r, lane) >= a.Nk) s[kb][r] = -INFINITY;
     }
-    // ---- online softmax: lane = one query, its two halves hold disjoint key rows ---------
-    float mx = max3(s[0][0], s[1][0], s[0][1]);
-    mx = max3(mx, s[1][1], s[0][2]);
+    // ---- online softmax: lane = one query, its two halves hold disjoint key rows; s is already
+    // relative to the running maximum ------------------------------------------------------
+    float mx;
+    if constexpr (HALF) {
+      mx = max3(s[0][0], s[0][1], s[0][2]);
 #pragma unroll
-    for (int r = 2; r < 15; ++r) mx = max3(mx, s[1][r], s[0][r + 1]);
-    mx = fmaxf(mx, s[1][15]);
-    mx = fmaxf(mx, other_half(mx)) * c;
+      for (int r = 3; r < 15; r += 2) mx = max3(mx, s[0][r], s[0][r + 1]);
+      mx = fmaxf(mx, s[0][15]);
+    } else {
+      mx = max3(s[0][0], s[1][0], s[0][1]);
+      mx = max3(mx, s[1][1], s[0][2]);
+#pragma unroll
+      for (int r = 2; r < 15; ++r) mx = max3(mx, s[1][r], s[0][r + 1]);
+      mx = fmaxf(mx, s[1][15]);
+    }
+    mx = fmaxf(mx, other_half(mx));
     // defer-max: only re-base when the max grew by more than 2^RESCALE_THR; until then P is
     // bounded by 2^THR instead of 1, which fp32 accumulation absorbs (cdna guide T13).  The
-    // previous tile's P.V is complete at this point, so O and l carry exactly one scale.
+    // previous tile's P.V is complete at this point, so O and l carry exactly one scale.  The
+    // first tile always re-bases (m_run starts at 0, which may be far ABOVE every score).
     constexpr float RESCALE_THR = 6.0f;
-    if (!__all(mx - m_run <= RESCALE_THR)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = fast_exp2(m_run - m_new);
-      lacc[0] *= alpha;
-      m_run = m_new;
+    if (t == 0 || !__all(mx <= RESCALE_THR)) {
+      asm volatile("; re-base" ::: "memory");
+      const float shift = t == 0 ? mx : fmaxf(mx, 0.f);      // m_new - m_run
+      if (t > 0) {
+        const float alpha = fast_exp2(-shift);
+        lacc[0] *= alpha;
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[j][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[j][r] *= alpha;
+      }
+      m_run += shift;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] -= shift;
     }
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = fast_exp2(__builtin_fmaf(s[kb][r], c, -m_run));
+      for (int r = 0; r < 16; ++r) s[kb][r] = fast_exp2(s[kb][r]);
     STAMP(8 + t * 8 + 3);
-    // ---- O^T += V^T . P^T (and l += 1^T P^T): group g+1's fragments are read while group g
-    // multiplies ---------------------------------------------------------------------------
-    __builtin_amdgcn_sched_barrier(0);   // no compiler-issued LDS op may slip between my counted waits
-    static_for<0, 4>([&](auto Gi) {
-      constexpr int g = decltype(Gi)::value, kb = g >> 1, sp = g & 1;
-      if constexpr (g + 1 < 4) {
-        issue_v(Int<g + 1>{}, vt[(g + 1) & 1]);
-        lgkm_release<6>(vt[g & 1]);
-      } else {
-        lgkm_release<0>(vt[g & 1]);
-      }
-      const bf16x8_t pf = acc_to_frag(s[kb], sp);
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        o[j] = mfma32(make_bf16x8(vt[g & 1][2 * j], vt[g & 1][2 * j + 1]), pf, o[j]);
-      lacc = mfma32(onesf, pf, lacc);
-      __builtin_amdgcn_sched_barrier(0);
+    // ---- O^T += V^T . P^T (and l += 1^T P^T) ------------------------------------------------
+    const bf16x8_t pf[4] = {acc_to_frag(s[0], 0), acc_to_frag(s[0], 1),
+                            HALF ? acc_to_frag(s[0], 0) : acc_to_frag(s[1], 0),
+                            HALF ? acc_to_frag(s[0], 1) : acc_to_frag(s[1], 1)};
+    vs.run(rdv, [&](auto J, const bf16x8_t& f) {
+      constexpr int i = decltype(J)::value, g = i / 3, j = i % 3;
+      o[j] = mfma32(f, pf[g], o[j]);
+      if constexpr (j == 2) lacc = mfma32(onesf, pf[g], lacc);
     });
     STAMP(8 + t * 8 + 4);
-  }
+  };
+  for (int t = 0; t + 1 < nt; ++t) tile(t, Int<0>{});
+  if (a.Nk - (nt - 1) * KT > 32) tile(nt - 1, Int<0>{});
+  else tile(nt - 1, Int<1>{});
 #ifdef SVIT_ATTN_STAMPS
   if (stamp_on) { g_attn_stamps[2] = __builtin_readcyclecounter(); g_attn_stamps[3] = wall_clock64(); }
 #endif
 
   // ---- epilogue: normalise, stage the wave's 32 x 96 tile in LDS, store whole rows with the
   // pooled query added (residual pooling), merge heads ---------------------------------------
+  // residual-pooling operand (the pooled q rows, in the row-major chunk order of the output
+  // stores): no LDS-DMA is in flight any more, plain loads are safe; they travel under the staging
+  uint4 qres[6];
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int id = it * 64 + lane, row = id / 12, ch = id % 12;
+    const int q = min(q0 + row, a.Nq - 1);
+    qres[it] = *(const uint4*)(qa + (size_t)q * DA + ch * 8);
+  }
   const float l_lo = __shfl(lacc[0], lane & 31, 64);   // row 0 of the sum block lives in lanes 0..31
   const float inv = 1.f / l_lo;
   if (hh == 0 && qi < a.Nq) a.lse2[(size_t)bh * a.Nq + qi] = m_run + log2f(l_lo);

@@ -111,12 +111,13 @@ __device__ __forceinline__ void pool_ln_finish(const svit_pool_args& a, float (&
   if (sub == 0 && a.mean) { a.mean[orow] = mean; a.rstd[orow] = rstd; }
   bf16_t* outp = (bf16_t*)a.out + orow * a.ld_out + c0;
   bf16_t* prep = a.pre ? (bf16_t*)a.pre + orow * HD + c0 : nullptr;   // NULL: nothing saved
+  const float osc = a.out_scale != 0.f ? a.out_scale : 1.f;
 #pragma unroll
   for (int v = 0; v < 3; ++v) {
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-      o[e] = (acc[v * 8 + e] - mean) * rstd * a.gamma[c0 + v * 8 + e] + a.beta[c0 + v * 8 + e];
+      o[e] = ((acc[v * 8 + e] - mean) * rstd * a.gamma[c0 + v * 8 + e] + a.beta[c0 + v * 8 + e]) * osc;
     *(uint4*)(outp + v * 8) = pack8(o);
     if (prep) *(uint4*)(prep + v * 8) = pack8(&acc[v * 8]);
   }
@@ -349,12 +350,13 @@ __device__ __forceinline__ void pool_tiled_body(
         if (wave == 0 && fa->mean) { fa->mean[orow] = mean; fa->rstd[orow] = rstd; }
         bf16_t* outp = (bf16_t*)fa->out + orow * fa->ld_out + c0;
         bf16_t* prep = fa->pre ? (bf16_t*)fa->pre + orow * HD + c0 : nullptr;
+        const float osc = fa->out_scale != 0.f ? fa->out_scale : 1.f;
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
           float o8[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e)
-            o8[e] = (acc[v * 8 + e] - mean) * rstd * fa->gamma[c0 + v * 8 + e] + fa->beta[c0 + v * 8 + e];
+            o8[e] = ((acc[v * 8 + e] - mean) * rstd * fa->gamma[c0 + v * 8 + e] + fa->beta[c0 + v * 8 + e]) * osc;
           *(uint4*)(outp + v * 8) = pack8(o8);
           if (prep) *(uint4*)(prep + v * 8) = pack8(&acc[v * 8]);
         }

@@ -18,6 +18,11 @@ from .input import U8Clips
 HD = arch.HEAD_DIM
 F32, BF16 = torch.float32, torch.bfloat16
 SCALE = HD ** -0.5
+LOG2E = 1.4426950408889634
+# the pooled keys leave the pooling kernel multiplied by scale * log2(e) and the rel-pos columns of qa
+# carry log2(e) * (q . R): qa . ka^T is then the attention score in the log2 domain and the fused
+# attention kernels exponentiate it without a multiply (csrc/attn_fwd.hip)
+K_SCALE = SCALE * LOG2E
 
 
 def _align(n, a=8):
@@ -309,7 +314,7 @@ class Engine:
             qkv, [f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
             [f.p(pre + "attn.norm_%s.weight" % r) for r in "qkv"],
             [f.p(pre + "attn.norm_%s.bias" % r) for r in "qkv"],
-            B, h, thw, n_obj, (sq, skv, skv), (DA, DA, HD), (0, 1, 0), save=save,
+            B, h, thw, n_obj, (sq, skv, skv), (DA, DA, HD), (0, 1, 0), save=save, out_scales=(1.0, K_SCALE, 1.0),
             sels=f.sels(pre) if thw[1] * thw[2] >= f.TILED_MIN_PLANE else None)
         qa, ka, v = pools[0][0], pools[1][0], pools[2][0]
         idx, mats, mcat, need = self._rel(blk, q_thw, k_thw)
@@ -324,7 +329,7 @@ class Engine:
             tabs = [r32[rows_off[0]:rows_off[0] + need[0]], r32[rows_off[1]:rows_off[1] + need[1]],
                     r32[rows_off[2]:rows_off[2] + need[2]]]
         P = ops.gemm_nt(qa.view(B * h * Nq, DA)[:, :HD], rcat, None, hip.EPI_BF16)
-        ops.relpos_gather(P, qa, idx, rows_off, B, h, q_thw, k_thw, n_obj, 1.0 / SCALE)
+        ops.relpos_gather(P, qa, idx, rows_off, B, h, q_thw, k_thw, n_obj, LOG2E)
         ctx, lse2 = ops.attn_fwd(qa, ka, v, SCALE, bias_cols=J)
         pool_idx = None
         if blk.has_proj:
@@ -481,7 +486,8 @@ class Engine:
                                 pre + "attn.proj.bias", True, epilogue=hip.EPI_BF16)
         (qa, preq, mq, rq), (ka, prek, mk, rk), (v, prev, mv, rv) = sv["pools"]
         dqa, dk, dv = ops.attn_bwd(qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE,
-                                   q_splits=1 if self.deterministic else self.attn_q_splits)
+                                   q_splits=1 if self.deterministic else self.attn_q_splits,
+                                   bias_cols=sum(sv["k_thw"]))
         # rel-pos backward as GEMMs over the scattered matrix D [tokens, Lpad]
         tabs, mats = sv["tabs"], sv["mats"]
         names = (pre + "attn.rel_pos_h", pre + "attn.rel_pos_w", pre + "attn.rel_pos_t")
@@ -493,7 +499,7 @@ class Engine:
             for o, t in zip(offs, tabs):
                 rcat[o:o + t.shape[0]] = t
             rcat_t = rcat.t().contiguous().to(BF16)
-        D = ops.relpos_scatter(dqa, sv["idx"], offs, lpad, B, h, q_thw, k_thw, n_obj, 1.0 / SCALE)
+        D = ops.relpos_scatter(dqa, sv["idx"], offs, lpad, B, h, q_thw, k_thw, n_obj, LOG2E)
         qa2 = qa.view(B * h * Nq, qa.shape[-1])
         for n, m, t, o in zip(names, mats, tabs, offs):
             rows = t.shape[0]

@@ -37,7 +37,7 @@ class PoolArgs(C.Structure):
     _fields_ = [("qkv", vp), ("which", i32), ("conv_w", vp), ("gamma", vp), ("beta", vp),
                 ("out", vp), ("ld_out", i32), ("pre", vp), ("mean", vp), ("rstd", vp),
                 ("B", i32), ("heads", i32), ("T", i32), ("H", i32), ("W", i32), ("n_obj", i32),
-                ("stride_hw", i32), ("mode", i32), ("eps", f32)]
+                ("stride_hw", i32), ("mode", i32), ("eps", f32), ("out_scale", f32)]
 
 
 class PoolLnBwdArgs(C.Structure):
@@ -98,7 +98,8 @@ class AttnFwdArgs(C.Structure):
 class AttnBwdArgs(C.Structure):
     _fields_ = [("qa", vp), ("ka", vp), ("v", vp), ("ctx", vp), ("dctx", vp), ("lse2", vp),
                 ("delta", vp), ("dqa", vp), ("dk", vp), ("dv", vp), ("B", i32), ("heads", i32),
-                ("Nq", i32), ("Nk", i32), ("DA", i32), ("q_splits", i32), ("scale", f32)]
+                ("Nq", i32), ("Nk", i32), ("DA", i32), ("q_splits", i32), ("scale", f32),
+                ("bias_cols", i32)]
 
 
 _SIGS = {

@@ -239,7 +239,7 @@ def pooled(n, s):
 
 
 def _pool_fwd_args(a, qkv, which, conv_w, gamma, beta, B, heads, thw, n_obj, stride_hw, ld_out, mode,
-                   eps, save=True):
+                   eps, save=True, out_scale=1.0):
     _chk_dev(qkv, conv_w, gamma, beta)
     T, H, W = thw
     Nout = 1 + T * pooled(H, stride_hw) * pooled(W, stride_hw) + n_obj
@@ -251,16 +251,16 @@ def _pool_fwd_args(a, qkv, which, conv_w, gamma, beta, B, heads, thw, n_obj, str
     a.qkv, a.which, a.conv_w, a.gamma, a.beta = ptr(qkv), which, ptr(conv_w), ptr(gamma), ptr(beta)
     a.out, a.ld_out, a.pre, a.mean, a.rstd = ptr(out), ld_out, ptr(pre), ptr(mean), ptr(rstd)
     a.B, a.heads, a.T, a.H, a.W, a.n_obj = B, heads, T, H, W, n_obj
-    a.stride_hw, a.mode, a.eps = stride_hw, mode, eps
+    a.stride_hw, a.mode, a.eps, a.out_scale = stride_hw, mode, eps, out_scale
     return out, pre, mean, rstd
 
 
 def pool_ln_fwd(qkv, which, conv_w, gamma, beta, B, heads, thw, n_obj, stride_hw, ld_out=HD,
-                mode=0, eps=1e-6):
+                mode=0, eps=1e-6, out_scale=1.0):
     """-> out bf16 [B,h,Nout,ld_out], pre bf16 [B,h,Nout,96], mean, rstd f32 [B*h*Nout]."""
     a = hip.PoolArgs()
     res = _pool_fwd_args(a, qkv, which, conv_w, gamma, beta, B, heads, thw, n_obj, stride_hw,
-                         ld_out, mode, eps)
+                         ld_out, mode, eps, out_scale=out_scale)
     hip.call("svit_pool_ln_fwd", C.byref(a))
     return res
 
@@ -281,13 +281,14 @@ def _sel_ptrs(sels):
 
 
 def pool_ln_fwd_qkv(qkv, conv_ws, gammas, betas, B, heads, thw, n_obj, strides, ld_outs, modes,
-                    eps=1e-6, save=True, sels=None):
+                    eps=1e-6, save=True, sels=None, out_scales=(1.0, 1.0, 1.0)):
     """q, k, v pooling + LayerNorm in one launch -> [(out, pre, mean, rstd)] * 3 (the last three
     are None with save=False: no-grad passes keep nothing for a backward).  sels: the three
     selector tables (pool_weight_sel) -- stride-1 tensors then run the LDS-tiled stencil."""
     arr = (hip.PoolArgs * 3)()
     res = [_pool_fwd_args(arr[i], qkv, i, conv_ws[i], gammas[i], betas[i], B, heads, thw, n_obj,
-                          strides[i], ld_outs[i], modes[i], eps, save) for i in range(3)]
+                          strides[i], ld_outs[i], modes[i], eps, save, out_scale=out_scales[i])
+           for i in range(3)]
     if sels is None:
         hip.call("svit_pool_ln_fwd_qkv", arr)
     else:
@@ -455,7 +456,7 @@ def attn_fwd(qa, ka, v, scale, bias_cols=0):
     return ctx, lse2
 
 
-def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0):
+def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0, bias_cols=0):
     """-> dqa bf16 [B,h,Nq,DA], dk f32 [B,h,Nk,96], dv f32 [B,h,Nk,96]."""
     _chk_dev(qa, ka, v, ctx, dctx, lse2)
     B, heads, Nq, DA = qa.shape
@@ -468,6 +469,7 @@ def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0):
     a.qa, a.ka, a.v, a.ctx, a.dctx, a.lse2 = (ptr(t) for t in (qa, ka, v, ctx, dctx, lse2))
     a.delta, a.dqa, a.dk, a.dv = ptr(delta), ptr(dqa), ptr(dkv[0]), ptr(dkv[1])
     a.B, a.heads, a.Nq, a.Nk, a.DA, a.q_splits, a.scale = B, heads, Nq, Nk, DA, q_splits, scale
+    a.bias_cols = bias_cols
     hip.call("svit_attn_bwd", C.byref(a), meta=("attn", B, heads, Nq, Nk, DA))
     return dqa, dkv[0], dkv[1]
 

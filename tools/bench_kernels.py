@@ -34,6 +34,9 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3  # us
 
 
+KSC = (96 ** -0.5) * 1.4426950408889634   # the pooled keys carry scale * log2(e) (engine.K_SCALE)
+
+
 def rnd(*shape, dtype=BF16):
     return (torch.randn(*shape, device=DEV) * 0.5).to(dtype)
 
@@ -91,7 +94,7 @@ def bench_tn():
 def bench_attn():
     print("== attention (fwd / bwd) ==")
     for blk, Nin, Nq, Nk, Ci, Co, h, DA in BLOCKS:
-        qa, ka, v = rnd(B, h, Nq, DA), rnd(B, h, Nk, DA), rnd(B, h, Nk, 96)
+        qa, ka, v = rnd(B, h, Nq, DA), (rnd(B, h, Nk, DA).float() * KSC).to(BF16), rnd(B, h, Nk, 96)
         scale = 96 ** -0.5
         us = timeit(lambda: ops.attn_fwd(qa, ka, v, scale))
         alg = 2.0 * B * h * Nq * Nk * 192
@@ -118,7 +121,7 @@ def bench_attn_fwd():
     mult = {0: 1, 1: 1, 2: 1, 3: 1, 4: 10, 14: 1, 15: 1}
     for blk, Nin, Nq, Nk, Ci, Co, h, DA in BLOCKS:
         J = 22 if DA == 128 else 36
-        qa, ka, v = rnd(B, h, Nq, DA), rnd(B, h, Nk, DA), rnd(B, h, Nk, 96)
+        qa, ka, v = rnd(B, h, Nq, DA), (rnd(B, h, Nk, DA).float() * KSC).to(BF16), rnd(B, h, Nk, 96)
         qa[..., 96 + J:] = 0
         ka[..., 96 + J:] = 0
         scale = 96 ** -0.5
@@ -299,7 +302,7 @@ def bench_attn_splits():
     """attention backward: forced query-split counts of the dkv kernel (us, whole backward)."""
     print("== attn_bwd us by q_splits (0 = heuristic) ==")
     for blk, Nin, Nq, Nk, Ci, Co, h, DA in BLOCKS:
-        qa, ka, v = rnd(B, h, Nq, DA), rnd(B, h, Nk, DA), rnd(B, h, Nk, 96)
+        qa, ka, v = rnd(B, h, Nq, DA), (rnd(B, h, Nk, DA).float() * KSC).to(BF16), rnd(B, h, Nk, 96)
         scale = 96 ** -0.5
         ctx, lse2 = ops.attn_fwd(qa, ka, v, scale)
         dctx = rnd(B, Nq, h * 96)
