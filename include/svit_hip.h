@@ -173,6 +173,8 @@ typedef struct {
   void* dpre; float* dgamma; float* dbeta;
   int32_t B, heads, Nout;
   float* workspace; int64_t workspace_floats;   /* scratch for the two-stage dgamma/dbeta sum */
+  int32_t main_parts; int64_t main_part_stride; /* f32 d_main only: sum of main_parts planes, main_part_stride
+                                                 * floats apart (svit_attn_bwd's dk / dv); 0 / 1 = one plane */
 } svit_pool_ln_bwd_args;
 int svit_pool_ln_bwd(const svit_pool_ln_bwd_args* a, void* stream);
 /* backward, step 2: depthwise-conv dgrad (gather form) + cls/object rows ->
@@ -289,11 +291,17 @@ typedef struct {
   const void* qa; const void* ka; const void* v; const void* ctx; const void* dctx;
   const float* lse2; float* delta;  /* delta: f32 [B,h,2,Nq] scratch (-lse2/c and -rowsum(dO*O) planes) */
   void* dqa;                        /* bf16 [B,h,Nq,DA]                                  */
-  float* dk; float* dv;             /* f32 [B,h,Nk,96], OVERWRITTEN (cleared inside when split) */
+  float* dk; float* dv;             /* f32 [parts,B,h,Nk,96], OVERWRITTEN: parts = svit_attn_bwd_parts(args)
+                                     * partial planes (one per chunk of the query range) whose SUM is the
+                                     * gradient; svit_pool_ln_bwd adds them while it reads (main_parts) */
   int32_t B, heads, Nq, Nk, DA, q_splits; float scale;
   int32_t bias_cols;                /* as in svit_attn_fwd_args: kt + kh + kw, 0 = all DA - 96 */
 } svit_attn_bwd_args;
 int svit_attn_bwd(const svit_attn_bwd_args* a, void* stream);
+/* number of dk / dv planes svit_attn_bwd will write for these arguments (>= 1; only the shape fields,
+ * DA and q_splits are read; q_splits > 0 asks for that many, the result is what is actually used);
+ * negative = error code */
+int svit_attn_bwd_parts(const svit_attn_bwd_args* a);
 
 /* ---------------------------------------------------------- max-pool skip path (K7) ---- */
 /* MaxPool3d((1,3,3),(1,2,2),(0,1,1)) on patch tokens, cls/objects copied

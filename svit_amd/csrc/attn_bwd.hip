@@ -10,8 +10,11 @@
 //   2. dkv kernel: per 32-key wave (128 keys per block), sweep 64-query stages of a query
 //                  chunk: S, P, dP, dS with the KEY on the lane; dV^T += dO^T P, dK^T += Q^T dS
 //                  accumulate in registers over the whole sweep; chunks of the query range run
-//                  in different blocks and meet in fp32 atomics shaped as whole 384-byte rows
-//                  (transposed through LDS first -- row-per-lane atomics are ~17x slower).
+//                  in different blocks, each of which stores its partial dK / dV into its own
+//                  plane dk[part] / dv[part] with plain stores straight from the accumulator
+//                  registers; the consumer (svit_pool_ln_bwd, main_parts) adds the planes while it
+//                  reads them.  (Rounds 1-2 met in fp32 atomics behind an LDS transpose: in-kernel
+//                  stamps put that epilogue at 7-14 us of a 40 us launch.)  Bit-reproducible.
 // No N x N matrix is ever stored.  The residual-pooling path (ctx += q) contributes dctx to dq
 // outside these kernels (svit_pool_ln_bwd's d_res input).
 //
@@ -31,6 +34,21 @@
 #include <atomic>
 #include "attn_common.h"
 #include "../../include/svit_hip.h"
+
+#ifdef SVIT_ATTN_STAMPS   // tools/attn_bwd_stamps.py: wall-clock (100 MHz) stamps of workgroup 0 / wave 0
+__device__ unsigned long long g_bwd_stamps[64];
+extern "C" int svit_debug_attn_bwd_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_stamps), sizeof(unsigned long long) * n);
+}
+#define BSTAMP(slot)                                                                    \
+  do {                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    if (stamp_on) g_bwd_stamps[(slot)] = wall_clock64();                                \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+  } while (0)
+#else
+#define BSTAMP(slot) do {} while (0)
+#endif
 
 namespace {
 using namespace attn;
@@ -61,7 +79,7 @@ struct FragAddr {
 // wave's exp/convert VALU work overlaps the other's MFMAs.  KSU = k-steps of the S contraction
 // that carry data (6 + ceil(bias columns / 16)).
 template <int DA, int KSU>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args a, int zero_dkv) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args a) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int NP = DA / 32;
   constexpr int K_BYTES = KT * DA * 2, V_BYTES = KT * HD * 2, STAGE = K_BYTES + V_BYTES;
@@ -69,15 +87,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
   using VLoad = BufTile<KT, HD, 4>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-  if (zero_dkv) {   // the dkv launch that follows accumulates with atomics: clear dk / dv here
-    const size_t n4 = (size_t)a.B * a.heads * a.Nk * HD / 4;
-    const size_t nthr = (size_t)gridDim.x * gridDim.y * 256;
-    const size_t me = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid;
-    for (size_t i = me; i < n4; i += nthr) {
-      ((float4*)a.dk)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      ((float4*)a.dv)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
+#ifdef SVIT_ATTN_STAMPS
+  const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+#endif
+  BSTAMP(0);
   const int wgid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
   const int bh = wgid / gridDim.x, b = bh / a.heads, head = bh % a.heads;
   const int qtile = wgid % gridDim.x;
@@ -103,7 +116,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
     kload.issue_auto(krs, k0 * DA * 2u, DA, a.Nk - (int)k0, st, wave, lane);
     vload.issue_auto(vrs, k0 * HD * 2u, HD, a.Nk - (int)k0, st + K_BYTES, wave, lane);
   };
+  BSTAMP(1);
   issue(0);                          // travels while the register operands are fetched
+  BSTAMP(2);
 
   bf16x8_t qf[KSU], dof[6];
 #pragma unroll
@@ -160,10 +175,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
 #pragma unroll
   for (int r = 0; r < 16; ++r) { s_init[r] = CINIT ? -lse_p : 0.f; dp_init[r] = CINIT ? -dlt_p : 0.f; }
 
+  BSTAMP(3);
   for (int t = 0; t < nt; ++t) {
+    if (t < 4) BSTAMP(8 + 4 * t);
     wait_vmcnt<0>();                 // this wave's share of tile t has landed
+    if (t < 4) BSTAMP(9 + 4 * t);
     __builtin_amdgcn_s_barrier();    // everyone's share has; everyone is done with tile t-1
+    if (t < 4) BSTAMP(10 + 4 * t);
     if (t + 1 < nt) issue(t + 1);    // travels while tile t is consumed
+    if (t < 4) BSTAMP(11 + 4 * t);
     const unsigned so = (t & 1) * STAGE;
     const unsigned ra[2] = {fa.rowa[0] + so, fa.rowa[1] + so};
     const unsigned ta[2] = {fa.tra[0] + so, fa.tra[1] + so};
@@ -213,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
     });
   }
 
+  BSTAMP(4);
   // ---- epilogue: x ln 2, stage the wave's 32 x DA tile in LDS, store whole rows --------------
   __builtin_amdgcn_s_barrier();        // every wave is done with the K/V ring
   constexpr int OROW = DA * 2 + 16;    // bytes per staged row (pad spreads the banks)
@@ -237,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
     if (q0 + row < a.Nq)
       *(uint4*)(out + (size_t)(q0 + row) * DA + ch * 8) = *(const uint4*)(ost + row * OROW + ch * 16);
   }
+  BSTAMP(5);
 #endif
 }
 
@@ -255,8 +277,6 @@ __global__ __launch_bounds__(256 * NH, NH == 2 ? 1 : 2) void attn_bwd_dkv_kernel
   constexpr int Q_BYTES = QR * DA * 2, O_BYTES = QR * HD * 2;
   constexpr int STAGE = Q_BYTES + O_BYTES + 2 * QR * 4;   // [Q | dO | -lse2 | -delta]
   constexpr int NSTAGE = NH == 2 ? 3 : 2;
-  constexpr int OUT_LD = HD + 1;                          // padded fp32 transpose buffer
-  constexpr int NTHR = 256 * NH;
   constexpr int DR = DA == 160 ? 3 : 4, DT = DA == 160 ? 2 : 3;   // read-ahead depths (register budget)
   using QLoad = BufTile<QR, DA, 4 * NH>;
   using OLoad = BufTile<QR, HD, 4 * NH>;
@@ -264,6 +284,10 @@ __global__ __launch_bounds__(256 * NH, NH == 2 ? 1 : 2) void attn_bwd_dkv_kernel
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
   const int kg = wave & 3, qh = wave >> 2;                // key group, query half
+#ifdef SVIT_ATTN_STAMPS
+  const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+#endif
+  BSTAMP(32);
   // all key tiles / query splits of one (batch, head) on one XCD: they stream the same Q / dO
   const int wgid = xcd_remap((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
                              gridDim.x * gridDim.y * gridDim.z);
@@ -301,8 +325,10 @@ __global__ __launch_bounds__(256 * NH, NH == 2 ? 1 : 2) void attn_bwd_dkv_kernel
         (const __attribute__((address_space(1))) void*)(sc_g + (size_t)part * a.Nq + qrow),
         (__attribute__((address_space(3))) void*)(st + Q_BYTES + O_BYTES + part * 256), 4, 0, 0);
   };
+  BSTAMP(33);
   if (t_begin < t_end) issue(t_begin);
   if (NSTAGE == 3 && t_begin + 1 < t_end) issue(t_begin + 1);
+  BSTAMP(34);
 
   bf16x8_t kf[KSU], vf[6];
 #pragma unroll
@@ -321,6 +347,7 @@ __global__ __launch_bounds__(256 * NH, NH == 2 ? 1 : 2) void attn_bwd_dkv_kernel
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[j][r] = 0.f; dv[j][r] = 0.f; }
 
+  BSTAMP(35);
   // NH = 2: this wave's query half is fixed -- its offset lives in the base addresses.  NH = 1: both
   // halves are unrolled and their offsets are instruction immediates.
   FragAddr fa;
@@ -328,10 +355,14 @@ __global__ __launch_bounds__(256 * NH, NH == 2 ? 1 : 2) void attn_bwd_dkv_kernel
   const unsigned cba = (unsigned)(size_t)smem + Q_BYTES + O_BYTES + 16 * hh + (NH == 2 ? qh * 128 : 0);   // row 4*hh of the planes
 
   for (int t = t_begin; t < t_end; ++t) {
+    if (t - t_begin < 4) BSTAMP(44 + 4 * (t - t_begin));
     if (NSTAGE == 3 && t + 1 < t_end) wait_vmcnt<PER_STAGE>();   // all but the youngest stage's loads are done
     else wait_vmcnt<0>();
+    if (t - t_begin < 4) BSTAMP(45 + 4 * (t - t_begin));
     __builtin_amdgcn_s_barrier();
+    if (t - t_begin < 4) BSTAMP(46 + 4 * (t - t_begin));
     if (t + NSTAGE - 1 < t_end) issue(t + NSTAGE - 1);           // into the stage consumed last
+    if (t - t_begin < 4) BSTAMP(47 + 4 * (t - t_begin));
     const unsigned so = ((t - t_begin) % NSTAGE) * STAGE;
     const unsigned ra[2] = {fa.rowa[0] + so, fa.rowa[1] + so};
     const unsigned ta[2] = {fa.tra[0] + so, fa.tra[1] + so};
@@ -396,98 +427,107 @@ __global__ __launch_bounds__(256 * NH, NH == 2 ? 1 : 2) void attn_bwd_dkv_kernel
       });
     });
   }
+  BSTAMP(36);
+  // ---- epilogue: each lane holds, for its key row, four 16-byte runs of every 32-column block
+  // (columns 32j + 8g + 4hh + 0..3): they go to this block's dk / dv plane as they stand.  With two
+  // query halves the second half first hands its accumulators to the first through LDS, in
+  // register layout ([run][thread] float4: conflict-free both ways).
+  if (NH == 2) {
+    __syncthreads();                       // every wave is done with the ring
+    float4* xb = (float4*)smem;            // [2 tensors][12 runs][256 threads]
+    const int th = kg * 64 + lane;
+    if (qh == 1) {
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
+      for (int j = 0; j < 3; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dk[j][r] *= a.scale;
-  // ---- transpose through LDS so that every atomic wave-instruction adds whole rows; with two
-  // ---- query halves the second half adds its accumulators to the first half's in the buffer
-  float* obuf = (float*)smem;  // [128 keys][OUT_LD]
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
+        for (int g = 0; g < 4; ++g) {
+          xb[(j * 4 + g) * 256 + th] = make_float4(dk[j][4 * g], dk[j][4 * g + 1], dk[j][4 * g + 2], dk[j][4 * g + 3]);
+          xb[(12 + j * 4 + g) * 256 + th] = make_float4(dv[j][4 * g], dv[j][4 * g + 1], dv[j][4 * g + 2], dv[j][4 * g + 3]);
+        }
+    }
     __syncthreads();
     if (qh == 0) {
 #pragma unroll
       for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          obuf[(kg * 32 + (lane & 31)) * OUT_LD + j * 32 + acc_row(r, lane)] =
-              pass == 0 ? dk[j][r] : dv[j][r];
-    }
-    if (NH == 2) {
-      __syncthreads();
-      if (qh == 1) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            obuf[(kg * 32 + (lane & 31)) * OUT_LD + j * 32 + acc_row(r, lane)] +=
-                pass == 0 ? dk[j][r] : dv[j][r];
-      }
-    }
-    __syncthreads();
-    float* dst = (pass == 0 ? a.dk : a.dv) + ((size_t)bh * a.Nk) * HD;
-    if (gridDim.y == 1) {   // this block owns its keys outright: plain coalesced row stores
-      for (int i = tid; i < 128 * HD; i += NTHR) {
-        const int kr = i / HD, d = i % HD;
-        if (key0 + kr < a.Nk) dst[(size_t)(key0 + kr) * HD + d] = obuf[kr * OUT_LD + d];
-      }
-    } else {
-      for (int i = tid; i < 128 * HD; i += NTHR) {
-        const int kr = i / HD, d = i % HD;
-        if (key0 + kr < a.Nk) atomicAdd(dst + (size_t)(key0 + kr) * HD + d, obuf[kr * OUT_LD + d]);
-      }
+        for (int g = 0; g < 4; ++g) {
+          const float4 x = xb[(j * 4 + g) * 256 + th], y = xb[(12 + j * 4 + g) * 256 + th];
+          dk[j][4 * g] += x.x; dk[j][4 * g + 1] += x.y; dk[j][4 * g + 2] += x.z; dk[j][4 * g + 3] += x.w;
+          dv[j][4 * g] += y.x; dv[j][4 * g + 1] += y.y; dv[j][4 * g + 2] += y.z; dv[j][4 * g + 3] += y.w;
+        }
     }
   }
+  BSTAMP(37);
+  if (qh == 0 && ki < a.Nk) {
+    const size_t plane = (size_t)a.B * a.heads * a.Nk * HD;
+    const size_t row = ((size_t)by * a.B * a.heads + bh) * a.Nk + ki;
+    float* dkp = a.dk + row * HD + 4 * hh;
+    float* dvp = a.dv + row * HD + 4 * hh;
+    (void)plane;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *(float4*)(dkp + j * 32 + 8 * g) = make_float4(dk[j][4 * g] * a.scale, dk[j][4 * g + 1] * a.scale,
+                                                       dk[j][4 * g + 2] * a.scale, dk[j][4 * g + 3] * a.scale);
+        *(float4*)(dvp + j * 32 + 8 * g) = make_float4(dv[j][4 * g], dv[j][4 * g + 1], dv[j][4 * g + 2], dv[j][4 * g + 3]);
+      }
+  }
+  BSTAMP(38);
 #endif
 }
 
 static std::atomic<int> g_dkv_halves{0};   // tuning knob (svit_attn_debug_set(0, n)): 1 / 2, 0 = heuristic
 
-template <int DA, int KSU>
-int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
-  static SvitOnce once_dq, once_kv, once_kv2;
-  const size_t lds_out = (size_t)128 * (HD + 1) * 4;
-  size_t lds_dq = 2 * (size_t)(KT * DA * 2 + KT * HD * 2);
-  const size_t lds_dq_out = (size_t)4 * 32 * (DA * 2 + 16);
-  if (lds_dq < lds_dq_out) lds_dq = lds_dq_out;
-  const size_t stage = (size_t)(QR * DA * 2 + QR * HD * 2 + 2 * QR * 4);
-  size_t lds_kv = 2 * stage, lds_kv2 = 3 * stage;
-  if (lds_kv < lds_out) lds_kv = lds_out;
-  if (lds_kv2 < lds_out) lds_kv2 = lds_out;
-  if (int rc = svit_max_lds_once(once_dq, (const void*)attn_bwd_dq_kernel<DA, KSU>, lds_dq)) return rc;
-  if (int rc = svit_max_lds_once(once_kv, (const void*)attn_bwd_dkv_kernel<DA, KSU, 1>, lds_kv)) return rc;
-  if (int rc = svit_max_lds_once(once_kv2, (const void*)attn_bwd_dkv_kernel<DA, KSU, 2>, lds_kv2)) return rc;
+// how the query range of the dkv kernel is cut: (dkv waves / 4, effective number of parts)
+struct DkvPlan { int halves, splits, tiles_per_split; };
+static DkvPlan dkv_plan(const svit_attn_bwd_args& a) {
   const int key_blocks = (a.Nk + 127) / 128;
   const int base = key_blocks * a.B * a.heads;
   // two query halves (8 waves) where the launch leaves one 4-wave workgroup per CU anyway: the
   // short-key blocks (tools/bench_kernels.py attn)
   int halves = g_dkv_halves.load();
-  if (halves != 1 && halves != 2) halves = (DA == 128 && base <= 256) ? 2 : 1;
+  if (halves != 1 && halves != 2) halves = (a.DA == 128 && base <= 256) ? 2 : 1;
   const int nqt = (a.Nq + QR - 1) / QR;
   int splits = a.q_splits;
   if (splits <= 0) {
-    // every split adds a full [128 keys x 192] fp32 tile per block with atomics (~1.3 TB/s
-    // chip-wide), so split the query range only as far as needed to fill the chip
-    // (measured, tools/bench_kernels.py attnsplits: ~1 block per CU is the sweet spot), and
-    // keep >= 2 query stages per block to amortise the epilogue
+    // split the query range only as far as needed to fill the chip (~1 block per CU: every part is
+    // one more dk / dv plane for the consumer to read) and keep >= 2 query stages per block
     splits = (256 + base - 1) / base;
     if (splits > nqt / 2) splits = nqt / 2;
   }
   if (splits > nqt) splits = nqt;
   if (splits < 1) splits = 1;
-  int tiles_per_split = (nqt + splits - 1) / splits;
+  const int tiles_per_split = (nqt + splits - 1) / splits;
   splits = (nqt + tiles_per_split - 1) / tiles_per_split;
+  return {halves, splits, tiles_per_split};
+}
+
+template <int DA, int KSU>
+int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
+  static SvitOnce once_dq, once_kv, once_kv2;
+  size_t lds_dq = 2 * (size_t)(KT * DA * 2 + KT * HD * 2);
+  const size_t lds_dq_out = (size_t)4 * 32 * (DA * 2 + 16);
+  if (lds_dq < lds_dq_out) lds_dq = lds_dq_out;
+  const size_t stage = (size_t)(QR * DA * 2 + QR * HD * 2 + 2 * QR * 4);
+  size_t lds_kv = 2 * stage, lds_kv2 = 3 * stage;
+  const size_t lds_merge = (size_t)2 * 12 * 256 * 16;     // the halves' dk / dv hand-over
+  if (lds_kv2 < lds_merge) lds_kv2 = lds_merge;
+  if (int rc = svit_max_lds_once(once_dq, (const void*)attn_bwd_dq_kernel<DA, KSU>, lds_dq)) return rc;
+  if (int rc = svit_max_lds_once(once_kv, (const void*)attn_bwd_dkv_kernel<DA, KSU, 1>, lds_kv)) return rc;
+  if (int rc = svit_max_lds_once(once_kv2, (const void*)attn_bwd_dkv_kernel<DA, KSU, 2>, lds_kv2)) return rc;
+  const DkvPlan pl = dkv_plan(a);
+  const int key_blocks = (a.Nk + 127) / 128;
   if (((uintptr_t)a.dk | (uintptr_t)a.dv) & 15) return SVIT_ERR_ALIGN;
   hipLaunchKernelGGL((attn_bwd_dq_kernel<DA, KSU>), dim3((a.Nq + 127) / 128, a.B * a.heads), dim3(256),
-                     lds_dq, st, a, splits > 1 ? 1 : 0);
+                     lds_dq, st, a);
   SVIT_LAUNCH_CHECK();
-  if (halves == 2)
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DA, KSU, 2>), dim3(key_blocks, splits, a.B * a.heads), dim3(512),
-                       lds_kv2, st, a, tiles_per_split);
+  if (pl.halves == 2)
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DA, KSU, 2>), dim3(key_blocks, pl.splits, a.B * a.heads), dim3(512),
+                       lds_kv2, st, a, pl.tiles_per_split);
   else
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DA, KSU, 1>), dim3(key_blocks, splits, a.B * a.heads), dim3(256),
-                       lds_kv, st, a, tiles_per_split);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DA, KSU, 1>), dim3(key_blocks, pl.splits, a.B * a.heads), dim3(256),
+                       lds_kv, st, a, pl.tiles_per_split);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }
@@ -497,6 +537,20 @@ extern "C" int svit_attn_debug_set(int key, int val) {
   if (key == 0) g_dkv_halves = val;
   else return SVIT_ERR_ARG;
   return SVIT_OK;
+}
+
+static int check_bwd_args(const svit_attn_bwd_args* a) {
+  if (!a) return SVIT_ERR_ARG;
+  if (a->B <= 0 || a->heads <= 0 || a->Nq <= 0 || a->Nk <= 0) return SVIT_ERR_SHAPE;
+  if (a->B * a->heads > 65535) return SVIT_ERR_SHAPE;
+  if (a->DA != 128 && a->DA != 160) return SVIT_ERR_SHAPE;
+  if (a->bias_cols < 0 || a->bias_cols > a->DA - 96) return SVIT_ERR_ARG;
+  return SVIT_OK;
+}
+
+extern "C" int svit_attn_bwd_parts(const svit_attn_bwd_args* a) {
+  if (int rc = check_bwd_args(a)) return rc;
+  return dkv_plan(*a).splits;
 }
 
 extern "C" int svit_attn_bwd(const svit_attn_bwd_args* a, void* stream) {

@@ -493,11 +493,14 @@ __device__ __forceinline__ void pool_ln_bwd_body(const svit_pool_ln_bwd_args& a,
       mean = a.mean[row]; rstd = a.rstd[row];
       if (a.d_main) {
         if (a.main_is_f32) {
+          // main_parts planes (the attention backward's per-query-split partial dk / dv) are added here
           const float* p = (const float*)a.d_main + row * a.ld_main + c0;
+          for (int part = 0; part < (a.main_parts > 1 ? a.main_parts : 1); ++part, p += a.main_part_stride) {
 #pragma unroll
-          for (int v = 0; v < 6; ++v) {
-            const float4 f = *(const float4*)(p + v * 4);
-            d[v * 4] += f.x; d[v * 4 + 1] += f.y; d[v * 4 + 2] += f.z; d[v * 4 + 3] += f.w;
+            for (int v = 0; v < 6; ++v) {
+              const float4 f = *(const float4*)(p + v * 4);
+              d[v * 4] += f.x; d[v * 4 + 1] += f.y; d[v * 4 + 2] += f.z; d[v * 4 + 3] += f.w;
+            }
           }
         } else {
           const bf16_t* p = (const bf16_t*)a.d_main + row * a.ld_main + c0;

@@ -44,7 +44,8 @@ class PoolLnBwdArgs(C.Structure):
     _fields_ = [("d_main", vp), ("main_is_f32", i32), ("ld_main", i32), ("d_res", vp),
                 ("d_extra", vp), ("pre", vp), ("mean", vp), ("rstd", vp), ("gamma", vp),
                 ("dpre", vp), ("dgamma", vp), ("dbeta", vp), ("B", i32), ("heads", i32),
-                ("Nout", i32), ("workspace", vp), ("workspace_floats", i64)]
+                ("Nout", i32), ("workspace", vp), ("workspace_floats", i64), ("main_parts", i32),
+                ("main_part_stride", i64)]
 
 
 class PoolDgradArgs(C.Structure):
@@ -141,6 +142,7 @@ _SIGS = {
     "svit_relpos_gather": (i32, [C.POINTER(RelqGatherArgs), vp]),
     "svit_attn_fwd": (i32, [C.POINTER(AttnFwdArgs), vp]),
     "svit_attn_bwd": (i32, [C.POINTER(AttnBwdArgs), vp]),
+    "svit_attn_bwd_parts": (i32, [C.POINTER(AttnBwdArgs)]),
     "svit_maxpool_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "svit_maxpool_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "svit_sumsq": (i32, [vp, i64, vp, vp, i64, vp]),

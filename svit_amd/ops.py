@@ -302,6 +302,10 @@ def _pool_ln_bwd_args(a, pre, mean, rstd, gamma, dgamma, dbeta, B, heads, Nout, 
     a.d_main = ptr(d_main)
     a.main_is_f32 = int(d_main is not None and d_main.dtype == F32)
     a.ld_main = ld_main
+    a.main_parts, a.main_part_stride = 1, 0
+    if d_main is not None and d_main.dim() == 5:        # [parts, B, h, N, 96]: attn_bwd's partial planes
+        assert d_main.dtype == F32
+        a.main_parts, a.main_part_stride = d_main.shape[0], d_main.stride(0)
     a.d_res, a.d_extra = ptr(d_res), ptr(d_extra)
     a.pre, a.mean, a.rstd, a.gamma = ptr(pre), ptr(mean), ptr(rstd), ptr(gamma)
     a.dpre, a.dgamma, a.dbeta = ptr(dpre), ptr(dgamma), ptr(dbeta)
@@ -457,19 +461,25 @@ def attn_fwd(qa, ka, v, scale, bias_cols=0):
 
 
 def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0, bias_cols=0):
-    """-> dqa bf16 [B,h,Nq,DA], dk f32 [B,h,Nk,96], dv f32 [B,h,Nk,96]."""
+    """-> dqa bf16 [B,h,Nq,DA], dk f32 [parts,B,h,Nk,96], dv f32 [parts,B,h,Nk,96]: the gradients of k
+    and v are the SUMS over the leading axis (one plane per chunk of the query range; pool_ln_bwd
+    adds them while it reads)."""
     _chk_dev(qa, ka, v, ctx, dctx, lse2)
     B, heads, Nq, DA = qa.shape
     Nk = ka.shape[2]
     dev = qa.device
-    dqa = torch.empty((B, heads, Nq, DA), device=dev, dtype=BF16)
-    dkv = torch.empty((2, B, heads, Nk, HD), device=dev, dtype=F32)   # cleared by the library
-    delta = torch.empty((B, heads, Nq, 2), device=dev, dtype=F32)
     a = hip.AttnBwdArgs()
-    a.qa, a.ka, a.v, a.ctx, a.dctx, a.lse2 = (ptr(t) for t in (qa, ka, v, ctx, dctx, lse2))
-    a.delta, a.dqa, a.dk, a.dv = ptr(delta), ptr(dqa), ptr(dkv[0]), ptr(dkv[1])
     a.B, a.heads, a.Nq, a.Nk, a.DA, a.q_splits, a.scale = B, heads, Nq, Nk, DA, q_splits, scale
     a.bias_cols = bias_cols
+    parts = hip.load().svit_attn_bwd_parts(C.byref(a))
+    if parts < 1:
+        raise hip.SvitHipError("svit_attn_bwd_parts failed: %d" % parts)
+    dqa = torch.empty((B, heads, Nq, DA), device=dev, dtype=BF16)
+    dkv = torch.empty((2, parts, B, heads, Nk, HD), device=dev, dtype=F32)
+    delta = torch.empty((B, heads, Nq, 2), device=dev, dtype=F32)
+    a.qa, a.ka, a.v, a.ctx, a.dctx, a.lse2 = (ptr(t) for t in (qa, ka, v, ctx, dctx, lse2))
+    a.delta, a.dqa, a.dk, a.dv = ptr(delta), ptr(dqa), ptr(dkv[0]), ptr(dkv[1])
+    a.q_splits = parts
     hip.call("svit_attn_bwd", C.byref(a), meta=("attn", B, heads, Nq, Nk, DA))
     return dqa, dkv[0], dkv[1]
 

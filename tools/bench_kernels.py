@@ -299,18 +299,27 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tngroup":
 
 
 def bench_attn_splits():
-    """attention backward: forced query-split counts of the dkv kernel (us, whole backward)."""
-    print("== attn_bwd us by q_splits (0 = heuristic) ==")
+    """attention backward: forced (dkv waves, query-split) combinations (us, whole backward)."""
+    import ctypes as C
+    lib = hip.load()
+    lib.svit_attn_debug_set.restype, lib.svit_attn_debug_set.argtypes = C.c_int32, [C.c_int32, C.c_int32]
+    print("== attn_bwd us by q_splits (0 = heuristic), 4-wave | 8-wave dkv kernel ==")
     for blk, Nin, Nq, Nk, Ci, Co, h, DA in BLOCKS:
+        J = 22 if DA == 128 else 36
         qa, ka, v = rnd(B, h, Nq, DA), (rnd(B, h, Nk, DA).float() * KSC).to(BF16), rnd(B, h, Nk, 96)
         scale = 96 ** -0.5
-        ctx, lse2 = ops.attn_fwd(qa, ka, v, scale)
+        ctx, lse2 = ops.attn_fwd(qa, ka, v, scale, bias_cols=J)
         dctx = rnd(B, Nq, h * 96)
         res = []
-        for sp in (0, 1, 2, 3, 4, 6, 8):
-            us = timeit(lambda: ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=sp), iters=10)
-            res.append("%d:%.0f" % (sp, us))
-        print("blk%-2d h=%d Nq=%6d Nk=%5d  " % (blk, h, Nq, Nk) + "  ".join(res))
+        for halves in (0, 1, 2):
+            lib.svit_attn_debug_set(0, halves)
+            for sp in (0, 1, 2, 3, 4, 6, 8):
+                if halves == 0 and sp:
+                    continue
+                us = timeit(lambda: ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=sp, bias_cols=J), iters=10)
+                res.append("%dw/%d:%.0f" % (4 * halves, sp, us))
+        lib.svit_attn_debug_set(0, 0)
+        print("blk%-2d h=%d Nq=%6d Nk=%5d  " % (blk, h, Nq, Nk) + "  ".join(res), flush=True)
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "attnsplits":
