@@ -712,6 +712,8 @@ def main():
         run_model_case("c2_fwd", 16, 224, 1, args.out, manifest, backward=False)
     if on("c2"):       # the config the headline metric is quoted on: forward AND backward
         run_model_case("c2", 16, 224, 1, args.out, manifest)
+    if on("c2_drop"):  # the bench regime: B = 2, DropPath 0.4 + head dropout 0.5, the reference's own masks
+        run_model_case("c2_drop", 16, 224, 2, args.out, manifest, drop=True)
     if on("consistency"):
         run_consistency_case(args.out, manifest)
     if on("cfg"):

@@ -20,14 +20,15 @@ SOURCES = ["gemm_nt.hip", "gemm_tn.hip", "norm.hip", "misc.hip", "pool.hip", "at
            "loss.hip", "meter.hip", "input.hip"]
 HEADERS = ["common.h", "attn_common.h", "gemm_epilogue.h", os.path.join("..", "..", "include", "svit_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-# -fno-slp-vectorize: hipcc's SLP pass packs adjacent fp32 multiplies / adds into v_pk_*_f32.  One of
-# the forms it emits -- destination pair == a source pair, with op_sel / op_sel_hi crossing the
-# halves of that pair, e.g. `v_pk_mul_f32 v[10:11], v[4:5], v[10:11] op_sel:[0,1]` -- returned wrong
-# low halves on MI355X whenever waves of another kernel (the TN weight-gradient GEMM) were
-# co-resident on the SIMD: the pooling-conv weight gradient lost exactly the three taps computed
-# from such a result (profiles/r02_wgrad_overlap_rootcause.md; tools/diag/).  Scalar fp32 VALU code is
-# also what the CDNA guide recommends beside MFMAs.  check_isa() below refuses a build that still
-# contains the form.
+# -fno-slp-vectorize: hipcc's SLP pass packs adjacent fp32 multiplies / adds into v_pk_*_f32.  The
+# forms it emits that read a VGPR pair across its halves (op_sel / op_sel_hi), e.g.
+# `v_pk_mul_f32 v[10:11], v[4:5], v[10:11] op_sel:[0,1]`, return wrong results on MI355X at a rate
+# of ~6e-6 whenever waves of the TN weight-gradient GEMM -- or of hipBLASLt's GEMM -- are co-resident
+# (standalone reproducer tools/diag/slp_repro.hip, profiles/r03_packed_fp32_hazard.md; round 2 found
+# it as three lost taps of the pooling-conv weight gradient, profiles/r02_wgrad_overlap_rootcause.md).
+# The SLP build is also 0.3 % SLOWER per step (14.57 vs 14.51 ms, tools/diag/slp_ab.py), as the CDNA
+# guide predicts for packed fp32 beside MFMAs.  check_isa() below refuses a library that contains
+# such an instruction.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffast-math",
          "-fno-finite-math-only", "-fno-slp-vectorize", "-Wno-unused-result"]
 TMP_DIR = os.path.join(OUT_DIR, "tmp")
@@ -43,38 +44,76 @@ def _sel(rest, name, n, default):
 
 
 def hazardous_packed_f32(asm_text):
-    """[(line number, instruction)] of packed-fp32 VALU instructions whose destination pair is also
-    a source pair read ACROSS its halves (low result from the high register or vice versa)."""
+    """[(line number, instruction)] of packed-fp32 VALU instructions that read a VGPR pair ACROSS its
+    halves (low result from the high register or the high result from the low one: op_sel 1 /
+    op_sel_hi 0 on a VGPR-pair source).  Round 3 (tools/diag/slp_repro.hip,
+    profiles/r03_packed_fp32_hazard.md): every such form -- destination == source or not -- returned
+    wrong results at a rate of ~6e-6 while waves of the TN GEMM or of hipBLASLt's GEMM were
+    co-resident; no cross-half selection, or a cross-half selection on an SGPR pair (scalar
+    broadcast), never did.  Round 2 had only caught the in-place form."""
     bad = []
     for ln, line in enumerate(asm_text.splitlines(), 1):
         m = _PK.match(line)
         if not m:
             continue
-        d0, rest = int(m.group(2)), m.group(3)
+        rest = m.group(3).split("//")[0]
         ops = [o.strip() for o in re.split(r",\s*(?![^\[]*\])", rest.split(" op_sel")[0].split(" neg_")[0])]
         sel = _sel(rest, "op_sel", len(ops), 0) if re.search(r"op_sel:\[", rest) else [0] * len(ops)
         sel_hi = _sel(rest, "op_sel_hi", len(ops), 1)
         for i, o in enumerate(ops):
-            mm = re.match(r"v\[(\d+):\d+\]", o)
-            if mm and int(mm.group(1)) == d0 and (sel[i] == 1 or sel_hi[i] == 0):
-                bad.append((ln, line.strip()))
+            if re.match(r"v\[(\d+):\d+\]", o) and (sel[i] == 1 or sel_hi[i] == 0):
+                bad.append((ln, line.split("//")[0].strip()))
                 break
     return bad
 
 
-def check_isa():
-    """scan the device assembly kept by the last build (lib/tmp/*.s)"""
-    found = []
-    for src in SOURCES:
-        path = os.path.join(TMP_DIR, src.replace(".hip", "") + "-hip-amdgcn-amd-amdhsa-gfx950.s")
-        if os.path.exists(path):
-            with open(path) as f:
-                found += [(src, ln, ins) for ln, ins in hazardous_packed_f32(f.read())]
+LLVM_OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
+
+
+def disassemble(lib=None):
+    """Device code of the SHIPPED library as text: llvm-objdump unbundles the gfx950 code objects of
+    the .so (into a scratch copy's directory) and disassembles each.  -> (text, number of objects)"""
+    import shutil
+    import tempfile
+    lib = lib or LIB
+    tmp = tempfile.mkdtemp(prefix="svit_isa_")
+    try:
+        cp = os.path.join(tmp, "lib.so")
+        shutil.copy(lib, cp)
+        r = subprocess.run([LLVM_OBJDUMP, "--offloading", cp], capture_output=True, text=True, cwd=tmp)
+        if r.returncode != 0:
+            raise RuntimeError("llvm-objdump --offloading failed: %s" % r.stderr[-300:])
+        objs = sorted(f for f in os.listdir(tmp) if "amdgcn" in f and "gfx950" in f)
+        text = []
+        for f in objs:
+            d = subprocess.run([LLVM_OBJDUMP, "-d", "--no-show-raw-insn", os.path.join(tmp, f)],
+                               capture_output=True, text=True)
+            if d.returncode != 0:
+                raise RuntimeError("llvm-objdump -d failed on %s: %s" % (f, d.stderr[-300:]))
+            text.append(d.stdout)
+        return "\n".join(text), len(objs)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def check_isa(lib=None):
+    """Scan the device code of the library that SHIPS (disassembled from the .so itself, so the check
+    means the same on the GPU box, where the build's scratch assembly does not travel) for in-place
+    cross-half packed-fp32 instructions.  Raises if it finds one -- or if it could not look: a gate
+    that scanned nothing must not read as a pass.  -> number of code objects scanned."""
+    lib = lib or LIB
+    if not os.path.exists(LLVM_OBJDUMP):
+        raise RuntimeError("check_isa: %s not found -- the library's device code was NOT checked" % LLVM_OBJDUMP)
+    text, nobj = disassemble(lib)
+    if nobj < len(SOURCES) or "v_mfma_f32_32x32x16_bf16" not in text:
+        raise RuntimeError("check_isa: only %d gfx950 code objects found in %s (expected %d) -- not checked"
+                           % (nobj, lib, len(SOURCES)))
+    found = hazardous_packed_f32(text)
     if found:
         raise RuntimeError("in-place cross-half packed-fp32 instructions in the device code "
                            "(wrong results beside other kernels on gfx950):\n" +
-                           "\n".join("%s:%d %s" % x for x in found[:10]))
-    return True
+                           "\n".join("%d %s" % x for x in found[:10]))
+    return nobj
 
 
 def _newer(target, deps):

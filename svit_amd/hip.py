@@ -167,6 +167,10 @@ def load():
             raise SvitHipError(
                 "libsvit_hip.so not found at %s -- run `python -m svit_amd.build` "
                 "(the SViT HIP path has no PyTorch/CPU fallback)" % LIB_PATH)
+        if os.environ.get("SVIT_HIP_LIB"):
+            import warnings
+            warnings.warn("SVIT_HIP_LIB is set: loading the SViT HIP library from %s instead of the "
+                          "in-tree build" % LIB_PATH)
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)

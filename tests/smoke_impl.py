@@ -66,14 +66,21 @@ def compare_step(num_frames=4, crop=64, batch=2, frames_path=False, verbose=Fals
     named = dict(model.named_parameters())
     gmax = max(float(v.grad.abs().max()) for v in p.values() if v.grad is not None)
     worst, worst_name = 1.0, ""
-    ratio_lo, ratio_hi, ratio_name = 1.0, 1.0, ""          # tensors carrying >= 1 % of the gradient norm
-    small_lo, small_hi, small_name = 1.0, 1.0, ""          # the rest (few-sample rel-pos tables, ...)
+    # scale test per tensor: s = <got, ref> / <ref, ref> is the factor by which the gradient is
+    # reproduced along the reference direction (a DropPath factor applied twice or mean-vs-sum moves
+    # s and leaves the cosine at 1).  The part of `got` orthogonal to ref is noise of norm
+    # nu = |got| sqrt(1 - cos^2); its projection on the ref direction has standard deviation
+    # nu / sqrt(n) for a tensor of n elements, so  |s - 1| <= 3 % + 4 nu / (sqrt(n) |ref|)  is an
+    # absolute criterion that follows each tensor's own measured bf16 noise and sample count
+    # (a [15, 96] rel-pos table with cosine 0.993 gets 3 % + 1.3 %, a 2-D weight 3 % + ~0).
+    scale_excess, scale_name, scale_worst = -1.0, "", (1.0, 0.0)
     ref_total = sum(float((v.grad.double() ** 2).sum()) for v in p.values() if v.grad is not None) ** 0.5
     num = den_a = den_b = 0.0
     for k, v in p.items():
         ref = v.grad if v.grad is not None else torch.zeros_like(v)
         got = named[k].grad.detach().cpu()
-        num += float((got.double() * ref.double()).sum())
+        dot = float((got.double() * ref.double()).sum())
+        num += dot
         den_a += float((got.double() ** 2).sum())
         den_b += float((ref.double() ** 2).sum())
         if float(ref.abs().max()) < 1e-4 * gmax:   # mathematically ~zero (e.g. norm_k.bias)
@@ -82,38 +89,32 @@ def compare_step(num_frames=4, crop=64, batch=2, frames_path=False, verbose=Fals
         c = cosine(got, ref)
         if c < worst:
             worst, worst_name = c, k
-        # a scale error (a DropPath factor applied twice, mean-vs-sum) leaves the cosine at 1:
-        # the norms must agree too
-        r = float(got.double().norm() / ref.double().norm())
-        if float(ref.double().norm()) >= 1e-2 * ref_total:
-            if r < ratio_lo or r > ratio_hi:
-                ratio_name = k
-            ratio_lo, ratio_hi = min(ratio_lo, r), max(ratio_hi, r)
-        else:
-            if r < small_lo or r > small_hi:
-                small_name = k
-            small_lo, small_hi = min(small_lo, r), max(small_hi, r)
+        rn = float(ref.double().norm())
+        sc = dot / (rn * rn)
+        nu = float(got.double().norm()) * max(0.0, 1.0 - c * c) ** 0.5
+        tol = SCALE_TOL + 4.0 * nu / (max(1, ref.numel()) ** 0.5 * rn)
+        if abs(sc - 1.0) - tol > scale_excess:
+            scale_excess, scale_name, scale_worst = abs(sc - 1.0) - tol, k, (sc, tol)
         if verbose:
-            print("%-40s cos %.5f  |ref| %.3e |got| %.3e" % (k, c, float(ref.norm()), float(got.norm())))
+            print("%-40s cos %.5f  scale %.4f (tol %.4f)  |ref| %.3e |got| %.3e"
+                  % (k, c, sc, tol, float(ref.norm()), float(got.norm())))
     out["grad_cos_worst"] = worst
     out["grad_cos_worst_name"] = worst_name
     out["grad_cos_global"] = num / ((den_a ** 0.5) * (den_b ** 0.5) + 1e-30)
-    out["grad_norm_ratio_min"], out["grad_norm_ratio_max"] = ratio_lo, ratio_hi
-    out["grad_norm_ratio_name"] = ratio_name
-    out["grad_norm_ratio_small"] = (small_lo, small_hi, small_name)
+    out["grad_scale_excess"] = scale_excess            # <= 0: every tensor's scale is inside its band
+    out["grad_scale_worst"] = (scale_name,) + scale_worst
     out["grad_norm_ratio_global"] = (den_a / den_b) ** 0.5
     return out
 
 
 # stated tolerance of the bf16 HIP path against the fp32 oracle (BASELINE.json north_star;
 # SURVEY.md 8(c)): logits max-abs <= 0.05 and cosine >= 0.999; per-tensor grad cosine >= 0.99.
-# gradient norm ratio |got| / |ref|: [0.97, 1.03] per tensor that carries >= 1 % of the global
-# gradient norm, [0.94, 1.06] for the smaller ones (measured: the outliers are rel-pos tables
-# with <= 0.6 % of the norm in the tiny T' = 1 case, scattered on both sides of 1 -- bf16 noise
-# on few samples, not a scale error), [0.99, 1.01] for the whole gradient.
+# gradient scale per tensor (s = <got, ref> / <ref, ref>): |s - 1| <= 3 % + 4 sigma, sigma = the
+# standard deviation of s that the tensor's own orthogonal (noise) component implies (compare_step);
+# norm ratio of the whole gradient within [0.99, 1.01].
+SCALE_TOL = 0.03
 TOL = {"logits_maxabs": 0.05, "logits_cos": 0.999, "grad_cos": 0.99, "obj_desc_cos": 0.999,
-       "grad_norm_ratio": (0.97, 1.03), "grad_norm_ratio_small": (0.94, 1.06),
-       "grad_norm_ratio_global": (0.99, 1.01)}
+       "grad_scale": SCALE_TOL, "grad_norm_ratio_global": (0.99, 1.01)}
 
 
 def check(res):
@@ -122,10 +123,7 @@ def check(res):
     assert res["obj_desc_cos"] >= TOL["obj_desc_cos"], res
     assert res["grad_cos_worst"] >= TOL["grad_cos"], res
     assert res["grad_cos_global"] >= 0.995, res
-    lo, hi = TOL["grad_norm_ratio"]
-    assert lo <= res["grad_norm_ratio_min"] and res["grad_norm_ratio_max"] <= hi, res
-    lo, hi = TOL["grad_norm_ratio_small"]
-    assert lo <= res["grad_norm_ratio_small"][0] and res["grad_norm_ratio_small"][1] <= hi, res
+    assert res["grad_scale_excess"] <= 0.0, res
     lo, hi = TOL["grad_norm_ratio_global"]
     assert lo <= res["grad_norm_ratio_global"] <= hi, res
 

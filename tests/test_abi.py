@@ -55,17 +55,20 @@ def test_product_path_has_no_oracle_import():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
 
 
-def test_no_inplace_cross_half_packed_fp32_in_the_device_code():
-    """profiles/r02_wgrad_overlap_rootcause.md: `v_pk_*_f32` with destination pair == source pair
-    read across its halves gave wrong results beside the TN GEMM on MI355X.  The build keeps the
-    device assembly and refuses it; the scanner itself is checked on the offending instruction."""
+def test_no_cross_half_packed_fp32_in_the_device_code():
+    """profiles/r03_packed_fp32_hazard.md: `v_pk_*_f32` reading a VGPR pair across its halves
+    (op_sel / op_sel_hi) gave wrong results beside the TN GEMM and beside hipBLASLt on MI355X,
+    destination == source or not.  check_isa() disassembles the SHIPPED .so and refuses it; the
+    scanner itself is checked on the offending forms and on the two measured-clean ones."""
     from svit_amd import build
     bad = build.hazardous_packed_f32(
         "\tv_pk_mul_f32 v[10:11], v[4:5], v[10:11] op_sel:[0,1]\n"
         "\tv_pk_mul_f32 v[10:11], v[10:11], v[16:17] op_sel_hi:[1,0]\n"
         "\tv_pk_fma_f32 v[76:77], v[74:75], s[12:13], v[76:77] op_sel_hi:[1,0,0]\n"
-        "\tv_pk_add_f32 v[2:3], v[4:5], v[6:7]\n")
-    assert [ln for ln, _ in bad] == [1, 3]
+        "\tv_pk_add_f32 v[2:3], v[4:5], v[6:7]\n"
+        "\tv_pk_mul_f32 v[8:9], v[6:7], v[4:5] op_sel:[0,1]          // 000000001C34: D3B14008\n"
+        "\tv_pk_fma_f32 v[20:21], v[50:51], s[10:11], v[20:21] op_sel_hi:[1,0,1]\n")
+    assert [ln for ln, _ in bad] == [1, 2, 3, 5]
     assert "-fno-slp-vectorize" in build.FLAGS
     build.build()
-    assert build.check_isa()
+    assert build.check_isa() >= len(build.SOURCES)      # number of code objects actually scanned

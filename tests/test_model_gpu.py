@@ -90,7 +90,10 @@ def _grad_vs_golden(named_grads, digests, arrays, prefix):
         if c < worst_cos[0]:
             worst_cos = (c, k)
     print("worst cosine", worst_cos, "worst norm ratio", worst_ratio)
-    assert worst_cos[0] >= 0.985, worst_cos       # 256-element samples: a little noisier than full
+    # 0.985 on the 256-element strided samples (the fixture cannot hold 34 M gradients; a cosine
+    # estimated from 256 elements scatters by ~ (1 - c) / sqrt(128) around the full tensor's); the
+    # full-tensor criterion (cosine >= 0.99, scale within 3 % + 4 sigma) is tests/smoke_impl.py's
+    assert worst_cos[0] >= 0.985, worst_cos
     assert 0.97 <= worst_ratio[0] <= 1.03, worst_ratio
 
 
@@ -169,6 +172,35 @@ def test_droppath_and_dropout_masks(manifest, golden_dir):
     ref = torch.from_numpy(arrays["logits"])
     assert float((logits.detach().cpu() - ref).abs().max()) <= 2 * S.TOL["logits_maxabs"]
     assert S.cosine(logits.detach(), ref) >= S.TOL["logits_cos"]
+
+
+def test_bench_regime_droppath_vs_reference_golden(manifest, golden_dir):
+    """The regime bench.py times -- 16x224^2, B = 2, DropPath 0.4 and head dropout 0.5 ON -- against
+    the reference's own forward + backward with the reference's own masks replayed
+    (tests/golden/c2_drop.npz: per-block per-sample DropPath factors, the dropout keep mask, logits,
+    loss, norms + strided samples of all 405 gradients)."""
+    case = manifest["cases"]["c2_drop"]
+    cfg, model, spec, sd = S.build_hip_model(16, 224, drop=True)
+    arrays = np.load(os.path.join(golden_dir, "c2_drop.npz"))
+    x, y = P.frames(case["batch"], 16, 224), P.labels(case["batch"])
+    ds = []
+    for i in range(16):
+        if "dp_attn_%d" % i in arrays:
+            ds.append((torch.from_numpy(arrays["dp_attn_%d" % i]).cuda().contiguous(),
+                       torch.from_numpy(arrays["dp_mlp_%d" % i]).cuda().contiguous()))
+        else:
+            ds.append(None)
+    keep = torch.from_numpy(arrays["dropout_keep"]).cuda()
+    logits, extra = model([x.cuda()], {}, drop_scales=ds, dropout_keep=keep)
+    loss = torch.nn.functional.cross_entropy(logits, y.cuda())
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(arrays["logits"])
+    assert float((logits.detach().cpu() - ref).abs().max()) <= 2 * S.TOL["logits_maxabs"]
+    assert S.cosine(logits.detach(), ref) >= S.TOL["logits_cos"]
+    assert abs(float(loss.detach()) - float(arrays["loss"])) < 3e-2
+    _grad_vs_golden({k: v.grad for k, v in model.named_parameters()}, case["digests"], arrays, "grad:")
 
 
 def test_state_dict_layout_and_interface():

@@ -59,7 +59,7 @@ def run_case(case, name, golden_dir, backward):
 
 
 @pytest.mark.parametrize("name", ["tiny", "tiny_drop", "tiny_odd", "tiny_frames", "c1",
-                                  "c2_fwd", "c2_frames", "c2"])
+                                  "c2_fwd", "c2_frames", "c2", "c2_drop"])
 def test_model_case(name, manifest, golden_dir):
     case = manifest["cases"][name]
     for k, v in case["restatement_vs_reference_maxabs"].items():
