@@ -183,15 +183,18 @@ def self_launch(n):
     rc = 0
     try:
         while any(p.poll() is None for p in procs):
-            if any(p.poll() not in (None, 0) for p in procs):
-                break            # a rank died: its peers would wait in a collective forever
+            failed = [p.returncode for p in procs if p.poll() not in (None, 0)]
+            if failed:
+                rc = failed[0]   # the rank that exited non-zero ON ITS OWN; its peers would wait in a collective forever
+                break
             time.sleep(0.2)
     finally:
         for p in procs:
             if p.poll() is None:
-                p.kill()
+                p.kill()         # (a killed peer's -9 must not mask the real failure recorded above)
                 p.wait()
-            rc = rc or p.returncode
+            elif rc == 0 and p.returncode:
+                rc = p.returncode
     return rc
 
 
@@ -342,7 +345,8 @@ def main():
                    "global_batch": args.batch * world, "seq_len": None,
                    "parallelism": "dp%d" % world, "ranks_seen": ranks_seen,
                    "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
-                   "launch": launch_note, "input": "uint8 frames" if args.u8 else "fp32 clips"},
+                   "launch": launch_note, "input": "uint8 frames" if args.u8 else "fp32 clips",
+                   "hip_library": os.path.relpath(__import__("svit_amd.hip", fromlist=["LIB_PATH"]).LIB_PATH, ROOT)},
         "loss": round(loss_val, 4),
         "step_mfma_frac": round(clips_per_s / max(1, n_vid) * STEP_GFLOP_PER_CLIP * 1e9 /
                                 (MFMA_PEAK_TFLOPS * 1e12), 4),

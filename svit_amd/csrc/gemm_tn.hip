@@ -275,7 +275,7 @@ extern "C" int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, floa
   return SVIT_OK;
 }
 
-// cost-model constants of the grouped launch (svit_debug_set keys 2 / 3 for sweeps)
+// cost-model constants of the grouped launch (svit_debug_set_tn / svit_debug_set_tn_tile for sweeps)
 static std::atomic<double> g_tn_step_us{0.85};      // one 64-row step of a workgroup, 512 resident
 static std::atomic<double> g_tn_atomic_tbs{0.75};   // effective fp32 atomic flush rate, TB/s
 static std::atomic<int> g_tn_big{1};                // 0: 128x96 tiles only, 1: heuristic, 2: 128x192 everywhere

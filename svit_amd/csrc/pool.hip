@@ -5,6 +5,9 @@
 // channels-last: 4 lanes own one output token (24 channels each, 16-byte bf16 vector loads),
 // the 27-tap stencil reads the qkv GEMM output in place, the object-token branch is the closed
 // form obj*g(w), and LayerNorm(96) is fused (4-lane shuffle reduce).
+#include <algorithm>
+#include <cstdlib>
+#include <atomic>
 #include "common.h"
 #include "../../include/svit_hip.h"
 
@@ -420,11 +423,12 @@ __global__ __launch_bounds__(256) void pool_ln_fwd_kernel(svit_pool_args a) {
 // q, k and v of one block in one launch (blockIdx.z = which): the three stencils differ only in
 // stride, and at the 14x14 / 7x7 stages each of them is a few-microsecond latency chain, so
 // running them side by side costs the time of the longest one.
-struct PoolFwd3 { svit_pool_args p[3]; PoolTilePlan plan[3]; const uint32_t* sel[3]; };
+struct PoolFwd3 { svit_pool_args p[3]; PoolTilePlan plan[3]; const uint32_t* sel[3]; int skip[3]; };
 __global__ __launch_bounds__(256) void pool_ln_fwd3_kernel(PoolFwd3 g) {
   __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];   // streaming body: selector weights
   __shared__ __attribute__((aligned(16))) float g_lds[HD];
   extern __shared__ __attribute__((aligned(16))) unsigned char pool_dyn[];   // tiled body: ring + exchange
+  if (g.skip[blockIdx.z]) return;               // this tensor went through the slab kernels
   const svit_pool_args& a = g.p[blockIdx.z];
   const PoolTilePlan& pl = g.plan[blockIdx.z];
   if (pl.tiled) {
@@ -1318,6 +1322,212 @@ __global__ __launch_bounds__(256) void relq_bwd_kernel(svit_relq_bwd_args a) {
   float* prow = a.workspace + (size_t)blockIdx.x * tab_n;
   for (int i = threadIdx.x; i < tab_n; i += blockDim.x) prow[i] = tabs[i];
 }
+
+// ---------------------------------------------------------------------------------------
+// Slab stencils (round 3): the forward depthwise conv of one (batch, head, tensor) for ONE group of
+// 24 channels, with the input "slab" it needs (a range of t-planes and y-rows, every x; 48 bytes
+// per token) resident in LDS.
+//   * The slab is fetched ONCE with LDS-DMA (global_load_lds, 16 bytes per lane, lanes = (token,
+//     chunk) so the LDS image is simply [token][24 channels]); the 27 taps are then LDS reads -- the
+//     streaming kernels above pull every tap through the texture path (27x re-reads, rocprof round
+//     2: 2.7x read amplification, the launches of the 14x14 stage 45 us for 45 MB).
+//   * lane = output token, the workgroup = one channel group: the 24 x 27 selector weights are
+//     uniform over the WHOLE workgroup and are read as scalar operands straight from the selector
+//     table (svit_pool_weight_sel) -- no LDS traffic, no vector registers for weights; a tap costs
+//     three conflict-free ds_read_b128 (consecutive tokens are 48 bytes apart: 16 lanes hit 16
+//     distinct 16-byte slots of the bank row) and 24 v_dot2.  ~75 VGPRs: 6 waves per SIMD.
+//   * LayerNorm(96) spans four channel groups, i.e. four workgroups: the conv writes `pre` (the
+//     bf16 pre-LN value, saved for the backward anyway) and a second, row-wise launch
+//     (pool_slab_ln_kernel -> pool_ln_finish) normalises.  The tap order and the arithmetic are those
+//     of pool_ln_fwd_body: the results are bit-identical to the streaming kernel's.
+#ifdef SVIT_POOL_STAMPS
+__device__ unsigned long long g_slab_stamps[16];
+#define PSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (pst) g_slab_stamps[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PSTAMP(i) do {} while (0)
+#endif
+struct SlabPlan { int on, TC, YC, nt, ny; };
+constexpr int SLAB_NT = 1024;                 // threads per slab workgroup: every wave does at most one 64-token unit
+// n / d for n < 65536 by one multiply-high with m = ceil(2^32 / d) (exact while n * d < 2^32)
+__device__ __forceinline__ int fdiv(int n, unsigned m) { return (int)__umulhi((unsigned)n, m); }
+__device__ __forceinline__ unsigned fdiv_magic_dev(int d) { return 0xFFFFFFFFu / (unsigned)d + 1u; }   // = ceil(2^32 / d)
+struct PoolSlab3 { svit_pool_args p[3]; SlabPlan plan[3]; const uint32_t* sel[3]; int max_chunks; };
+constexpr int SLAB_MAXTOK = 1600;
+
+__global__ __launch_bounds__(SLAB_NT) void pool_slab_fwd_kernel(PoolSlab3 g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
+  // 1-D grid, XCD-aware: consecutive logical ids run on ONE XCD, and the four channel groups of a slab
+  // are consecutive logical ids -- they read interleaved 48-byte pieces of the same 128-byte lines, which
+  // then come from HBM once and from that XCD's L2 three times (dealt round-robin the four landed on
+  // four XCDs: 3.3x over-fetch, the 14x14 launch 30 us instead of ~12)
+  const int nwg = gridDim.x, lin = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+  int lg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  const int cg = lg & 3; lg >>= 2;
+  const int wg = lg % g.max_chunks; lg /= g.max_chunks;
+  const int which = lg % 3, bh = lg / 3;
+  const svit_pool_args& a = g.p[which];
+  const SlabPlan& pl = g.plan[which];
+  if (!pl.on || wg >= pl.nt * pl.ny) return;
+  const int tid = threadIdx.x, wave = tid >> 6;
+#ifdef SVIT_POOL_STAMPS
+  const bool pst = which == 0 && cg == 0 && wg == 0 && bh == 3 && tid == 0;
+#endif
+  PSTAMP(0);
+  const int s = a.stride_hw, T = a.T, H = a.H, W = a.W;
+  const int Ho = pooled(H, s), Wo = pooled(W, s);
+  const int L = T * H * W, Lo = T * Ho * Wo;
+  const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
+  const int b = bh / a.heads, head = bh % a.heads;
+  const int tci = wg / pl.ny, yci = wg % pl.ny;
+  const int to0 = tci * pl.TC, to1 = min(T, to0 + pl.TC);          // output planes
+  const int yo0 = yci * pl.YC, yo1 = min(Ho, yo0 + pl.YC);         // output rows
+  const int t_lo = max(0, to0 - 1), t_hi = min(T, to1 + 1);        // input slab, clipped to the volume
+  const int y_lo = max(0, s * yo0 - 1), y_hi = min(H, s * (yo1 - 1) + 2);
+  const int RT = t_hi - t_lo, RY = y_hi - y_lo, ntok = RT * RY * W;
+  const size_t tok_stride = (size_t)3 * a.heads * HD;
+  const bf16_t* src = (const bf16_t*)a.qkv + (size_t)b * N * tok_stride + ((size_t)which * a.heads + head) * HD + cg * 24;
+  // ---- fill: chunk q = 16 bytes at LDS offset 16 q = channels 8 (q % 3) .. of slab token q / 3
+  const int nchunks = ntok * 3;
+  const unsigned mW = fdiv_magic_dev(W), mRY = fdiv_magic_dev(RY), mWo = fdiv_magic_dev(Wo);
+  for (int q0 = 0; q0 < nchunks; q0 += SLAB_NT) {
+    if (q0 + wave * 64 >= nchunks) break;          // (whole wave past the end: nothing to fetch)
+    const int q = min(q0 + tid, nchunks - 1);      // lanes past the end re-read the last chunk (into the pad)
+    const int j = fdiv(q, 0x55555556u), ch = q - 3 * j;
+    const int r = fdiv(j, mW), xj = j - r * W, tj = fdiv(r, mRY), yj = r - tj * RY;
+    const size_t tok = 1 + (size_t)((t_lo + tj) * H + (y_lo + yj)) * W + xj;
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(src + tok * tok_stride + ch * 8),
+        (__attribute__((address_space(3))) void*)(slab + (size_t)(q0 + wave * 64) * 16), 16, 0, 0);
+  }
+  PSTAMP(1);
+  const int zero_off = ((nchunks * 16 + 1023) / 1024) * 1024;      // behind the image, padded to whole wave-instructions
+  if (tid < 3) *(uint4*)(slab + zero_off + tid * 16) = make_uint4(0, 0, 0, 0);
+  float* g_lds = (float*)(slab + zero_off + 64);                   // object gain of the 24 channels
+  if (wg == 0 && tid < 24) {     // (27 independent loads per thread: one memory round trip)
+    float nt3[3], nh3[3], ipt, iph;
+    obj_counts(1, nt3, &ipt);
+    obj_counts(s, nh3, &iph);
+    const float* cw = a.conv_w + (size_t)(cg * 24 + tid) * 27;
+    float gsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) gsum += cw[k] * nt3[k / 9] * nh3[(k / 3) % 3] * nh3[k % 3];
+    g_lds[tid] = gsum * ipt * iph * iph;
+  }
+  PSTAMP(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PSTAMP(3);
+  __syncthreads();
+  PSTAMP(4);
+
+  // selector dwords [27][96] read through the constant address space: uniform addresses there
+  // become s_load (scalar operands of the v_dot2), not vector loads
+  typedef const __attribute__((address_space(4))) uint32_t* cptr_t;
+  const cptr_t selw = (cptr_t)(g.sel[which] + cg * 24);
+  const int ny_o = yo1 - yo0, n_out = (to1 - to0) * ny_o * Wo;
+  bf16_t* pre = (bf16_t*)a.pre + ((size_t)bh * Nout + 1) * HD + cg * 24;
+  const unsigned mNY = fdiv_magic_dev(ny_o);
+  for (int o = tid; o < n_out; o += SLAB_NT) {
+    const int r = fdiv(o, mWo), xo = o - r * Wo, tq = fdiv(r, mNY), yo = yo0 + r - tq * ny_o, to = to0 + tq;
+    const int yi = s * yo, xi = s * xo;
+    bool vx[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vx[k] = xi - 1 + k >= 0 && xi - 1 + k < W;
+    const int ib = ((to - 1 - t_lo) * RY + (yi - 1 - y_lo)) * W + (xi - 1);
+    float acc[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) acc[i] = 0.f;
+    // (kt, ky) stay loops: one row of three taps = 72 scalar weights at a time
+#pragma unroll 1
+    for (int kt = 0; kt < 3; ++kt) {
+      const bool vtk = to - 1 + kt >= 0 && to - 1 + kt < T;
+#pragma unroll 1
+      for (int ky = 0; ky < 3; ++ky) {
+        const bool vyk = vtk && yi - 1 + ky >= 0 && yi - 1 + ky < H;
+        const int rowoff = ib + (kt * RY + ky) * W;
+        const cptr_t wrow = selw + (kt * 3 + ky) * 3 * HD;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const bool ok = vyk && vx[kx];
+          const int off = ok ? (rowoff + kx) * 48 : zero_off;
+          const uint4 v0 = *(const uint4*)(slab + off), v1 = *(const uint4*)(slab + off + 16),
+                      v2 = *(const uint4*)(slab + off + 32);
+          const cptr_t w = wrow + kx * HD;
+          acc[0] = dot2_sel(v0.x, w[0], acc[0]);   acc[1] = dot2_sel(v0.x, w[1], acc[1]);
+          acc[2] = dot2_sel(v0.y, w[2], acc[2]);   acc[3] = dot2_sel(v0.y, w[3], acc[3]);
+          acc[4] = dot2_sel(v0.z, w[4], acc[4]);   acc[5] = dot2_sel(v0.z, w[5], acc[5]);
+          acc[6] = dot2_sel(v0.w, w[6], acc[6]);   acc[7] = dot2_sel(v0.w, w[7], acc[7]);
+          acc[8] = dot2_sel(v1.x, w[8], acc[8]);   acc[9] = dot2_sel(v1.x, w[9], acc[9]);
+          acc[10] = dot2_sel(v1.y, w[10], acc[10]); acc[11] = dot2_sel(v1.y, w[11], acc[11]);
+          acc[12] = dot2_sel(v1.z, w[12], acc[12]); acc[13] = dot2_sel(v1.z, w[13], acc[13]);
+          acc[14] = dot2_sel(v1.w, w[14], acc[14]); acc[15] = dot2_sel(v1.w, w[15], acc[15]);
+          acc[16] = dot2_sel(v2.x, w[16], acc[16]); acc[17] = dot2_sel(v2.x, w[17], acc[17]);
+          acc[18] = dot2_sel(v2.y, w[18], acc[18]); acc[19] = dot2_sel(v2.y, w[19], acc[19]);
+          acc[20] = dot2_sel(v2.z, w[20], acc[20]); acc[21] = dot2_sel(v2.z, w[21], acc[21]);
+          acc[22] = dot2_sel(v2.w, w[22], acc[22]); acc[23] = dot2_sel(v2.w, w[23], acc[23]);
+        }
+      }
+    }
+    bf16_t* dst = pre + (size_t)((to * Ho + yo) * Wo + xo) * HD;
+    *(uint4*)(dst) = pack8(&acc[0]);
+    *(uint4*)(dst + 8) = pack8(&acc[8]);
+    *(uint4*)(dst + 16) = pack8(&acc[16]);
+  }
+  PSTAMP(5);
+  // ---- cls and object tokens (first workgroup of the tensor): pre = x, x * g(w) (the closed form
+  // of the cube branch), 8 channels per thread
+  if (wg == 0) {
+    for (int i = tid; i < (1 + a.n_obj) * 3; i += SLAB_NT) {
+      const int idx = i / 3, ch = i - 3 * idx;
+      const int tin = idx == 0 ? 0 : L + idx, tout = idx == 0 ? 0 : Lo + idx;
+      float f[8];
+      unpack8(*(const uint4*)(src + (size_t)tin * tok_stride + ch * 8), f);
+      if (idx > 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= g_lds[ch * 8 + e];
+      }
+      *(uint4*)((bf16_t*)a.pre + ((size_t)bh * Nout + tout) * HD + cg * 24 + ch * 8) = pack8(f);
+    }
+  }
+  PSTAMP(6);
+}
+#ifdef SVIT_POOL_STAMPS
+extern "C" int svit_debug_pool_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_slab_stamps), sizeof(unsigned long long) * n);
+}
+#endif
+
+// LayerNorm(96) + one-hot key coordinates over the `pre` rows the slab conv wrote (pool_ln_finish)
+__global__ __launch_bounds__(256) void pool_slab_ln_kernel(PoolSlab3 g) {
+  const int which = blockIdx.z;
+  if (!g.plan[which].on) return;
+  svit_pool_args a = g.p[which];
+  const int s = a.stride_hw, Ho = pooled(a.H, s), Wo = pooled(a.W, s), Lo = a.T * Ho * Wo;
+  const int Nout = 1 + Lo + a.n_obj, bh = blockIdx.y;
+  const bf16_t* prep = (const bf16_t*)a.pre;
+  a.pre = nullptr;                                  // (do not write back what is being read)
+  const int sub = threadIdx.x & 3, c0 = sub * 24;
+  for (int tb = blockIdx.x; tb * 64 < Nout; tb += gridDim.x) {
+    const int tok = tb * 64 + (threadIdx.x >> 2);
+    const bool live = tok < Nout;
+    float acc[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) acc[i] = 0.f;
+    int py = 0, px = 0, pt = 0;
+    bool is_patch = false;
+    if (live) {
+      const bf16_t* p = prep + ((size_t)bh * Nout + tok) * HD + c0;
+#pragma unroll
+      for (int v = 0; v < 3; ++v) unpack8(*(const uint4*)(p + v * 8), &acc[v * 8]);
+      if (tok >= 1 && tok <= Lo) {
+        is_patch = true;
+        const int q = tok - 1;
+        px = q % Wo; py = (q / Wo) % Ho; pt = q / (Wo * Ho);
+      }
+    }
+    pool_ln_finish(a, acc, live, tok, is_patch, py, px, pt, bh, Nout, Ho, Wo);
+  }
+}
 }  // namespace
 
 // grid.x of the persistent stencil kernels: token blocks are dealt round-robin to workgroups so
@@ -1388,18 +1598,88 @@ static size_t tiled_lds_bytes(int W) {
   return 512 * sizeof(float) + 3 * (size_t)htok * TL_ROW;
 }
 
+// Slab plan of one tensor (pool_slab_fwd_kernel): output t-planes (TC) x output rows (YC) per
+// workgroup such that the input slab -- min(T, TC + 2) planes x min(H, s (YC - 1) + 3) rows x W --
+// fits SLAB_MAXTOK tokens; among those the one that re-reads the input least, then cut in t until the
+// launch has >= 256 workgroups.  Strides 1 and 2 only (a stride-4 / -8 stencil touches a small part
+// of the planes a slab would load), and only where `pre` is given (the LayerNorm launch reads it).
+static std::atomic<int> g_pool_slab{1};        // tuning knob (svit_debug_set_pool(0, v)): 0 = streaming kernels
+static SlabPlan plan_slab(const svit_pool_args& a) {
+  SlabPlan pl = {0, 0, 0, 0, 0};
+  const int s = a.stride_hw;
+  // measured (tools/pool_one.py under rocprofv3, profiles/r03_pool_slab.txt): ahead of the streaming
+  // kernel on the 14x14 and 7x7 planes (12 of 16 blocks), behind it on 28x28 and behind the tiled
+  // stencil on 56x56 -- the conv phase is VALU-bound (27 v_dot2 per output channel) and a slab
+  // workgroup serialises fill -> conv -> store with one 16-wave workgroup per CU (106 SGPRs)
+  if (!g_pool_slab.load() || s > 2 || !a.pre || a.H * a.W > 196) return pl;
+  const int Ho = (a.H - 1) / s + 1;
+  double best = 1e30;
+  for (int tc = 1; tc <= a.T; ++tc)
+    for (int yc = Ho; yc <= Ho; ++yc) {     // whole planes only: the planes this path is used on (<= 14x14) fit
+      const int pin = std::min(a.T, tc + 2), rin = std::min(a.H, s * (yc - 1) + 3);
+      if ((long)pin * rin * a.W > SLAB_MAXTOK) continue;
+      const double cost = ((double)pin / tc) * ((double)rin / (s * yc)) - 1e-6 * tc * yc;
+      if (cost < best) { best = cost; pl.TC = tc; pl.YC = yc; }
+    }
+  if (pl.TC == 0) return pl;
+  pl.ny = (Ho + pl.YC - 1) / pl.YC;
+  // at most one 64-token unit per wave (the conv phase of a workgroup is then ONE pass of ~750 VALU
+  // instructions per wave), then cut in t until the tensor alone gives the chip >= 128 workgroups
+  const int Wo = (a.W - 1) / s + 1;
+  while (pl.TC > 1 && (long)pl.TC * pl.YC * Wo > SLAB_NT) pl.TC = (pl.TC + 1) / 2;
+  while (pl.TC > 1 && (long)((a.T + pl.TC - 1) / pl.TC) * pl.ny * a.B * a.heads * 4 < 128) pl.TC = (pl.TC + 1) / 2;
+  pl.nt = (a.T + pl.TC - 1) / pl.TC;
+  pl.on = 1;
+  return pl;
+}
+
 static int pool_ln_fwd_qkv_impl(const svit_pool_args* a3, const uint32_t* const* sel3, void* stream) {
   if (!a3) return SVIT_ERR_ARG;
   PoolFwd3 g;
   unsigned gx = 1;
   size_t lds = 0;
+  PoolSlab3 sg;
+  unsigned sgx = 0;
+  size_t slds = 0;
+  int n_slab = 0, ln_blocks = 1;
   for (int i = 0; i < 3; ++i) {
     const int rc = check_pool_fwd(&a3[i]);
     if (rc) return rc;
     if (a3[i].B != a3[0].B || a3[i].heads != a3[0].heads) return SVIT_ERR_SHAPE;
+    sg.p[i] = a3[i];
+    sg.sel[i] = sel3 ? sel3[i] : nullptr;
+    sg.plan[i] = sel3 ? plan_slab(a3[i]) : SlabPlan{0, 0, 0, 0, 0};
+    g.skip[i] = sg.plan[i].on;
+    if (sg.plan[i].on) {
+      const SlabPlan& pl = sg.plan[i];
+      const int s = a3[i].stride_hw;
+      const int pin = std::min(a3[i].T, pl.TC + 2), rin = std::min(a3[i].H, s * (pl.YC - 1) + 3);
+      const size_t need = ((size_t)pin * rin * a3[i].W * 48 + 1023) / 1024 * 1024 + 64 + 96;
+      if (need > slds) slds = need;
+      if ((unsigned)(pl.nt * pl.ny) > sgx) sgx = pl.nt * pl.ny;
+      const int nout = 1 + a3[i].T * ((a3[i].H - 1) / s + 1) * ((a3[i].W - 1) / s + 1) + a3[i].n_obj;
+      ln_blocks = std::max(ln_blocks, (int)persistent_x((nout + 63) / 64, a3[0].B * a3[0].heads * 3));
+      ++n_slab;
+    }
+  }
+  if (n_slab) {
+    static SvitOnce once_slab;
+    if (int rc = svit_max_lds_once(once_slab, (const void*)pool_slab_fwd_kernel, 80 * 1024)) return rc;
+    sg.max_chunks = (int)sgx;
+    if (getenv("SVIT_SLAB_LDS_MIN")) slds = std::max(slds, (size_t)atoi(getenv("SVIT_SLAB_LDS_MIN")));
+    hipLaunchKernelGGL(pool_slab_fwd_kernel, dim3(sgx * a3[0].B * a3[0].heads * 12), dim3(SLAB_NT), slds,
+                       (hipStream_t)stream, sg);
+    SVIT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pool_slab_ln_kernel, dim3(ln_blocks, a3[0].B * a3[0].heads, 3), dim3(256), 0,
+                       (hipStream_t)stream, sg);
+    SVIT_LAUNCH_CHECK();
+    if (n_slab == 3) return SVIT_OK;
+  }
+  for (int i = 0; i < 3; ++i) {
     g.p[i] = a3[i];
     g.sel[i] = sel3 ? sel3[i] : nullptr;
     g.plan[i].tiled = 0;
+    if (g.skip[i]) continue;
     const int s = a3[i].stride_hw;
     const int nout = 1 + a3[i].T * ((a3[i].H - 1) / s + 1) * ((a3[i].W - 1) / s + 1) + a3[i].n_obj;
     unsigned x = persistent_x((nout + 63) / 64, a3[0].B * a3[0].heads * 3);
@@ -1416,6 +1696,12 @@ static int pool_ln_fwd_qkv_impl(const svit_pool_args* a3, const uint32_t* const*
   hipLaunchKernelGGL(pool_ln_fwd3_kernel, dim3(gx, a3[0].B * a3[0].heads, 3), dim3(256), lds,
                      (hipStream_t)stream, g);
   SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_debug_set_pool(int key, int val) {   // tuning knob for tools/: 0 -> slab stencils on / off
+  if (key == 0) g_pool_slab = val;
+  else return SVIT_ERR_ARG;
   return SVIT_OK;
 }
 

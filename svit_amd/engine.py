@@ -146,6 +146,9 @@ class FlatParams:
     # below the same or slower: those launches are bound by per-workgroup latency chains, not by
     # the 27x re-reads -- DESIGN.md section 5)
     TILED_MIN_PLANE = 2048
+    # round 3: the slab stencil (csrc/pool.hip::pool_slab_fwd_kernel: input slab resident in LDS, scalar
+    # weights, LayerNorm as a second row-wise launch) on the small planes -- 14x14 and 7x7, 12 of 16 blocks
+    SLAB_MAX_PLANE = 196
 
     def refresh_low_precision(self):
         ops.cast_bf16(self.data, self.w16[:self.total])
@@ -315,7 +318,8 @@ class Engine:
             [f.p(pre + "attn.norm_%s.weight" % r) for r in "qkv"],
             [f.p(pre + "attn.norm_%s.bias" % r) for r in "qkv"],
             B, h, thw, n_obj, (sq, skv, skv), (DA, DA, HD), (0, 1, 0), save=save, out_scales=(1.0, K_SCALE, 1.0),
-            sels=f.sels(pre) if thw[1] * thw[2] >= f.TILED_MIN_PLANE else None)
+            sels=f.sels(pre) if (thw[1] * thw[2] >= f.TILED_MIN_PLANE or thw[1] * thw[2] <= f.SLAB_MAX_PLANE)
+            else None)
         qa, ka, v = pools[0][0], pools[1][0], pools[2][0]
         idx, mats, mcat, need = self._rel(blk, q_thw, k_thw)
         # rel-pos query side: P = q . Rcat^T on the MFMA GEMM, then a 2-byte gather per (q, j)

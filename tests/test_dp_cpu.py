@@ -84,8 +84,13 @@ def _worker(rank, world, port, ok):
     dist.destroy_process_group()
 
 
-def test_flat_allreduce_gloo_world2():
-    world = 2
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_flat_allreduce_gloo(world):
+    """world 2: the N > 1 path; world 8: the rank / port / bucket bookkeeping at the world size the
+    driver's scaling run uses (SCALE_rNN.json: --gpus 8), on the real 34.4 M-element parameter table."""
     port = _free_port()
     # spawn, not fork: earlier tests of the same pytest process may have started OpenMP threads
     # (any multi-threaded torch op), and a forked child then deadlocks in its first parallel region
@@ -95,6 +100,41 @@ def test_flat_allreduce_gloo_world2():
     for p in procs:
         p.start()
     for p in procs:
-        p.join(180)
+        p.join(300)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert list(ok) == [1] * world
+
+
+def test_bucket_message_sizes_of_the_real_layout():
+    """What the exchange looks like on the wire at 16x224^2: with bucket_ranks = 4
+    the 137.5 MB fp32 gradient leaves in 5 launches -- sizes and order pinned here so that the first
+    real SCALE line can be read against them."""
+    sys.path.insert(0, ROOT)
+    from svit_amd import arch, config
+    from svit_amd.engine import FlatParams
+    from svit_amd.model import _weight_decayed
+    cfg = config.ssv2_cfg(16, 224)
+    shapes = arch.param_shapes(arch.build_plan(cfg))
+    flat = FlatParams(shapes, _weight_decayed, torch.device("cpu"), arch.readiness_rank)
+    launches, pending = [], []
+    for r in range(flat.n_ranks):
+        pending.extend(flat.ready_ranges[r])
+        if (r + 1) % 4 == 0 or r == flat.n_ranks - 1:
+            merged = []
+            for a, b in sorted(pending):
+                if merged and merged[-1][1] == a:
+                    merged[-1] = (merged[-1][0], b)
+                else:
+                    merged.append((a, b))
+            launches.append([4 * (b - a) for a, b in merged])
+            pending = []
+    total = sum(sum(l) for l in launches)
+    assert total == 4 * flat.total and abs(total - 137.5e6) < 1.0e6
+    assert len(launches) == 5
+    # every bucket is at most two contiguous messages (the decayed and the not-decayed group)
+    assert all(len(l) <= 2 for l in launches), launches
+    # the first bucket (head, final norm, blocks 15-13) carries ~40 % of the bytes: the 768-wide
+    # blocks; the last one (blocks 1-0, stem, tokens) less than 1 % -- the un-overlappable tail
+    first, last = sum(launches[0]), sum(launches[-1])
+    assert 0.30 * total < first < 0.50 * total, first / total
+    assert last < 0.01 * total, last / total

@@ -130,15 +130,18 @@ def test_rccl_two_gpus_equal_one_rank(tmp_path, graphed):
     assert cos > 0.999999
 
 
-def test_bench_self_launches_two_ranks():
-    """`python bench.py --gpus 2` with no launcher: bench.py starts the ranks itself (here both on
-    the box's one GPU over gloo -- the rehearsal knobs) and rank 0 prints ONE JSON line."""
+@pytest.mark.parametrize("n", [2, 5])
+def test_bench_self_launches_its_ranks(n):
+    """`python bench.py --gpus N` with no launcher: bench.py starts the ranks itself (here all on
+    the box's one GPU over gloo -- the rehearsal knobs) and rank 0 prints ONE JSON line.  N = 5 ranks
+    plus this test process is the most processes one GPU box admits on its card (6); the world-size-8
+    bookkeeping of the exchange is rehearsed on the CPU (tests/test_dp_cpu.py)."""
     import json
     import subprocess
     env = dict(os.environ, SVIT_BENCH_SHARE_GPU="1", SVIT_BENCH_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2",
                         "--warmup", "1", "--batch", "1", "--frames", "4", "--crop", "64",
                         "--no-cpu-baseline", "--no-kernel-trace"], env=env, capture_output=True,
                        text=True, timeout=900)
@@ -146,8 +149,9 @@ def test_bench_self_launches_two_ranks():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["ranks_seen"] == 2 and out["value"] > 0
+    assert out["n_gpus"] == n and out["config"]["ranks_seen"] == n and out["value"] > 0
     assert out["config"]["backend"] == "gloo" and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == n
 
 
 # ---- heterogeneous ranks of the published recipe: rank 0 trains clips with

@@ -534,6 +534,66 @@ def test_relpos_q(ops, q_thw, k_thw):
     assert rel_err(dq2.view(B, h, -1, 96), q.grad) < 1e-2 and cos(dq2.view(B, h, -1, 96), q.grad) > 0.9999
 
 
+
+@pytest.mark.parametrize("B,h,thw,sq,skv,n_obj", [
+    (2, 4, (8, 14, 14), 1, 2, 64),     # blocks 4-13 of 16x224^2
+    (1, 4, (16, 14, 14), 1, 2, 128),   # 32x224^2: three t-chunks per tensor
+    (1, 8, (16, 14, 14), 2, 1, 128),   # block 14 at 32 frames
+    (3, 4, (1, 14, 14), 1, 2, 4),      # frames pass (T' = 1)
+    (2, 8, (8, 7, 7), 1, 1, 64),       # block 15
+    (2, 2, (5, 9, 13), 2, 1, 8),       # odd plane, odd T
+])
+def test_pool_slab_forward_vs_conv3d(ops, B, h, thw, sq, skv, n_obj):
+    """Round-3 slab stencil (csrc/pool.hip::pool_slab_fwd_kernel + pool_slab_ln_kernel; the path the
+    engine takes on planes <= 14x14): pre-LN values against torch's depthwise conv3d on the same bf16
+    operands, object / cls rows against the closed form, and out / mean / rstd against the streaming
+    kernels of the same library (svit_debug_set_pool switches the path)."""
+    import ctypes as C
+    from svit_amd import hip
+    lib = hip.load()
+    lib.svit_debug_set_pool.restype, lib.svit_debug_set_pool.argtypes = C.c_int32, [C.c_int32, C.c_int32]
+    T, H, W = thw
+    L = T * H * W
+    N = 1 + L + n_obj
+    qkv = rnd("sl%d%d%d" % (T, H, h), (B, N, 3, h, 96), 0.5, BF16)
+    ws = [rnd("sw%d%d" % (i, H), (96, 27), 0.2) for i in range(3)]
+    g = [rnd("sg%d" % i, (96,), 0.3) + 1.0 for i in range(3)]
+    b = [rnd("sb%d" % i, (96,), 0.1) for i in range(3)]
+    wflat = torch.cat([w.flatten() for w in ws]).contiguous()
+    offs = torch.tensor([0, 2592, 5184], dtype=torch.int64, device=DEV)
+    sel = ops.pool_weight_sel(wflat, offs, torch.zeros((3, 2592), dtype=torch.int32, device=DEV))
+    sels = [sel[i] for i in range(3)]
+    J = 2 * ops.pooled(H, skv) + T
+    da = 128 if J <= 32 else 160
+    res = []
+    try:
+        for on in (0, 1):
+            lib.svit_debug_set_pool(0, on)
+            r = ops.pool_ln_fwd_qkv(qkv, ws, g, b, B, h, thw, n_obj, (sq, skv, skv), (da, da, 96), (0, 1, 0),
+                                    sels=sels, out_scales=(1.0, KSC, 1.0))
+            torch.cuda.synchronize()
+            res.append(r)
+    finally:
+        lib.svit_debug_set_pool(0, 1)
+    for which, s in ((0, sq), (1, skv), (2, skv)):
+        x = qkv[:, 1:1 + L, which].float()
+        vol = x.reshape(B, T, H, W, h, 96).permute(0, 4, 5, 1, 2, 3).reshape(B * h, 96, T, H, W)
+        w = ws[which].to(BF16).float().reshape(96, 1, 3, 3, 3)
+        ref = F.conv3d(vol, w, None, stride=(1, s, s), padding=1, groups=96)
+        Lo = ref.shape[2] * ref.shape[3] * ref.shape[4]
+        ref = ref.reshape(B, h, 96, -1).transpose(2, 3)
+        out, pre, mean, rstd = res[1][which]
+        assert rel_err(pre[:, :, 1:1 + Lo], ref) < 1e-2          # bf16 rounding of the stored value
+        gain = R.object_gain(ws[which].to(BF16).float().cpu().reshape(96, 1, 3, 3, 3), (1, s, s))
+        obj = qkv[:, 1 + L:, which].float().cpu().permute(0, 2, 1, 3) * gain
+        assert rel_err(pre[:, :, 1 + Lo:], obj) < 2e-2
+        assert torch.equal(pre[:, :, 0].cpu(), qkv[:, 0, which].cpu())
+        so, sp, sm, sr = res[0][which]
+        cols = slice(0, 96) if which == 0 else slice(None)     # q's bias columns are the gather's to write
+        assert rel_err(out[..., cols], so[..., cols]) < 2e-2
+        assert rel_err(mean, sm) < 1e-3 and rel_err(rstd, sr) < 1e-3
+
+
 # -------------------------------------------------------------------- fused attention ----
 KSC = (96 ** -0.5) * math.log2(math.e)   # what the pooling kernel multiplies the keys by (engine.K_SCALE)
 

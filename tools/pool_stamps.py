@@ -1,0 +1,22 @@
+"""Wall-clock anatomy of one workgroup of the slab pooling forward: builds pool.hip (+misc.hip for the
+reduce helper) with -DSVIT_POOL_STAMPS, runs one block shape, prints the phases in us."""
+import ctypes, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+out = os.path.join(ROOT, "gpurun_out", "libpool_stamps.so")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+from svit_amd import build as B
+srcs = [os.path.join(B.CSRC, f) for f in B.SOURCES]
+subprocess.check_call([B.HIPCC] + B.FLAGS + ["-DSVIT_POOL_STAMPS", "-shared"] + srcs + ["-o", out])
+os.environ["SVIT_HIP_LIB"] = out
+import runpy
+sys.argv = ["pool_one.py"] + sys.argv[1:]
+runpy.run_path(os.path.join(ROOT, "tools", "pool_one.py"), run_name="__main__")
+lib = ctypes.CDLL(out)
+buf = (ctypes.c_ulonglong * 16)()
+assert lib.svit_debug_pool_stamps(buf, 16) == 0
+s = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
+us = lambda i, j: (s[j] - s[i]) / 100.0
+print("slab fwd WG (q, cg 0, chunk 0, bh 3): decode %.2f | fill issue %.2f | gain %.2f | dma wait %.2f | barrier %.2f | conv %.2f | special %.2f | total %.2f us"
+      % (us(0, 1) * 0, us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(0, 6)))
