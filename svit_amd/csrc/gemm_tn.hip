@@ -2,11 +2,21 @@
 //   svit_gemm_tn : dW[N,K] += A[M,N]^T * B[M,K]  (reduction over rows, operands consumed
 //                  through ds_read_b64_tr_b16 transposed LDS reads; fused bias gradient)
 // (the forward / dgrad kernel svit_gemm_nt lives in gemm_nt.hip)
+#include <algorithm>
 #include <atomic>
+#include <type_traits>
 #include "common.h"
 #include "../../include/svit_hip.h"
 
 namespace {
+
+template <int B, int E, typename F>
+__device__ __forceinline__ void tn_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    tn_static_for<B + 1, E>(f);
+  }
+}
 
 // ---------------------------------------------------------------------------------------
 // TN kernel.  Both operands are [rows=m][cols] in LDS and read transposed (ds_read_b64_tr_b16).
@@ -27,67 +37,102 @@ struct TnCfg {
 };
 using TnSmall = TnCfg<1, 4, 1, 64>;
 using TnBig = TnCfg<2, 2, 2, 32>;
-constexpr int TN_LDS_BYTES = 2 * (TnSmall::STAGE > TnBig::STAGE ? TnSmall::STAGE : TnBig::STAGE);
 
+// ---------------------------------------------------------------------------------------
 // One workgroup's share: rows [m_begin, m_end) of the reduction for the TN x TK tile at (n0, k0).
+// Round 3: through an LDS-DMA ring.  The round-2 body (git history) staged both operands
+// through registers (global_load -> VGPR -> ds_write_b128: 20-28 KB of LDS stores per 12 MFMAs,
+// half of them behind bounds-check branches) and takes one __syncthreads per 12 MFMAs with the
+// transposed reads left to the compiler.  Here:
+//   * A / B stages [m][cols] arrive by buffer-descriptor LDS-DMA (no VGPR staging, no ds_write, no
+//     per-piece address arithmetic: per-lane byte offsets are stage-invariant, the stage's first
+//     row is the scalar offset), NS stages deep behind a counted vmcnt and ONE raw barrier per stage;
+//   * rows are unpadded (a DMA writes 1 KB linearly); the 4 rows x 64 B of a transposed read land on
+//     disjoint banks through a swizzle of the 64-byte blocks on the per-lane SOURCE address
+//     (A, 256-B rows: block ^ (row & 3); B, 384-B rows: block ^ ((row >> 1) & 1); 192-B rows skew by
+//     themselves) and the same swizzle in the read address;
+//   * the transposed fragment reads of k-step s+1 are issued (inline asm) before the MFMAs of k-step
+//     s and released by counted lgkmcnt waits;
+//   * a ragged last stage (rows past m_end) is fetched through clamped rows and its A rows are
+//     zeroed in LDS; columns past N / K are clamped in the source address (their products are
+//     never stored).
+template <int RB_, int WN_, int WK_, int BM_, int NS_>
+struct TnDma {
+  static constexpr int RB = RB_, WN = WN_, WK = WK_, BM = BM_, NS = NS_;
+  static constexpr int TN = 32 * RB * WN, TK = 96 * WK;
+  static constexpr int ROWA = TN * 2, ROWB = TK * 2;             // 256 B; 192 / 384 B
+  static constexpr int A_BYTES = BM * ROWA, B_BYTES = BM * ROWB, STAGE = A_BYTES + B_BYTES;
+  static constexpr int A_INSTR = A_BYTES / 1024, B_INSTR = B_BYTES / 1024;
+  static constexpr int PER = (A_INSTR + B_INSTR) / 4;            // DMA instructions per wave and stage
+  static_assert((A_INSTR + B_INSTR) % 4 == 0, "every wave issues the same number of pieces");
+  __host__ __device__ static constexpr int swz_a(int row) { return row & 3; }
+  __host__ __device__ static constexpr int swz_b(int row) { return ROWB == 384 ? ((row >> 1) & 1) : 0; }
+};
+using TnSmallD = TnDma<1, 4, 1, 64, 2>;     // 128 x 96 tiles, 64 rows per stage, 2 stages (56 KB)
+using TnBigD = TnDma<2, 2, 2, 32, 3>;       // 128 x 192 tiles, 32 rows per stage, 3 stages (60 KB)
+constexpr int TN_DMA_LDS = 2 * TnSmallD::STAGE > 3 * TnBigD::STAGE ? 2 * TnSmallD::STAGE : 3 * TnBigD::STAGE;
+
+template <int OFF>
+__device__ __forceinline__ void tn_read_tr(s16x4_t& d, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "i"(OFF) : "memory");
+}
+
 template <class C>
-__device__ __forceinline__ void tn_tile(unsigned char* lds, const bf16_t* __restrict__ A, int lda,
-                                        const bf16_t* __restrict__ B, int ldb,
-                                        float* __restrict__ dW, int lddw, int N, int K, int n0,
-                                        int k0, int m_begin, int m_end,
-                                        float* __restrict__ dbias, bool bias_tile) {
-  constexpr int RB = C::RB, TN_BM = C::BM, TN_TN = C::TN, TN_TK = C::TK, TN_ROWA = C::ROWA, TN_ROWB = C::ROWB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void tn_tile_dma(unsigned char* lds, const bf16_t* __restrict__ A, int lda,
+                                            const bf16_t* __restrict__ B, int ldb,
+                                            float* __restrict__ dW, int lddw, int M, int N, int K, int n0,
+                                            int k0, int m_begin, int m_end,
+                                            float* __restrict__ dbias, bool bias_tile) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int RB = C::RB, BM = C::BM, NS = C::NS, PER = C::PER;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave / C::WK, wk = wave % C::WK;
   if (m_begin >= m_end) return;
-
-  constexpr int A_CH = TN_TN / 8, B_CH = TN_TK / 8;        // 16-byte chunks per row
-  constexpr int A_PER = TN_BM * A_CH / 256, B_PER = TN_BM * B_CH / 256;
-  static_assert(A_PER * 256 == TN_BM * A_CH && B_PER * 256 == TN_BM * B_CH, "staging must divide evenly");
-  static_assert(A_CH == 16, "the fused bias gradient assumes 16 chunks per A row");
-  bf16x8_t ra[A_PER], rb[B_PER];
-  const bf16x8_t zero8 = __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
-  auto load_tiles = [&](int mb) {
+  // ---- per-lane source offsets of this wave's DMA pieces (stage-invariant)
+  // (a wave's first A_INSTR / 4 pieces are A pieces wave, wave + 4, ...; the rest B pieces)
+  constexpr int PA = C::A_INSTR / 4;
+  static_assert(C::A_INSTR % 4 == 0 && C::B_INSTR % 4 == 0, "pieces split evenly over the four waves");
+  unsigned voff[PER];
+  const int na8 = (N - n0 + 7) / 8, nb8 = (K - k0 + 7) / 8;     // valid 16-byte column chunks of this tile
+  auto piece = [&](int i, bool a) { return wave + 4 * (a ? i : i - PA); };
 #pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
-      const int c = tid + i * 256, r = c / A_CH, cc = c % A_CH;
-      const int gm = mb + r, gn = n0 + cc * 8;
-      ra[i] = zero8;
-      if (gm < m_end && gn < N) ra[i] = *(const bf16x8_t*)(A + (size_t)gm * lda + gn);
-    }
+  for (int i = 0; i < PER; ++i) {
+    const bool a = i < PA;
+    const int o = piece(i, a) * 1024 + lane * 16;                // byte offset inside the A / B image
+    const int rowb = a ? C::ROWA : C::ROWB;
+    const int row = o / rowb, inrow = o % rowb;
+    const int pb = inrow >> 6, c16 = (inrow >> 4) & 3;
+    const int lb = pb ^ (a ? C::swz_a(row) : C::swz_b(row));     // logical 64-byte block
+    const int ch = min(lb * 4 + c16, (a ? na8 : nb8) - 1);       // logical 16-byte chunk, clamped into the matrix
+    voff[i] = (unsigned)(row * (a ? lda : ldb) + (a ? n0 : k0) + ch * 8) * 2u;
+  }
+  const auto ars = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)std::min<size_t>((size_t)M * lda * 2, 0x7fffffffu), 0x00020000);
+  const auto brs = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)std::min<size_t>((size_t)M * ldb * 2, 0x7fffffffu), 0x00020000);
+  const int nsteps = (m_end - m_begin + BM - 1) / BM;
+  auto issue = [&](int s) {
+    unsigned char* st = lds + (s % NS) * C::STAGE;
+    const int m0 = m_begin + s * BM;
+    const int valid = m_end - m0;               // >= BM except in a ragged last stage (uniform)
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i) {
-      const int c = tid + i * 256, r = c / B_CH, cc = c % B_CH;
-      const int gm = mb + r, gk = k0 + cc * 8;
-      rb[i] = zero8;
-      if (gm < m_end && gk < K) rb[i] = *(const bf16x8_t*)(B + (size_t)gm * ldb + gk);
-    }
-  };
-  // fused bias gradient: column sums of A (= dY) ride along on the k-tile-0 blocks; a thread
-  // always stages the same 8-column chunk (tid % 16), so it keeps 8 running sums
-  const bool do_bias = (dbias != nullptr) && bias_tile;
-  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  auto store_tiles = [&](int buf) {
-    unsigned char* la = lds + buf * C::STAGE;
-    unsigned char* lb = la + TN_BM * TN_ROWA;
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
-      const int c = tid + i * 256;
-      *(bf16x8_t*)(la + (c / A_CH) * TN_ROWA + (c % A_CH) * 16) = ra[i];
-      if (do_bias) {
-        const uint4 u = __builtin_bit_cast(uint4, ra[i]);
-        bsum[0] += lo_bf16(u.x); bsum[1] += hi_bf16(u.x);
-        bsum[2] += lo_bf16(u.y); bsum[3] += hi_bf16(u.y);
-        bsum[4] += lo_bf16(u.z); bsum[5] += hi_bf16(u.z);
-        bsum[6] += lo_bf16(u.w); bsum[7] += hi_bf16(u.w);
+    for (int i = 0; i < PER; ++i) {
+      const bool a = i < PA;
+      unsigned vo = voff[i];
+      if (valid < BM) {                         // rows past m_end re-read the last valid row
+        const int row = (piece(i, a) * 1024 + lane * 16) / (a ? C::ROWA : C::ROWB);
+        vo -= (unsigned)(row - min(row, valid - 1)) * (a ? lda : ldb) * 2u;
       }
-    }
-#pragma unroll
-    for (int i = 0; i < B_PER; ++i) {
-      const int c = tid + i * 256;
-      *(bf16x8_t*)(lb + (c / B_CH) * TN_ROWB + (c % B_CH) * 16) = rb[i];
+      unsigned char* dst = st + (a ? 0 : C::A_BYTES) + piece(i, a) * 1024;
+      if (a)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)dst, 16, vo,
+                                                 (unsigned)m0 * lda * 2u, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void*)dst, 16, vo,
+                                                 (unsigned)m0 * ldb * 2u, 0, 0);
     }
   };
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nsteps) issue(s);
 
   f32x16_t acc[RB][3];
 #pragma unroll
@@ -96,38 +141,86 @@ __device__ __forceinline__ void tn_tile(unsigned char* lds, const bf16_t* __rest
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // fused bias gradient: column sums of A (= dY) ride along on the k-tile-0 blocks: thread ->
+  // (row tid / 16 (+16, ...), logical 16-byte chunk tid % 16), 8 running sums
+  const bool do_bias = (dbias != nullptr) && bias_tile;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  // transposed-read addressing: lane -> (half hh, column group cg, in-group i -> (q,p))
+  // transposed-read addressing: lane -> (half hh, column group cg, (q, pp));
+  // rows of one read are 8 hh + q (+ 4 for the second), so the swizzle term is a per-lane constant
   const int hh = lane >> 5, cg = (lane >> 4) & 1, ii = lane & 15, q = ii >> 2, pp = ii & 3;
-  const int a_off = (8 * hh + q) * TN_ROWA + (wn * 32 * RB + 16 * cg + 4 * pp) * 2;
-  const int b_off = (8 * hh + q) * TN_ROWB + (wk * 96 + 16 * cg + 4 * pp) * 2;
-
-  const int nsteps = (m_end - m_begin + TN_BM - 1) / TN_BM;
-  load_tiles(m_begin);
-  store_tiles(0);
-  __syncthreads();
+  const unsigned lds0 = (unsigned)(size_t)lds;
+  unsigned a_addr[RB], b_addr[3];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    const int col = wn * 32 * RB + i * 32 + 16 * cg + 4 * pp;          // n column of the tile
+    a_addr[i] = lds0 + (8 * hh + q) * C::ROWA + (((col >> 5) ^ C::swz_a(q)) << 6) + (col & 31) * 2;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int col = wk * 96 + j * 32 + 16 * cg + 4 * pp;               // k column of the tile
+    // rows 8 hh + q and 8 hh + q + 4: (row >> 1) & 1 = (q >> 1) & 1 for both
+    b_addr[j] = lds0 + C::A_BYTES + (8 * hh + q) * C::ROWB + (((col >> 5) ^ C::swz_b(q)) << 6) + (col & 31) * 2;
+  }
+  constexpr int KS = BM / 16;
   for (int s = 0; s < nsteps; ++s) {
-    const int cur = s & 1;
-    if (s + 1 < nsteps) load_tiles(m_begin + (s + 1) * TN_BM);
-    const unsigned char* la = lds + cur * C::STAGE + a_off;
-    const unsigned char* lb = lds + cur * C::STAGE + TN_BM * TN_ROWA + b_off;
+    if (s + NS - 2 < nsteps - 0 && NS > 2 && s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // everyone's share of stage s has landed; everyone is done with stage s-1
+    if (s + NS - 1 < nsteps) issue(s + NS - 1);
+    const unsigned so = (unsigned)((s % NS) * C::STAGE);
+    if (m_begin + (s + 1) * BM > m_end) {      // ragged last stage: the re-read rows count nothing
+      const int valid = m_end - (m_begin + s * BM);
+      for (int c = tid; c < (BM - valid) * (C::ROWA / 16); c += 256)
+        *(uint4*)(lds + so + valid * C::ROWA + c * 16) = make_uint4(0, 0, 0, 0);
+      __syncthreads();
+    }
+    if (do_bias) {
 #pragma unroll
-    for (int ks = 0; ks < TN_BM / 16; ++ks) {
-      bf16x8_t af[RB];
-#pragma unroll
-      for (int i = 0; i < RB; ++i)
-        af[i] = make_bf16x8(lds_read_tr16(la + (ks * 16) * TN_ROWA + i * 64),
-                            lds_read_tr16(la + (ks * 16 + 4) * TN_ROWA + i * 64));
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const bf16x8_t bfr = make_bf16x8(lds_read_tr16(lb + (ks * 16) * TN_ROWB + j * 64),
-                                         lds_read_tr16(lb + (ks * 16 + 4) * TN_ROWB + j * 64));
-#pragma unroll
-        for (int i = 0; i < RB; ++i) acc[i][j] = mfma32(af[i], bfr, acc[i][j]);
+      for (int r0 = 0; r0 < BM; r0 += 16) {
+        const int row = r0 + (tid >> 4), lc = tid & 15;
+        uint4 u;    // (asm: a compiler-visible LDS load behind an LDS-DMA draws an s_waitcnt vmcnt(0))
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(u)
+                     : "v"(lds0 + so + row * C::ROWA + ((((lc >> 2) ^ C::swz_a(row))) << 6) + (lc & 3) * 16) : "memory");
+        bsum[0] += lo_bf16(u.x); bsum[1] += hi_bf16(u.x);
+        bsum[2] += lo_bf16(u.y); bsum[3] += hi_bf16(u.y);
+        bsum[4] += lo_bf16(u.z); bsum[5] += hi_bf16(u.z);
+        bsum[6] += lo_bf16(u.w); bsum[7] += hi_bf16(u.w);
       }
     }
-    if (s + 1 < nsteps) store_tiles(cur ^ 1);
-    __syncthreads();
+    // fragments of k-step ks: RB A fragments + 3 B fragments, two transposed reads each
+    s16x4_t fl[2][RB + 3], fh[2][RB + 3];
+    auto rd = [&](auto KS_, auto BUF_) {
+      constexpr int ks = decltype(KS_)::value, buf = decltype(BUF_)::value;
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        tn_read_tr<ks * 16 * C::ROWA>(fl[buf][i], a_addr[i] + so);
+        tn_read_tr<(ks * 16 + 4) * C::ROWA>(fh[buf][i], a_addr[i] + so);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        tn_read_tr<ks * 16 * C::ROWB>(fl[buf][RB + j], b_addr[j] + so);
+        tn_read_tr<(ks * 16 + 4) * C::ROWB>(fh[buf][RB + j], b_addr[j] + so);
+      }
+    };
+    rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    tn_static_for<0, KS>([&](auto KS_) {
+      constexpr int ks = decltype(KS_)::value, cur = ks & 1;
+      if constexpr (ks + 1 < KS) {
+        rd(std::integral_constant<int, ks + 1>{}, std::integral_constant<int, (cur ^ 1)>{});
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (RB + 3)) : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+#pragma unroll
+      for (int f = 0; f < RB + 3; ++f) asm volatile("" : "+v"(fl[cur][f]), "+v"(fh[cur][f]));
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+          acc[i][j] = mfma32(make_bf16x8(fl[cur][i], fh[cur][i]), make_bf16x8(fl[cur][RB + j], fh[cur][RB + j]), acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
   }
 #pragma unroll
   for (int i = 0; i < RB; ++i)
@@ -142,17 +235,19 @@ __device__ __forceinline__ void tn_tile(unsigned char* lds, const bf16_t* __rest
       }
     }
   if (do_bias) {  // 16 threads share a column chunk: reduce through LDS, one atomic per column
+    __syncthreads();                  // (the ring is read by nobody any more)
     float* red = (float*)lds;  // [16][128]
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[(tid / A_CH) * TN_TN + (tid % A_CH) * 8 + e] = bsum[e];
+    for (int e = 0; e < 8; ++e) red[(tid >> 4) * C::TN + (tid & 15) * 8 + e] = bsum[e];
     __syncthreads();
-    if (tid < TN_TN && n0 + tid < N) {
+    if (tid < C::TN && n0 + tid < N) {
       float sum = 0.f;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) sum += red[g * TN_TN + tid];
+      for (int g = 0; g < 16; ++g) sum += red[g * C::TN + tid];
       atomicAdd(dbias + n0 + tid, sum);
     }
   }
+#endif
 }
 
 constexpr int TN_BM = TnSmall::BM, TN_TN = TnSmall::TN, TN_TK = TnSmall::TK;   // the single-GEMM entry point
@@ -162,10 +257,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
                                                       float* __restrict__ dW, int lddw, int M,
                                                       int N, int K, int rows_per_split,
                                                       float* __restrict__ dbias) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[TN_LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[TN_DMA_LDS];
   const int m_begin = blockIdx.z * rows_per_split;
-  tn_tile<TnSmall>(lds, A, lda, B, ldb, dW, lddw, N, K, blockIdx.x * TN_TN, blockIdx.y * TN_TK, m_begin,
-          min(M, m_begin + rows_per_split), dbias, blockIdx.y == 0);
+  tn_tile_dma<TnSmallD>(lds, A, lda, B, ldb, dW, lddw, M, N, K, blockIdx.x * TN_TN, blockIdx.y * TN_TK, m_begin,
+                        min(M, m_begin + rows_per_split), dbias, blockIdx.y == 0);
 }
 
 // Grouped launch: up to SVIT_TN_GROUP_MAX independent weight-gradient GEMMs share one grid, so
@@ -183,7 +278,7 @@ struct TnGroup {
 };
 
 __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup g) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[TN_LDS_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[TN_DMA_LDS];
   // Logical ids are (problem, split)-major, tile-minor: the tiles of one split walk the SAME
   // rows in lock-step and re-read each other's A / B column panels (A once per k-tile, B once
   // per n-tile).  Consecutive logical ids are therefore placed on ONE XCD, so those re-reads
@@ -202,13 +297,13 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup g) {
   const int tn = tile % g.tiles_n[pi], tk = tile / g.tiles_n[pi];
   const int m_begin = split * g.rows_per_split[pi];
   if (g.big[pi])
-    tn_tile<TnBig>(lds, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.dW, p.lddw, p.N, p.K,
-                   tn * TnBig::TN, tk * TnBig::TK, m_begin, min(p.M, m_begin + g.rows_per_split[pi]),
-                   p.dbias, tk == 0);
+    tn_tile_dma<TnBigD>(lds, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.dW, p.lddw, p.M, p.N, p.K,
+                        tn * TnBig::TN, tk * TnBig::TK, m_begin, min(p.M, m_begin + g.rows_per_split[pi]),
+                        p.dbias, tk == 0);
   else
-    tn_tile<TnSmall>(lds, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.dW, p.lddw, p.N, p.K,
-                     tn * TnSmall::TN, tk * TnSmall::TK, m_begin, min(p.M, m_begin + g.rows_per_split[pi]),
-                     p.dbias, tk == 0);
+    tn_tile_dma<TnSmallD>(lds, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.dW, p.lddw, p.M, p.N, p.K,
+                          tn * TnSmall::TN, tk * TnSmall::TK, m_begin, min(p.M, m_begin + g.rows_per_split[pi]),
+                          p.dbias, tk == 0);
 }
 
 __global__ void colsum_kernel(const bf16_t* __restrict__ A, int lda, float* __restrict__ out,
@@ -328,11 +423,13 @@ static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void
     double tile_bytes[SVIT_TN_GROUP_MAX];
     for (int i = 0; i < g.count; ++i) {
       g.p[i] = probs[base + i];
-      // 128 x 192 tiles where they are fully used (K a multiple of 192) AND the reduction is short
-      // (measured, tools/bench_kernels.py tngroup, profiles/r02_tn_tile_modes.txt: -7 % on the
-      // M = 3656 groups of blocks 14-15; +4..9 % on the M >= 13064 groups, where the doubled fp32
-      // tile a workgroup flushes with atomics outweighs the smaller operand traffic)
-      g.big[i] = big_mode == 1 ? (g.p[i].K % TnBig::TK == 0 && g.p[i].N >= 128 && g.p[i].M <= 4096)
+      // 128 x 192 tiles where they are fully used (K a multiple of 192) and measured faster with the
+      // round-3 LDS-DMA body (tools/bench_kernels.py tngroup, profiles/r03_tn_tile_modes.txt): the
+      // M = 3656 groups of blocks 14-15 (-5 / -11 %) and the M = 50696 groups of blocks 2-3 (-16 / -22 %);
+      // not the M = 13064 groups of blocks 4-13 (+10 %: the doubled fp32 tile a workgroup flushes with
+      // atomics outweighs the smaller operand traffic) nor the M = 201224 group of block 0 (+11 %)
+      g.big[i] = big_mode == 1 ? (g.p[i].K % TnBig::TK == 0 && g.p[i].N >= 128 &&
+                                  (g.p[i].M <= 4096 || (g.p[i].M >= 32768 && g.p[i].M < 131072)))
                                : (big_mode == 2);
       const int tn = g.big[i] ? TnBig::TN : TnSmall::TN, tk = g.big[i] ? TnBig::TK : TnSmall::TK;
       bm[i] = g.big[i] ? TnBig::BM : TnSmall::BM;
