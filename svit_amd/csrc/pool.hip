@@ -1394,8 +1394,13 @@ __global__ __launch_bounds__(SLAB_NT) void pool_slab_fwd_kernel(PoolSlab3 g) {
     if (q0 + wave * 64 >= nchunks) break;          // (whole wave past the end: nothing to fetch)
     const int q = min(q0 + tid, nchunks - 1);      // lanes past the end re-read the last chunk (into the pad)
     const int j = fdiv(q, 0x55555556u), ch = q - 3 * j;
-    const int r = fdiv(j, mW), xj = j - r * W, tj = fdiv(r, mRY), yj = r - tj * RY;
-    const size_t tok = 1 + (size_t)((t_lo + tj) * H + (y_lo + yj)) * W + xj;
+    size_t tok;
+    if (RY == H) {                 // whole planes (what plan_slab picks): slab tokens are consecutive input tokens
+      tok = 1 + (size_t)t_lo * H * W + j;
+    } else {
+      const int r = fdiv(j, mW), xj = j - r * W, tj = fdiv(r, mRY), yj = r - tj * RY;
+      tok = 1 + (size_t)((t_lo + tj) * H + (y_lo + yj)) * W + xj;
+    }
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void*)(src + tok * tok_stride + ch * 8),
         (__attribute__((address_space(3))) void*)(slab + (size_t)(q0 + wave * 64) * 16), 16, 0, 0);
