@@ -124,6 +124,43 @@ def cpu_baseline(frames, crop, timed_steps=3):
                       % (frames, crop, timed_steps, head["best_s"], head["median_s"])}
 
 
+def aten_gpu_baseline(frames, crop, batch, timed_steps=3):
+    """Context only, never credit: the SAME oracle (oracle/svit_ref.py: plain
+    ATen ops -- hipBLASLt GEMMs, MIOpen depthwise conv, materialised attention matrices) on THIS GPU
+    under torch.autocast("cuda", bfloat16), fwd + CE + bwd at the bench batch, DropPath / dropout on,
+    1 warm-up + 3 timed steps.  Says what stock PyTorch-ROCm does with the same math on the same chip."""
+    from oracle import svit_ref as R
+    dev = torch.device("cuda")
+    spec = R.make_spec(num_frames=frames, crop=crop)
+    torch.manual_seed(0)
+    p = {k: (torch.randn(s, device=dev) * 0.02).requires_grad_(True) for k, s in R.param_shapes(spec).items()}
+    for k in p:
+        if k.endswith("norm.weight") or ".norm" in k and k.endswith("weight"):
+            p[k].data.fill_(1.0)
+    x = torch.randn(batch, 3, frames, crop, crop, device=dev)
+    y = torch.randint(0, 174, (batch,), device=dev)
+    times = []
+    for i in range(1 + timed_steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ds = [None if d is None else tuple(t.to(dev) for t in d) for d in R.sample_drop_scales(spec, batch)]
+        keep = (torch.rand(batch, 1 + frames * 4, spec.final_dim, device=dev) > 0.5).float() * 2.0
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            logits, _ = R.forward(p, spec, x, training=True, drop_scales=ds, dropout_keep=keep)
+            loss = R.video_loss(logits.float(), y)
+        loss.backward()
+        for v in p.values():
+            v.grad = None
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])
+    peak_gb = torch.cuda.max_memory_allocated() / 1e9
+    return {"value": round(batch / t[0], 2), "unit": "clips/s", "median": round(batch / t[len(t) // 2], 2),
+            "ms_per_step": round(t[0] * 1e3, 2), "batch": batch, "kind": "stock ATen ops on the same GPU, bf16 autocast",
+            "note": "fwd + CE + bwd, no optimizer step, eager; context only (oracle/svit_ref.py on cuda)",
+            "peak_mem_gb": round(peak_gb, 1)}
+
+
 def kernel_report(trace, batch):
     """Aggregate the HIP-event trace of one profiled step per C-ABI entry point."""
     torch.cuda.synchronize()
@@ -413,6 +450,12 @@ def main():
         step(args.warmup + args.steps, eager=True)  # keep ranks in lock-step with rank 0's traced step
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.frames, args.crop)
+        del graphed, model, opt
+        torch.cuda.empty_cache()
+        try:
+            out["aten_gpu_baseline"] = aten_gpu_baseline(args.frames, args.crop, args.batch)
+        except Exception as exc:        # context only: never lose the line to it
+            out["aten_gpu_baseline"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

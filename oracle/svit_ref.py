@@ -199,7 +199,7 @@ def object_gain(weight, stride):
             for tap in range(3):
                 if 0 <= o * s - 1 + tap < 3:
                     n[tap] += 1
-        return torch.tensor(n, dtype=weight.dtype), n_out
+        return torch.tensor(n, dtype=weight.dtype, device=weight.device), n_out
     nt, pt = counts(stride[0])
     nh, ph = counts(stride[1])
     nw, pw = counts(stride[2])
@@ -255,7 +255,7 @@ def resize_table(table, rows):
     if L == rows:
         return table
     scale = L / rows
-    pos = (torch.arange(rows, dtype=torch.float32) + 0.5) * scale - 0.5
+    pos = (torch.arange(rows, dtype=torch.float32, device=table.device) + 0.5) * scale - 0.5
     pos = pos.clamp(min=0.0)
     i0 = pos.floor().long().clamp(max=L - 1)
     i1 = (i0 + 1).clamp(max=L - 1)

@@ -91,26 +91,49 @@ def bench_tn():
                   (blk, tag, M, N, K, us, flop / us / 1e6, byts / us / 1e6))
 
 
-def bench_attn():
-    print("== attention (fwd / bwd) ==")
-    for blk, Nin, Nq, Nk, Ci, Co, h, DA in BLOCKS:
+# 32x224^2 (BASELINE config C4, B = 4): objects 128, Nk 913 / 3265, bias columns 16 + 7 + 7 / 16 + 14 + 14
+BLOCKS_C4 = [(0, 50305, 50305, 913, 96, 96, 1, 128), (1, 50305, 12673, 3265, 96, 192, 2, 160),
+             (2, 12673, 12673, 913, 192, 192, 2, 128), (3, 12673, 3265, 3265, 192, 384, 4, 160),
+             (4, 3265, 3265, 913, 384, 384, 4, 128), (14, 3265, 913, 3265, 384, 768, 8, 160),
+             (15, 913, 913, 913, 768, 768, 8, 128)]
+
+
+def bench_attn(cfg="c2"):
+    """fused attention forward and backward per block shape of 16x224^2 B = 8 (c2) or 32x224^2 B = 4 (c4),
+    with the bias-column counts the engine passes; step totals (blocks 4-13 counted ten times)."""
+    blocks, B = (BLOCKS_C4, 4) if cfg == "c4" else (BLOCKS, 8)
+    print("== attention (fwd / bwd), %s, B = %d ==" % ("32x224^2" if cfg == "c4" else "16x224^2", B))
+    tot = {"f": 0.0, "b": 0.0, "alg": 0.0}
+    for blk, Nin, Nq, Nk, Ci, Co, h, DA in blocks:
+        if cfg == "c4":
+            J = 30 if DA == 128 else 44
+        else:
+            J = 22 if DA == 128 else 36
         qa, ka, v = rnd(B, h, Nq, DA), (rnd(B, h, Nk, DA).float() * KSC).to(BF16), rnd(B, h, Nk, 96)
+        qa[..., 96 + J:] = 0
+        ka[..., 96 + J:] = 0
         scale = 96 ** -0.5
-        us = timeit(lambda: ops.attn_fwd(qa, ka, v, scale))
+        us = timeit(lambda: ops.attn_fwd(qa, ka, v, scale, bias_cols=J))
         alg = 2.0 * B * h * Nq * Nk * 192
-        ctx, lse2 = ops.attn_fwd(qa, ka, v, scale)
+        ctx, lse2 = ops.attn_fwd(qa, ka, v, scale, bias_cols=J)
         dctx = rnd(B, Nq, h * 96)
         import ctypes as C
         lib = hip.load()
         lib.svit_attn_debug_set.restype, lib.svit_attn_debug_set.argtypes = C.c_int32, [C.c_int32, C.c_int32]
         lib.svit_attn_debug_set(0, 1)
-        usb1 = timeit(lambda: ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, scale), iters=10)
+        usb1 = timeit(lambda: ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, bias_cols=J), iters=10)
         lib.svit_attn_debug_set(0, 2)
-        usb2 = timeit(lambda: ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, scale), iters=10)
+        usb2 = timeit(lambda: ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, bias_cols=J), iters=10)
         lib.svit_attn_debug_set(0, 0)
-        usb = timeit(lambda: ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, scale), iters=10)
-        print("blk%-2d h=%d Nq=%6d Nk=%5d DA=%d  fwd %8.1f us %7.1f TF | bwd %8.1f us %7.1f TF  (dkv 4 waves %.1f, 8 waves %.1f)" %
-              (blk, h, Nq, Nk, DA, us, alg / us / 1e6, usb, 2 * alg / usb / 1e6, usb1, usb2))
+        usb = timeit(lambda: ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, bias_cols=J), iters=10)
+        mult = 10 if blk == 4 else 1
+        tot["f"] += us * mult; tot["b"] += usb * mult; tot["alg"] += alg * mult
+        print("blk%-2d h=%d Nq=%6d Nk=%5d DA=%d J=%d  fwd %8.1f us %7.1f TF (%.3f) | bwd %8.1f us %7.1f TF (%.3f)  (dkv 4 waves %.1f, 8 waves %.1f)" %
+              (blk, h, Nq, Nk, DA, J, us, alg / us / 1e6, alg / us / 1e6 / 2500, usb, 2 * alg / usb / 1e6,
+               2 * alg / usb / 1e6 / 2500, usb1, usb2), flush=True)
+    print("step totals (16 launches): fwd %.1f us = %.1f TF = %.3f of 2.5 PF | bwd %.1f us = %.1f TF = %.3f of 2.5 PF" %
+          (tot["f"], tot["alg"] / tot["f"] / 1e6, tot["alg"] / tot["f"] / 1e6 / 2500,
+           tot["b"], 2 * tot["alg"] / tot["b"] / 1e6, 2 * tot["alg"] / tot["b"] / 1e6 / 2500))
 
 
 def bench_attn_fwd():
@@ -149,7 +172,7 @@ if __name__ == "__main__":
     if what in ("tn", "all"):
         bench_tn()
     if what in ("attn", "all"):
-        bench_attn()
+        bench_attn(sys.argv[2] if len(sys.argv) > 2 else "c2")
 
 
 
