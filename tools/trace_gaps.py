@@ -38,6 +38,29 @@ def main():
     print("idle time by preceding kernel:")
     for k, (g, c) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:25]:
         print("  %8.1f us  %5d gaps  avg %6.2f us  %s" % (g / 1e3, c, g / 1e3 / c, k))
+    per_step(path)
+
+
+def per_step(path):
+    """One line per training step (delimited by the optimizer's last kernel): wall span against the sum of
+    kernel durations, the idle time before the step's first dispatch and inside it.  The window above mixes
+    in the warm-up -> capture -> timed-region boundaries (each a host synchronisation); this does not."""
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Grid_Size_X"]))
+    rows.sort()
+    adam = [i for i, r in enumerate(rows) if "adamw_kernel" in r[2]]
+    ends = [i for i, j in zip(adam, adam[1:] + [None]) if j is None or j != i + 1]    # last adamw of each step
+    print("per step (last optimizer kernel to last optimizer kernel):")
+    for a, b in zip(ends[:-1], ends[1:]):
+        seg = rows[a + 1:b + 1]
+        span = seg[-1][1] - seg[0][0]
+        ksum = sum(e - s for s, e, _, _ in seg)
+        gaps = [y[0] - x[1] for x, y in zip(seg[:-1], seg[1:])]
+        print("  %4d dispatches  span %.3f ms  kernels %.3f ms  idle before %.1f us  idle inside %.1f us (largest %.1f)"
+              % (len(seg), span / 1e6, ksum / 1e6, (seg[0][0] - rows[a][1]) / 1e3,
+                 sum(g for g in gaps if g > 0) / 1e3, max(gaps) / 1e3))
 
 
 def window(path, needle, before, after):
