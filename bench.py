@@ -255,6 +255,8 @@ def main():
     ap.add_argument("--no-kernel-trace", action="store_true")
     ap.add_argument("--eager", action="store_true",
                     help="launch every kernel from Python instead of replaying the HIP graphs")
+    ap.add_argument("--nt-cfg", type=int, default=None,
+                    help="A/B knob for measurements: svit_debug_set(1, N) -- 8 = the NT GEMM heuristic without the ring kernels")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -283,6 +285,12 @@ def main():
 
     from svit_amd import config, optim
     from svit_amd.model import build_model
+    if args.nt_cfg is not None:
+        import ctypes
+        from svit_amd import hip as _hip
+        _lib = _hip.load()
+        _lib.svit_debug_set.restype, _lib.svit_debug_set.argtypes = ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32]
+        _lib.svit_debug_set(1, args.nt_cfg)
     cfg = config.ssv2_cfg(num_frames=args.frames, crop=args.crop, num_gpus=world)
     if not 0 <= args.image_ranks <= world:
         raise SystemExit("--image-ranks must be between 0 and --gpus")

@@ -10,7 +10,17 @@
 // bf16-output epilogues (plain, GELU, GELU-backward) with 8 columns = one 16-byte store per lane
 // (the 4-column form below issues twice as many 8-byte stores; the stage-1 GEMMs write 150-310 MB
 // per launch and are bound by exactly that).  Needs 16-byte aligned rows: ldo / ldo2 / ldaux % 8.
-template <int RB, int NB, int EPI>
+// WAVE_PRIVATE: the staging region belongs to the calling wave alone and the LDS operations of one wave
+// complete in order, so a drained lgkmcnt (plus the compiler barrier of the asm) is all the
+// synchronisation the write -> read -> overwrite sequence needs; callers whose OTHER waves have left the
+// kernel or are elsewhere (gemm_nt_ring_kernel's loader waves) must use it -- no s_barrier is executed.
+template <bool WAVE_PRIVATE>
+__device__ __forceinline__ void nt_epi_sync() {
+  if constexpr (WAVE_PRIVATE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  else __syncthreads();
+}
+
+template <int RB, int NB, int EPI, bool WAVE_PRIVATE = false>
 __device__ __forceinline__ void nt_epilogue_wide(const svit_gemm_args& p, f32x16_t (&acc)[RB][NB],
                                                  unsigned char* smem, int m0, int n0, int wm, int wn,
                                                  int lane, int wave) {
@@ -48,7 +58,7 @@ __device__ __forceinline__ void nt_epilogue_wide(const svit_gemm_args& p, f32x16
         stg[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] =
             acc[i][j][half * 8 + rr];
     if (EPI == SVIT_EPI_DGELU && ih + 1 < 2 * RB) fetch_aux(ih + 1, aux_nxt);
-    __syncthreads();
+    nt_epi_sync<WAVE_PRIVATE>();
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
       const int idx = lane + 64 * it, rl = idx / GPR, c8 = idx % GPR;
@@ -86,11 +96,11 @@ __device__ __forceinline__ void nt_epilogue_wide(const svit_gemm_args& p, f32x16
 #pragma unroll
       for (int it = 0; it < NB; ++it) aux_cur[it] = aux_nxt[it];
     }
-    if (ih + 1 < 2 * RB) __syncthreads();
+    if (ih + 1 < 2 * RB) nt_epi_sync<WAVE_PRIVATE>();
   }
 }
 
-template <int RB, int NB, int EPI>
+template <int RB, int NB, int EPI, bool WAVE_PRIVATE = false>
 __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&acc)[RB][NB],
                                             unsigned char* smem, int m0, int n0, int wm, int wn,
                                             int lane, int wave) {
@@ -98,7 +108,7 @@ __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&
     const bool rows16 = (p.ldo % 8 == 0) && (EPI != SVIT_EPI_GELU || !p.out2 || p.ldo2 % 8 == 0) &&
                         (EPI != SVIT_EPI_DGELU || p.ldaux % 8 == 0);
     if (rows16) {     // (uniform over the launch)
-      nt_epilogue_wide<RB, NB, EPI>(p, acc, smem, m0, n0, wm, wn, lane, wave);
+      nt_epilogue_wide<RB, NB, EPI, WAVE_PRIVATE>(p, acc, smem, m0, n0, wm, wn, lane, wave);
       return;
     }
   }
@@ -168,7 +178,7 @@ __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&
         stg[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] =
             acc[i][j][half * 8 + rr];
     if (use_aux && ih + 1 < 2 * RB) fetch_aux(ih + 1, aux_nxt);
-    __syncthreads();
+    nt_epi_sync<WAVE_PRIVATE>();
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int idx = lane + 64 * it;
@@ -225,6 +235,6 @@ __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&
 #pragma unroll
       for (int it = 0; it < NIT; ++it) aux_cur[it] = aux_nxt[it];
     }
-    if (ih + 1 < 2 * RB) __syncthreads();
+    if (ih + 1 < 2 * RB) nt_epi_sync<WAVE_PRIVATE>();
   }
 }

@@ -77,7 +77,7 @@ def test_gemm_nt_epilogues(ops, M, K, N):
 
 
 @pytest.mark.parametrize("M,N,K", [(700, 384, 128), (1333, 1152, 384), (2049, 768, 192), (515, 384, 2304),
-                                   (20000, 576, 96)])
+                                   (20000, 576, 96), (130, 96, 64), (3001, 288, 448)])
 def test_gemm_nt_tile_variants(ops, M, N, K):
     """every (tile, pipeline depth, K-step) variant the heuristic can pick gives the same product"""
     import ctypes as C
@@ -97,6 +97,19 @@ def test_gemm_nt_tile_variants(ops, M, N, K):
                     lib.svit_debug_set(0, st), lib.svit_debug_set(1, cfg), lib.svit_debug_set(2, bk)
                     out = ops.gemm_nt(a, w, bias, hip.EPI_F32)
                     assert rel_err(out, ref) < 1e-3, (cfg, st, bk)
+        # ring kernels (loader waves + MFMA waves, K-steps of 64): 128x192, 128x96, 128x128 tiles, every depth
+        resid = rnd("vr%d" % M, (M, N), 1.0)
+        for cfg in (5, 6, 7):
+            if K % 64 or (cfg == 5 and N % 96):
+                continue
+            for st in (2, 3, 4):
+                lib.svit_debug_set(0, st), lib.svit_debug_set(1, cfg), lib.svit_debug_set(2, 0)
+                out = ops.gemm_nt(a, w, bias, hip.EPI_F32)
+                assert rel_err(out, ref) < 1e-3, (cfg, st)
+                out = ops.gemm_nt(a, w, bias, hip.EPI_RESID, aux=resid)
+                assert rel_err(out, ref + resid) < 1e-3, (cfg, st, "resid")
+                out = ops.gemm_nt(a, w, bias, hip.EPI_BF16)
+                assert rel_err(out, ref) < 1e-2, (cfg, st, "bf16")
     finally:
         lib.svit_debug_set(0, 0), lib.svit_debug_set(1, -1), lib.svit_debug_set(2, 0)
 

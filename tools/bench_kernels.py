@@ -265,6 +265,60 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ntstages":
     bench_nt_stages()
 
 
+def bench_nt_ring():
+    """NT GEMM: the heuristic's choice against the ring kernels (cfg 5 = 128x192, 6 = 128x96, 7 = 128x128; 2/3/4 stages),
+    the pre-ring heuristic (v2) and the library's GEMM; `ntring resid|f32|gelu|dgelu` picks the epilogue (default bf16)."""
+    import ctypes as C
+    lib = hip.load()
+    lib.svit_debug_set.restype, lib.svit_debug_set.argtypes = C.c_int32, [C.c_int32, C.c_int32]
+    epi_name = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+    print("== gemm_nt (%s epilogue): us, heuristic vs v2 heuristic vs ring(cfg, stages) vs torch.mm ==" % epi_name)
+    shapes = [(13064, 384, 1536), (13064, 384, 1152), (3656, 768, 3072), (50696, 192, 768), (13064, 384, 2304),
+              (50696, 192, 1152), (3656, 768, 2304), (50696, 192, 576), (201224, 96, 384), (201224, 96, 576),
+              (13064, 384, 768), (13064, 384, 384), (13064, 1536, 384), (13064, 1152, 384), (50696, 768, 192),
+              (3656, 3072, 768), (3656, 768, 768), (50696, 192, 192), (200704, 96, 448)]
+    for (M, N, K) in shapes:
+        a, w = rnd(M, K), rnd(N, K)
+        bias = torch.zeros(N, device=DEV)
+        if epi_name == "resid":
+            aux, out = rnd(M, N, dtype=torch.float32), torch.empty(M, N, device=DEV)
+            rs = torch.ones(8, device=DEV)
+            run = lambda: ops.gemm_nt(a, w, bias, hip.EPI_RESID, out=out, aux=aux, row_scale=rs, rows_per_sample=(M + 7) // 8)
+        elif epi_name == "f32":
+            out = torch.empty(M, N, device=DEV)
+            run = lambda: ops.gemm_nt(a, w, bias, hip.EPI_F32, out=out)
+        elif epi_name == "gelu":
+            out, out2 = torch.empty(M, N, device=DEV, dtype=BF16), torch.empty(M, N, device=DEV, dtype=BF16)
+            run = lambda: ops.gemm_nt(a, w, bias, hip.EPI_GELU, out=out, out2=out2)
+        elif epi_name == "dgelu":
+            aux, out = rnd(M, N), torch.empty(M, N, device=DEV, dtype=BF16)
+            run = lambda: ops.gemm_nt(a, w, None, hip.EPI_DGELU, out=out, aux=aux)
+        else:
+            out = torch.empty(M, N, device=DEV, dtype=BF16)
+            run = lambda: ops.gemm_nt(a, w, bias, hip.EPI_BF16, out=out)
+        res = []
+        lib.svit_debug_set(0, 0), lib.svit_debug_set(1, -1), lib.svit_debug_set(2, 0)
+        res.append("auto:%.1f" % timeit(run, iters=10))
+        lib.svit_debug_set(1, 8)        # the pre-ring (v2) heuristic: what "auto" was before
+        res.append("v2:%.1f" % timeit(run, iters=10))
+        if K % 64 == 0:
+            for cfg in (5, 6, 7):
+                if (cfg == 5 and N % 192) or (cfg == 7 and N % 128):
+                    continue
+                for st in (2, 3, 4):
+                    lib.svit_debug_set(0, st), lib.svit_debug_set(1, cfg)
+                    res.append("r%ds%d:%.1f" % (cfg, st, timeit(run, iters=10)))
+        lib.svit_debug_set(0, 0), lib.svit_debug_set(1, -1), lib.svit_debug_set(2, 0)
+        if epi_name == "bf16":
+            wt = w.t()
+            res.append("lib:%.1f" % timeit(lambda: torch.mm(a, wt), iters=10))
+        print("M=%6d N=%4d K=%4d  " % (M, N, K), " ".join(res), flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ntring":
+    bench_nt_ring()
+
+
 def bench_ln():
     """LayerNorm fwd / bwd (with the fused bf16 operand) at the residual-stream shapes (us)."""
     print("== layernorm rows x C: fwd / bwd us, bwd GB/s ==")
