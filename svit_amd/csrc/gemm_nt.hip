@@ -381,23 +381,20 @@ extern "C" int svit_debug_set(int key, int val) {
   return SVIT_OK;
 }
 
-// Which ring kernel, if any (measured per epilogue family on MI355X, tools/bench_kernels.py ntring <epilogue>,
-// profiles/r03_nt_ring.txt).  *cfg stays < 0 where the v2 kernels are as fast or faster.
+// Which ring kernel, if any.  Two sets of measurements on MI355X decide (profiles/r03_nt_ring.txt):
+// isolated loops per epilogue family (tools/bench_kernels.py ntring <epilogue>), where the ring kernels win
+// almost everywhere K % 64 == 0, and the replayed training step with every NT launch matched by position
+// (tools/nt_by_position.py), where the short-K wins do NOT survive (a launch's neighbours are other kernels,
+// not copies of itself: 128x128 / 2 stages for fc1 was +5 % there, 128x96 / 2 stages at K = 384 +11 %).
+// Kept are the two rules that win in both: *cfg stays < 0 otherwise (v2 kernels).
 static void ring_choice(const svit_gemm_args& a, int* cfg, int* stages) {
   const long tm = (a.M + 127) / 128;
-  const bool heavy = a.epilogue == SVIT_EPI_RESID || a.epilogue == SVIT_EPI_F32;   // read-modify-write fp32 rows
   const long t192 = a.N % 192 == 0 ? tm * (a.N / 192) : 0, t96 = tm * ((a.N + 95) / 96);
-  // few, long tiles: every 128x96 tile has a CU to itself -> deep ring (3656 x 768 x 768..3072: -10..-30 %)
+  // few, long tiles: every 128x96 tile has a CU to itself -> 4-deep ring (3656 x 768 x 768..3072: -30 %)
   if (t96 <= 256 && a.K >= 768) { *cfg = 6, *stages = 4; return; }
-  // long K, narrow output, enough 128x192 tiles for most CUs (13064 x 384 x 1152..2304: -8..-20 %)
+  // long K, narrow output, enough 128x192 tiles for most CUs (13064 x 384 x 1152..2304: -6..-10 % in the
+  // step, -15..-20 % isolated; on a par with hipBLASLt's 128x160x64 macro-tile)
   if (t192 >= 160 && a.N <= 768 && a.K >= 1024) { *cfg = 5, *stages = 3; return; }
-  if (heavy) {
-    // wide fp32 outputs at short K: 128x128 / 2 stages (fc-sized N, K <= 512)
-    if (a.epilogue == SVIT_EPI_F32 && a.N % 128 == 0 && a.N >= 768 && a.K <= 512) { *cfg = 7, *stages = 2; return; }
-    return;
-  }
-  if (a.N % 128 == 0 && a.N >= 1024 && a.K <= 512) { *cfg = 7, *stages = 2; return; }   // fc1 / qkv / fc2-dgrad
-  if (a.epilogue == SVIT_EPI_BF16) { *cfg = 6, *stages = t96 <= 256 ? 4 : 2; return; }
 }
 
 extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
