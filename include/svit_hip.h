@@ -197,14 +197,15 @@ int svit_pool_conv_wgrad(const svit_pool_wgrad_args* a, void* stream);
  * chain, so three side by side cost the time of one (attention.py:263-304 runs them serially).
  * The two-stage reductions use args[0].workspace (>= 1024 * 3 * 27 * 96 floats for wgrad). */
 int svit_pool_ln_fwd_qkv(const svit_pool_args* args3, void* stream);
-/* Round 2: LDS-tiled stride-1 stencils.  svit_pool_weight_sel turns a list of depthwise weights
+/* Stride-1 stencils that keep their input in LDS.  svit_pool_weight_sel turns a list of depthwise weights
  * (fp32 [96][27] each, at src_base + src_off[i]) into "selector" tables dst[i][27][96] (uint32:
- * bf16(w) in the half of the dword that matches the channel's position in a packed bf16 pair) --
- * the SCALAR operands of the tiled kernels (run once per step for all blocks).  The *_sel entry
- * points take the three tables of a block; tensors with stride 1 then read every input element
- * once into an LDS halo ring instead of 27 times through the texture path.  (End of round 2: the
- * tiled kernels build their LDS weight image from conv_w themselves and only consult WHETHER a
- * table is given; the tables' contents are what the channel-lane experiment consumed) */
+ * bf16(w) in the half of the dword that matches the channel's position in a packed bf16 pair); run
+ * once per step for all blocks.  The *_sel entry points take the three tables of a block.  Who reads
+ * them: the SLAB forward (round 3; planes of <= 196 tokens, i.e. the 14x14 and 7x7 stages) fetches a
+ * channel group's 27 x 24 entries as SCALAR operands (s_load) -- its stencil has no vector weight loads
+ * at all; the LDS-tiled kernels of round 2 (56x56 planes; halo ring in LDS) build their own LDS weight
+ * image from conv_w and only consult WHETHER a table is given.  Without tables every tensor runs the
+ * streaming kernels. */
 int svit_pool_weight_sel(const float* src_base, const int64_t* src_off, uint32_t* dst, int n_tables,
                          void* stream);
 int svit_pool_ln_fwd_qkv_sel(const svit_pool_args* args3, const uint32_t* const* sel3, void* stream);

@@ -340,11 +340,13 @@ def test_pool_ln_fwd_bwd(ops, stride, thw):
                                          (2, 2, (4, 14, 14)), (1, 2, (8, 14, 14)), (2, 2, (2, 28, 28)),
                                          (1, 1, (8, 7, 7)), (1, 2, (3, 56, 56)), (2, 4, (2, 33, 31))])
 def test_pool_tiled_stride1_equals_streaming(ops, sq, skv, thw):
-    """Round-2 LDS-tiled stride-1 stencils (halo ring in LDS, scalar weight operands; forward with
-    the LayerNorm spanning four waves, and the conv dgrad with the flipped kernel) against the
-    streaming kernels they replace: the forward is BIT-identical (same taps in the same order),
-    the dgrad equal to fp32 rounding.  Covers partial tiles, the 7x7 tile, two x tiles, a t walk
-    cut in chunks, T = 1 and non-square planes."""
+    """LDS-tiled / slab stride-1 stencils (whichever the planner picks for the plane: halo ring in LDS
+    with the LayerNorm spanning four waves, or the slab kernel with scalar weights; and the conv
+    dgrad with the flipped kernel) against the streaming kernels they replace.  Same taps, but the
+    accumulation order and -ffast-math contraction differ between the code paths, so the claim is
+    "equal to one bf16 ulp" (rel_err < 2e-2, cosine > 0.9999), NOT bit identity; only the one-hot
+    rel-pos columns, which are copied, must be exactly equal.  Covers partial tiles, the 7x7 tile,
+    two x tiles, a t walk cut in chunks, T = 1 and non-square planes."""
     B, h, O = 2, 2, 3
     qkv = _qkv(B, h, thw, O, "t%d%d%d" % (sq, skv, thw[1]))
     ws = [rnd("tw%d" % i, (96, 27), 0.3) for i in range(3)]
