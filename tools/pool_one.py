@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""One block shape of the q/k/v pooling forward (slab path) a few times, for rocprofv3 --kernel-trace.
-python tools/pool_one.py [blk]"""
+"""One block shape of the q/k/v pooling forward (slab path) and of the conv backward (dgrad + wgrad) a few times,
+for rocprofv3 --kernel-trace.   python tools/pool_one.py [blk]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,5 +23,10 @@ sels = [sel[i] for i in range(3)]
 J = 2 * ops.pooled(thw[1], skv) + thw[0]
 da = 128 if J <= 32 else 160
 for _ in range(6):
-    ops.pool_ln_fwd_qkv(qkv, ws, g, b, B, h, thw, n_obj, (sq, skv, skv), (da, da, 96), (0, 1, 0), sels=sels)
+    outs = ops.pool_ln_fwd_qkv(qkv, ws, g, b, B, h, thw, n_obj, (sq, skv, skv), (da, da, 96), (0, 1, 0), sels=sels)
+dpres = [torch.randn_like(outs[i][1].float()).to(outs[i][1].dtype) for i in range(3)]
+dws = [torch.zeros(96, 27, device=DEV) for _ in range(3)]
+dqkv = torch.zeros_like(qkv)
+for _ in range(6):
+    ops.pool_conv_bwd_qkv(dpres, ws, dqkv, qkv, dws, B, h, thw, n_obj, (sq, skv, skv))
 torch.cuda.synchronize()
