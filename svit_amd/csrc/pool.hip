@@ -839,27 +839,29 @@ __device__ __forceinline__ void pool_wgrad_body(const svit_pool_wgrad_args& a, i
     const int yo0 = yc * R, xo0 = xc * TX;
     const int t_begin = tc * t_len, t_end = min(a.T, t_begin + t_len);
     const bf16_t* xin = qkv + (size_t)b * N * tok_stride + (size_t)head * HD;
-    uint4 sreg[SLAB_PER], dreg[DY_PER];
-    auto fetch_plane = [&](int tp) {   // global -> registers (zero outside the volume)
+    uint4 sreg[SLAB_PER], sreg_a[SLAB_PER], sreg_b[SLAB_PER], dreg[DY_PER];
+    auto fetch_plane_to = [&](int tp, uint4 (&dst)[SLAB_PER]) {   // global -> registers (zero outside the volume)
 #pragma unroll
       for (int u = 0; u < SLAB_PER; ++u) {
         const int q = tid + u * 192;
         const int tok = q / 12, cc = q % 12, j = tok / CI, i = tok % CI;
         const int y = TL::SPARSE ? (yo0 + j / 3) * s - 1 + j % 3 : yo0 * s - 1 + j;
         const int x = TL::SPARSE ? (xo0 + i / 3) * s - 1 + i % 3 : xo0 * s - 1 + i;
-        sreg[u] = make_uint4(0, 0, 0, 0);
+        dst[u] = make_uint4(0, 0, 0, 0);
         if (q < SLAB_CH && tp >= 0 && tp < a.T && y >= 0 && y < a.H && x >= 0 && x < a.W)
-          sreg[u] = *(const uint4*)(xin + (size_t)(1 + (tp * a.H + y) * a.W + x) * tok_stride + cc * 8);
+          dst[u] = *(const uint4*)(xin + (size_t)(1 + (tp * a.H + y) * a.W + x) * tok_stride + cc * 8);
       }
     };
-    auto store_plane = [&](int tp) {   // registers -> ring slot (tp+1) % 3
+    auto store_plane_from = [&](int tp, const uint4 (&src)[SLAB_PER]) {   // registers -> ring slot (tp+1) % 3
       bf16_t* dst = ring + ((tp + 1) % 3) * PLANE;
 #pragma unroll
       for (int u = 0; u < SLAB_PER; ++u) {
         const int q = tid + u * 192;
-        if (q < SLAB_CH) *(uint4*)(dst + (size_t)(q / 12) * HD + (q % 12) * 8) = sreg[u];
+        if (q < SLAB_CH) *(uint4*)(dst + (size_t)(q / 12) * HD + (q % 12) * 8) = src[u];
       }
     };
+    auto fetch_plane = [&](int tp) { fetch_plane_to(tp, sreg); };
+    auto store_plane = [&](int tp) { store_plane_from(tp, sreg); };
     auto fetch_dy = [&](int t) {
 #pragma unroll
       for (int u = 0; u < DY_PER; ++u) {
@@ -878,11 +880,23 @@ __device__ __forceinline__ void pool_wgrad_body(const svit_pool_wgrad_args& a, i
         if (q < DY_CH) *(uint4*)(dyt + (size_t)(q / 12) * HD + (q % 12) * 8) = dreg[u];
       }
     };
-    __syncthreads();            // previous tile's readers are done with the ring
-    fetch_plane(t_begin - 1); store_plane(t_begin - 1);
-    fetch_plane(t_begin);     store_plane(t_begin);
-    fetch_plane(t_begin + 1);
-    fetch_dy(t_begin);
+    // all four loads of the tile's first step leave together (one memory round trip, not three in a row);
+    // they do not touch LDS, so they may fly above the barrier that protects the ring
+    if constexpr (!TL::SPARSE) {
+      fetch_plane_to(t_begin - 1, sreg_a);
+      fetch_plane_to(t_begin, sreg_b);
+      fetch_plane(t_begin + 1);
+      fetch_dy(t_begin);
+      __syncthreads();            // previous tile's readers are done with the ring
+      store_plane_from(t_begin - 1, sreg_a);
+      store_plane_from(t_begin, sreg_b);
+    } else {                      // (the sparse slabs are twice as large: three register sets would spill)
+      __syncthreads();
+      fetch_plane(t_begin - 1); store_plane(t_begin - 1);
+      fetch_plane(t_begin);     store_plane(t_begin);
+      fetch_plane(t_begin + 1);
+      fetch_dy(t_begin);
+    }
     for (int t = t_begin; t < t_end; ++t) {
       store_plane(t + 1);       // slot of plane t-2: its readers passed the barrier below
       store_dy();
@@ -950,14 +964,18 @@ __global__ __launch_bounds__(192) void pool_wgrad_kernel(svit_pool_wgrad_args a,
 }
 struct WgradPlan { int n_tiles, tiles_x, tiles_y, t_chunks, t_len, sclass; };
 struct PoolWgrad3 { svit_pool_wgrad_args p[3]; WgradPlan plan[3]; };
-__global__ __launch_bounds__(192) void pool_wgrad3_kernel(PoolWgrad3 g) {
+// HAS_SPARSE = false: no tensor of the launch has a stride >= 3 (blocks 3-15).  The sparse body needs 208
+// VGPRs and, compiled into the same kernel, held every launch at two waves per SIMD; without it the
+// kernel fits three (163 VGPRs), i.e. three resident workgroups per CU instead of two.
+template <bool HAS_SPARSE>
+__global__ __launch_bounds__(192, HAS_SPARSE ? 2 : 3) void pool_wgrad3_kernel(PoolWgrad3 g) {
   const svit_pool_wgrad_args& a = g.p[blockIdx.y];
   const WgradPlan& pl = g.plan[blockIdx.y];
   // partial rows [block][which][c][tap] in the first entry's workspace
   float* prow = g.p[0].workspace + ((size_t)blockIdx.x * 3 + blockIdx.y) * 27 * HD;
   if (pl.sclass == 1)
     pool_wgrad_body<1>(a, pl.n_tiles, pl.tiles_x, pl.tiles_y, pl.t_chunks, pl.t_len, prow);
-  else if (pl.sclass == 2)
+  else if (pl.sclass == 2 || !HAS_SPARSE)
     pool_wgrad_body<2>(a, pl.n_tiles, pl.tiles_x, pl.tiles_y, pl.t_chunks, pl.t_len, prow);
   else
     pool_wgrad_body<3>(a, pl.n_tiles, pl.tiles_x, pl.tiles_y, pl.t_chunks, pl.t_len, prow);
@@ -971,7 +989,11 @@ static WgradPlan plan_wgrad(const svit_pool_wgrad_args& a, int Ho, int Wo) {
   pl.tiles_y = (Ho + TL::R - 1) / TL::R;
   // split the t walk when the (y, x) tiling alone gives too few workgroups
   int t_chunks = 1;
-  while (t_chunks < a.T && (long)pl.tiles_x * pl.tiles_y * a.B * a.heads * t_chunks < 768 &&
+  // (round 3: 768 -> 224.  Every t chunk re-fetches two halo planes and writes its own 31-KB partial row;
+  // un-chunked walks were 20-35 % faster wherever (y, x, batch, head) alone gives ~1 workgroup per CU:
+  // tools/_run_pool2.sh sweep, profiles/r03_pool_slab.txt)
+  static const long want = [] { const char* e = getenv("SVIT_WGRAD_TILES"); return e ? atol(e) : 224L; }();
+  while (t_chunks < a.T && (long)pl.tiles_x * pl.tiles_y * a.B * a.heads * t_chunks < want &&
          a.T / (t_chunks * 2) >= 2)
     t_chunks *= 2;
   pl.t_chunks = t_chunks;
@@ -1823,15 +1845,20 @@ extern "C" int svit_pool_conv_wgrad_qkv(const svit_pool_wgrad_args* a3, void* st
   if (blocks > 1024) blocks = 1024;
   if (blocks > a3[0].workspace_floats / (3 * 27 * HD)) blocks = a3[0].workspace_floats / (3 * 27 * HD);
   if (blocks < 1) return SVIT_ERR_ARG;
+  bool sparse = false;
+  for (int i = 0; i < 3; ++i) sparse = sparse || g.plan[i].sclass >= 3;
   {
     size_t mx = WgradTile<1>::LDS_BYTES;
     if ((size_t)WgradTile<2>::LDS_BYTES > mx) mx = WgradTile<2>::LDS_BYTES;
     if ((size_t)WgradTile<3>::LDS_BYTES > mx) mx = WgradTile<3>::LDS_BYTES;
-    static SvitOnce once;
-    if (int rc = svit_max_lds_once(once, (const void*)pool_wgrad3_kernel, mx)) return rc;
+    static SvitOnce once[2];
+    if (int rc = svit_max_lds_once(once[0], (const void*)pool_wgrad3_kernel<false>, mx)) return rc;
+    if (int rc = svit_max_lds_once(once[1], (const void*)pool_wgrad3_kernel<true>, mx)) return rc;
   }
-  hipLaunchKernelGGL(pool_wgrad3_kernel, dim3((unsigned)blocks, 3), dim3(192), lds,
-                     (hipStream_t)stream, g);
+  if (sparse)
+    hipLaunchKernelGGL(pool_wgrad3_kernel<true>, dim3((unsigned)blocks, 3), dim3(192), lds, (hipStream_t)stream, g);
+  else
+    hipLaunchKernelGGL(pool_wgrad3_kernel<false>, dim3((unsigned)blocks, 3), dim3(192), lds, (hipStream_t)stream, g);
   SVIT_LAUNCH_CHECK();
   SvitReduceDst dst = {{a3[0].dw, a3[1].dw, a3[2].dw, a3[2].dw, a3[2].dw, a3[2].dw},
                        {27 * HD, 2 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD}};
