@@ -34,7 +34,11 @@ enum {
   SVIT_EPI_RESID = 2,  /* out(f32)   = aux(f32) + row_scale[row/rows_per_sample]*(acc+bias)
                           (proj / fc2 + DropPath + residual, attention.py:565,570)    */
   SVIT_EPI_F32 = 3,    /* out(f32)   = [out +] acc + bias, optional row remap         */
-  SVIT_EPI_DGELU = 4   /* out(bf16)  = acc * aux(bf16), aux = the saved gelu_erf'(h) (fc2 dgrad) */
+  SVIT_EPI_DGELU = 4,  /* out(bf16)  = acc * aux(bf16), aux = the saved gelu_erf'(h) (fc2 dgrad) */
+  SVIT_EPI_RELQ = 5    /* rel-pos query side in ONE launch (round 3; replaces svit_gemm_nt + svit_relpos_gather,
+                          attention.py:84-183): acc = q . Rcat^T is not stored; instead
+                          relq_out[row, 96 + j] = bf16(bf16(acc[row, relq_map[(row % relq_rows) * relq_extra + j]])
+                          * relq_scale) for j < relq_extra, 0 where the map holds -1 (cls / object rows, padding) */
 };
 typedef struct {
   const void* A; int32_t lda;      /* bf16 [M,K] row-major                             */
@@ -47,6 +51,11 @@ typedef struct {
   int32_t M, N, K;                 /* N % 96 == 0, K % 32 == 0                         */
   int32_t epilogue; int32_t accumulate;
   int32_t remap_L, remap_N, remap_off; /* EPI_F32: out row = (r/L)*remap_N + remap_off + r%L */
+  /* EPI_RELQ only (zero otherwise): */
+  const int32_t* relq_map;         /* i32 [relq_rows, relq_extra]: column of acc for (token, j), or -1  */
+  void* relq_out; int32_t relq_ld; /* bf16 qa rows [M, relq_ld]; columns 96 .. 96+relq_extra are written */
+  int32_t relq_extra, relq_rows;   /* relq_extra = relq_ld - 96 in {32, 64}; relq_rows = tokens per (b, head) */
+  float relq_scale;
 } svit_gemm_args;
 /* C[M,N] = A[M,K] * W[N,K]^T with fused epilogue (forward Linear; dgrad with W^T copy). */
 int svit_gemm_nt(const svit_gemm_args* args, void* stream);

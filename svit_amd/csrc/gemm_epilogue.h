@@ -100,10 +100,57 @@ __device__ __forceinline__ void nt_epilogue_wide(const svit_gemm_args& p, f32x16
   }
 }
 
+// SVIT_EPI_RELQ: the product q . Rcat^T is consumed where it is produced -- every (row, j) of the query
+// side's rel-pos columns picks its table row out of the staged 16-row slab (relq_map: the column of the
+// product for (token, j), -1 = zero) and goes to qa[row, 96 + j].  The product itself is never stored.
+// A column tile writes the entries whose column it owns; the tile at column 0 also writes the zeros.
+template <int RB, int NB>
+__device__ __forceinline__ void nt_epilogue_relq(const svit_gemm_args& p, f32x16_t (&acc)[RB][NB],
+                                                 unsigned char* smem, int m0, int n0, int wm, int wn,
+                                                 int lane, int wave) {
+  constexpr int WN = 32 * NB, EP_LD = WN + 4;
+  float* stg = (float*)smem + wave * (16 * EP_LD);
+  const int extra = p.relq_extra, sh = extra == 64 ? 6 : 5;        // 32 or 64 columns per row
+  const int c_lo = n0 + wn * WN;
+  bf16_t* qa = (bf16_t*)p.relq_out;
+#pragma unroll
+  for (int ih = 0; ih < 2 * RB; ++ih) {
+    const int i = ih >> 1, half = ih & 1;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr)
+        stg[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] =
+            acc[i][j][half * 8 + rr];
+    __syncthreads();
+    const int row0 = m0 + wm * 32 * RB + i * 32 + half * 16;
+    const int tok0 = row0 % p.relq_rows;                            // (wave-uniform)
+    for (int e = lane; e < 16 * extra; e += 64) {
+      const int rl = e >> sh, j = e & (extra - 1), row = row0 + rl;
+      if (row >= p.M) break;
+      int tok = tok0 + rl;
+      while (tok >= p.relq_rows) tok -= p.relq_rows;      // (once at most unless a (b, head) has < 16 tokens)
+      const int col = p.relq_map[tok * extra + j];
+      if (col < 0) {
+        if (c_lo == 0) qa[(size_t)row * p.relq_ld + 96 + j] = 0;
+      } else if (col >= c_lo && col < c_lo + WN) {
+        // two roundings, as the unfused pair had (the product stored as bf16, then scaled)
+        const float v = bf16_to_f32(f32_to_bf16(stg[rl * EP_LD + col - c_lo])) * p.relq_scale;
+        qa[(size_t)row * p.relq_ld + 96 + j] = f32_to_bf16(v);
+      }
+    }
+    if (ih + 1 < 2 * RB) __syncthreads();
+  }
+}
+
 template <int RB, int NB, int EPI, bool WAVE_PRIVATE = false>
 __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&acc)[RB][NB],
                                             unsigned char* smem, int m0, int n0, int wm, int wn,
                                             int lane, int wave) {
+  if constexpr (EPI == SVIT_EPI_RELQ) {
+    nt_epilogue_relq<RB, NB>(p, acc, smem, m0, n0, wm, wn, lane, wave);
+    return;
+  }
   if constexpr (EPI == SVIT_EPI_BF16 || EPI == SVIT_EPI_GELU || EPI == SVIT_EPI_DGELU) {
     const bool rows16 = (p.ldo % 8 == 0) && (EPI != SVIT_EPI_GELU || !p.out2 || p.ldo2 % 8 == 0) &&
                         (EPI != SVIT_EPI_DGELU || p.ldaux % 8 == 0);

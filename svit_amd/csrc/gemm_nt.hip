@@ -151,12 +151,12 @@ int launch_v2(const svit_gemm_args& a, hipStream_t st) {
   const size_t lds_epi = (size_t)WAVES_M * WAVES_N * 16 * (32 * NB + 4) * sizeof(float);
   if (lds < lds_epi) lds = lds_epi;
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM);
-  static SvitOnce once[5];
+  static SvitOnce once[6];
 #define SVIT_V2_ATTR(E)                                                                              \
   if (int rc = svit_max_lds_once(once[E], (const void*)gemm_nt_v2_kernel<RB, NB, WAVES_M, WAVES_N, STAGES, E, BK2>, lds)) \
     return rc
   SVIT_V2_ATTR(SVIT_EPI_BF16); SVIT_V2_ATTR(SVIT_EPI_GELU); SVIT_V2_ATTR(SVIT_EPI_RESID);
-  SVIT_V2_ATTR(SVIT_EPI_F32); SVIT_V2_ATTR(SVIT_EPI_DGELU);
+  SVIT_V2_ATTR(SVIT_EPI_F32); SVIT_V2_ATTR(SVIT_EPI_DGELU); SVIT_V2_ATTR(SVIT_EPI_RELQ);
 #undef SVIT_V2_ATTR
 #define SVIT_V2_CASE(E)                                                                       \
   case E:                                                                                     \
@@ -169,6 +169,7 @@ int launch_v2(const svit_gemm_args& a, hipStream_t st) {
     SVIT_V2_CASE(SVIT_EPI_RESID)
     SVIT_V2_CASE(SVIT_EPI_F32)
     SVIT_V2_CASE(SVIT_EPI_DGELU)
+    SVIT_V2_CASE(SVIT_EPI_RELQ)
     default:
       return SVIT_ERR_ARG;
   }
@@ -398,13 +399,20 @@ static void ring_choice(const svit_gemm_args& a, int* cfg, int* stages) {
 }
 
 extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
-  if (!args || !args->A || !args->W || !args->out) return SVIT_ERR_ARG;
+  if (!args || !args->A || !args->W) return SVIT_ERR_ARG;
   const svit_gemm_args& a = *args;
+  const bool relq = a.epilogue == SVIT_EPI_RELQ;
+  if (!relq && !a.out) return SVIT_ERR_ARG;
+  if (relq) {
+    if (!a.relq_map || !a.relq_out || (a.relq_extra != 32 && a.relq_extra != 64) || a.relq_rows < 1 ||
+        a.relq_ld < 96 + a.relq_extra || a.bias)
+      return SVIT_ERR_ARG;
+  }
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % 32 != 0 || a.N % 96 != 0) return SVIT_ERR_SHAPE;
-  if (a.lda % 8 != 0 || a.ldw % 8 != 0 || a.lda < a.K || a.ldw < a.K || a.ldo < a.N)
+  if (a.lda % 8 != 0 || a.ldw % 8 != 0 || a.lda < a.K || a.ldw < a.K || (!relq && a.ldo < a.N))
     return SVIT_ERR_ALIGN;
   if (((uintptr_t)a.A | (uintptr_t)a.W) & 15) return SVIT_ERR_ALIGN;
-  if (a.ldo % 4 != 0 || ((uintptr_t)a.out & 15)) return SVIT_ERR_ALIGN;
+  if (!relq && (a.ldo % 4 != 0 || ((uintptr_t)a.out & 15))) return SVIT_ERR_ALIGN;
   if (a.bias && ((uintptr_t)a.bias & 15)) return SVIT_ERR_ALIGN;
   if (a.aux && (a.ldaux % 4 != 0 || ((uintptr_t)a.aux & 15))) return SVIT_ERR_ALIGN;
   if (a.out2 && (a.ldo2 % 4 != 0 || ((uintptr_t)a.out2 & 15))) return SVIT_ERR_ALIGN;
@@ -440,7 +448,7 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
   const int force_cfg = force_raw == 8 ? -1 : force_raw;
   // Ring kernels (loader waves + MFMA waves, K-steps of 64; tools/bench_kernels.py ntring, profiles/
   // r03_nt_ring.txt): see ring_choice().
-  if (a.K % 64 == 0 && ((force_cfg < 0 && !no_ring) || (force_cfg >= 5 && force_cfg <= 7))) {
+  if (a.K % 64 == 0 && !relq && ((force_cfg < 0 && !no_ring) || (force_cfg >= 5 && force_cfg <= 7))) {
     int cfg = force_cfg, rs = force_stages;
     if (cfg < 0) ring_choice(a, &cfg, &rs);
     if (cfg >= 5) {

@@ -195,6 +195,7 @@ class Engine:
         self.plan, self.flat = plan, flat
         self.dev = flat.data.device
         self._rel_cache = {}
+        self._relq_cache = {}
         self.patch_w16 = torch.zeros((plan.embed_dim, 448), device=self.dev, dtype=BF16)
         self._tn = []           # weight-gradient GEMMs queued by the running block backward
         # a block's four second-stage reductions (LN2, pooled LN, conv wgrad, LN1) run as one
@@ -250,6 +251,26 @@ class Engine:
             ent = ([t.contiguous().to(self.dev) for t in idx], mats, mcat, tuple(need))
             self._rel_cache[key] = ent
         return ent
+
+    def _relq_map(self, blk, q_thw, k_thw, idx, rows_off, n_obj, extra):
+        """i32 [Nq, extra]: the column of P = q . Rcat^T that (token, j) reads, -1 for cls / object
+        rows and for the padding columns j >= kh + kw + kt (svit_gemm_args.relq_map)."""
+        key = (blk.index, q_thw, k_thw, tuple(rows_off), n_obj, extra)
+        m = self._relq_cache.get(key)
+        if m is None:
+            qt, qh, qw = q_thw
+            kt, kh, kw = k_thw
+            ih, iw, it = (t.cpu().view(n, k) for t, n, k in zip(idx, (qh, qw, qt), (kh, kw, kt)))
+            Lq = qt * qh * qw
+            body = torch.full((qt, qh, qw, extra), -1, dtype=torch.int32)
+            body[..., :kh] = (rows_off[0] + ih).view(1, qh, 1, kh)
+            body[..., kh:kh + kw] = (rows_off[1] + iw).view(1, 1, qw, kw)
+            body[..., kh + kw:kh + kw + kt] = (rows_off[2] + it).view(qt, 1, 1, kt)
+            m = torch.full((1 + Lq + n_obj, extra), -1, dtype=torch.int32)
+            m[1:1 + Lq] = body.view(Lq, extra)
+            m = m.contiguous().to(self.dev)
+            self._relq_cache[key] = m
+        return m
 
     def _tables(self, pre, mats):
         names = (pre + "attn.rel_pos_h", pre + "attn.rel_pos_w", pre + "attn.rel_pos_t")
@@ -332,8 +353,10 @@ class Engine:
             rows_off = (0, need[0], need[0] + need[1])
             tabs = [r32[rows_off[0]:rows_off[0] + need[0]], r32[rows_off[1]:rows_off[1] + need[1]],
                     r32[rows_off[2]:rows_off[2] + need[2]]]
-        P = ops.gemm_nt(qa.view(B * h * Nq, DA)[:, :HD], rcat, None, hip.EPI_BF16)
-        ops.relpos_gather(P, qa, idx, rows_off, B, h, q_thw, k_thw, n_obj, LOG2E)
+        # rel-pos query side in one launch: P = q . Rcat^T on the MFMA GEMM whose epilogue picks, per
+        # (query, j), the table row it needs and writes qa's extra columns (P itself is never stored)
+        ops.gemm_nt(qa.view(B * h * Nq, DA)[:, :HD], rcat, None, hip.EPI_RELQ,
+                    relq=(self._relq_map(blk, q_thw, k_thw, idx, rows_off, n_obj, DA - HD), qa, LOG2E))
         ctx, lse2 = ops.attn_fwd(qa, ka, v, SCALE, bias_cols=J)
         pool_idx = None
         if blk.has_proj:

@@ -17,7 +17,7 @@ _lib = None
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
-EPI_BF16, EPI_GELU, EPI_RESID, EPI_F32, EPI_DGELU = 0, 1, 2, 3, 4
+EPI_BF16, EPI_GELU, EPI_RESID, EPI_F32, EPI_DGELU, EPI_RELQ = 0, 1, 2, 3, 4, 5
 
 
 class TnProblem(C.Structure):
@@ -30,7 +30,8 @@ class GemmArgs(C.Structure):
                 ("ldo", i32), ("out2", vp), ("ldo2", i32), ("aux", vp), ("ldaux", i32),
                 ("row_scale", vp), ("rows_per_sample", i32), ("M", i32), ("N", i32), ("K", i32),
                 ("epilogue", i32), ("accumulate", i32), ("remap_L", i32), ("remap_N", i32),
-                ("remap_off", i32)]
+                ("remap_off", i32), ("relq_map", vp), ("relq_out", vp), ("relq_ld", i32),
+                ("relq_extra", i32), ("relq_rows", i32), ("relq_scale", f32)]
 
 
 class PoolArgs(C.Structure):

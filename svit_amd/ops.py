@@ -43,14 +43,28 @@ def _chk_dev(*ts):
 
 
 def gemm_nt(a, w, bias=None, epilogue=hip.EPI_BF16, out=None, out2=None, aux=None,
-            row_scale=None, rows_per_sample=0, accumulate=False, remap=None, save=True):
+            row_scale=None, rows_per_sample=0, accumulate=False, remap=None, save=True, relq=None):
     """C = A[M,K] @ W[N,K]^T with a fused epilogue (see include/svit_hip.h).  `a` may be a
-    column slice of a wider matrix (row-strided view)."""
+    column slice of a wider matrix (row-strided view).  epilogue EPI_RELQ: relq = (map i32 [Nq, extra],
+    qa bf16 [..., Nq, 96 + extra], scale) -- the product is not stored, qa's rel-pos columns are written."""
     _chk_rows(a)
     _chk_dev(w, bias, out, out2, aux, row_scale)
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K and a.dtype == BF16 and w.dtype == BF16
+    if epilogue == hip.EPI_RELQ:
+        cmap, qa, scale = relq
+        _chk_dev(cmap, qa)
+        extra = qa.shape[-1] - 96
+        assert cmap.dtype == torch.int32 and cmap.is_contiguous() and cmap.shape == (qa.shape[-2], extra)
+        assert qa.is_contiguous() and qa.numel() == M * qa.shape[-1] and bias is None
+        g = hip.GemmArgs()
+        g.A, g.lda, g.W, g.ldw = ptr(a), a.stride(0), ptr(w), w.stride(0)
+        g.M, g.N, g.K, g.epilogue = M, N, K, epilogue
+        g.relq_map, g.relq_out, g.relq_ld = ptr(cmap), ptr(qa), qa.shape[-1]
+        g.relq_extra, g.relq_rows, g.relq_scale = extra, qa.shape[-2], scale
+        hip.call("svit_gemm_nt", C.byref(g), meta=("mnk", M, N, K, epilogue, 2 * M * K + 2 * N * K + 2 * M * extra))
+        return qa
     if out is None:
         dt = F32 if epilogue in (hip.EPI_RESID, hip.EPI_F32) else BF16
         out = torch.empty((M, N), device=a.device, dtype=dt)

@@ -474,7 +474,7 @@ def test_pool_ln_bwd_three_inputs(ops):
 
 @pytest.mark.parametrize("q_thw,k_thw", [((2, 8, 8), (2, 2, 2)), ((2, 4, 4), (2, 4, 4)),
                                          ((3, 5, 5), (3, 3, 3)), ((1, 4, 4), (1, 2, 2)),
-                                         ((2, 14, 14), (2, 14, 14))])
+                                         ((2, 14, 14), (2, 14, 14)), ((2, 56, 56), (2, 7, 7))])
 def test_relpos_q(ops, q_thw, k_thw):
     B, h, O = 2, 2, 3
     Lq = q_thw[0] * q_thw[1] * q_thw[2]
@@ -533,6 +533,19 @@ def test_relpos_q(ops, q_thw, k_thw):
             rel2[:, :, 1:1 + Lq][..., kh + kw + p // (kw * kh)])
     assert rel_err(got2, bias) < 3e-2 and cos(got2, bias) > 0.9998
     assert float(rel2[:, :, 0].abs().max()) == 0 and float(rel2[..., J:].abs().max()) == 0
+    # round 3: the same in ONE launch (EPI_RELQ: the GEMM's epilogue does the gather, P is never stored) --
+    # bit-identical to the pair above; the map is what Engine._relq_map builds
+    Nq_ = 1 + Lq + O
+    cmap = torch.full((Nq_, ld - 96), -1, dtype=torch.int32)
+    body = torch.full((q_thw[0], q_thw[1], q_thw[2], ld - 96), -1, dtype=torch.int32)
+    body[..., :kh] = (rows_off[0] + idx[0].to(torch.int32)).view(1, q_thw[1], 1, kh)
+    body[..., kh:kh + kw] = (rows_off[1] + idx[1].to(torch.int32)).view(1, 1, q_thw[2], kw)
+    body[..., kh + kw:J] = (rows_off[2] + idx[2].to(torch.int32)).view(q_thw[0], 1, 1, kt)
+    cmap[1:1 + Lq] = body.view(Lq, ld - 96)
+    qc = qa.clone()
+    qc[..., 96:] = 5.0
+    ops.gemm_nt(qc.view(-1, ld)[:, :96], rc16, None, hip.EPI_RELQ, relq=(cmap.to(DEV).contiguous(), qc, 1.0 / scale))
+    assert torch.equal(qc, qb)
     # the GEMM formulation the engine uses: scatter -> D, dR = D^T q, dq = D Rcat
     from svit_amd.engine import rel_sections
     offs, lpad = rel_sections(rows)
