@@ -306,6 +306,11 @@ typedef struct {
                                      * gradient; svit_pool_ln_bwd adds them while it reads (main_parts) */
   int32_t B, heads, Nq, Nk, DA, q_splits; float scale;
   int32_t bias_cols;                /* as in svit_attn_fwd_args: kt + kh + kw, 0 = all DA - 96 */
+  /* optional (round 3; NULL / 0 = off): the dq kernel also writes the scattered matrix of the rel-pos backward,
+   * relD bf16 [B*h*Nq, relD_ld] = zeros except relD[row, relD_map[(row % Nq) * (DA - 96) + j]] =
+   * bf16(dqa[row, 96 + j] * relD_scale) where the map is >= 0 -- what svit_relpos_scatter builds in a launch
+   * of its own (bit-identical).  relD_ld % 8 == 0, relD_ld <= 544, relD 16-byte aligned. */
+  void* relD; int32_t relD_ld; const int32_t* relD_map; float relD_scale;
 } svit_attn_bwd_args;
 int svit_attn_bwd(const svit_attn_bwd_args* a, void* stream);
 /* number of dk / dv planes svit_attn_bwd will write for these arguments (>= 1; only the shape fields,

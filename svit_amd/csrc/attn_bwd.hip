@@ -250,6 +250,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
         *(uint2*)(orow + (j * 32 + 8 * g + 4 * hh) * 2) = pk;
       }
   }
+  // (relD, below) the map entries of this wave's rows: requested now, so that their round trip overlaps the
+  // row stores of dqa instead of standing in front of the scatter
+  constexpr int EXTRA = DA - 96, NV = 32 * EXTRA / 64;
+  int cols[NV];
+  if (a.relD) {
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+      const int e = it * 64 + lane, rl = e / EXTRA, j = e % EXTRA;
+      cols[it] = q0 + rl < a.Nq ? a.relD_map[(size_t)(q0 + rl) * EXTRA + j] : -1;
+    }
+  }
   constexpr int CPR = DA / 8;          // 16-byte chunks per row
   bf16_t* out = (bf16_t*)a.dqa + ((size_t)bh * a.Nq) * DA;
 #pragma unroll
@@ -257,6 +268,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
     const int id = it * 64 + lane, row = id / CPR, ch = id % CPR;
     if (q0 + row < a.Nq)
       *(uint4*)(out + (size_t)(q0 + row) * DA + ch * 8) = *(const uint4*)(ost + row * OROW + ch * 16);
+  }
+  // ---- optional: the rel-pos backward's scattered matrix D, rows of this wave (svit_attn_bwd_args.relD).
+  // The staged tile still holds d(relq) in its columns 96..DA: they go to registers, then the wave's
+  // staging region (private to it: LDS operations of one wave complete in order) is reused to build whole
+  // D rows -- zero-fill, 2-byte scatter through the map, 16-byte row stores.
+  if (a.relD) {
+    bf16_t vals[NV];
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+      const int e = it * 64 + lane, rl = e / EXTRA, j = e % EXTRA;
+      vals[it] = *(const bf16_t*)(ost + rl * OROW + (96 + j) * 2);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int ldd = a.relD_ld, cpr = ldd >> 3;                   // 16-byte chunks per D row
+    const int rpp = ldd <= 128 ? 32 : 8;                         // rows per pass: rpp * ldd * 2 <= 32 * OROW
+    bf16_t* Dg = (bf16_t*)a.relD + ((size_t)bh * a.Nq) * ldd;
+    for (int r0 = 0; r0 < 32; r0 += rpp) {
+      const int n16 = rpp * cpr;
+      for (int i = lane; i < n16; i += 64) *(uint4*)(ost + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < NV; ++it) {
+        const int e = it * 64 + lane, rl = e / EXTRA, j = e % EXTRA;
+        if (rl >= r0 && rl < r0 + rpp && cols[it] >= 0)
+          *(bf16_t*)(ost + ((rl - r0) * ldd + cols[it]) * 2) = f32_to_bf16(bf16_to_f32(vals[it]) * a.relD_scale);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int i = lane; i < n16; i += 64) {
+        const int rl = i / cpr, ch = i % cpr;
+        if (q0 + r0 + rl < a.Nq)
+          *(uint4*)(Dg + (size_t)(q0 + r0 + rl) * ldd + ch * 8) = *(const uint4*)(ost + i * 16);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
   }
   BSTAMP(5);
 #endif
@@ -563,6 +608,10 @@ extern "C" int svit_attn_bwd(const svit_attn_bwd_args* a, void* stream) {
   if (a->bias_cols < 0 || a->bias_cols > a->DA - 96) return SVIT_ERR_ARG;
   if (((uintptr_t)a->qa | (uintptr_t)a->ka | (uintptr_t)a->v | (uintptr_t)a->dctx | (uintptr_t)a->dqa) & 15)
     return SVIT_ERR_ALIGN;
+  if (a->relD) {
+    if (!a->relD_map || a->relD_ld <= 0 || a->relD_ld % 8 != 0 || a->relD_ld > 544) return SVIT_ERR_ARG;
+    if ((uintptr_t)a->relD & 15) return SVIT_ERR_ALIGN;
+  }
   const int bias_cols = a->bias_cols > 0 ? a->bias_cols : a->DA - 96;
   const int ksu = 6 + (bias_cols + 15) / 16;
   hipStream_t st = (hipStream_t)stream;

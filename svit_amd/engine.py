@@ -10,6 +10,8 @@ memory, streams and a handful of O(B*65*C) index/reduction ops on the special to
 """
 import math
 
+import os
+
 import torch
 
 from . import arch, hip, ops
@@ -196,6 +198,7 @@ class Engine:
         self.dev = flat.data.device
         self._rel_cache = {}
         self._relq_cache = {}
+        self.fused_scatter = os.environ.get("SVIT_FUSED_SCATTER", "1") != "0"
         self.patch_w16 = torch.zeros((plan.embed_dim, 448), device=self.dev, dtype=BF16)
         self._tn = []           # weight-gradient GEMMs queued by the running block backward
         # a block's four second-stage reductions (LN2, pooled LN, conv wgrad, LN1) run as one
@@ -512,9 +515,6 @@ class Engine:
         dctx = self._linear_bwd(dy, sv["ctx"].view(Mq, Co), pre + "attn.proj.weight",
                                 pre + "attn.proj.bias", True, epilogue=hip.EPI_BF16)
         (qa, preq, mq, rq), (ka, prek, mk, rk), (v, prev, mv, rv) = sv["pools"]
-        dqa, dk, dv = ops.attn_bwd(qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE,
-                                   q_splits=1 if self.deterministic else self.attn_q_splits,
-                                   bias_cols=sum(sv["k_thw"]))
         # rel-pos backward as GEMMs over the scattered matrix D [tokens, Lpad]
         tabs, mats = sv["tabs"], sv["mats"]
         names = (pre + "attn.rel_pos_h", pre + "attn.rel_pos_w", pre + "attn.rel_pos_t")
@@ -526,7 +526,17 @@ class Engine:
             for o, t in zip(offs, tabs):
                 rcat[o:o + t.shape[0]] = t
             rcat_t = rcat.t().contiguous().to(BF16)
-        D = ops.relpos_scatter(dqa, sv["idx"], offs, lpad, B, h, q_thw, k_thw, n_obj, LOG2E)
+        # the dq kernel writes D itself (its epilogue holds d(relq) of whole rows): no scatter launch
+        if self.fused_scatter:
+            dmap = self._relq_map(blk, q_thw, k_thw, sv["idx"], offs, n_obj, qa.shape[-1] - HD)
+            dqa, dk, dv, D = ops.attn_bwd(qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE,
+                                          q_splits=1 if self.deterministic else self.attn_q_splits,
+                                          bias_cols=sum(sv["k_thw"]), reld=(dmap, lpad, LOG2E))
+        else:   # (A/B knob for measurements: SVIT_FUSED_SCATTER=0)
+            dqa, dk, dv = ops.attn_bwd(qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE,
+                                       q_splits=1 if self.deterministic else self.attn_q_splits,
+                                       bias_cols=sum(sv["k_thw"]))
+            D = ops.relpos_scatter(dqa, sv["idx"], offs, lpad, B, h, q_thw, k_thw, n_obj, LOG2E)
         qa2 = qa.view(B * h * Nq, qa.shape[-1])
         for n, m, t, o in zip(names, mats, tabs, offs):
             rows = t.shape[0]

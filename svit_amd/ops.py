@@ -474,10 +474,11 @@ def attn_fwd(qa, ka, v, scale, bias_cols=0):
     return ctx, lse2
 
 
-def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0, bias_cols=0):
+def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0, bias_cols=0, reld=None):
     """-> dqa bf16 [B,h,Nq,DA], dk f32 [parts,B,h,Nk,96], dv f32 [parts,B,h,Nk,96]: the gradients of k
     and v are the SUMS over the leading axis (one plane per chunk of the query range; pool_ln_bwd
-    adds them while it reads)."""
+    adds them while it reads).  reld = (map i32 [Nq, DA - 96], ldd, scale): the dq kernel also writes the
+    rel-pos backward's scattered matrix D bf16 [B*h*Nq, ldd] (what relpos_scatter builds), returned 4th."""
     _chk_dev(qa, ka, v, ctx, dctx, lse2)
     B, heads, Nq, DA = qa.shape
     Nk = ka.shape[2]
@@ -494,7 +495,16 @@ def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0, bias_cols=0):
     a.qa, a.ka, a.v, a.ctx, a.dctx, a.lse2 = (ptr(t) for t in (qa, ka, v, ctx, dctx, lse2))
     a.delta, a.dqa, a.dk, a.dv = ptr(delta), ptr(dqa), ptr(dkv[0]), ptr(dkv[1])
     a.q_splits = parts
+    D = None
+    if reld is not None:
+        cmap, ldd, rscale = reld
+        _chk_dev(cmap)
+        assert cmap.dtype == torch.int32 and cmap.is_contiguous() and cmap.shape == (Nq, DA - HD)
+        D = torch.empty((B * heads * Nq, ldd), device=dev, dtype=BF16)
+        a.relD, a.relD_ld, a.relD_map, a.relD_scale = ptr(D), ldd, ptr(cmap), rscale
     hip.call("svit_attn_bwd", C.byref(a), meta=("attn", B, heads, Nq, Nk, DA))
+    if reld is not None:
+        return dqa, dkv[0], dkv[1], D
     return dqa, dkv[0], dkv[1]
 
 

@@ -472,6 +472,40 @@ def test_pool_ln_bwd_three_inputs(ops):
     assert rel_err(dpre, xr.grad) < 2e-2 and cos(dpre, xr.grad) > 0.9999
 
 
+@pytest.mark.parametrize("q_thw,k_thw,h", [((8, 14, 14), (8, 7, 7), 4), ((2, 28, 28), (2, 7, 7), 2), ((1, 5, 3), (1, 5, 3), 1)])
+def test_attention_bwd_writes_the_relpos_scatter_matrix(ops, q_thw, k_thw, h):
+    """svit_attn_bwd_args.relD: the dq kernel's epilogue builds the rel-pos backward's scattered matrix D
+    (zero rows for cls / objects, d(relq) * scale at the mapped columns) -- BIT-identical to svit_relpos_scatter
+    run on the dqa the same launch wrote, for one- and multi-pass row widths and a ragged last query tile."""
+    from svit_amd.engine import rel_sections
+    B, O = 2, 3
+    Lq, Lk = q_thw[0] * q_thw[1] * q_thw[2], k_thw[0] * k_thw[1] * k_thw[2]
+    Nq, Nk, J = 1 + Lq + O, 1 + Lk + O, sum(k_thw)
+    DA = 128 if J <= 32 else 160
+    qa = rnd("sq%d" % Lq, (B, h, Nq, DA), 1.0, BF16)
+    ka = (rnd("sk%d" % Lq, (B, h, Nk, DA), 1.0) * 0.15).to(BF16)
+    v = rnd("sv%d" % Lq, (B, h, Nk, 96), 1.0, BF16)
+    ctx, lse2 = ops.attn_fwd(qa, ka, v, 96 ** -0.5, bias_cols=J)
+    dctx = rnd("sd%d" % Lq, tuple(ctx.shape), 1.0, BF16)
+    rows = [2 * max(q_thw[i], k_thw[i]) - 1 for i in (1, 2, 0)]
+    offs, lpad = rel_sections(rows)
+    idx = [R.rel_index(q_thw[1], k_thw[1]), R.rel_index(q_thw[2], k_thw[2]), R.rel_index(q_thw[0], k_thw[0])]
+    idx_d = [t.to(torch.int32).to(DEV).contiguous() for t in idx]
+    kt, kh, kw = k_thw
+    body = torch.full((q_thw[0], q_thw[1], q_thw[2], DA - 96), -1, dtype=torch.int32)
+    body[..., :kh] = (offs[0] + idx[0].to(torch.int32)).view(1, q_thw[1], 1, kh)
+    body[..., kh:kh + kw] = (offs[1] + idx[1].to(torch.int32)).view(1, 1, q_thw[2], kw)
+    body[..., kh + kw:J] = (offs[2] + idx[2].to(torch.int32)).view(q_thw[0], 1, 1, kt)
+    cmap = torch.full((Nq, DA - 96), -1, dtype=torch.int32)
+    cmap[1:1 + Lq] = body.view(Lq, DA - 96)
+    dqa, dk, dv, D = ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, 96 ** -0.5, bias_cols=J,
+                                  reld=(cmap.to(DEV).contiguous(), lpad, 1.4426950408889634))
+    D_ref = ops.relpos_scatter(dqa, idx_d, offs, lpad, B, h, q_thw, k_thw, O, 1.4426950408889634)
+    assert torch.equal(D, D_ref)
+    dqa2, dk2, dv2 = ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, 96 ** -0.5, bias_cols=J)
+    assert torch.equal(dqa, dqa2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
+
+
 @pytest.mark.parametrize("q_thw,k_thw", [((2, 8, 8), (2, 2, 2)), ((2, 4, 4), (2, 4, 4)),
                                          ((3, 5, 5), (3, 3, 3)), ((1, 4, 4), (1, 2, 2)),
                                          ((2, 14, 14), (2, 14, 14)), ((2, 56, 56), (2, 7, 7))])
