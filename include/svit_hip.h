@@ -311,6 +311,10 @@ typedef struct {
    * bf16(dqa[row, 96 + j] * relD_scale) where the map is >= 0 -- what svit_relpos_scatter builds in a launch
    * of its own (bit-identical).  relD_ld % 8 == 0, relD_ld <= 544, relD 16-byte aligned. */
   void* relD; int32_t relD_ld; const int32_t* relD_map; float relD_scale;
+  /* and, when relD_ld <= 128 (one 32-row pass): dq_extra f32 [B*h*Nq, 96] = relD . relR^T with relR bf16
+   * [96, relD_ld] (the transposed concatenated tables) -- the rel-pos backward's "dq = D R" GEMM, multiplied by
+   * the same kernel from the rows it has just built (NULL = off; the caller then runs svit_gemm_nt on relD) */
+  const void* relR; float* relX;
 } svit_attn_bwd_args;
 int svit_attn_bwd(const svit_attn_bwd_args* a, void* stream);
 /* number of dk / dv planes svit_attn_bwd will write for these arguments (>= 1; only the shape fields,

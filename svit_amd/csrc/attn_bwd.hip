@@ -300,6 +300,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
         if (q0 + r0 + rl < a.Nq)
           *(uint4*)(Dg + (size_t)(q0 + r0 + rl) * ldd + ch * 8) = *(const uint4*)(ost + i * 16);
       }
+      if (a.relX && rpp == 32) {
+        // dq_extra[query, channel] = sum_k D[query, k] R^T[channel, k]: the wave's 32 D rows are in LDS, the
+        // table fragments come straight from L2 (<= 24 KB, shared by every wave of the launch); swapped
+        // operands as everywhere in this kernel -- the lane owns a query, its registers the channels
+        f32x16_t ex[3];
+#pragma unroll
+        for (int pb = 0; pb < 3; ++pb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ex[pb][r] = 0.f;
+        const bf16_t* R = (const bf16_t*)a.relR;
+        for (int ks = 0; ks < ldd / 16; ++ks) {
+          const bf16x8_t dfrag = *(const bf16x8_t*)(ost + ((lane & 31) * ldd + 16 * ks + 8 * hh) * 2);
+#pragma unroll
+          for (int pb = 0; pb < 3; ++pb) {
+            const bf16x8_t rfrag = *(const bf16x8_t*)(R + (size_t)(pb * 32 + (lane & 31)) * ldd + 16 * ks + 8 * hh);
+            ex[pb] = mfma32(rfrag, dfrag, ex[pb]);
+          }
+        }
+        if (qi < a.Nq) {
+          float* xr = a.relX + ((size_t)bh * a.Nq + qi) * HD;
+#pragma unroll
+          for (int pb = 0; pb < 3; ++pb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *(float4*)(xr + pb * 32 + 8 * g + 4 * hh) =
+                  make_float4(ex[pb][4 * g], ex[pb][4 * g + 1], ex[pb][4 * g + 2], ex[pb][4 * g + 3]);
+        }
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
@@ -611,6 +639,11 @@ extern "C" int svit_attn_bwd(const svit_attn_bwd_args* a, void* stream) {
   if (a->relD) {
     if (!a->relD_map || a->relD_ld <= 0 || a->relD_ld % 8 != 0 || a->relD_ld > 544) return SVIT_ERR_ARG;
     if ((uintptr_t)a->relD & 15) return SVIT_ERR_ALIGN;
+    if (a->relX && (!a->relR || a->relD_ld > 128 || a->relD_ld % 16 != 0 ||
+                    (((uintptr_t)a->relR | (uintptr_t)a->relX) & 15)))
+      return SVIT_ERR_ARG;
+  } else if (a->relX) {
+    return SVIT_ERR_ARG;
   }
   const int bias_cols = a->bias_cols > 0 ? a->bias_cols : a->DA - 96;
   const int ksu = 6 + (bias_cols + 15) / 16;

@@ -529,14 +529,16 @@ class Engine:
         # the dq kernel writes D itself (its epilogue holds d(relq) of whole rows): no scatter launch
         if self.fused_scatter:
             dmap = self._relq_map(blk, q_thw, k_thw, sv["idx"], offs, n_obj, qa.shape[-1] - HD)
-            dqa, dk, dv, D = ops.attn_bwd(qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE,
-                                          q_splits=1 if self.deterministic else self.attn_q_splits,
-                                          bias_cols=sum(sv["k_thw"]), reld=(dmap, lpad, LOG2E))
+            dqa, dk, dv, D, dq_extra = ops.attn_bwd(
+                qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE,
+                q_splits=1 if self.deterministic else self.attn_q_splits, bias_cols=sum(sv["k_thw"]),
+                reld=(dmap, lpad, LOG2E, rcat_t if rcat_t.is_contiguous() else None))
         else:   # (A/B knob for measurements: SVIT_FUSED_SCATTER=0)
             dqa, dk, dv = ops.attn_bwd(qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE,
                                        q_splits=1 if self.deterministic else self.attn_q_splits,
                                        bias_cols=sum(sv["k_thw"]))
             D = ops.relpos_scatter(dqa, sv["idx"], offs, lpad, B, h, q_thw, k_thw, n_obj, LOG2E)
+            dq_extra = None
         qa2 = qa.view(B * h * Nq, qa.shape[-1])
         for n, m, t, o in zip(names, mats, tabs, offs):
             rows = t.shape[0]
@@ -546,7 +548,8 @@ class Engine:
                 d = torch.zeros_like(t)
                 ops.gemm_tn(D[:, o:o + rows], qa2[:, :HD], d, splits=1 if self.deterministic else 0)
                 f.g(n).add_(m.t() @ d)
-        dq_extra = ops.gemm_nt(D, rcat_t, None, hip.EPI_F32)
+        if dq_extra is None:      # wide tables (56x56 / 28x28 stages) or the A/B path: dq = D R as its own GEMM
+            dq_extra = ops.gemm_nt(D, rcat_t, None, hip.EPI_F32)
         Nk = ka.shape[2]
         dqkv = torch.empty_like(sv["qkv"])
         entries = []

@@ -101,7 +101,8 @@ class AttnBwdArgs(C.Structure):
     _fields_ = [("qa", vp), ("ka", vp), ("v", vp), ("ctx", vp), ("dctx", vp), ("lse2", vp),
                 ("delta", vp), ("dqa", vp), ("dk", vp), ("dv", vp), ("B", i32), ("heads", i32),
                 ("Nq", i32), ("Nk", i32), ("DA", i32), ("q_splits", i32), ("scale", f32),
-                ("bias_cols", i32), ("relD", vp), ("relD_ld", i32), ("relD_map", vp), ("relD_scale", f32)]
+                ("bias_cols", i32), ("relD", vp), ("relD_ld", i32), ("relD_map", vp), ("relD_scale", f32),
+                ("relR", vp), ("relX", vp)]
 
 
 _SIGS = {

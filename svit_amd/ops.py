@@ -477,8 +477,10 @@ def attn_fwd(qa, ka, v, scale, bias_cols=0):
 def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0, bias_cols=0, reld=None):
     """-> dqa bf16 [B,h,Nq,DA], dk f32 [parts,B,h,Nk,96], dv f32 [parts,B,h,Nk,96]: the gradients of k
     and v are the SUMS over the leading axis (one plane per chunk of the query range; pool_ln_bwd
-    adds them while it reads).  reld = (map i32 [Nq, DA - 96], ldd, scale): the dq kernel also writes the
-    rel-pos backward's scattered matrix D bf16 [B*h*Nq, ldd] (what relpos_scatter builds), returned 4th."""
+    adds them while it reads).  reld = (map i32 [Nq, DA - 96], ldd, scale[, rt]): the dq kernel also writes the
+    rel-pos backward's scattered matrix D bf16 [B*h*Nq, ldd] (what relpos_scatter builds), returned 4th, and --
+    given rt = the transposed tables bf16 [96, ldd], ldd <= 128 -- dq_extra = D . rt^T f32 [B*h*Nq, 96], returned
+    5th (None when it was not computed: the caller then runs the GEMM)."""
     _chk_dev(qa, ka, v, ctx, dctx, lse2)
     B, heads, Nq, DA = qa.shape
     Nk = ka.shape[2]
@@ -495,16 +497,21 @@ def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0, bias_cols=0, reld=No
     a.qa, a.ka, a.v, a.ctx, a.dctx, a.lse2 = (ptr(t) for t in (qa, ka, v, ctx, dctx, lse2))
     a.delta, a.dqa, a.dk, a.dv = ptr(delta), ptr(dqa), ptr(dkv[0]), ptr(dkv[1])
     a.q_splits = parts
-    D = None
+    D = X = None
     if reld is not None:
-        cmap, ldd, rscale = reld
-        _chk_dev(cmap)
+        cmap, ldd, rscale = reld[:3]
+        rt = reld[3] if len(reld) > 3 else None      # bf16 [96, ldd]: also multiply dq_extra = D . rt^T
+        _chk_dev(cmap, rt)
         assert cmap.dtype == torch.int32 and cmap.is_contiguous() and cmap.shape == (Nq, DA - HD)
         D = torch.empty((B * heads * Nq, ldd), device=dev, dtype=BF16)
         a.relD, a.relD_ld, a.relD_map, a.relD_scale = ptr(D), ldd, ptr(cmap), rscale
+        if rt is not None and ldd <= 128 and ldd % 16 == 0:
+            assert rt.dtype == BF16 and rt.is_contiguous() and tuple(rt.shape) == (HD, ldd)
+            X = torch.empty((B * heads * Nq, HD), device=dev, dtype=F32)
+            a.relR, a.relX = ptr(rt), ptr(X)
     hip.call("svit_attn_bwd", C.byref(a), meta=("attn", B, heads, Nq, Nk, DA))
     if reld is not None:
-        return dqa, dkv[0], dkv[1], D
+        return dqa, dkv[0], dkv[1], D, X
     return dqa, dkv[0], dkv[1]
 
 

@@ -498,10 +498,17 @@ def test_attention_bwd_writes_the_relpos_scatter_matrix(ops, q_thw, k_thw, h):
     body[..., kh + kw:J] = (offs[2] + idx[2].to(torch.int32)).view(q_thw[0], 1, 1, kt)
     cmap = torch.full((Nq, DA - 96), -1, dtype=torch.int32)
     cmap[1:1 + Lq] = body.view(Lq, DA - 96)
-    dqa, dk, dv, D = ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, 96 ** -0.5, bias_cols=J,
-                                  reld=(cmap.to(DEV).contiguous(), lpad, 1.4426950408889634))
+    from svit_amd import hip
+    rt = rnd("srt%d" % Lq, (96, lpad), 0.3, BF16)
+    dqa, dk, dv, D, X = ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, 96 ** -0.5, bias_cols=J,
+                                     reld=(cmap.to(DEV).contiguous(), lpad, 1.4426950408889634, rt))
     D_ref = ops.relpos_scatter(dqa, idx_d, offs, lpad, B, h, q_thw, k_thw, O, 1.4426950408889634)
     assert torch.equal(D, D_ref)
+    # ... and (narrow tables only) dq_extra = D . rt^T from the same launch, against the GEMM it replaces
+    assert (X is None) == (lpad > 128)
+    if X is not None:
+        X_ref = ops.gemm_nt(D_ref, rt, None, hip.EPI_F32)
+        assert rel_err(X, X_ref) < 1e-5
     dqa2, dk2, dv2 = ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, 96 ** -0.5, bias_cols=J)
     assert torch.equal(dqa, dqa2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
 
