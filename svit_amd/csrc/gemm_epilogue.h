@@ -122,7 +122,7 @@ __device__ __forceinline__ void nt_epilogue_relq(const svit_gemm_args& p, f32x16
       for (int rr = 0; rr < 8; ++rr)
         stg[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] =
             acc[i][j][half * 8 + rr];
-    __syncthreads();
+    nt_epi_sync<true>();      // (the staging region is the wave's own)
     const int row0 = m0 + wm * 32 * RB + i * 32 + half * 16;
     const int tok0 = row0 % p.relq_rows;                            // (wave-uniform)
     for (int e = lane; e < 16 * extra; e += 64) {
@@ -139,7 +139,7 @@ __device__ __forceinline__ void nt_epilogue_relq(const svit_gemm_args& p, f32x16
         qa[(size_t)row * p.relq_ld + 96 + j] = f32_to_bf16(v);
       }
     }
-    if (ih + 1 < 2 * RB) __syncthreads();
+    if (ih + 1 < 2 * RB) nt_epi_sync<true>();
   }
 }
 

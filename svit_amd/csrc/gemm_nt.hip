@@ -139,7 +139,9 @@ gemm_nt_v2_kernel(svit_gemm_args p) {
     __builtin_amdgcn_sched_barrier(0);
   }
   __syncthreads();   // all LDS reads of the last tiles done before the epilogue reuses LDS
-  nt_epilogue<RB, NB, EPI>(p, acc, smem, m0, n0, wm, wn, lane, wave);
+  // (staging regions are per wave: no workgroup barrier inside the epilogue -- eight of them per 128x128 tile
+  // kept the four waves in lock step through their stores)
+  nt_epilogue<RB, NB, EPI, true>(p, acc, smem, m0, n0, wm, wn, lane, wave);
 }
 
 template <int RB, int NB, int WAVES_M, int WAVES_N, int STAGES, int BK2 = 32>
