@@ -311,9 +311,12 @@ typedef struct {
    * bf16(dqa[row, 96 + j] * relD_scale) where the map is >= 0 -- what svit_relpos_scatter builds in a launch
    * of its own (bit-identical).  relD_ld % 8 == 0, relD_ld <= 544, relD 16-byte aligned. */
   void* relD; int32_t relD_ld; const int32_t* relD_map; float relD_scale;
-  /* and, when relD_ld <= 128 (one 32-row pass): dq_extra f32 [B*h*Nq, 96] = relD . relR^T with relR bf16
-   * [96, relD_ld] (the transposed concatenated tables) -- the rel-pos backward's "dq = D R" GEMM, multiplied by
-   * the same kernel from the rows it has just built (NULL = off; the caller then runs svit_gemm_nt on relD) */
+  /* and, when relD_ld <= 128 (one 32-row pass), with relR bf16 [96, relD_ld] (the transposed concatenated tables)
+   * the rel-pos backward's "dq = D R" GEMM is multiplied by the same kernel from the rows it builds:
+   *   relX != NULL: dq_extra f32 [B*h*Nq, 96] = relD . relR^T is written there;
+   *   relX == NULL ("fold"): the product is ADDED to dqa[:, 0:96] before it is rounded to bf16 -- dqa then is
+   *   the whole gradient of the pooled q and svit_pool_ln_bwd needs no d_extra.
+   * relR == NULL = off (the caller runs svit_gemm_nt on relD). */
   const void* relR; float* relX;
 } svit_attn_bwd_args;
 int svit_attn_bwd(const svit_attn_bwd_args* a, void* stream);

@@ -238,6 +238,63 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
   __builtin_amdgcn_s_barrier();        // every wave is done with the K/V ring
   constexpr int OROW = DA * 2 + 16;    // bytes per staged row (pad spreads the banks)
   unsigned char* ost = smem + wave * (32 * OROW);
+  // ---- fold mode (relD + relR, no relX, narrow tables): the rel-pos backward's query-side work happens HERE,
+  // from the accumulators, before anything is staged.  The lane owns a query: its d(relq) values (the extra
+  // column blocks of dq) are scattered into the wave's own 32 x ldd D rows in LDS, D . R^T is multiplied on the
+  // matrix pipe (table fragments straight from L2) in the accumulator layout of dq, and ADDED to dq's first
+  // 96 columns -- dqa then is the whole gradient of the pooled q and no dq_extra tensor exists.
+  const bool fold = a.relD && a.relR && !a.relX && a.relD_ld <= 128;
+  if (fold) {
+    constexpr int EXTRA_ = DA - 96;
+    unsigned char* dst = smem + 4 * (32 * OROW) + wave * (32 * 128 * 2);
+    const int ldd = a.relD_ld, cpr = ldd >> 3, q = lane & 31;
+    for (int i = lane; i < 32 * cpr; i += 64) *(uint4*)(dst + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+    int4 mp[NP - 3][4];
+#pragma unroll
+    for (int pj = 0; pj < NP - 3; ++pj)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        mp[pj][g] = q0 + q < a.Nq ? *(const int4*)(a.relD_map + (size_t)(q0 + q) * EXTRA_ + pj * 32 + 8 * g + 4 * hh)
+                                  : make_int4(-1, -1, -1, -1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int pj = 0; pj < NP - 3; ++pj)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cc[4] = {mp[pj][g].x, mp[pj][g].y, mp[pj][g].z, mp[pj][g].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // the two roundings of the unfused pair: dqa's bf16 column, then the scattered value
+          const bf16_t v1 = f32_to_bf16(dq[3 + pj][4 * g + e] * LN2);
+          if (cc[e] >= 0) *(bf16_t*)(dst + (q * ldd + cc[e]) * 2) = f32_to_bf16(bf16_to_f32(v1) * a.relD_scale);
+        }
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    f32x16_t ex[3];
+#pragma unroll
+    for (int pb = 0; pb < 3; ++pb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ex[pb][r] = 0.f;
+    const bf16_t* R = (const bf16_t*)a.relR;
+    for (int ks = 0; ks < ldd / 16; ++ks) {
+      const bf16x8_t dfrag = *(const bf16x8_t*)(dst + (q * ldd + 16 * ks + 8 * hh) * 2);
+#pragma unroll
+      for (int pb = 0; pb < 3; ++pb) {
+        const bf16x8_t rfrag = *(const bf16x8_t*)(R + (size_t)(pb * 32 + q) * ldd + 16 * ks + 8 * hh);
+        ex[pb] = mfma32(rfrag, dfrag, ex[pb]);
+      }
+    }
+    constexpr float INV_LN2 = 1.4426950408889634f;      // dq is in log2 units until the x ln 2 below
+#pragma unroll
+    for (int pb = 0; pb < 3; ++pb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[pb][r] += ex[pb][r] * INV_LN2;
+    bf16_t* Dg = (bf16_t*)a.relD + ((size_t)bh * a.Nq) * ldd;
+    for (int i = lane; i < 32 * cpr; i += 64) {
+      const int rl = i / cpr, ch = i % cpr;
+      if (q0 + rl < a.Nq) *(uint4*)(Dg + (size_t)(q0 + rl) * ldd + ch * 8) = *(const uint4*)(dst + i * 16);
+    }
+  }
   {
     unsigned char* orow = ost + (lane & 31) * OROW;
 #pragma unroll
@@ -254,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
   // row stores of dqa instead of standing in front of the scatter
   constexpr int EXTRA = DA - 96, NV = 32 * EXTRA / 64;
   int cols[NV];
-  if (a.relD) {
+  if (a.relD && !fold) {
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
       const int e = it * 64 + lane, rl = e / EXTRA, j = e % EXTRA;
@@ -273,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
   // The staged tile still holds d(relq) in its columns 96..DA: they go to registers, then the wave's
   // staging region (private to it: LDS operations of one wave complete in order) is reused to build whole
   // D rows -- zero-fill, 2-byte scatter through the map, 16-byte row stores.
-  if (a.relD) {
+  if (a.relD && !fold) {
     bf16_t vals[NV];
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
@@ -580,7 +637,7 @@ template <int DA, int KSU>
 int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
   static SvitOnce once_dq, once_kv, once_kv2;
   size_t lds_dq = 2 * (size_t)(KT * DA * 2 + KT * HD * 2);
-  const size_t lds_dq_out = (size_t)4 * 32 * (DA * 2 + 16);
+  const size_t lds_dq_out = (size_t)4 * 32 * (DA * 2 + 16) + (size_t)4 * 32 * 128 * 2;   // + the fold mode's D rows
   if (lds_dq < lds_dq_out) lds_dq = lds_dq_out;
   const size_t stage = (size_t)(QR * DA * 2 + QR * HD * 2 + 2 * QR * 4);
   size_t lds_kv = 2 * stage, lds_kv2 = 3 * stage;
@@ -642,7 +699,10 @@ extern "C" int svit_attn_bwd(const svit_attn_bwd_args* a, void* stream) {
     if (a->relX && (!a->relR || a->relD_ld > 128 || a->relD_ld % 16 != 0 ||
                     (((uintptr_t)a->relR | (uintptr_t)a->relX) & 15)))
       return SVIT_ERR_ARG;
-  } else if (a->relX) {
+    if (a->relR && !a->relX && (a->relD_ld > 128 || a->relD_ld % 16 != 0 || ((uintptr_t)a->relR & 15) ||
+                                ((uintptr_t)a->relD_map & 15)))
+      return SVIT_ERR_ARG;     // fold mode exists for narrow tables only
+  } else if (a->relX || a->relR) {
     return SVIT_ERR_ARG;
   }
   const int bias_cols = a->bias_cols > 0 ? a->bias_cols : a->DA - 96;

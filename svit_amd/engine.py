@@ -532,7 +532,7 @@ class Engine:
             dqa, dk, dv, D, dq_extra = ops.attn_bwd(
                 qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE,
                 q_splits=1 if self.deterministic else self.attn_q_splits, bias_cols=sum(sv["k_thw"]),
-                reld=(dmap, lpad, LOG2E, rcat_t if rcat_t.is_contiguous() else None))
+                reld=(dmap, lpad, LOG2E, rcat_t if rcat_t.is_contiguous() else None, "fold"))
         else:   # (A/B knob for measurements: SVIT_FUSED_SCATTER=0)
             dqa, dk, dv = ops.attn_bwd(qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE,
                                        q_splits=1 if self.deterministic else self.attn_q_splits,
@@ -550,6 +550,8 @@ class Engine:
                 f.g(n).add_(m.t() @ d)
         if dq_extra is None:      # wide tables (56x56 / 28x28 stages) or the A/B path: dq = D R as its own GEMM
             dq_extra = ops.gemm_nt(D, rcat_t, None, hip.EPI_F32)
+        elif isinstance(dq_extra, str):     # "folded": dqa[..., :96] already holds it (narrow tables)
+            dq_extra = None
         Nk = ka.shape[2]
         dqkv = torch.empty_like(sv["qkv"])
         entries = []

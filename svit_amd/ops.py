@@ -480,7 +480,8 @@ def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0, bias_cols=0, reld=No
     adds them while it reads).  reld = (map i32 [Nq, DA - 96], ldd, scale[, rt]): the dq kernel also writes the
     rel-pos backward's scattered matrix D bf16 [B*h*Nq, ldd] (what relpos_scatter builds), returned 4th, and --
     given rt = the transposed tables bf16 [96, ldd], ldd <= 128 -- dq_extra = D . rt^T f32 [B*h*Nq, 96], returned
-    5th (None when it was not computed: the caller then runs the GEMM)."""
+    5th (None when it was not computed: the caller then runs the GEMM); with a fifth element "fold" the product
+    is added into dqa[..., :96] inside the kernel instead and the 5th result is the string "folded"."""
     _chk_dev(qa, ka, v, ctx, dctx, lse2)
     B, heads, Nq, DA = qa.shape
     Nk = ka.shape[2]
@@ -505,10 +506,15 @@ def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0, bias_cols=0, reld=No
         assert cmap.dtype == torch.int32 and cmap.is_contiguous() and cmap.shape == (Nq, DA - HD)
         D = torch.empty((B * heads * Nq, ldd), device=dev, dtype=BF16)
         a.relD, a.relD_ld, a.relD_map, a.relD_scale = ptr(D), ldd, ptr(cmap), rscale
+        mode = reld[4] if len(reld) > 4 else "separate"
         if rt is not None and ldd <= 128 and ldd % 16 == 0:
             assert rt.dtype == BF16 and rt.is_contiguous() and tuple(rt.shape) == (HD, ldd)
-            X = torch.empty((B * heads * Nq, HD), device=dev, dtype=F32)
-            a.relR, a.relX = ptr(rt), ptr(X)
+            a.relR = ptr(rt)
+            if mode == "fold":        # dqa[:, :96] += D . rt^T inside the kernel: no dq_extra tensor at all
+                X = "folded"
+            else:
+                X = torch.empty((B * heads * Nq, HD), device=dev, dtype=F32)
+                a.relX = ptr(X)
     hip.call("svit_attn_bwd", C.byref(a), meta=("attn", B, heads, Nq, Nk, DA))
     if reld is not None:
         return dqa, dkv[0], dkv[1], D, X

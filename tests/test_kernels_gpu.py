@@ -509,6 +509,14 @@ def test_attention_bwd_writes_the_relpos_scatter_matrix(ops, q_thw, k_thw, h):
     if X is not None:
         X_ref = ops.gemm_nt(D_ref, rt, None, hip.EPI_F32)
         assert rel_err(X, X_ref) < 1e-5
+        # fold mode: the same product added into dqa's first 96 columns inside the kernel (one rounding to bf16
+        # instead of two); D and the extra columns stay bit-identical
+        dqa_f, dk_f, dv_f, D_f, tag = ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, 96 ** -0.5, bias_cols=J,
+                                                   reld=(cmap.to(DEV).contiguous(), lpad, 1.4426950408889634, rt, "fold"))
+        assert tag == "folded" and torch.equal(D_f, D_ref) and torch.equal(dqa_f[..., 96:], dqa[..., 96:])
+        want = dqa[..., :96].float() + X_ref.view(B, h, Nq, 96)
+        assert rel_err(dqa_f[..., :96], want) < 1e-2 and cos(dqa_f[..., :96], want) > 0.99999
+        assert torch.equal(dk_f, dk) and torch.equal(dv_f, dv)
     dqa2, dk2, dv2 = ops.attn_bwd(qa, ka, v, ctx, dctx, lse2, 96 ** -0.5, bias_cols=J)
     assert torch.equal(dqa, dqa2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
 
