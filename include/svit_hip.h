@@ -344,6 +344,35 @@ int svit_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, con
                     float max_norm, float lr, float beta1, float beta2, float eps, float wd,
                     int step, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------ head (K15) ---------- */
+/* SViT head (slowfast/models/video_model_builder.py:408-551) in one launch each way, fp32: dropout factors
+ * applied to the cls / object rows of the final norm's output, class logits from the cls row, box MLP +
+ * sigmoid and objectness logit from every object row, contact-state logits from the first two objects of a
+ * frame.  tokens f32 [B,N,C]: row 0 = cls, the last T*O rows = objects (t-major).  keep f32 [B,1+T*O,C]
+ * (mask / (1-p)) or NULL.  Outputs: logits [B,n_cls]; boxes [B,T,O,5] (col 0 objectness logit, 1..4 sigmoid
+ * boxes = the reference's pred_bboxes); contact [B,T,2,5]; xobj [B,T*O,C] (optional: the dropped object
+ * features = the reference's obj_desc). */
+typedef struct {
+  const float* tokens; int32_t B, N, C, T, O;
+  const float* keep;
+  const float* w_proj; const float* b_proj; int32_t n_cls;
+  const float* w_box; const float* b_box;
+  const float* w_bce; const float* b_bce;
+  const float* w_con; const float* b_con;
+  float* logits; float* boxes; float* contact; float* xobj;
+} svit_head_args;
+int svit_head_fwd(const svit_head_args* a, void* stream);
+/* Backward: any of dlogits / dboxes / dcontact / dxobj may be NULL (no gradient).  dtokens f32 [B,N,C] is
+ * OVERWRITTEN (zero rows for the patch tokens); the eight parameter gradients are ACCUMULATED (+=) -- they are
+ * meant to be the views of the flat gradient buffer. */
+typedef struct {
+  svit_head_args f;
+  const float* dlogits; const float* dboxes; const float* dcontact; const float* dxobj;
+  float* dtokens;
+  float* gw_proj; float* gb_proj; float* gw_box; float* gb_box; float* gw_bce; float* gb_bce; float* gw_con; float* gb_con;
+} svit_head_bwd_args;
+int svit_head_bwd(const svit_head_bwd_args* g, void* stream);
+
 /* ------------------------------------------------ image-rank HAOG losses ---- */
 /* boxes_loss_ + contact-state CE of VideoImageLoss._haog_loss (slowfast/models/losses.py:50-93,
  * 138-155; slowfast/utils/box_ops.py:10-77) without the reference's boolean-index host syncs:

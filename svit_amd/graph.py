@@ -66,12 +66,6 @@ class GraphedTrainStep:
         with torch.no_grad():
             y, st = eng.forward(x, ds, save=True)
         n_obj = Tx * core.O
-        feat = torch.cat((y[:, :1], y[:, -n_obj:]), dim=1).requires_grad_(True)
-        # the head runs on fresh leaf aliases of its parameters and explicit autograd.grad instead
-        # of loss.backward(): AccumulateGrad nodes of the real parameters may be pinned to another
-        # stream by an earlier eager step, which a stream capture cannot follow
-        named = list(core.head.named_parameters())
-        alias = {n: p.detach().requires_grad_(True) for n, p in named}
         frames_out = None
         if self.frames_pass and Tx > 1:
             with torch.no_grad():       # B*T single frames through the same kernels (T' = 1)
@@ -80,21 +74,43 @@ class GraphedTrainStep:
                 ffeat = torch.cat((fy[:, :1], fy[:, -core.O:]), dim=1)
                 fp, fe = core.head(ffeat, T=1)
                 frames_out = {"preds": fp, "extra_preds": fe}
-        with torch.enable_grad():
-            preds, extra = torch.func.functional_call(core.head, alias, (feat,), {"T": Tx})
-            if frames_out is not None:
-                extra = dict(extra)
-                extra["frames_output"] = frames_out
-            loss = self.loss_fun(preds, extra, self.labels)
-        grads = torch.autograd.grad(loss, [feat] + [alias[n] for n, _ in named], allow_unused=True)
+        if core.fused_head:
+            # the head as one launch each way (csrc/head.hip): its backward writes the head's parameter
+            # gradients straight into the flat buffer's views and returns d(tokens) whole -- no AccumulateGrad
+            # node of a real parameter is involved (those may be pinned to another stream by an earlier eager
+            # step, which a stream capture cannot follow), no slice / cat plumbing either
+            yt = y.detach().requires_grad_(True)
+            with torch.enable_grad():
+                preds, extra = core.head_train(yt, Tx)
+                if frames_out is not None:
+                    extra = dict(extra)
+                    extra["frames_output"] = frames_out
+                loss = self.loss_fun(preds, extra, self.labels)
+            dy, = torch.autograd.grad(loss, [yt])
+            feat = yt
+        else:
+            feat = torch.cat((y[:, :1], y[:, -n_obj:]), dim=1).requires_grad_(True)
+            # the head runs on fresh leaf aliases of its parameters and explicit autograd.grad instead
+            # of loss.backward(): AccumulateGrad nodes of the real parameters may be pinned to another
+            # stream by an earlier eager step, which a stream capture cannot follow
+            named = list(core.head.named_parameters())
+            alias = {n: p.detach().requires_grad_(True) for n, p in named}
+            with torch.enable_grad():
+                preds, extra = torch.func.functional_call(core.head, alias, (feat,), {"T": Tx})
+                if frames_out is not None:
+                    extra = dict(extra)
+                    extra["frames_output"] = frames_out
+                loss = self.loss_fun(preds, extra, self.labels)
+            grads = torch.autograd.grad(loss, [feat] + [alias[n] for n, _ in named], allow_unused=True)
+            with torch.no_grad():
+                for (n, p), g in zip(named, grads[1:]):
+                    if g is not None:
+                        p.grad.add_(g)
+                dfeat = grads[0]
+                dy = torch.zeros_like(y)
+                dy[:, :1] = dfeat[:, :1]
+                dy[:, -n_obj:] = dfeat[:, 1:]
         with torch.no_grad():
-            for (n, p), g in zip(named, grads[1:]):
-                if g is not None:
-                    p.grad.add_(g)
-            dfeat = grads[0]
-            dy = torch.zeros_like(y)
-            dy[:, :1] = dfeat[:, :1]
-            dy[:, -n_obj:] = dfeat[:, 1:]
             eng.backward(st, dy, on_ready=boundary,
                          ready_ranks=self.dp.launch_ranks() if self.dp is not None else None)
         return (loss.detach(), preds.detach(),

@@ -105,6 +105,19 @@ class AttnBwdArgs(C.Structure):
                 ("relR", vp), ("relX", vp)]
 
 
+class HeadArgs(C.Structure):
+    _fields_ = [("tokens", vp), ("B", i32), ("N", i32), ("C", i32), ("T", i32), ("O", i32), ("keep", vp),
+                ("w_proj", vp), ("b_proj", vp), ("n_cls", i32), ("w_box", vp), ("b_box", vp),
+                ("w_bce", vp), ("b_bce", vp), ("w_con", vp), ("b_con", vp),
+                ("logits", vp), ("boxes", vp), ("contact", vp), ("xobj", vp)]
+
+
+class HeadBwdArgs(C.Structure):
+    _fields_ = [("f", HeadArgs), ("dlogits", vp), ("dboxes", vp), ("dcontact", vp), ("dxobj", vp), ("dtokens", vp),
+                ("gw_proj", vp), ("gb_proj", vp), ("gw_box", vp), ("gb_box", vp), ("gw_bce", vp), ("gb_bce", vp),
+                ("gw_con", vp), ("gb_con", vp)]
+
+
 _SIGS = {
     "svit_version": (i32, []),
     "svit_arch": (C.c_char_p, []),
@@ -149,6 +162,8 @@ _SIGS = {
     "svit_maxpool_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "svit_sumsq": (i32, [vp, i64, vp, vp, i64, vp]),
     "svit_adamw_step": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, i32, f32, vp]),
+    "svit_head_fwd": (i32, [C.POINTER(HeadArgs), vp]),
+    "svit_head_bwd": (i32, [C.POINTER(HeadBwdArgs), vp]),
     "svit_haog_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "svit_haog_loss_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "svit_ensemble_update": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),

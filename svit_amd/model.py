@@ -10,12 +10,13 @@ launch schedules of svit_amd/engine.py.  There is no PyTorch fallback for the ba
 a GPU or without libsvit_hip.so the forward raises.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import arch, hip
+from . import arch, hip, ops
 from .engine import Engine, FlatParams
 
 
@@ -77,6 +78,34 @@ class _Backbone(torch.autograd.Function):
         return None, None, None, None, None
 
 
+class _HeadFn(torch.autograd.Function):
+    """The training-mode head as ONE launch each way (svit_head_fwd / svit_head_bwd, csrc/head.hip) instead of
+    ~45 stock ATen launches: the backward writes the eight parameter gradients straight into the flat gradient
+    buffer's views (like the backbone's node does) and returns d(tokens) whole."""
+
+    @staticmethod
+    def forward(ctx, model, tokens, T, O, keep):
+        head = model.head
+        tokens = tokens.contiguous()
+        with torch.no_grad():
+            outs = ops.head_fwd(tokens, T, O, keep, [(w.data, b.data) for w, b in head.param_pairs()])
+        ctx.model, ctx.T, ctx.O = model, T, O
+        ctx.save_for_backward(tokens, keep, outs[1])
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    def backward(ctx, dlogits, dboxes, dcontact, dxobj):
+        tokens, keep, boxes = ctx.saved_tensors
+        model = ctx.model
+        model._attach_grads()      # (zeroes the flat buffer first if zero_grad() dropped the views)
+        pairs = model.head.param_pairs()
+        with torch.no_grad():
+            dtok = ops.head_bwd(tokens, ctx.T, ctx.O, keep, [(w.data, b.data) for w, b in pairs], boxes,
+                                (dlogits, dboxes, dcontact, dxobj), [(w.grad, b.grad) for w, b in pairs])
+        return None, dtok, None, None, None
+
+
 class SViTHead(nn.Module):
     """slowfast/models/video_model_builder.py:408-551 -- tiny ([B,65,768]) fp32 torch ops."""
 
@@ -91,6 +120,11 @@ class SViTHead(nn.Module):
         self.boxes_mlp = nn.Sequential(nn.Linear(dim_in, 4, bias=True), nn.Sigmoid())
         self.boxes_bce_mlp = nn.Linear(dim_in, 1, bias=True)
         self.contact_mlp = nn.Linear(dim_in, 5, bias=True)
+
+    def param_pairs(self):
+        """(weight, bias) of the class projection, the box MLP, the objectness Linear and the contact MLP."""
+        return [(self.projection.weight, self.projection.bias), (self.boxes_mlp[0].weight, self.boxes_mlp[0].bias),
+                (self.boxes_bce_mlp.weight, self.boxes_bce_mlp.bias), (self.contact_mlp.weight, self.contact_mlp.bias)]
 
     def forward(self, x, T=None, dropout_keep=None):
         T = self.T if T is None else T
@@ -157,6 +191,8 @@ class SViT(nn.Module):
                 _trunc_normal_(m.weight)
                 nn.init.constant_(m.bias, 0)
         self.engine = None
+        self.fused_head = os.environ.get("SVIT_FUSED_HEAD", "1") != "0"   # A/B knob: 0 = ATen head in training too
+        self._head_ones = None
         self.flat = None
         self._grad_ready_hook = None   # set by the data-parallel wrapper (svit_amd/dp.py)
         self._grad_ready_ranks = None  # ranks at which that hook launches collectives
@@ -262,6 +298,22 @@ class SViT(nn.Module):
         m = torch.floor(self._keep + torch.rand((len(blocks), 2, batch), device=device)) / self._keep
         return [(m[i, 0], m[i, 1]) if b.drop_path > 0.0 else None for i, b in enumerate(blocks)]
 
+    def head_train(self, tokens, Tx, dropout_keep=None):
+        """Training-mode head on the final norm's output tokens f32 [B,N,C] as one launch each way
+        (csrc/head.hip through _HeadFn); eval keeps the ATen ops (softmax / sigmoid outputs).  Also what
+        graph.GraphedTrainStep calls."""
+        n_obj = Tx * self.O
+        keep = dropout_keep
+        if keep is None and self.head.dropout_rate > 0.0:
+            shp = (tokens.shape[0], 1 + n_obj, tokens.shape[2])
+            if self._head_ones is None or tuple(self._head_ones.shape) != shp:
+                self._head_ones = torch.ones(shp, device=tokens.device)
+            keep = F.dropout(self._head_ones, self.head.dropout_rate, True)     # mask / (1 - p), one launch
+        elif keep is not None:
+            keep = keep.to(torch.float32).expand(tokens.shape[0], 1 + n_obj, tokens.shape[2]).contiguous()
+        logits, boxes, contact, xobj = _HeadFn.apply(self, tokens, Tx, self.O, keep)
+        return logits, {"obj_desc": xobj, "pred_bboxes": boxes, "pred_contact_state": contact}
+
     def forward(self, x, metadata=None, bboxes=None, drop_scales=None, dropout_keep=None):
         if self.engine is None:
             raise hip.SvitHipError("SViT (svit_amd) has no CPU path: build it with "
@@ -276,6 +328,8 @@ class SViT(nn.Module):
         need_grad = torch.is_grad_enabled()
         tokens = _Backbone.apply(self, x, drop_scales, need_grad, self._anchor)
         n_obj = Tx * self.O
+        if self.training and self.fused_head:
+            return self.head_train(tokens, Tx, dropout_keep)
         feat = torch.cat((tokens[:, :1], tokens[:, -n_obj:]), dim=1)
         return self.head(feat, T=Tx, dropout_keep=dropout_keep)
 

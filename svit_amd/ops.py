@@ -549,6 +549,52 @@ def adamw_step(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, wd, step, g
              lr, beta1, beta2, eps, wd, step, grad_scale)
 
 
+# ---------------------------------------------------------------- head (K15) ----------------
+def _head_args(tokens, T, O, keep, head_params, outs):
+    a = hip.HeadArgs()
+    B, N, C_ = tokens.shape
+    a.tokens, a.B, a.N, a.C, a.T, a.O = ptr(tokens), B, N, C_, T, O
+    a.keep = ptr(keep)
+    (wp, bp), (wb, bb), (we, be), (wc, bc) = head_params
+    a.w_proj, a.b_proj, a.n_cls = ptr(wp), ptr(bp), wp.shape[0]
+    a.w_box, a.b_box, a.w_bce, a.b_bce, a.w_con, a.b_con = ptr(wb), ptr(bb), ptr(we), ptr(be), ptr(wc), ptr(bc)
+    a.logits, a.boxes, a.contact, a.xobj = (ptr(t) for t in outs)
+    return a
+
+
+def head_fwd(tokens, T, O, keep, head_params):
+    """SViT head in one launch (svit_head_fwd): tokens f32 [B,N,C] -> logits [B,n_cls], pred_bboxes [B,T,O,5],
+    contact [B,T,2,5], obj_desc [B,T,O,C].  head_params = ((w,b) of projection, box MLP, objectness, contact)."""
+    assert tokens.is_contiguous() and tokens.dtype == F32
+    _chk_dev(tokens, keep, *[t for wb in head_params for t in wb])
+    B, N, C_ = tokens.shape
+    dev = tokens.device
+    outs = (torch.empty((B, head_params[0][0].shape[0]), device=dev), torch.empty((B, T, O, 5), device=dev),
+            torch.empty((B, T, 2, 5), device=dev), torch.empty((B, T, O, C_), device=dev))
+    a = _head_args(tokens, T, O, keep, head_params, outs)
+    hip.call("svit_head_fwd", C.byref(a))
+    return outs
+
+
+def head_bwd(tokens, T, O, keep, head_params, boxes, grads_out, param_grads):
+    """-> d(tokens) f32 [B,N,C] (zero rows for the patch tokens); the parameter gradients are ADDED into
+    param_grads (same nesting as head_params).  grads_out = (dlogits, dboxes, dcontact, dxobj), None allowed."""
+    assert tokens.is_contiguous() and tokens.dtype == F32
+    go = [None if t is None else t.contiguous() for t in grads_out]
+    _chk_dev(tokens, keep, boxes, *[t for t in go if t is not None])
+    g = hip.HeadBwdArgs()
+    # of the forward outputs only the sigmoid boxes are read; the argument check wants the three pointers set
+    g.f = _head_args(tokens, T, O, keep, head_params, (boxes, boxes, boxes, None))
+    g.dlogits, g.dboxes, g.dcontact, g.dxobj = (ptr(t) for t in go)
+    dtok = torch.empty_like(tokens)
+    g.dtokens = ptr(dtok)
+    (gwp, gbp), (gwb, gbb), (gwe, gbe), (gwc, gbc) = param_grads
+    g.gw_proj, g.gb_proj, g.gw_box, g.gb_box = ptr(gwp), ptr(gbp), ptr(gwb), ptr(gbb)
+    g.gw_bce, g.gb_bce, g.gw_con, g.gb_con = ptr(gwe), ptr(gbe), ptr(gwc), ptr(gbc)
+    hip.call("svit_head_bwd", C.byref(g))
+    return dtok
+
+
 # ---------------------------------------------------------------- image-rank HAOG losses ----
 def haog_loss_fwd(pred, tar, contact, contact_tar):
     """-> (losses f32 [8], (g_l1, g_bce, g_giou, g_contact)); see include/svit_hip.h."""

@@ -472,6 +472,51 @@ def test_pool_ln_bwd_three_inputs(ops):
     assert rel_err(dpre, xr.grad) < 2e-2 and cos(dpre, xr.grad) > 0.9999
 
 
+@pytest.mark.parametrize("T,O,drop,which,B", [(16, 4, True, "all", 3), (2, 3, False, "logits", 3), (1, 4, True, "image", 63),
+                                               (1, 4, True, "all", 21)])
+def test_head_fused_vs_aten(ops, T, O, drop, which, B):
+    """svit_head_fwd / svit_head_bwd (one launch each way) against the ATen head they replace in training mode
+    (slowfast/models/video_model_builder.py:505-551): all four outputs, d(tokens) incl. the zero rows of the
+    patch tokens, and the eight parameter gradients, for the video loss (logits only), the image losses (boxes
+    + contact only) and everything at once; with and without dropout factors."""
+    C_, n_cls = 768, 174
+    N = 1 + 37 + T * O
+    tokens = rnd("ht%d" % T, (B, N, C_), 1.0).requires_grad_(True)
+    R_ = 1 + T * O
+    keep = None
+    if drop:
+        keep = (torch.rand((B, R_, C_), device=DEV, generator=torch.Generator(DEV).manual_seed(5)) > 0.5).float() * 2.0
+    ws = [rnd("hw%d%d" % (i, T), (n, C_), 0.05).requires_grad_(True) for i, n in enumerate((n_cls, 4, 1, 5))]
+    bs = [rnd("hb%d%d" % (i, T), (n,), 0.1).requires_grad_(True) for i, n in enumerate((n_cls, 4, 1, 5))]
+    # reference: the ATen ops of SViTHead.forward
+    feat = torch.cat((tokens[:, :1], tokens[:, -T * O:]), dim=1)
+    x = feat * keep if keep is not None else feat
+    cls, xo = x[:, 0], x[:, 1:].reshape(B, T, O, C_)
+    r_logits = F.linear(cls, ws[0], bs[0])
+    r_boxes = torch.cat((F.linear(xo, ws[2], bs[2]), torch.sigmoid(F.linear(xo, ws[1], bs[1]))), dim=-1)
+    r_contact = F.linear(xo[:, :, :2], ws[3], bs[3])
+    params = [(w.detach(), b.detach()) for w, b in zip(ws, bs)]
+    logits, boxes, contact, xobj = ops.head_fwd(tokens.detach(), T, O, keep, params)
+    assert rel_err(logits, r_logits) < 1e-5 and rel_err(boxes, r_boxes) < 1e-5 and rel_err(contact, r_contact) < 1e-5
+    assert torch.equal(xobj, xo.detach())
+    gl, gb, gc, gx = (rnd("hg%d%s" % (i, which), tuple(t.shape), 1.0) for i, t in enumerate((r_logits, r_boxes, r_contact, xo)))
+    if which == "logits":
+        gb = gc = gx = None
+    elif which == "image":
+        gl = gx = None
+    loss = sum((r * g).sum() for r, g in zip((r_logits, r_boxes, r_contact, xo), (gl, gb, gc, gx)) if g is not None)
+    loss.backward()
+    pg = [(torch.full_like(w, 0.25), torch.full_like(b, 0.25)) for w, b in zip(ws, bs)]      # += semantics
+    dtok = ops.head_bwd(tokens.detach(), T, O, keep, params, boxes, (gl, gb, gc, gx), pg)
+    assert rel_err(dtok, tokens.grad) < 1e-5
+    assert float(dtok[:, 1:N - T * O].abs().max()) == 0.0
+    for (gw, gbias), w, b in zip(pg, ws, bs):
+        wg = w.grad if w.grad is not None else torch.zeros_like(w)
+        bg = b.grad if b.grad is not None else torch.zeros_like(b)
+        assert rel_err(gw - 0.25, wg) < 1e-4 or float(wg.abs().max()) == 0.0 and float((gw - 0.25).abs().max()) == 0.0
+        assert rel_err(gbias - 0.25, bg) < 1e-4 or float(bg.abs().max()) == 0.0 and float((gbias - 0.25).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("q_thw,k_thw,h", [((8, 14, 14), (8, 7, 7), 4), ((2, 28, 28), (2, 7, 7), 2), ((1, 5, 3), (1, 5, 3), 1)])
 def test_attention_bwd_writes_the_relpos_scatter_matrix(ops, q_thw, k_thw, h):
     """svit_attn_bwd_args.relD: the dq kernel's epilogue builds the rel-pos backward's scattered matrix D
