@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <type_traits>
+#include <cstdlib>
 #include "common.h"
 #include "../../include/svit_hip.h"
 
@@ -371,11 +372,21 @@ extern "C" int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, floa
 }
 
 // cost-model constants of the grouped launch (svit_debug_set_tn / svit_debug_set_tn_tile for sweeps)
-static std::atomic<double> g_tn_step_us{0.85};      // one 64-row step of a workgroup, 512 resident
-static std::atomic<double> g_tn_atomic_tbs{0.75};   // effective fp32 atomic flush rate, TB/s
-static std::atomic<int> g_tn_big{1};                // 0: 128x96 tiles only, 1: heuristic, 2: 128x192 everywhere
+// (environment overrides for in-step A/B runs -- isolated loops keep the operands in the Infinity Cache and
+// hide what the planner costs in HBM re-reads: SVIT_TN_STEP_US, SVIT_TN_ATOMIC_TBS, SVIT_TN_TILE)
+static double tn_env(const char* name, double dflt) {
+  const char* e = getenv(name);
+  return e ? atof(e) : dflt;
+}
+static std::atomic<double> g_tn_step_us{tn_env("SVIT_TN_STEP_US", 0.85)};      // one 64-row step of a workgroup, 512 resident
+static std::atomic<double> g_tn_atomic_tbs{tn_env("SVIT_TN_ATOMIC_TBS", 0.75)};   // effective fp32 atomic flush rate, TB/s
+// 0: 128x96 tiles only, 1: the per-problem heuristic fitted on ISOLATED launches, 2: 128x192 everywhere (default since
+// the in-step A/B of round 3: 13.46 -> 13.30 ms per step, profiles/r03_tn_tile_modes.txt -- inside the step the
+// operands come from HBM, not from the Infinity Cache an isolated loop keeps them in, and fewer, fatter tiles
+// re-read less), 3: 128x192 where K % 192 == 0
+static std::atomic<int> g_tn_big{(int)tn_env("SVIT_TN_TILE", 2)};
 extern "C" int svit_debug_set_tn_tile(int mode) {
-  if (mode < 0 || mode > 2) return SVIT_ERR_ARG;
+  if (mode < 0 || mode > 3) return SVIT_ERR_ARG;
   g_tn_big = mode;
   return SVIT_OK;
 }
@@ -430,7 +441,8 @@ static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void
       // atomics outweighs the smaller operand traffic) nor the M = 201224 group of block 0 (+11 %)
       g.big[i] = big_mode == 1 ? (g.p[i].K % TnBig::TK == 0 && g.p[i].N >= 128 &&
                                   (g.p[i].M <= 4096 || (g.p[i].M >= 32768 && g.p[i].M < 131072)))
-                               : (big_mode == 2);
+                 : big_mode == 3 ? (g.p[i].K % TnBig::TK == 0 && g.p[i].N >= 128)
+                                 : (big_mode == 2);
       const int tn = g.big[i] ? TnBig::TN : TnSmall::TN, tk = g.big[i] ? TnBig::TK : TnSmall::TK;
       bm[i] = g.big[i] ? TnBig::BM : TnSmall::BM;
       tile_bytes[i] = (double)tn * tk * 4.0;

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for b in 4 14 15 3 2 1; do
+for b in 4 14 3 2 1; do
 rm -rf gpurun_out/p1_tr
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/p1_tr -- python tools/pool_one.py $b > gpurun_out/p1_tr.log 2>&1
 python - $b <<'PY'
