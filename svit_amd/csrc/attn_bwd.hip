@@ -32,6 +32,7 @@
 // addressed by buffer descriptor + scalar offset (no per-piece address arithmetic); the dkv kernel
 // consumes 64 queries per barrier (was 32); dQa leaves through LDS as whole rows in 16-byte stores.
 #include <atomic>
+#include <cstdlib>
 #include "attn_common.h"
 #include "../../include/svit_hip.h"
 
@@ -607,7 +608,9 @@ __global__ __launch_bounds__(256 * NH, NH == 2 ? 1 : 2) void attn_bwd_dkv_kernel
 #endif
 }
 
-static std::atomic<int> g_dkv_halves{0};   // tuning knob (svit_attn_debug_set(0, n)): 1 / 2, 0 = heuristic
+static int dkv_env(const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; }
+static std::atomic<int> g_dkv_halves{dkv_env("SVIT_DKV_HALVES", 0)};   // tuning knob (svit_attn_debug_set(0, n) / env for in-step A/Bs): 1 / 2, 0 = heuristic
+static const int g_dkv_target = dkv_env("SVIT_DKV_TARGET", 256);      // workgroups the query split aims at
 
 // how the query range of the dkv kernel is cut: (dkv waves / 4, effective number of parts)
 struct DkvPlan { int halves, splits, tiles_per_split; };
@@ -623,7 +626,7 @@ static DkvPlan dkv_plan(const svit_attn_bwd_args& a) {
   if (splits <= 0) {
     // split the query range only as far as needed to fill the chip (~1 block per CU: every part is
     // one more dk / dv plane for the consumer to read) and keep >= 2 query stages per block
-    splits = (256 + base - 1) / base;
+    splits = (g_dkv_target + base - 1) / base;
     if (splits > nqt / 2) splits = nqt / 2;
   }
   if (splits > nqt) splits = nqt;
