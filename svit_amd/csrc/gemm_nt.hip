@@ -15,6 +15,7 @@
 // ((row>>2)&3) on the per-lane SOURCE address, and the same XOR is applied on the fragment
 // reads -> ds_read_b128 of 16 consecutive rows hits 16 distinct slots of the 256-B bank row.
 #include <atomic>
+#include <cstdlib>
 #include "gemm_epilogue.h"
 #include "attn_common.h"   // Int / static_for / lds_read128 / lgkm_release1
 
@@ -394,10 +395,12 @@ static void ring_choice(const svit_gemm_args& a, int* cfg, int* stages) {
   const long tm = (a.M + 127) / 128;
   const long t192 = a.N % 192 == 0 ? tm * (a.N / 192) : 0, t96 = tm * ((a.N + 95) / 96);
   // few, long tiles: every 128x96 tile has a CU to itself -> 4-deep ring (3656 x 768 x 768..3072: -30 %)
-  if (t96 <= 256 && a.K >= 768) { *cfg = 6, *stages = 4; return; }
+  static const int k_min5 = getenv("SVIT_NT_RING_K5") ? atoi(getenv("SVIT_NT_RING_K5")) : 1024;     // (in-step A/B knobs)
+  static const int t_max6 = getenv("SVIT_NT_RING_T6") ? atoi(getenv("SVIT_NT_RING_T6")) : 256;
+  if (t96 <= t_max6 && a.K >= 768) { *cfg = 6, *stages = 4; return; }
   // long K, narrow output, enough 128x192 tiles for most CUs (13064 x 384 x 1152..2304: -6..-10 % in the
   // step, -15..-20 % isolated; on a par with hipBLASLt's 128x160x64 macro-tile)
-  if (t192 >= 160 && a.N <= 768 && a.K >= 1024) { *cfg = 5, *stages = 3; return; }
+  if (t192 >= 160 && a.N <= 768 && a.K >= k_min5) { *cfg = 5, *stages = 3; return; }
 }
 
 extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
