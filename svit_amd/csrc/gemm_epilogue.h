@@ -109,10 +109,30 @@ __device__ __forceinline__ void nt_epilogue_relq(const svit_gemm_args& p, f32x16
                                                  unsigned char* smem, int m0, int n0, int wm, int wn,
                                                  int lane, int wave) {
   constexpr int WN = 32 * NB, EP_LD = WN + 4;
+  constexpr int MAXV = 16;                                          // (row, j) entries per lane and slab: 16 * 64 / 64
   float* stg = (float*)smem + wave * (16 * EP_LD);
   const int extra = p.relq_extra, sh = extra == 64 ? 6 : 5;        // 32 or 64 columns per row
+  const int nv = 16 * extra / 64;                                   // 8 or 16
   const int c_lo = n0 + wn * WN;
   bf16_t* qa = (bf16_t*)p.relq_out;
+  // every map entry this wave will need, requested before anything is staged: one memory round trip for
+  // all slabs instead of one per slab in front of its stores
+  int cols[2 * RB][MAXV];
+#pragma unroll
+  for (int ih = 0; ih < 2 * RB; ++ih) {
+    const int row0 = m0 + wm * 32 * RB + (ih >> 1) * 32 + (ih & 1) * 16;
+    const int tok0 = row0 % p.relq_rows;
+#pragma unroll
+    for (int it = 0; it < MAXV; ++it) {
+      const int e = it * 64 + lane, rl = e >> sh, j = e & (extra - 1);
+      cols[ih][it] = -2;                                            // -2: no such entry / row past M
+      if (it < nv && row0 + rl < p.M) {
+        int tok = tok0 + rl;
+        while (tok >= p.relq_rows) tok -= p.relq_rows;              // (once at most unless a (b, head) has < 16 tokens)
+        cols[ih][it] = p.relq_map[tok * extra + j];
+      }
+    }
+  }
 #pragma unroll
   for (int ih = 0; ih < 2 * RB; ++ih) {
     const int i = ih >> 1, half = ih & 1;
@@ -124,19 +144,16 @@ __device__ __forceinline__ void nt_epilogue_relq(const svit_gemm_args& p, f32x16
             acc[i][j][half * 8 + rr];
     nt_epi_sync<true>();      // (the staging region is the wave's own)
     const int row0 = m0 + wm * 32 * RB + i * 32 + half * 16;
-    const int tok0 = row0 % p.relq_rows;                            // (wave-uniform)
-    for (int e = lane; e < 16 * extra; e += 64) {
-      const int rl = e >> sh, j = e & (extra - 1), row = row0 + rl;
-      if (row >= p.M) break;
-      int tok = tok0 + rl;
-      while (tok >= p.relq_rows) tok -= p.relq_rows;      // (once at most unless a (b, head) has < 16 tokens)
-      const int col = p.relq_map[tok * extra + j];
+#pragma unroll
+    for (int it = 0; it < MAXV; ++it) {
+      const int e = it * 64 + lane, rl = e >> sh, j = e & (extra - 1), col = cols[ih][it];
+      if (col == -2) continue;
+      const size_t o = (size_t)(row0 + rl) * p.relq_ld + 96 + j;
       if (col < 0) {
-        if (c_lo == 0) qa[(size_t)row * p.relq_ld + 96 + j] = 0;
+        if (c_lo == 0) qa[o] = 0;
       } else if (col >= c_lo && col < c_lo + WN) {
         // two roundings, as the unfused pair had (the product stored as bf16, then scaled)
-        const float v = bf16_to_f32(f32_to_bf16(stg[rl * EP_LD + col - c_lo])) * p.relq_scale;
-        qa[(size_t)row * p.relq_ld + 96 + j] = f32_to_bf16(v);
+        qa[o] = f32_to_bf16(bf16_to_f32(f32_to_bf16(stg[rl * EP_LD + col - c_lo])) * p.relq_scale);
       }
     }
     if (ih + 1 < 2 * RB) nt_epi_sync<true>();
