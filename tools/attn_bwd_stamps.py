@@ -1,7 +1,9 @@
 """Wall-clock anatomy (100 MHz timer) of workgroup 0 / wave 0 of the attention backward kernels:
 builds attn_bwd.hip with -DSVIT_ATTN_STAMPS into gpurun_out/, runs one shape, prints the timeline.
 
-    python tools/attn_bwd_stamps.py [Nq Nk DA heads halves splits]
+    python tools/attn_bwd_stamps.py [Nq Nk DA heads halves splits [fold]]
+(7th argument 1: with the rel-pos backward folded into the dq epilogue -- relD / relR, synthetic map -- so that
+"epilogue" shows what the scatter + D.R^T + fold cost)
 """
 import ctypes
 import os
@@ -39,6 +41,17 @@ def main():
     a.qa, a.ka, a.v, a.ctx, a.dctx, a.lse2 = (t.data_ptr() for t in (qa, ka, v, ctx, dctx, lse2))
     a.delta, a.dqa = delta.data_ptr(), dqa.data_ptr()
     a.B, a.heads, a.Nq, a.Nk, a.DA, a.q_splits, a.scale, a.bias_cols = B, h, Nq, Nk, DA, splits, 96 ** -0.5, J
+    if len(sys.argv) > 7 and sys.argv[7] == "1":
+        ldd = 96
+        jj = torch.arange(DA - 96)
+        cmap = ((jj[None, :] * 3 + torch.arange(Nq)[:, None]) % 69).to(torch.int32)
+        cmap[:, J:] = -1
+        cmap[0] = -1
+        cmap = cmap.contiguous().to(dev)
+        D = torch.empty(B * h * Nq, ldd, device=dev, dtype=torch.bfloat16)
+        rt = (torch.randn(96, ldd, device=dev) * 0.1).bfloat16()
+        a.relD, a.relD_ld, a.relD_map, a.relD_scale, a.relR = D.data_ptr(), ldd, cmap.data_ptr(), 1.4426950408889634, rt.data_ptr()
+        print("(rel-pos backward folded into the dq epilogue: relD / relR, ldd 96)")
     lib.svit_attn_debug_set(0, halves)
     parts = lib.svit_attn_bwd_parts(ctypes.byref(a))
     assert parts >= 1, parts
