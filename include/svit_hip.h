@@ -145,6 +145,10 @@ int svit_im2col_patch_u8(const uint8_t* frames, int64_t frames_bytes, const void
 /* cls / object token rows of the block-0 input (video_model_builder.py:326-363). */
 int svit_fill_special_tokens(float* x, const float* cls, const float* objq, const float* pos_t,
                              int B, int N, int L, int Tx, int O, int C, int add_pos, void* stream);
+/* its backward in one launch: g_cls [C] += sum_b dx[b,0]; g_obj [O,C] += sum_{b,t} dx[b,1+L+t*O+o];
+ * g_pos [Tx,C] += sum_{b,o} of the same rows (add_pos) -- dx f32 [B,N,C]. */
+int svit_special_token_grads(const float* dx, float* g_cls, float* g_obj, float* g_pos, int B, int N,
+                             int L, int Tx, int O, int C, int add_pos, void* stream);
 
 /* ------------------------------------------------- pooled q/k/v (K5, K6, K3 fused) ---- */
 /* attention_pool with depthwise Conv3d(96,96,3^3,stride (1,s,s),pad 1) + object gain +

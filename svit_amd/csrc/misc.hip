@@ -161,6 +161,31 @@ __global__ void fill_special_kernel(float* __restrict__ x, const float* __restri
   }
 }
 
+// backward of the above in one launch: g_cls[c] += sum_b dx[b,0,c]; g_obj[o,c] += sum_{b,t} dx[b,obj(t,o),c];
+// g_pos[t,c] += sum_{b,o} dx[b,obj(t,o),c] (add_pos).  One thread per output element, B*Tx (resp. B*O) terms.
+__global__ void special_grads_kernel(const float* __restrict__ dx, float* __restrict__ g_cls,
+                                     float* __restrict__ g_obj, float* __restrict__ g_pos, int B, int N, int L,
+                                     int Tx, int O, int C, int add_pos) {
+  const int n_out = C + O * C + (add_pos ? Tx * C : 0);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  float acc = 0.f;
+  if (i < C) {
+    for (int b = 0; b < B; ++b) acc += dx[(int64_t)b * N * C + i];
+    g_cls[i] += acc;
+  } else if (i < C + O * C) {
+    const int o = (i - C) / C, c = (i - C) % C;
+    for (int b = 0; b < B; ++b)
+      for (int t = 0; t < Tx; ++t) acc += dx[((int64_t)b * N + 1 + L + t * O + o) * C + c];
+    g_obj[o * C + c] += acc;
+  } else {
+    const int t = (i - C - O * C) / C, c = (i - C - O * C) % C;
+    for (int b = 0; b < B; ++b)
+      for (int o = 0; o < O; ++o) acc += dx[((int64_t)b * N + 1 + L + t * O + o) * C + c];
+    g_pos[t * C + c] += acc;
+  }
+}
+
 // ---- max-pool skip: kernel (1,3,3), stride (1,2,2), pad (0,1,1) on patch tokens -----------
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                    uint8_t* __restrict__ idx, int B, int T, int H, int W, int Ho,
@@ -429,6 +454,17 @@ extern "C" int svit_fill_special_tokens(float* x, const float* cls, const float*
   const int64_t total = (int64_t)B * (1 + Tx * O) * C;
   hipLaunchKernelGGL(fill_special_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, x, cls, objq, pos_t, B, N, L, Tx, O, C, add_pos);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+extern "C" int svit_special_token_grads(const float* dx, float* g_cls, float* g_obj, float* g_pos, int B, int N,
+                                        int L, int Tx, int O, int C, int add_pos, void* stream) {
+  if (!dx || !g_cls || !g_obj || (add_pos && !g_pos)) return SVIT_ERR_ARG;
+  if (N != 1 + L + Tx * O || B <= 0 || C <= 0) return SVIT_ERR_SHAPE;
+  const int n_out = C + O * C + (add_pos ? Tx * C : 0);
+  hipLaunchKernelGGL(special_grads_kernel, dim3((n_out + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx, g_cls,
+                     g_obj, g_pos, B, N, L, Tx, O, C, add_pos);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }

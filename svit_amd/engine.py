@@ -424,11 +424,8 @@ class Engine:
             ready(1 + (depth - 1 - blk.index))
         # block-0 input: [cls | patches | objects]
         B, Tx, L, O, C = st["B"], st["Tx"], st["L0"], plan.objects, plan.embed_dim
-        f.g("cls_token").add_(dx[:, 0].sum(0).view(1, 1, C))
-        dobj = dx[:, 1 + L:].reshape(B, Tx, O, C)
-        f.g("object_queries").add_(dobj.sum((0, 1)).view(1, O, C))
-        if Tx > 1:
-            f.g("pos_embed_temporal").add_(dobj.sum((0, 2)).view(1, Tx, C))
+        ops.special_token_grads(dx, f.g("cls_token"), f.g("object_queries"),
+                                f.g("pos_embed_temporal") if Tx > 1 else None, L, Tx, O, Tx > 1)
         dtok = ops.scale_cast(dx, gather=(L, 1))       # patch rows of every clip -> bf16 [B*L, C]
         ops.gemm_tn(dtok, st["cols"], f.g("patch_embed.proj.weight").view(C, 441),
                     splits=1 if self.deterministic else 0, dbias=f.g("patch_embed.proj.bias"))

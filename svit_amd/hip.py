@@ -139,6 +139,7 @@ _SIGS = {
     "svit_im2col_patch": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "svit_im2col_patch_u8": (i32, [vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "svit_fill_special_tokens": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "svit_special_token_grads": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "svit_pool_ln_fwd": (i32, [C.POINTER(PoolArgs), vp]),
     "svit_pool_ln_bwd": (i32, [C.POINTER(PoolLnBwdArgs), vp]),
     "svit_pool_conv_dgrad": (i32, [C.POINTER(PoolDgradArgs), vp]),

@@ -248,6 +248,13 @@ def fill_special_tokens(x, cls, objq, pos_t, L, Tx, O, add_pos):
              C_, int(add_pos))
 
 
+def special_token_grads(dx, g_cls, g_obj, g_pos, L, Tx, O, add_pos):
+    """gradients of cls_token / object_queries / pos_embed_temporal from d(block-0 input), ACCUMULATED, one launch"""
+    B, N, C_ = dx.shape
+    assert dx.is_contiguous() and dx.dtype == F32
+    hip.call("svit_special_token_grads", ptr(dx), ptr(g_cls), ptr(g_obj), ptr(g_pos), B, N, L, Tx, O, C_, int(add_pos))
+
+
 def pooled(n, s):
     return (n - 1) // s + 1
 
