@@ -172,6 +172,13 @@ typedef struct {
   float out_scale;                 /* columns 0..95 of out = LN(pooled) * out_scale (0 = 1): the keys
                                     * carry scale * log2(e) so that qa . ka^T is the score in the
                                     * log2 domain (svit_attn_fwd)                          */
+  /* optional, the q tensor of the *_qkv entry points only (round 3; NULL = off): also write the rel-pos columns
+   * out[:, 96 + j] = bf16(bf16(LN(q) . relq_R[relq_map[token, j]]) * relq_scale), 0 where the map is -1 --
+   * what svit_gemm_nt with SVIT_EPI_RELQ does in a launch of its own.  relq_R bf16 [relq_lpad, 96] (the
+   * concatenated tables, relq_lpad % 96 == 0), relq_map i32 [Nout, ld_out - 96].  The slab LayerNorm
+   * kernel multiplies it on the matrix pipe from the rows it has just normalised; when the tensor takes
+   * another path the entry point runs the GEMM itself, so the columns are written either way. */
+  const void* relq_R; const int32_t* relq_map; int32_t relq_lpad; float relq_scale;
 } svit_pool_args;
 int svit_pool_ln_fwd(const svit_pool_args* a, void* stream);
 

@@ -96,7 +96,7 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ conv_w, f
 // threads of the workgroup call it (the quad shuffles need the whole quad).
 __device__ __forceinline__ void pool_ln_finish(const svit_pool_args& a, float (&acc)[24], bool live,
                                                int tok, bool is_patch, int py, int px, int pt,
-                                               int bh, int Nout, int Ho, int Wo) {
+                                               int bh, int Nout, int Ho, int Wo, bf16_t* lds_row = nullptr) {
   const int sub = threadIdx.x & 3, c0 = sub * 24;
   // the saved pre-LN value is the bf16-rounded one: normalise exactly what backward will see
 #pragma unroll
@@ -121,7 +121,9 @@ __device__ __forceinline__ void pool_ln_finish(const svit_pool_args& a, float (&
 #pragma unroll
     for (int e = 0; e < 8; ++e)
       o[e] = ((acc[v * 8 + e] - mean) * rstd * a.gamma[c0 + v * 8 + e] + a.beta[c0 + v * 8 + e]) * osc;
-    *(uint4*)(outp + v * 8) = pack8(o);
+    const uint4 pk = pack8(o);
+    *(uint4*)(outp + v * 8) = pk;
+    if (lds_row) *(uint4*)(lds_row + c0 + v * 8) = pk;     // (the slab kernel's rel-pos product reads it back)
     if (prep) *(uint4*)(prep + v * 8) = pack8(&acc[v * 8]);
   }
   if (a.mode == 1) {  // one-hot key coordinates [y | kh+x | kh+kw+t], zeros elsewhere
@@ -1525,8 +1527,15 @@ extern "C" int svit_debug_pool_stamps(unsigned long long* host, int n) {
 }
 #endif
 
-// LayerNorm(96) + one-hot key coordinates over the `pre` rows the slab conv wrote (pool_ln_finish)
+// LayerNorm(96) + one-hot key coordinates over the `pre` rows the slab conv wrote (pool_ln_finish).
+// For the q tensor with relq_R set, the rel-pos query-side columns ride along (svit_pool_args.relq_*): the 64
+// normalised rows of a pass stay in LDS as bf16, the four waves multiply them with the concatenated tables on
+// the matrix pipe (P = q . R^T, table fragments straight from L2, swapped operands: a lane owns a token), P goes
+// back through LDS rounded to bf16, and every (token, j) picks its table row through the map -- the same two
+// roundings as svit_gemm_nt + SVIT_EPI_RELQ, which this replaces for the slab blocks.
+constexpr int SLN_QROW = 208;      // LDS bytes per staged q row (192 + 16 pad)
 __global__ __launch_bounds__(256) void pool_slab_ln_kernel(PoolSlab3 g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sln[];
   const int which = blockIdx.z;
   if (!g.plan[which].on) return;
   svit_pool_args a = g.p[which];
@@ -1534,15 +1543,27 @@ __global__ __launch_bounds__(256) void pool_slab_ln_kernel(PoolSlab3 g) {
   const int Nout = 1 + Lo + a.n_obj, bh = blockIdx.y;
   const bf16_t* prep = (const bf16_t*)a.pre;
   a.pre = nullptr;                                  // (do not write back what is being read)
-  const int sub = threadIdx.x & 3, c0 = sub * 24;
+  const int sub = threadIdx.x & 3, c0 = sub * 24, tl = threadIdx.x >> 2;
+  const bool relq = which == 0 && a.relq_R != nullptr;     // (uniform over the block)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int lpad = a.relq_lpad, extra = a.ld_out - HD, per = extra >> 2;    // rel-pos columns per lane: 8 or 16
+  unsigned char* qt = sln;                                   // [64][SLN_QROW] bf16 rows
+  bf16_t* pt_ = (bf16_t*)(sln + 64 * SLN_QROW);              // [64][lpad] bf16 products
   for (int tb = blockIdx.x; tb * 64 < Nout; tb += gridDim.x) {
-    const int tok = tb * 64 + (threadIdx.x >> 2);
+    const int tok = tb * 64 + tl;
     const bool live = tok < Nout;
     float acc[24];
 #pragma unroll
     for (int i = 0; i < 24; ++i) acc[i] = 0.f;
     int py = 0, px = 0, pt = 0;
     bool is_patch = false;
+    int4 mp[4];                                      // this lane's map entries, requested before the LayerNorm
+    if (relq) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        mp[v] = (live && v * 4 < per) ? *(const int4*)(a.relq_map + (size_t)tok * extra + sub * per + v * 4)
+                                      : make_int4(-1, -1, -1, -1);
+    }
     if (live) {
       const bf16_t* p = prep + ((size_t)bh * Nout + tok) * HD + c0;
 #pragma unroll
@@ -1553,7 +1574,57 @@ __global__ __launch_bounds__(256) void pool_slab_ln_kernel(PoolSlab3 g) {
         px = q % Wo; py = (q / Wo) % Ho; pt = q / (Wo * Ho);
       }
     }
-    pool_ln_finish(a, acc, live, tok, is_patch, py, px, pt, bh, Nout, Ho, Wo);
+    if (relq) {
+      __syncthreads();                              // the previous pass's readers are done with the tiles
+      if (!live) {
+#pragma unroll
+        for (int v = 0; v < 3; ++v) *(uint4*)(qt + tl * SLN_QROW + (c0 + v * 8) * 2) = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+    pool_ln_finish(a, acc, live, tok, is_patch, py, px, pt, bh, Nout, Ho, Wo,
+                   relq ? (bf16_t*)(qt + tl * SLN_QROW) : nullptr);
+    if (!relq) continue;
+    __syncthreads();
+    // P[token, table row] for the 64 tokens: 2 token blocks x lpad/32 table blocks of 32 x 32, 6 k-steps each
+    const int ncb = lpad >> 5;
+    const bf16_t* R = (const bf16_t*)a.relq_R;
+    for (int blk = wave; blk < 2 * ncb; blk += 4) {
+      const int rb = blk / ncb, cb = blk % ncb;
+      bf16x8_t rf[6];
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) rf[ks] = *(const bf16x8_t*)(R + (size_t)(cb * 32 + l31) * HD + 16 * ks + 8 * hh);
+      f32x16_t c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) {
+        const bf16x8_t qf = *(const bf16x8_t*)(qt + (rb * 32 + l31) * SLN_QROW + (16 * ks + 8 * hh) * 2);
+        c = mfma32(rf[ks], qf, c);                  // c[r] = P[token rb*32 + l31][table row cb*32 + acc_row(r)]
+      }
+      bf16_t* prow = pt_ + (size_t)(rb * 32 + l31) * lpad + cb * 32 + 4 * hh;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        uint2 pk;
+        pk.x = pack_bf16x2(c[4 * gq], c[4 * gq + 1]);
+        pk.y = pack_bf16x2(c[4 * gq + 2], c[4 * gq + 3]);
+        *(uint2*)(prow + 8 * gq) = pk;
+      }
+    }
+    __syncthreads();
+    if (live) {
+      bf16_t* ex = (bf16_t*)a.out + ((size_t)bh * Nout + tok) * a.ld_out + HD + sub * per;
+      const bf16_t* prow = pt_ + (size_t)tl * lpad;
+#pragma unroll
+      for (int v8 = 0; v8 < 2; ++v8) {
+        if (v8 * 8 >= per) break;
+        const int cc[8] = {mp[2 * v8].x, mp[2 * v8].y, mp[2 * v8].z, mp[2 * v8].w,
+                           mp[2 * v8 + 1].x, mp[2 * v8 + 1].y, mp[2 * v8 + 1].z, mp[2 * v8 + 1].w};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = cc[e] < 0 ? 0.f : bf16_to_f32(prow[cc[e]]) * a.relq_scale;
+        *(uint4*)(ex + v8 * 8) = pack8(o);
+      }
+    }
   }
 }
 }  // namespace
@@ -1661,7 +1732,35 @@ static SlabPlan plan_slab(const svit_pool_args& a) {
   return pl;
 }
 
+static int pool_ln_fwd_qkv_kernels(const svit_pool_args* a3, const uint32_t* const* sel3, void* stream, int* q_on_slab);
+
+// rel-pos columns of the q tensor (svit_pool_args.relq_*): the slab LayerNorm kernel writes them itself; on any
+// other path the product + gather runs as its own launch (svit_gemm_nt, SVIT_EPI_RELQ) right behind the pooling
 static int pool_ln_fwd_qkv_impl(const svit_pool_args* a3, const uint32_t* const* sel3, void* stream) {
+  if (!a3) return SVIT_ERR_ARG;
+  const svit_pool_args& q = a3[0];
+  if (q.relq_R) {
+    if (!q.relq_map || q.relq_lpad <= 0 || q.relq_lpad % 96 != 0 || q.which != 0 || q.mode != 0 ||
+        (q.ld_out != 128 && q.ld_out != 160) || (((uintptr_t)q.relq_R | (uintptr_t)q.relq_map) & 15))
+      return SVIT_ERR_ARG;
+  }
+  int q_on_slab = 0;
+  if (int rc = pool_ln_fwd_qkv_kernels(a3, sel3, stream, &q_on_slab)) return rc;
+  if (q.relq_R && !q_on_slab) {
+    const int s = q.stride_hw, Nout = 1 + q.T * ((q.H - 1) / s + 1) * ((q.W - 1) / s + 1) + q.n_obj;
+    svit_gemm_args g = {};
+    g.A = q.out; g.lda = q.ld_out;
+    g.W = q.relq_R; g.ldw = HD;
+    g.M = q.B * q.heads * Nout; g.N = (q.relq_lpad + 95) / 96 * 96; g.K = HD;
+    g.epilogue = SVIT_EPI_RELQ;
+    g.relq_map = q.relq_map; g.relq_out = q.out; g.relq_ld = q.ld_out;
+    g.relq_extra = q.ld_out - HD; g.relq_rows = Nout; g.relq_scale = q.relq_scale;
+    return svit_gemm_nt(&g, stream);
+  }
+  return SVIT_OK;
+}
+
+static int pool_ln_fwd_qkv_kernels(const svit_pool_args* a3, const uint32_t* const* sel3, void* stream, int* q_on_slab) {
   if (!a3) return SVIT_ERR_ARG;
   PoolFwd3 g;
   unsigned gx = 1;
@@ -1678,6 +1777,13 @@ static int pool_ln_fwd_qkv_impl(const svit_pool_args* a3, const uint32_t* const*
     sg.sel[i] = sel3 ? sel3[i] : nullptr;
     sg.plan[i] = sel3 ? plan_slab(a3[i]) : SlabPlan{0, 0, 0, 0, 0};
     g.skip[i] = sg.plan[i].on;
+    if (i == 0) {
+      // (A/B knob for in-step measurements: SVIT_SLAB_RELQ=0 keeps the rel-pos product as its own GEMM launch)
+      static const bool fuse_env = !(getenv("SVIT_SLAB_RELQ") && atoi(getenv("SVIT_SLAB_RELQ")) == 0);
+      const bool fuse = fuse_env && a3[0].relq_lpad <= 288;       // (the product tile of 64 tokens must fit LDS)
+      if (!fuse) sg.p[0].relq_R = nullptr;
+      *q_on_slab = sg.plan[0].on && fuse;
+    }
     if (sg.plan[i].on) {
       const SlabPlan& pl = sg.plan[i];
       const int s = a3[i].stride_hw;
@@ -1698,7 +1804,8 @@ static int pool_ln_fwd_qkv_impl(const svit_pool_args* a3, const uint32_t* const*
     hipLaunchKernelGGL(pool_slab_fwd_kernel, dim3(sgx * a3[0].B * a3[0].heads * 12), dim3(SLAB_NT), slds,
                        (hipStream_t)stream, sg);
     SVIT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(pool_slab_ln_kernel, dim3(ln_blocks, a3[0].B * a3[0].heads, 3), dim3(256), 0,
+    const size_t ln_lds = (sg.plan[0].on && sg.p[0].relq_R) ? (size_t)64 * SLN_QROW + (size_t)64 * a3[0].relq_lpad * 2 : 0;
+    hipLaunchKernelGGL(pool_slab_ln_kernel, dim3(ln_blocks, a3[0].B * a3[0].heads, 3), dim3(256), ln_lds,
                        (hipStream_t)stream, sg);
     SVIT_LAUNCH_CHECK();
     if (n_slab == 3) return SVIT_OK;

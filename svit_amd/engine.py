@@ -337,16 +337,10 @@ class Engine:
                                                 save_stats=save)
         xn2d = xn.view(B * N, C)
         qkv = ops.gemm_nt(xn2d, f.w(pre + "attn.qkv.weight"), f.p(pre + "attn.qkv.bias"), hip.EPI_BF16)
-        pools = ops.pool_ln_fwd_qkv(
-            qkv, [f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
-            [f.p(pre + "attn.norm_%s.weight" % r) for r in "qkv"],
-            [f.p(pre + "attn.norm_%s.bias" % r) for r in "qkv"],
-            B, h, thw, n_obj, (sq, skv, skv), (DA, DA, HD), (0, 1, 0), save=save, out_scales=(1.0, K_SCALE, 1.0),
-            sels=f.sels(pre) if (thw[1] * thw[2] >= f.TILED_MIN_PLANE or thw[1] * thw[2] <= f.SLAB_MAX_PLANE)
-            else None)
-        qa, ka, v = pools[0][0], pools[1][0], pools[2][0]
         idx, mats, mcat, need = self._rel(blk, q_thw, k_thw)
-        # rel-pos query side: P = q . Rcat^T on the MFMA GEMM, then a 2-byte gather per (q, j)
+        # rel-pos query side: P = q . Rcat^T on the matrix pipe, then per (query, j) the table row it needs --
+        # inside the slab LayerNorm kernel where the q tensor takes that path, else as one GEMM launch whose
+        # epilogue does the gather (the pooling entry point adds it); P itself is never stored
         if mcat is None:
             tabs = self._tables(pre, mats)
             rcat, rows_off = f.rel_cat(pre)
@@ -356,10 +350,15 @@ class Engine:
             rows_off = (0, need[0], need[0] + need[1])
             tabs = [r32[rows_off[0]:rows_off[0] + need[0]], r32[rows_off[1]:rows_off[1] + need[1]],
                     r32[rows_off[2]:rows_off[2] + need[2]]]
-        # rel-pos query side in one launch: P = q . Rcat^T on the MFMA GEMM whose epilogue picks, per
-        # (query, j), the table row it needs and writes qa's extra columns (P itself is never stored)
-        ops.gemm_nt(qa.view(B * h * Nq, DA)[:, :HD], rcat, None, hip.EPI_RELQ,
-                    relq=(self._relq_map(blk, q_thw, k_thw, idx, rows_off, n_obj, DA - HD), qa, LOG2E))
+        pools = ops.pool_ln_fwd_qkv(
+            qkv, [f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
+            [f.p(pre + "attn.norm_%s.weight" % r) for r in "qkv"],
+            [f.p(pre + "attn.norm_%s.bias" % r) for r in "qkv"],
+            B, h, thw, n_obj, (sq, skv, skv), (DA, DA, HD), (0, 1, 0), save=save, out_scales=(1.0, K_SCALE, 1.0),
+            sels=f.sels(pre) if (thw[1] * thw[2] >= f.TILED_MIN_PLANE or thw[1] * thw[2] <= f.SLAB_MAX_PLANE)
+            else None,
+            relq=(rcat.contiguous(), self._relq_map(blk, q_thw, k_thw, idx, rows_off, n_obj, DA - HD), LOG2E))
+        qa, ka, v = pools[0][0], pools[1][0], pools[2][0]
         ctx, lse2 = ops.attn_fwd(qa, ka, v, SCALE, bias_cols=J)
         pool_idx = None
         if blk.has_proj:

@@ -38,7 +38,8 @@ class PoolArgs(C.Structure):
     _fields_ = [("qkv", vp), ("which", i32), ("conv_w", vp), ("gamma", vp), ("beta", vp),
                 ("out", vp), ("ld_out", i32), ("pre", vp), ("mean", vp), ("rstd", vp),
                 ("B", i32), ("heads", i32), ("T", i32), ("H", i32), ("W", i32), ("n_obj", i32),
-                ("stride_hw", i32), ("mode", i32), ("eps", f32), ("out_scale", f32)]
+                ("stride_hw", i32), ("mode", i32), ("eps", f32), ("out_scale", f32),
+                ("relq_R", vp), ("relq_map", vp), ("relq_lpad", i32), ("relq_scale", f32)]
 
 
 class PoolLnBwdArgs(C.Structure):

@@ -302,14 +302,23 @@ def _sel_ptrs(sels):
 
 
 def pool_ln_fwd_qkv(qkv, conv_ws, gammas, betas, B, heads, thw, n_obj, strides, ld_outs, modes,
-                    eps=1e-6, save=True, sels=None, out_scales=(1.0, 1.0, 1.0)):
+                    eps=1e-6, save=True, sels=None, out_scales=(1.0, 1.0, 1.0), relq=None):
     """q, k, v pooling + LayerNorm in one launch -> [(out, pre, mean, rstd)] * 3 (the last three
     are None with save=False: no-grad passes keep nothing for a backward).  sels: the three
-    selector tables (pool_weight_sel) -- stride-1 tensors then run the LDS-tiled stencil."""
+    selector tables (pool_weight_sel) -- stride-1 tensors then run the LDS-tiled stencil.
+    relq = (rcat bf16 [Lpad, 96], map i32 [Nq, ld_out - 96], scale): the q tensor's rel-pos columns
+    out[..., 96:] are written too (inside the slab LayerNorm kernel, or by a GEMM the entry point adds)."""
     arr = (hip.PoolArgs * 3)()
     res = [_pool_fwd_args(arr[i], qkv, i, conv_ws[i], gammas[i], betas[i], B, heads, thw, n_obj,
                           strides[i], ld_outs[i], modes[i], eps, save, out_scale=out_scales[i])
            for i in range(3)]
+    if relq is not None:
+        rcat, cmap, rscale = relq
+        _chk_dev(rcat, cmap)
+        assert rcat.dtype == BF16 and rcat.is_contiguous() and rcat.shape[1] == HD
+        assert cmap.dtype == torch.int32 and cmap.is_contiguous()
+        assert tuple(cmap.shape) == (res[0][0].shape[2], ld_outs[0] - HD)
+        arr[0].relq_R, arr[0].relq_map, arr[0].relq_lpad, arr[0].relq_scale = ptr(rcat), ptr(cmap), rcat.shape[0], rscale
     if sels is None:
         hip.call("svit_pool_ln_fwd_qkv", arr)
     else:

@@ -472,6 +472,65 @@ def test_pool_ln_bwd_three_inputs(ops):
     assert rel_err(dpre, xr.grad) < 2e-2 and cos(dpre, xr.grad) > 0.9999
 
 
+@pytest.mark.parametrize("B,h,thw,sq,skv,n_obj,slab", [
+    (2, 4, (8, 14, 14), 1, 2, 64, True),       # blocks 4-13: the slab LayerNorm kernel multiplies q . R^T itself
+    (2, 8, (8, 14, 14), 2, 1, 64, True),       # block 14 (q pooled to 7x7, 36 key coordinates: DA = 160)
+    (1, 4, (8, 28, 28), 2, 2, 64, False),      # 28x28: not a slab plane -> the entry point adds the GEMM launch
+    (2, 4, (8, 14, 14), 1, 2, 64, None),       # no selector tables at all (streaming kernels) -> GEMM launch
+])
+def test_pool_qkv_writes_the_relpos_columns(ops, B, h, thw, sq, skv, n_obj, slab):
+    """svit_pool_args.relq_*: the q tensor's rel-pos columns qa[..., 96 + j] come out of the pooling call -- from
+    the slab LayerNorm kernel's own MFMA product where q takes that path, from an SVIT_EPI_RELQ GEMM the entry
+    point launches otherwise -- BIT-identical to the stand-alone GEMM on the qa the same call produced, and the
+    other outputs unchanged."""
+    from svit_amd import hip
+    T, H, W = thw
+    L = T * H * W
+    N = 1 + L + n_obj
+    q_thw = (T, ops.pooled(H, sq), ops.pooled(W, sq))
+    k_thw = (T, ops.pooled(H, skv), ops.pooled(W, skv))
+    kt, kh, kw = k_thw
+    J = kt + kh + kw
+    da = 128 if J <= 32 else 160
+    Lq = q_thw[0] * q_thw[1] * q_thw[2]
+    Nq = 1 + Lq + n_obj
+    qkv = rnd("rq%d%d%d" % (T, H, h), (B, N, 3, h, 96), 0.5, BF16)
+    ws = [rnd("rw%d%d" % (i, H), (96, 27), 0.2) for i in range(3)]
+    g = [rnd("rg%d" % i, (96,), 0.3) + 1.0 for i in range(3)]
+    b = [rnd("rb%d" % i, (96,), 0.1) for i in range(3)]
+    sels = None
+    if slab is not None:
+        wflat = torch.cat([w.flatten() for w in ws]).contiguous()
+        offs = torch.tensor([0, 2592, 5184], dtype=torch.int64, device=DEV)
+        sel = ops.pool_weight_sel(wflat, offs, torch.zeros((3, 2592), dtype=torch.int32, device=DEV))
+        sels = [sel[i] for i in range(3)]
+    rows = [2 * max(q_thw[i], k_thw[i]) - 1 for i in (1, 2, 0)]
+    rows_off = (0, rows[0], rows[0] + rows[1])
+    lp = (sum(rows) + 95) // 96 * 96
+    rcat = torch.zeros((lp, 96), device=DEV, dtype=BF16)
+    rcat[:sum(rows)] = rnd("rr%d%d" % (H, h), (sum(rows), 96), 0.3, BF16)
+    idx = [R.rel_index(q_thw[1], k_thw[1]), R.rel_index(q_thw[2], k_thw[2]), R.rel_index(q_thw[0], k_thw[0])]
+    body = torch.full((q_thw[0], q_thw[1], q_thw[2], da - 96), -1, dtype=torch.int32)
+    body[..., :kh] = (rows_off[0] + idx[0].to(torch.int32)).view(1, q_thw[1], 1, kh)
+    body[..., kh:kh + kw] = (rows_off[1] + idx[1].to(torch.int32)).view(1, 1, q_thw[2], kw)
+    body[..., kh + kw:J] = (rows_off[2] + idx[2].to(torch.int32)).view(q_thw[0], 1, 1, kt)
+    cmap = torch.full((Nq, da - 96), -1, dtype=torch.int32)
+    cmap[1:1 + Lq] = body.view(Lq, da - 96)
+    cmap = cmap.to(DEV).contiguous()
+    args = (qkv, ws, g, b, B, h, thw, n_obj, (sq, skv, skv), (da, da, 96), (0, 1, 0))
+    plain = ops.pool_ln_fwd_qkv(*args, sels=sels, out_scales=(1.0, KSC, 1.0))
+    qa_ref = plain[0][0].clone()
+    qa_ref[..., 96:] = 7.0
+    ops.gemm_nt(qa_ref.view(-1, da)[:, :96], rcat, None, hip.EPI_RELQ, relq=(cmap, qa_ref, 1.4426950408889634))
+    fused = ops.pool_ln_fwd_qkv(*args, sels=sels, out_scales=(1.0, KSC, 1.0), relq=(rcat, cmap, 1.4426950408889634))
+    assert torch.equal(fused[0][0], qa_ref)
+    for i in (1, 2):
+        assert torch.equal(fused[i][0], plain[i][0])
+    for i in range(3):
+        for a_, b_ in zip(fused[i][1:], plain[i][1:]):
+            assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("T,O,drop,which,B", [(16, 4, True, "all", 3), (2, 3, False, "logits", 3), (1, 4, True, "image", 63),
                                                (1, 4, True, "all", 21)])
 def test_head_fused_vs_aten(ops, T, O, drop, which, B):
