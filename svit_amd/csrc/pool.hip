@@ -1632,8 +1632,9 @@ __global__ __launch_bounds__(256) void pool_slab_ln_kernel(PoolSlab3 g) {
 // grid.x of the persistent stencil kernels: token blocks are dealt round-robin to workgroups so
 // that about 1024 workgroups (2 per CU on two resident rounds) exist in total
 static unsigned persistent_x(int token_blocks, int other_dims) {
+  static const long want = getenv("SVIT_POOL_WGS") ? atol(getenv("SVIT_POOL_WGS")) : 1024;    // (in-step A/B knob)
   const long total = (long)token_blocks * other_dims;
-  const long chunks = (total + 1023) / 1024;
+  const long chunks = (total + want - 1) / want;
   long x = (token_blocks + chunks - 1) / chunks;
   if (x < 1) x = 1;
   return (unsigned)x;
