@@ -1549,6 +1549,13 @@ __global__ __launch_bounds__(256) void pool_slab_ln_kernel(PoolSlab3 g) {
   const int lpad = a.relq_lpad, extra = a.ld_out - HD, per = extra >> 2;    // rel-pos columns per lane: 8 or 16
   unsigned char* qt = sln;                                   // [64][SLN_QROW] bf16 rows
   bf16_t* pt_ = (bf16_t*)(sln + 64 * SLN_QROW);              // [64][lpad] bf16 products
+  bf16x8_t rf0[6];                                          // table fragments of this wave's first table block
+  if (relq) {
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks)
+      rf0[ks] = (wave << 5) < lpad ? *(const bf16x8_t*)((const bf16_t*)a.relq_R + (size_t)(wave * 32 + l31) * HD + 16 * ks + 8 * hh)
+                                   : bf16x8_t{};
+  }
   for (int tb = blockIdx.x; tb * 64 < Nout; tb += gridDim.x) {
     const int tok = tb * 64 + tl;
     const bool live = tok < Nout;
@@ -1585,29 +1592,34 @@ __global__ __launch_bounds__(256) void pool_slab_ln_kernel(PoolSlab3 g) {
                    relq ? (bf16_t*)(qt + tl * SLN_QROW) : nullptr);
     if (!relq) continue;
     __syncthreads();
-    // P[token, table row] for the 64 tokens: 2 token blocks x lpad/32 table blocks of 32 x 32, 6 k-steps each
+    // P[token, table row] for the 64 tokens: 2 token blocks x lpad/32 table blocks of 32 x 32, 6 k-steps each.
+    // A wave owns table blocks (wave, wave + 4, ...) and both token blocks of each; the fragments of its FIRST
+    // table block are pass-invariant and stay in registers (rf0, loaded once in front of the loop).
     const int ncb = lpad >> 5;
     const bf16_t* R = (const bf16_t*)a.relq_R;
-    for (int blk = wave; blk < 2 * ncb; blk += 4) {
-      const int rb = blk / ncb, cb = blk % ncb;
+    for (int cb = wave; cb < ncb; cb += 4) {
       bf16x8_t rf[6];
 #pragma unroll
-      for (int ks = 0; ks < 6; ++ks) rf[ks] = *(const bf16x8_t*)(R + (size_t)(cb * 32 + l31) * HD + 16 * ks + 8 * hh);
-      f32x16_t c;
+      for (int ks = 0; ks < 6; ++ks)
+        rf[ks] = cb == wave ? rf0[ks] : *(const bf16x8_t*)(R + (size_t)(cb * 32 + l31) * HD + 16 * ks + 8 * hh);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) c[r] = 0.f;
+      for (int rb = 0; rb < 2; ++rb) {
+        f32x16_t c;
 #pragma unroll
-      for (int ks = 0; ks < 6; ++ks) {
-        const bf16x8_t qf = *(const bf16x8_t*)(qt + (rb * 32 + l31) * SLN_QROW + (16 * ks + 8 * hh) * 2);
-        c = mfma32(rf[ks], qf, c);                  // c[r] = P[token rb*32 + l31][table row cb*32 + acc_row(r)]
-      }
-      bf16_t* prow = pt_ + (size_t)(rb * 32 + l31) * lpad + cb * 32 + 4 * hh;
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        uint2 pk;
-        pk.x = pack_bf16x2(c[4 * gq], c[4 * gq + 1]);
-        pk.y = pack_bf16x2(c[4 * gq + 2], c[4 * gq + 3]);
-        *(uint2*)(prow + 8 * gq) = pk;
+        for (int ks = 0; ks < 6; ++ks) {
+          const bf16x8_t qf = *(const bf16x8_t*)(qt + (rb * 32 + l31) * SLN_QROW + (16 * ks + 8 * hh) * 2);
+          c = mfma32(rf[ks], qf, c);                // c[r] = P[token rb*32 + l31][table row cb*32 + acc_row(r)]
+        }
+        bf16_t* prow = pt_ + (size_t)(rb * 32 + l31) * lpad + cb * 32 + 4 * hh;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          uint2 pk;
+          pk.x = pack_bf16x2(c[4 * gq], c[4 * gq + 1]);
+          pk.y = pack_bf16x2(c[4 * gq + 2], c[4 * gq + 3]);
+          *(uint2*)(prow + 8 * gq) = pk;
+        }
       }
     }
     __syncthreads();
