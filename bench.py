@@ -185,9 +185,11 @@ def kernel_report(trace, batch):
         elif meta and meta[0] == "flop":
             a["flop"] += meta[1]
         elif meta and meta[0] == "attn":
-            _, B, h, Nq, Nk, DA = meta
+            _, B, h, Nq, Nk, DA = meta[:6]
             alg = 2.0 * B * h * Nq * Nk * (96 + 96)        # QK^T + AV at head_dim 96
             a["flop"] += alg * (2.0 if name.endswith("bwd") else 1.0)
+            if len(meta) > 6:                              # rel-pos dq = D . R^T folded into the dq kernel (a GEMM before)
+                a["flop"] += meta[6]
     total = sum(a["ms"] for a in agg.values())
     rows = []
     for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):

@@ -531,7 +531,10 @@ def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0, bias_cols=0, reld=No
             else:
                 X = torch.empty((B * heads * Nq, HD), device=dev, dtype=F32)
                 a.relX = ptr(X)
-    hip.call("svit_attn_bwd", C.byref(a), meta=("attn", B, heads, Nq, Nk, DA))
+    # (the D . R^T product of the rel-pos backward, when this launch carries it: 2 * rows * 96 * ldd flops that the
+    # step used to spend in a GEMM launch of its own -- bench.py adds them to this kernel's algorithmic count)
+    folded = 2.0 * B * heads * Nq * HD * reld[1] if (reld is not None and X is not None) else 0.0
+    hip.call("svit_attn_bwd", C.byref(a), meta=("attn", B, heads, Nq, Nk, DA, folded))
     if reld is not None:
         return dqa, dkv[0], dkv[1], D, X
     return dqa, dkv[0], dkv[1]
