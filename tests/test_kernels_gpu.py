@@ -531,6 +531,22 @@ def test_pool_qkv_writes_the_relpos_columns(ops, B, h, thw, sq, skv, n_obj, slab
             assert torch.equal(a_, b_)
 
 
+@pytest.mark.parametrize("B,L,Tx,O,C", [(3, 37, 8, 4, 96), (2, 5, 1, 3, 192)])
+def test_special_token_grads(ops, B, L, Tx, O, C):
+    """svit_special_token_grads: gradients of cls_token / object_queries / pos_embed_temporal from d(block-0 input)
+    in one launch (video_model_builder.py:326-363 backward), ACCUMULATED into the given buffers."""
+    N = 1 + L + Tx * O
+    dx = rnd("sg%d%d" % (B, Tx), (B, N, C), 1.0)
+    g_cls, g_obj = torch.full((1, 1, C), 0.5, device=DEV), torch.full((1, O, C), 0.5, device=DEV)
+    g_pos = torch.full((1, Tx, C), 0.5, device=DEV) if Tx > 1 else None
+    ops.special_token_grads(dx, g_cls, g_obj, g_pos, L, Tx, O, Tx > 1)
+    dobj = dx[:, 1 + L:].reshape(B, Tx, O, C)
+    assert rel_err(g_cls - 0.5, dx[:, 0].sum(0).view(1, 1, C)) < 1e-6
+    assert rel_err(g_obj - 0.5, dobj.sum((0, 1)).view(1, O, C)) < 1e-6
+    if Tx > 1:
+        assert rel_err(g_pos - 0.5, dobj.sum((0, 2)).view(1, Tx, C)) < 1e-6
+
+
 @pytest.mark.parametrize("T,O,drop,which,B", [(16, 4, True, "all", 3), (2, 3, False, "logits", 3), (1, 4, True, "image", 63),
                                                (1, 4, True, "all", 21)])
 def test_head_fused_vs_aten(ops, T, O, drop, which, B):
