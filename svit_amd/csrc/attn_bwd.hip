@@ -257,6 +257,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
       for (int g = 0; g < 4; ++g)
         mp[pj][g] = q0 + q < a.Nq ? *(const int4*)(a.relD_map + (size_t)(q0 + q) * EXTRA_ + pj * 32 + 8 * g + 4 * hh)
                                   : make_int4(-1, -1, -1, -1);
+    // the table fragments of the first k-step are requested together with the map: both round trips overlap,
+    // and every later k-step's fragments fly while the MFMAs of the step before run
+    const bf16_t* R = (const bf16_t*)a.relR;
+    bf16x8_t rcur[3], rnxt[3];
+#pragma unroll
+    for (int pb = 0; pb < 3; ++pb) rcur[pb] = *(const bf16x8_t*)(R + (size_t)(pb * 32 + q) * ldd + 8 * hh);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int pj = 0; pj < NP - 3; ++pj)
@@ -276,14 +282,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
     for (int pb = 0; pb < 3; ++pb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) ex[pb][r] = 0.f;
-    const bf16_t* R = (const bf16_t*)a.relR;
-    for (int ks = 0; ks < ldd / 16; ++ks) {
+    const int nks = ldd / 16;
+    for (int ks = 0; ks < nks; ++ks) {
+      if (ks + 1 < nks) {
+#pragma unroll
+        for (int pb = 0; pb < 3; ++pb)
+          rnxt[pb] = *(const bf16x8_t*)(R + (size_t)(pb * 32 + q) * ldd + 16 * (ks + 1) + 8 * hh);
+      }
       const bf16x8_t dfrag = *(const bf16x8_t*)(dst + (q * ldd + 16 * ks + 8 * hh) * 2);
 #pragma unroll
-      for (int pb = 0; pb < 3; ++pb) {
-        const bf16x8_t rfrag = *(const bf16x8_t*)(R + (size_t)(pb * 32 + q) * ldd + 16 * ks + 8 * hh);
-        ex[pb] = mfma32(rfrag, dfrag, ex[pb]);
-      }
+      for (int pb = 0; pb < 3; ++pb) ex[pb] = mfma32(rcur[pb], dfrag, ex[pb]);
+#pragma unroll
+      for (int pb = 0; pb < 3; ++pb) rcur[pb] = rnxt[pb];
     }
     constexpr float INV_LN2 = 1.4426950408889634f;      // dq is in log2 units until the x ln 2 below
 #pragma unroll
