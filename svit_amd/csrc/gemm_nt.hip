@@ -374,7 +374,7 @@ int launch_ring(const svit_gemm_args& a, hipStream_t st) {
 }
 }  // namespace
 
-static std::atomic<int> g_nt_stages{0};     // tuning knob (svit_debug_set(0, n)); 2..4, 0 = heuristic
+static std::atomic<int> g_nt_stages{getenv("SVIT_NT_STAGES") ? atoi(getenv("SVIT_NT_STAGES")) : 0};     // tuning knob (svit_debug_set(0, n) or env for in-step A/Bs); 2..4, 0 = heuristic
 static std::atomic<int> g_nt_force_cfg{-1}; // tuning knob (svit_debug_set(1, c)); -1 = heuristic
 static std::atomic<int> g_nt_force_bk{0};   // tuning knob (svit_debug_set(2, bk)); 32 / 64, 0 = heuristic
 extern "C" int svit_debug_set(int key, int val) {
