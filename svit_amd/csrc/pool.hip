@@ -1891,7 +1891,8 @@ extern "C" int svit_pool_ln_bwd_qkv(const svit_pool_ln_bwd_args* a3, void* strea
     const int64_t total = (int64_t)a3[i].B * a3[i].heads * a3[i].Nout;
     if (total > max_total) max_total = total;
   }
-  int64_t blocks = (max_total + 255) / 256;
+  static const int tpb = getenv("SVIT_POOL_LNB_TPB") ? atoi(getenv("SVIT_POOL_LNB_TPB")) : 256;   // (in-step A/B knob)
+  int64_t blocks = (max_total + tpb - 1) / tpb;
   if (blocks < 128) blocks = (max_total + 63) / 64 < 128 ? (max_total + 63) / 64 : 128;
   if (blocks > 1024) blocks = 1024;
   if (blocks > a3[0].workspace_floats / (6 * HD)) blocks = a3[0].workspace_floats / (6 * HD);
