@@ -254,10 +254,12 @@ __device__ __forceinline__ int b128_group_order(int lane) {
   return (lane & 32) + g * 16 + k;
 }
 
-template <int TX, int TY, bool DGRAD>
+template <int TX, int TY, bool DGRAD, bool SW>
 __device__ __forceinline__ void pool_tiled_body(
     const bf16_t* __restrict__ in_base, size_t in_tok_stride /* elements */, int in_first /* token index of patch 0 */,
-    const float* __restrict__ w_lds /* [27][96] selector dwords in LDS */, int T, int H, int W, int wg,
+    const float* __restrict__ w_lds /* [27][96] selector dwords in LDS (!SW) */,
+    const uint32_t* __restrict__ sel /* the same table in global memory (SW: read as scalar operands) */,
+    int T, int H, int W, int wg,
     const PoolTilePlan& pl, unsigned char* ring, float* xch /* [2][4][64] */,
     const svit_pool_args* fa, const svit_pool_dgrad_args* da, int bh) {
   constexpr int HX = TX + 2, HY = TY + 2, HTOK = HX * HY, PLANE_B = HTOK * TL_ROW;
@@ -307,6 +309,38 @@ __device__ __forceinline__ void pool_tiled_body(
     for (int i = 0; i < 24; ++i) acc[i] = 0.f;
     // one t-plane (9 taps, 27 LDS reads in flight) at a time: fully unrolled the scheduler hoists
     // all 81 reads and spills
+    if constexpr (SW) {
+      // weights as scalar operands (uniform constant-address loads -> s_load): the LDS pipe then serves the
+      // 81 data reads of a plane only, not 162 broadcast weight reads on top; one (kt, ky) row = 72 SGPRs at a time
+      typedef const __attribute__((address_space(4))) uint32_t* cptr_t;
+      const cptr_t selw = (cptr_t)(sel + wave * 24);
+#pragma unroll 1
+      for (int kt = 0; kt < 3; ++kt) {
+        const unsigned char* pl_base = ring + ((t + kt) % 3) * PLANE_B + ldsoff;
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+          const int tap0 = (kt * 3 + ky) * 3;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const cptr_t w = selw + (DGRAD ? 26 - (tap0 + kx) : tap0 + kx) * HD;
+            const unsigned char* p = pl_base + (ky * HX + kx) * TL_ROW;
+            const uint4 v0 = *(const uint4*)(p), v1 = *(const uint4*)(p + 16), v2 = *(const uint4*)(p + 32);
+            acc[0] = dot2_sel(v0.x, w[0], acc[0]);   acc[1] = dot2_sel(v0.x, w[1], acc[1]);
+            acc[2] = dot2_sel(v0.y, w[2], acc[2]);   acc[3] = dot2_sel(v0.y, w[3], acc[3]);
+            acc[4] = dot2_sel(v0.z, w[4], acc[4]);   acc[5] = dot2_sel(v0.z, w[5], acc[5]);
+            acc[6] = dot2_sel(v0.w, w[6], acc[6]);   acc[7] = dot2_sel(v0.w, w[7], acc[7]);
+            acc[8] = dot2_sel(v1.x, w[8], acc[8]);   acc[9] = dot2_sel(v1.x, w[9], acc[9]);
+            acc[10] = dot2_sel(v1.y, w[10], acc[10]); acc[11] = dot2_sel(v1.y, w[11], acc[11]);
+            acc[12] = dot2_sel(v1.z, w[12], acc[12]); acc[13] = dot2_sel(v1.z, w[13], acc[13]);
+            acc[14] = dot2_sel(v1.w, w[14], acc[14]); acc[15] = dot2_sel(v1.w, w[15], acc[15]);
+            acc[16] = dot2_sel(v2.x, w[16], acc[16]); acc[17] = dot2_sel(v2.x, w[17], acc[17]);
+            acc[18] = dot2_sel(v2.y, w[18], acc[18]); acc[19] = dot2_sel(v2.y, w[19], acc[19]);
+            acc[20] = dot2_sel(v2.z, w[20], acc[20]); acc[21] = dot2_sel(v2.z, w[21], acc[21]);
+            acc[22] = dot2_sel(v2.w, w[22], acc[22]); acc[23] = dot2_sel(v2.w, w[23], acc[23]);
+          }
+        }
+      }
+    } else {
 #pragma unroll 1
     for (int kt = 0; kt < 3; ++kt) {
       const unsigned char* pl_base = ring + ((t + kt) % 3) * PLANE_B + ldsoff;
@@ -320,6 +354,7 @@ __device__ __forceinline__ void pool_tiled_body(
 #pragma unroll
           for (int u = 0; u < 3; ++u) fma8_sel(acc, u, *(const uint4*)(p + u * 16), wt);
         }
+    }
     }
     const int y = y0 + ty, x = x0 + tx;
     if constexpr (DGRAD) {
@@ -448,11 +483,11 @@ __global__ __launch_bounds__(256) void pool_ln_fwd3_kernel(PoolFwd3 g) {
     const bf16_t* base = (const bf16_t*)a.qkv + (size_t)b * N * ts + ((size_t)a.which * a.heads + head) * HD;
     float* xch = (float*)pool_dyn;
     unsigned char* ring = pool_dyn + 512 * sizeof(float);
-    load_weights(a.conv_w, w_lds, nullptr, a.stride_hw);
+    const uint32_t* sel = g.sel[blockIdx.z];      // scalar weights: nothing to stage in LDS
     if (a.W > 8)
-      pool_tiled_body<16, 4, false>(base, ts, 1, w_lds, a.T, a.H, a.W, wg, pl, ring, xch, &a, nullptr, bh);
+      pool_tiled_body<16, 4, false, true>(base, ts, 1, w_lds, sel, a.T, a.H, a.W, wg, pl, ring, xch, &a, nullptr, bh);
     else
-      pool_tiled_body<8, 8, false>(base, ts, 1, w_lds, a.T, a.H, a.W, wg, pl, ring, xch, &a, nullptr, bh);
+      pool_tiled_body<8, 8, false, true>(base, ts, 1, w_lds, sel, a.T, a.H, a.W, wg, pl, ring, xch, &a, nullptr, bh);
     return;
   }
   const int Nout = 1 + a.T * pooled(a.H, a.stride_hw) * pooled(a.W, a.stride_hw) + a.n_obj;
@@ -777,11 +812,12 @@ __global__ __launch_bounds__(256) void pool_dgrad3_kernel(PoolDgrad3 g) {
     const bf16_t* base = (const bf16_t*)a.dpre + (size_t)bh * N * HD;
     float* xch = (float*)pool_dyn;
     unsigned char* ring = pool_dyn + 512 * sizeof(float);
+    // (weights from LDS here: as scalar operands -- the forward's way -- the dgrad measured no faster in the step)
     load_weights(a.conv_w, w_lds, nullptr, a.stride_hw);
     if (a.W > 8)
-      pool_tiled_body<16, 4, true>(base, HD, 1, w_lds, a.T, a.H, a.W, wg, pl, ring, xch, nullptr, &a, bh);
+      pool_tiled_body<16, 4, true, false>(base, HD, 1, w_lds, nullptr, a.T, a.H, a.W, wg, pl, ring, xch, nullptr, &a, bh);
     else
-      pool_tiled_body<8, 8, true>(base, HD, 1, w_lds, a.T, a.H, a.W, wg, pl, ring, xch, nullptr, &a, bh);
+      pool_tiled_body<8, 8, true, false>(base, HD, 1, w_lds, nullptr, a.T, a.H, a.W, wg, pl, ring, xch, nullptr, &a, bh);
     return;
   }
   if (a.stride_hw == 1) pool_dgrad_loop<1>(a, w_lds, g_lds);
