@@ -343,6 +343,10 @@ int svit_maxpool_fwd(const float* x, float* y, uint8_t* idx, int B, int T, int H
                      int n_obj, int C, void* stream);
 int svit_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int T, int H, int W,
                      int n_obj, int C, void* stream);
+/* the same with dx rounded to bf16 [B,N,C]: what the dim-change projection's backward consumes
+ * (attention.py:520-523 under autocast), without the f32 round trip */
+int svit_maxpool_bwd_bf16(const float* dy, const uint8_t* idx, void* dx_bf16, int B, int T, int H, int W,
+                          int n_obj, int C, void* stream);
 
 /* ------------------------------------------------------------- optimiser tail (K17) ---- */
 /* clip_grad_norm_(1.0) + AdamW (tools/train_net.py:144-151, models/optimizer.py:102-108)

@@ -232,8 +232,10 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
 }
 
 // gather form: each input position sums the grads of the (<= 2x2) windows that selected it
+// (DX16: dx as bf16 -- the operand of the dim-change projection's backward GEMMs, saves the cast pass)
+template <bool DX16>
 __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
-                                   float* __restrict__ dx, int B, int T, int H, int W, int Ho,
+                                   void* __restrict__ dx, int B, int T, int H, int W, int Ho,
                                    int Wo, int n_obj, int C) {
   const int c4 = C >> 2;
   const int Nin = 1 + T * H * W + n_obj, Nout = 1 + T * Ho * Wo + n_obj;
@@ -276,7 +278,14 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
         if (s[k].w == tap[k]) g.w += d[k].w;
       }
     }
-    ((float4*)dx)[i] = g;
+    if constexpr (DX16) {
+      uint2 h;
+      h.x = pack_bf16x2(g.x, g.y);
+      h.y = pack_bf16x2(g.z, g.w);
+      ((uint2*)dx)[i] = h;
+    } else {
+      ((float4*)dx)[i] = g;
+    }
   }
 }
 
@@ -485,8 +494,18 @@ extern "C" int svit_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, 
   if (!dy || !dx || !idx || C % 4 != 0) return SVIT_ERR_ARG;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const int64_t total = (int64_t)B * (1 + T * H * W + n_obj) * (C / 4);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, dy, idx, dx, B, T, H, W, Ho, Wo, n_obj, C);
+  hipLaunchKernelGGL(maxpool_bwd_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dy, idx, (void*)dx, B, T, H, W, Ho, Wo, n_obj, C);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+extern "C" int svit_maxpool_bwd_bf16(const float* dy, const uint8_t* idx, void* dx_bf16, int B, int T, int H,
+                                     int W, int n_obj, int C, void* stream) {
+  if (!dy || !dx_bf16 || !idx || C % 4 != 0) return SVIT_ERR_ARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int64_t total = (int64_t)B * (1 + T * H * W + n_obj) * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dy, idx, dx_bf16, B, T, H, W, Ho, Wo, n_obj, C);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }

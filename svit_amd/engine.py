@@ -572,10 +572,10 @@ class Engine:
                                epilogue=hip.EPI_F32 if blk.has_proj else hip.EPI_BF16)
         # ---- skip path ------------------------------------------------------------------------
         dskip = dx1
-        if blk.pools_q:
-            dskip = ops.maxpool_bwd(dskip, sv["pool_idx"], thw, n_obj)
+        if blk.pools_q:       # (bf16 straight away when only the projection's backward GEMMs read it)
+            dskip = ops.maxpool_bwd(dskip, sv["pool_idx"], thw, n_obj, bf16=blk.has_proj)
         if blk.has_proj:
-            ds16 = ops.scale_cast(dskip.view(M, Co))
+            ds16 = dskip.view(M, Co) if blk.pools_q else ops.scale_cast(dskip.view(M, Co))
             self._linear_bwd(ds16, sv["xn"], pre + "proj.weight", pre + "proj.bias", True, out=dxn,
                              accumulate=True)
             dskip = None

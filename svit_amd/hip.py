@@ -162,6 +162,7 @@ _SIGS = {
     "svit_attn_bwd_parts": (i32, [C.POINTER(AttnBwdArgs)]),
     "svit_maxpool_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "svit_maxpool_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "svit_maxpool_bwd_bf16": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "svit_sumsq": (i32, [vp, i64, vp, vp, i64, vp]),
     "svit_adamw_step": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, i32, f32, vp]),
     "svit_head_fwd": (i32, [C.POINTER(HeadArgs), vp]),

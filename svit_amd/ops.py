@@ -550,11 +550,13 @@ def maxpool_fwd(x, thw, n_obj):
     return y, idx
 
 
-def maxpool_bwd(dy, idx, thw, n_obj):
+def maxpool_bwd(dy, idx, thw, n_obj, bf16=False):
+    """bf16=True: dx rounded to bf16 (= scale_cast(maxpool_bwd(...)) bit for bit, one launch)."""
     B, Nout, C_ = dy.shape
     T, H, W = thw
-    dx = torch.empty((B, 1 + T * H * W + n_obj, C_), device=dy.device, dtype=F32)
-    hip.call("svit_maxpool_bwd", ptr(dy), ptr(idx), ptr(dx), B, T, H, W, n_obj, C_)
+    dx = torch.empty((B, 1 + T * H * W + n_obj, C_), device=dy.device, dtype=BF16 if bf16 else F32)
+    hip.call("svit_maxpool_bwd_bf16" if bf16 else "svit_maxpool_bwd", ptr(dy), ptr(idx), ptr(dx),
+             B, T, H, W, n_obj, C_)
     return dx
 
 

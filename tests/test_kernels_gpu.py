@@ -942,6 +942,9 @@ def test_maxpool(ops, thw):
     ref.backward(dy.cpu())
     dx = ops.maxpool_bwd(dy, idx, thw, O)
     assert rel_err(dx, xr.grad) < 1e-6
+    # bf16 output (the dim-change blocks): the same sums, rounded once -- bit for bit the cast of the f32 result
+    dx16 = ops.maxpool_bwd(dy, idx, thw, O, bf16=True)
+    assert torch.equal(dx16, ops.scale_cast(dx))
 
 
 # ------------------------------------------------------------------ optimiser tail ------
