@@ -621,6 +621,7 @@ __global__ __launch_bounds__(256 * NH, NH == 2 ? 1 : 2) void attn_bwd_dkv_kernel
 static int dkv_env(const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; }
 static std::atomic<int> g_dkv_halves{dkv_env("SVIT_DKV_HALVES", 0)};   // tuning knob (svit_attn_debug_set(0, n) / env for in-step A/Bs): 1 / 2, 0 = heuristic
 static const int g_dkv_target = dkv_env("SVIT_DKV_TARGET", 256);      // workgroups the query split aims at
+static std::atomic<int> g_bwd_skip{0};     // tools only (svit_attn_debug_set(2, m)): bit 0 skips the dq launch, bit 1 the dkv launch
 
 // how the query range of the dkv kernel is cut: (dkv waves / 4, effective number of parts)
 struct DkvPlan { int halves, splits, tiles_per_split; };
@@ -662,9 +663,12 @@ int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
   const DkvPlan pl = dkv_plan(a);
   const int key_blocks = (a.Nk + 127) / 128;
   if (((uintptr_t)a.dk | (uintptr_t)a.dv) & 15) return SVIT_ERR_ALIGN;
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<DA, KSU>), dim3((a.Nq + 127) / 128, a.B * a.heads), dim3(256),
-                     lds_dq, st, a);
+  const int skip = g_bwd_skip.load();
+  if (!(skip & 1))
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DA, KSU>), dim3((a.Nq + 127) / 128, a.B * a.heads), dim3(256),
+                       lds_dq, st, a);
   SVIT_LAUNCH_CHECK();
+  if (skip & 2) return SVIT_OK;
   if (pl.halves == 2)
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DA, KSU, 2>), dim3(key_blocks, pl.splits, a.B * a.heads), dim3(512),
                        lds_kv2, st, a, pl.tiles_per_split);
@@ -678,6 +682,7 @@ int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
 
 extern "C" int svit_attn_debug_set(int key, int val) {
   if (key == 0) g_dkv_halves = val;
+  else if (key == 2) g_bwd_skip = val;
   else return SVIT_ERR_ARG;
   return SVIT_OK;
 }
