@@ -221,10 +221,10 @@ __device__ __forceinline__ void pool_ln_fwd_body(const svit_pool_args& a, const 
 // plane per step, fetched ONCE with coalesced 16-byte loads while the previous plane is being
 // computed), so global memory sees each element ~1.7 times and the 27 taps are LDS reads.
 //   * Wave w owns the channels [24w, 24w+24) of every token of the patch, lane = token.  The
-//     weights of a wave are therefore wave-uniform; this kernel reads them from an LDS image it
-//     builds from conv_w (two thirds of its LDS traffic -- the reason it only pays at 56x56).  The
-//     scalar-operand form of the same idea (s_load from the "selector" tables of
-//     svit_pool_weight_sel) is the round-3 slab kernel further down, pool_slab_fwd_kernel.
+//     weights of a wave are therefore wave-uniform: the forward takes them as scalar operands
+//     (SW = true: s_load from the "selector" tables of svit_pool_weight_sel, one (kt, ky) row of
+//     72 dwords at a time, like the slab kernel further down); the dgrad reads them from an LDS
+//     image it builds from conv_w (two thirds of its LDS reads; as scalars it measured no faster).
 //   * Token rows are 208 bytes apart in LDS (13 sixteen-byte slots, odd): the 16 lanes of a
 //     ds_read_b128 group are 16 consecutive tokens and hit 16 distinct slots of the bank row.
 //   * LayerNorm(96) spans the four waves: two tiny exchanges (sum, then squared deviations)
