@@ -201,6 +201,16 @@ class GraphedTrainStep:
         return self.loss, (self.preds, self.extra)
 
     @property
+    def static_inputs(self):
+        """the buffers the captured step reads: a loader that makes them the TARGET of its host-to-device copy and
+        passes them back to __call__ saves the device-to-device copy of every step (77 MB at B = 8, 16x224^2 fp32)"""
+        return [self.x]
+
+    @property
+    def static_labels(self):
+        return self.labels
+
+    @property
     def n_graphs(self):
         return sum(1 for k, _ in self.segments if k == "graph")
 
@@ -217,7 +227,8 @@ def _tree_map(fn, obj):
 
 def _tree_copy(dst, src):
     if torch.is_tensor(dst):
-        dst.copy_(src, non_blocking=True)
+        if dst.data_ptr() != src.data_ptr():     # (the static buffer itself was handed back: nothing to copy)
+            dst.copy_(src, non_blocking=True)
     elif isinstance(dst, dict):
         for k in dst:
             _tree_copy(dst[k], src[k])
