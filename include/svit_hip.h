@@ -422,6 +422,26 @@ int svit_ensemble_update(const float* preds, const int64_t* labels, const int64_
  * nk <= 8; counts int32 [nk] pre-zeroed. */
 int svit_topk_correct(const float* video_preds, const int64_t* video_labels, int V, int C,
                       const int* ks, int nk, int* counts, int* err, void* stream);
+/* ------------------------------------------------ diagnostics (tools/ only) ------------------ */
+/* Process-wide tuning knobs for the measurement scripts under tools/ (A/B runs of kernel variants inside one
+ * process).  NOT part of the drop-in surface: the product path (svit_amd/engine.py, bench.py) never calls them,
+ * their defaults are the measured heuristics, and every one takes effect for launches issued after the call.
+ * They replace nothing in the reference (it has no native code).  Return 0 or SVIT_ERR_ARG. */
+/* NT GEMM (csrc/gemm_nt.hip): key 0 = pipeline stages (2..4, 0 = heuristic), key 1 = forced tile/ring
+ * configuration (-1 = heuristic, 8 = the pre-ring v2 heuristic), key 2 = forced K-step (32 / 64, 0 = heuristic). */
+int svit_debug_set(int key, int val);
+/* grouped TN GEMM (csrc/gemm_tn.hip): cost-model constants of the row-chunk planner (x 0.01: microseconds per
+ * k-step, TB/s of the fp32-atomic flush; <= 0 leaves a constant unchanged), and the tile mode (0: 128x96 only,
+ * 1: per-problem heuristic fitted on isolated launches, 2: 128x192 everywhere (default), 3: 128x192 where
+ * K % 192 == 0). */
+int svit_debug_set_tn(int step_us_x100, int atomic_tbs_x100);
+int svit_debug_set_tn_tile(int mode);
+/* pooling (csrc/pool.hip): key 0 = slab stencils on (1, default) / off (0). */
+int svit_debug_set_pool(int key, int val);
+/* attention (csrc/attn_fwd.hip, attn_bwd.hip): key 0 = dkv kernel form (0 heuristic, 1 four waves, 2 eight waves with
+ * query halves), key 1 = forward kernel form (0 heuristic, see svit_attn_fwd), key 2 = run only one of the backward's
+ * two kernels (0 both, 1 dkv only, 2 dq only; timing only -- the skipped outputs are not written). */
+int svit_attn_debug_set(int key, int val);
 #ifdef __cplusplus
 }
 #endif

@@ -54,21 +54,36 @@ class _PathManagerFactory:
 
 
 class _Registry:
+    """Stand-in for fvcore.common.registry.Registry with fvcore's own attribute and method names
+    (`_obj_map`, `_do_register`, duplicate names refused, KeyError on a missing name), so that what
+    INTEGRATION.md section A does to the reference's MODEL_REGISTRY can be executed here."""
+
     def __init__(self, name):
         self._name = name
-        self._map = {}
+        self._obj_map = {}
+
+    def _do_register(self, name, obj):
+        assert name not in self._obj_map, \
+            "An object named '{}' was already registered in '{}' registry!".format(name, self._name)
+        self._obj_map[name] = obj
 
     def register(self, obj=None):
         if obj is None:
             def deco(o):
-                self._map[o.__name__] = o
+                self._do_register(o.__name__, o)
                 return o
             return deco
-        self._map[obj.__name__] = obj
+        self._do_register(obj.__name__, obj)
         return obj
 
     def get(self, name):
-        return self._map[name]
+        ret = self._obj_map.get(name)
+        if ret is None:
+            raise KeyError("No object named '{}' found in '{}' registry!".format(name, self._name))
+        return ret
+
+    def __contains__(self, name):
+        return name in self._obj_map
 
 
 class _CfgNode(dict):

@@ -171,6 +171,12 @@ _SIGS = {
     "svit_haog_loss_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "svit_ensemble_update": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "svit_topk_correct": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, vp]),
+    # diagnostics block of the header: knobs for tools/ (never called by the product path)
+    "svit_debug_set": (i32, [i32, i32]),
+    "svit_debug_set_tn": (i32, [i32, i32]),
+    "svit_debug_set_tn_tile": (i32, [i32]),
+    "svit_debug_set_pool": (i32, [i32, i32]),
+    "svit_attn_debug_set": (i32, [i32, i32]),
 }
 EXPORTS = tuple(sorted(_SIGS))
 

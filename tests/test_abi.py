@@ -30,6 +30,19 @@ def test_library_loads_and_exports_everything():
     assert lib.svit_arch() == b"gfx950"
 
 
+def test_library_exports_nothing_the_header_does_not_declare():
+    """Every `svit_*` function symbol of the shipped .so is declared in include/svit_hip.h (the tuning knobs of
+    tools/ sit in its diagnostics block) -- no undeclared entry points."""
+    import shutil
+    import subprocess
+    import __graft_entry__
+    lib = __graft_entry__.build()
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    exported = sorted({l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("svit_")})
+    assert exported == header_functions()
+
+
 def test_argument_validation_without_gpu():
     """Host-side shape/argument checks reject bad calls before any launch."""
     import ctypes as C
