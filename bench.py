@@ -27,6 +27,9 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 FWD_GFLOP_PER_CLIP = 138.16    # SURVEY.md 8(d), 16x224^2, 2*MAC, reference flop counter
 STEP_GFLOP_PER_CLIP = 412.4    # fwd+bwd: 3x GEMM/bmm/depthwise + 2x patch-embed
+# BASELINE.md section 2, per config: (frames, crop) -> fwd+bwd GFLOP per clip (the denominator of step_mfma_frac);
+# a shape that is not in the table gets no whole-step fraction (None) rather than the 16x224^2 constant
+STEP_GFLOP_BY_SHAPE = {(8, 224): 181.0, (16, 224): STEP_GFLOP_PER_CLIP, (32, 224): 1024.0}
 
 
 def synth_batch(cfg, batch, device, seed):
@@ -400,9 +403,12 @@ def main():
                    ("fp32 clips, resident in the replayed step's input buffers" if graphed is not None else "fp32 clips"),
                    "hip_library": os.path.relpath(__import__("svit_amd.hip", fromlist=["LIB_PATH"]).LIB_PATH, ROOT)},
         "loss": round(loss_val, 4),
-        "step_mfma_frac": round(clips_per_s / max(1, n_vid) * STEP_GFLOP_PER_CLIP * 1e9 /
-                                (MFMA_PEAK_TFLOPS * 1e12), 4),
+        "step_mfma_frac": None,
     }
+    step_gflop = STEP_GFLOP_BY_SHAPE.get((cfg.DATA.NUM_FRAMES, cfg.DATA.TRAIN_CROP_SIZE))
+    if step_gflop is not None:      # clips/s per video rank x FLOPs per clip / peak
+        out["step_mfma_frac"] = round(clips_per_s / max(1, n_vid) * step_gflop * 1e9 / (MFMA_PEAK_TFLOPS * 1e12), 4)
+        out["step_gflop_per_clip"] = step_gflop
     if args.image_ranks:
         # heterogeneous layout: `value` counts the clips of the video ranks only
         out["config"]["workload"] += "; %d image rank(s) x %d stills with HAOG losses" % (

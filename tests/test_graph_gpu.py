@@ -51,6 +51,31 @@ def test_graphed_step_equals_eager_step():
         step([xa[:1]], ya[:1])
 
 
+def test_new_batch_written_into_static_inputs_is_what_the_next_replay_consumes():
+    """bench.py hands the graph its own input buffers back (`static_inputs` / `static_labels`: where a
+    loader's host-to-device copy lands), so no copy runs inside the timed region.  A batch WRITTEN INTO those
+    buffers must be what the next replay computes on: loss, logits and gradients change to the eager
+    results of the new batch, and writing the first batch back restores the first results."""
+    from svit_amd.graph import GraphedTrainStep
+    cfg, model, spec, sd = S.build_hip_model(4, 64)
+    xa, ya = P.frames(2, 4, 64).cuda(), P.labels(2).cuda()
+    xb = (xa.flip(0) * 0.5 + 0.1).contiguous()
+    yb = (ya + 5) % 174
+    ref_a, ref_b = _eager(model, xa, ya), _eager(model, xb, yb)
+    assert abs(ref_a[0] - ref_b[0]) > 1e-3                    # the two batches are told apart by the loss
+    step = GraphedTrainStep(model, _ce, [xa], ya)
+    sx, sy = step.static_inputs[0], step.static_labels
+    assert sx.data_ptr() != xa.data_ptr()                       # the step owns its buffers
+    for x, y, ref in ((xa, ya, ref_a), (xb, yb, ref_b), (xa, ya, ref_a)):
+        sx.copy_(x)                                             # what a loader does: write in place ...
+        sy.copy_(y)
+        loss, (logits, _) = step([sx], sy)                      # ... and hand the same buffers back (no copy)
+        torch.cuda.synchronize()
+        assert abs(float(loss) - ref[0]) < 1e-4 * max(1.0, abs(ref[0]))
+        assert float((logits - ref[1]).abs().max()) < 1e-4
+        assert S.cosine(model.flat.grad, ref[2]) > 0.99999
+
+
 def test_graphed_step_with_droppath_trains():
     """DropPath/dropout sampling lives inside the graph (torch's graph-safe Philox state): two
     replays on the same input must draw different masks, and the loss must go down under AdamW."""

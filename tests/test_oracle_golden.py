@@ -59,7 +59,8 @@ def run_case(case, name, golden_dir, backward):
 
 
 @pytest.mark.parametrize("name", ["tiny", "tiny_drop", "tiny_odd", "tiny_frames", "c1",
-                                  "c2_fwd", "c2_frames", "c2", "c2_drop"])
+                                  "c2_fwd", "c2_frames", "c2", "c2_drop",
+                                  "c4_fwd", "c5_eval", "c2_b8_fwd"])   # round 4: the reference at C4 / C5 / B = 8
 def test_model_case(name, manifest, golden_dir):
     case = manifest["cases"][name]
     for k, v in case["restatement_vs_reference_maxabs"].items():
@@ -82,13 +83,17 @@ def test_model_case(name, manifest, golden_dir):
                 continue
             close_digest(g, d, rtol=1e-3)
             if "grad:" + k in arrays:
+                # rel-pos tables (stored whole since round 4) are scatter-added over up to 25 k query rows in
+                # fp32: the two summation orders differ by up to 3.9e-3 of the tensor's scale (manifest:
+                # grad_rel_worst, pinned < 5e-3 above); everything else small agrees to 2e-3
+                tol = 5e-3 if "rel_pos_" in k else 2e-3
                 np.testing.assert_allclose(g.numpy(), arrays["grad:" + k], rtol=0,
-                                           atol=2e-3 * float(np.abs(arrays["grad:" + k]).max()) + 1e-7)
+                                           atol=tol * float(np.abs(arrays["grad:" + k]).max()) + 1e-7)
             if "sample:grad:" + k in arrays:      # strided sample of a large gradient
                 close_sample(g, arrays["sample:grad:" + k])
 
 
-@pytest.mark.parametrize("name", ["tiny", "c1"])
+@pytest.mark.parametrize("name", ["tiny", "c1", "c5_eval"])
 def test_eval_mode(name, manifest, golden_dir):
     case = manifest["cases"][name]
     spec = R.make_spec(num_frames=case["num_frames"], crop=case["crop"], drop_path_rate=0.0,

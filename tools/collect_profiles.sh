@@ -15,7 +15,7 @@ python bench.py --steps 20 --warmup 5 --frames-pass --no-cpu-baseline --no-kerne
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/profN -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-trace > gpurun_out/profN.log 2>&1
 K=$(ls gpurun_out/profN/*/*kernel_trace.csv | head -1)
 python tools/trace_gaps.py $K 3000 > gpurun_out/rNN_device_busy.txt
-python tools/trace_gaps.py $K --blocks > gpurun_out/rNN_backward_by_block.txt 2>&1 || true
+python tools/trace_gaps.py $K --blocks > gpurun_out/rNN_backward_by_block.txt
 cp $(ls gpurun_out/profN/*/*kernel_stats.csv | head -1) gpurun_out/rNN_bench_kernel_stats.csv
 # keep the merge small
 rm -rf gpurun_out/profN gpurun_out/pmcNf gpurun_out/pmcNw

@@ -112,7 +112,20 @@ def blocks(path):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
     sh = lambda n: n.replace("void ", "").replace("(anonymous namespace)::", "").replace("at::native::", "").split("(")[0][:34]
-    marks = [i for i, r in enumerate(rows) if ", 4>(svit_gemm_args)" in r[2]]
+    # epilogue id of an NT GEMM dispatch: the 6th template argument of gemm_nt_v2_kernel<RB, NB, WM, WN, STAGES, EPI, BK>,
+    # the last of gemm_nt_ring_kernel<RB, NB, WM, WN, NL, STAGES, EPI> (csrc/gemm_nt.hip); 4 = SVIT_EPI_DGELU = fc2 dgrad
+    import re
+
+    def epi(name):
+        m = re.search(r"gemm_nt_(v2|ring)_kernel<([^>]*)>", name)
+        if not m:
+            return None
+        a = [x.strip() for x in m.group(2).split(",")]
+        return int(a[5] if m.group(1) == "v2" else a[-1])
+    marks = [i for i, r in enumerate(rows) if epi(r[2]) == 4]
+    if len(marks) < 16:
+        sys.exit("trace_gaps --blocks: only %d fc2-dgrad (SVIT_EPI_DGELU) dispatches found in %s -- kernel names changed?"
+                 % (len(marks), path))
     marks = marks[-16:]
     last_adam = max(i for i, r in enumerate(rows) if "adamw_kernel" in r[2])
     bounds = marks + [last_adam]
