@@ -31,6 +31,7 @@
 // dQ / dK tiles; the LDS-DMA pieces are
 // addressed by buffer descriptor + scalar offset (no per-piece address arithmetic); the dkv kernel
 // consumes 64 queries per barrier (was 32); dQa leaves through LDS as whole rows in 16-byte stores.
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include "attn_common.h"
@@ -49,6 +50,10 @@ extern "C" int svit_debug_attn_bwd_stamps(unsigned long long* host, int n) {
   } while (0)
 #else
 #define BSTAMP(slot) do {} while (0)
+#endif
+
+#ifndef SVIT_ATTN_QSTAGE      // 0 in a diagnostic build: the round-3 row-per-lane Q loads (A/B)
+#define SVIT_ATTN_QSTAGE 1
 #endif
 
 namespace {
@@ -122,10 +127,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
   BSTAMP(2);
 
   bf16x8_t qf[KSU], dof[6];
-#pragma unroll
-  for (int ks = 0; ks < KSU; ++ks) qf[ks] = *(const bf16x8_t*)(qa + (size_t)qc * DA + ks * 16 + hh * 8);
+  // (round 4) the wave's 32 Q rows come through LDS, coalesced (attn_common.h RowStage; by ablation the row-per-lane
+  // loads of the forward's Q cost 1.9 us of a 20.7 us launch), into stage 1 and the tail of the allocation, free
+  // until tile 1 is issued behind the first barrier; dO and O stay row-per-lane loads (no room for three regions
+  // beside stage 0 at two workgroups per CU) and are requested first
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks) dof[ks] = *(const bf16x8_t*)(dor + ks * 16 + hh * 8);
+  using QStage = RowStage<DA>;
+  if constexpr (SVIT_ATTN_QSTAGE != 0) {
+    unsigned char* qreg = smem + STAGE + wave * QStage::BYTES;
+    QStage::issue(qa, DA, q0, a.Nq, qreg, lane);
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int ks = 0; ks < KSU; ++ks) qf[ks] = QStage::frag(qreg, ks, lane);
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < KSU; ++ks) qf[ks] = *(const bf16x8_t*)(qa + (size_t)qc * DA + ks * 16 + hh * 8);
+  }
   // delta = rowsum(dO . O) with O = ctx - q (residual pooling adds q to every token but cls):
   // each half-wave lane holds 48 of the 96 channels.  (-lse2, -delta) are what the dkv kernel
   // loads as the initial accumulators of its S and dP chains, so they are written in that form.
@@ -653,6 +671,8 @@ int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
   size_t lds_dq = 2 * (size_t)(KT * DA * 2 + KT * HD * 2);
   const size_t lds_dq_out = (size_t)4 * 32 * (DA * 2 + 16) + (size_t)4 * 32 * 128 * 2;   // + the fold mode's D rows
   if (lds_dq < lds_dq_out) lds_dq = lds_dq_out;
+  // the Q staging region behind stage 0 (attn_common.h RowStage: 8 / 11 KiB per wave)
+  lds_dq = std::max(lds_dq, (size_t)(KT * DA * 2 + KT * HD * 2) + 4 * (size_t)attn::RowStage<DA>::BYTES);
   const size_t stage = (size_t)(QR * DA * 2 + QR * HD * 2 + 2 * QR * 4);
   size_t lds_kv = 2 * stage, lds_kv2 = 3 * stage;
   const size_t lds_merge = (size_t)2 * 12 * 256 * 16;     // the halves' dk / dv hand-over

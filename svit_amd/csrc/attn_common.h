@@ -367,6 +367,44 @@ struct BufTile {
 #endif
 };
 
+// A wave's own 32 operand rows (COLS bf16 columns of each, row stride ld elements in HBM) fetched COALESCED by
+// LDS-DMA into a wave-private LDS region and read back as MFMA row fragments.  The row-per-lane register loads
+// this replaces (lane -> its own row, 16 bytes per k-step) touch 32 different 128-byte lines per instruction and
+// come back to every line once per k-step pair: by ablation (tools/diag/run_attn_ablate.sh, round 4) the eight
+// such loads of the forward's Q rows cost 1.9 us of a 20.7 us launch at the 14x14 stage.  Here one 1-KiB piece
+// = RPP whole rows (lane -> row lane / CPR, 16-byte chunk lane % CPR; the lanes left over re-read chunk 0 into
+// the piece's pad), i.e. whole lines, each fetched once.  Inside a row the chunks are ROTATED by the row index
+// (slot = (chunk + row) % CPR, applied on the source side -- the LDS side of an LDS-DMA is always base + 16 lane),
+// so that the 16 lanes of a ds_read_b128 group, which read the same chunk of 16 different rows, hit different
+// 16-byte slots of the 256-byte bank row.
+template <int COLS>
+struct RowStage {
+  static constexpr int CPR = COLS / 8;                 // 16-byte chunks per row
+  static constexpr int RPP = 64 / CPR;                 // rows per piece: 4 (128 columns), 3 (160), 5 (96)
+  static constexpr int PIECES = (32 + RPP - 1) / RPP;
+  static constexpr int BYTES = PIECES * 1024;          // LDS bytes per wave
+  // base = row 0 of the matrix, first = this wave's first row, rows >= nrows re-read the last one
+  __device__ static __forceinline__ void issue(const bf16_t* __restrict__ base, size_t ld, int first, int nrows,
+                                               unsigned char* region, int lane) {
+    int rl = lane / CPR, c = lane % CPR;
+    if (rl >= RPP) { rl = RPP - 1; c = 0; }            // (left-over lanes: a harmless re-read into the pad)
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) {
+      const int r = min(p * RPP + rl, 31);
+      const int g = (c + CPR - r % CPR) % CPR;         // the chunk that belongs in slot c of row r
+      const int row = min(first + r, nrows - 1);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(base + (size_t)row * ld + g * 8),
+          (__attribute__((address_space(3))) void*)(region + p * 1024), 16, 0, 0);
+    }
+  }
+  // fragment of k-step ks (columns 16 ks + 8 (lane >> 5) ..) of row lane & 31
+  __device__ static __forceinline__ bf16x8_t frag(const unsigned char* region, int ks, int lane) {
+    const int r = lane & 31, g = 2 * ks + (lane >> 5);
+    return *(const bf16x8_t*)(region + (r / RPP) * 1024 + (r % RPP) * (CPR * 16) + ((g + r) % CPR) * 16);
+  }
+};
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

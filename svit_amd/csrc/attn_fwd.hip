@@ -15,6 +15,7 @@
 // 32x32 block, so the online-softmax row reduction is in-register plus one lane<->lane+32
 // exchange, and the exponentiated tile feeds the PV MFMA as its B operand without leaving
 // registers.  O^T accumulates as 3 x (32 dv x 32 query) blocks.
+#include <algorithm>
 #include <cstdlib>
 #include "attn_common.h"
 #include "../../include/svit_hip.h"
@@ -32,6 +33,16 @@ extern "C" int svit_debug_attn_stamps(unsigned long long* host, int n) {
   } while (0)
 #else
 #define STAMP(slot) do {} while (0)
+#endif
+
+// Diagnostic builds only (tools/diag/build_variant.py ... -DSVIT_ATTN_ABL=<mask>): anatomy of the per-launch fixed
+// cost by ablation -- 1: no Q row loads, 2: no residual-row loads, 4: no ctx stores, 8: no K/V DMA (and no waits).
+// Results are wrong by construction; never defined in the product build.
+#ifndef SVIT_ATTN_ABL
+#define SVIT_ATTN_ABL 0
+#endif
+#ifndef SVIT_ATTN_QSTAGE      // 0 in a diagnostic build: the round-3 row-per-lane Q loads (A/B)
+#define SVIT_ATTN_QSTAGE 1
 #endif
 
 namespace {
@@ -72,6 +83,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
   using KLoad = BufTile<KT, KCOLS, NW>;
   using VLoad = BufTile<KT, HD, NW>;
   constexpr int PIECES = KLoad::PER_WAVE + VLoad::PER_WAVE;   // DMA instructions per wave and tile
+  using QStage = RowStage<(KSU <= 8 ? 128 : 160)>;
+  constexpr bool QSTAGE = (SVIT_ATTN_ABL & 1) == 0 && SVIT_ATTN_QSTAGE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
@@ -132,6 +145,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
   const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)ka, 0, a.Nk * DA * 2, 0x00020000);
   const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vv, 0, a.Nk * HD * 2, 0x00020000);
   auto issue = [&](int t) {
+    if constexpr ((SVIT_ATTN_ABL & 8) != 0) return;
     unsigned char* st = smem + (t % NS) * STAGE;
     const unsigned k0 = (unsigned)t * KT;
     kload.issue_auto(krs, k0 * DA * 2u, DA, a.Nk - (int)k0, st, wave, lane);
@@ -140,9 +154,26 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
   issue(0);                        // the first tile(s) travel while the Q fragments are fetched
   if (NS == 3 && nt > 1) issue(1);
   bf16x8_t qf[KSU];
+  if constexpr (QSTAGE) {
+    // round 4: the wave's 32 Q rows come through LDS, coalesced (attn_common.h RowStage), into a region of their
+    // own behind the stages the prologue fills (NS - 1 of them) -- the last stage and the tail of the allocation,
+    // free until the next tile is issued after the first barrier, which every wave reaches only after it has read
+    // its fragments
+    unsigned char* qreg = smem + (NS - 1) * STAGE + wave * QStage::BYTES;
+    QStage::issue(qa, DA, q0, a.Nq, qreg, lane);
+    wait_vmcnt<0>();
 #pragma unroll
-  for (int ks = 0; ks < KSU; ++ks)
-    qf[ks] = *(const bf16x8_t*)(qa + (size_t)qc * DA + ks * 16 + hh * 8);
+    for (int ks = 0; ks < KSU; ++ks) qf[ks] = QStage::frag(qreg, ks, lane);
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < KSU; ++ks) {
+      if constexpr ((SVIT_ATTN_ABL & 1) != 0) {
+        for (int e = 0; e < 8; ++e) qf[ks][e] = (__bf16)(0.01f * (float)(lane + ks));
+      } else {
+        qf[ks] = *(const bf16x8_t*)(qa + (size_t)qc * DA + ks * 16 + hh * 8);
+      }
+    }
+  }
   // pin the register operands before the tile loop: their first use must not sit inside it,
   // or the compiler's wait for them (vmcnt(0)) would drain the LDS-DMA pipeline every tile
   // (here that wait also covers the tiles issued above, which tile 0 needs anyway)
@@ -267,7 +298,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
   for (int it = 0; it < 6; ++it) {
     const int id = it * 64 + lane, row = id / 12, ch = id % 12;
     const int q = min(q0 + row, a.Nq - 1);
-    qres[it] = *(const uint4*)(qa + (size_t)q * DA + ch * 8);
+    if constexpr ((SVIT_ATTN_ABL & 2) != 0) qres[it] = make_uint4(0u, 0u, 0u, 0u);
+    else qres[it] = *(const uint4*)(qa + (size_t)q * DA + ch * 8);
   }
   const float l_lo = __shfl(lacc[0], lane & 31, 64);   // row 0 of the sum block lives in lanes 0..31
   const float inv = 1.f / l_lo;
@@ -303,7 +335,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
         ov.z = pack_bf16x2(lo_bf16(ov.z) + lo_bf16(qq.z), hi_bf16(ov.z) + hi_bf16(qq.z));
         ov.w = pack_bf16x2(lo_bf16(ov.w) + lo_bf16(qq.w), hi_bf16(ov.w) + hi_bf16(qq.w));
       }
-      *(uint4*)((bf16_t*)a.ctx + ((size_t)b * a.Nq + q) * a.heads * HD + head * HD + ch * 8) = ov;
+      if constexpr ((SVIT_ATTN_ABL & 4) != 0) { if (ov.x == 0x12345678u && a.Nk < 0) a.lse2[0] = 1.f; }
+      else *(uint4*)((bf16_t*)a.ctx + ((size_t)b * a.Nq + q) * a.heads * HD + head * HD + ch * 8) = ov;
     }
   }
 #ifdef SVIT_ATTN_STAMPS
@@ -316,9 +349,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
 template <int KSU, int NW, int NS>
 int launch_cfg(const svit_attn_fwd_args& a, hipStream_t st) {
   constexpr int NP = (KSU + 1) / 2;
-  size_t lds = NS * (size_t)(KT * NP * 32 * 2 + KT * HD * 2);
+  const size_t stage = (size_t)(KT * NP * 32 * 2 + KT * HD * 2);
+  size_t lds = NS * stage;
   const size_t lds_out = (size_t)NW * 32 * 208;
   if (lds < lds_out) lds = lds_out;
+  if (SVIT_ATTN_QSTAGE)      // the Q staging region behind the prologue's stages (RowStage, 8 / 11 KiB per wave)
+    lds = std::max(lds, (NS - 1) * stage + NW * (size_t)attn::RowStage<(KSU <= 8 ? 128 : 160)>::BYTES);
   static SvitOnce once;
   if (int rc = svit_max_lds_once(once, (const void*)attn_fwd_kernel<KSU, NW, NS>, lds)) return rc;
   dim3 grid((a.Nq + NW * 32 - 1) / (NW * 32), a.B * a.heads);

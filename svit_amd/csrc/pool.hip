@@ -1384,6 +1384,233 @@ __global__ __launch_bounds__(256) void relq_bwd_kernel(svit_relq_bwd_args a) {
   for (int i = threadIdx.x; i < tab_n; i += blockDim.x) prow[i] = tabs[i];
 }
 
+#ifdef SVIT_POOL_STAMPS
+__device__ unsigned long long g_slab_stamps[16];
+#define PSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (pst) g_slab_stamps[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PSTAMP(i) do {} while (0)
+#endif
+// ---------------------------------------------------------------------------------------
+// MFMA stencil (round 4): the forward depthwise 3x3x3 conv of the small planes (W <= 14, T % 4 == 0, strides 1 / 2)
+// on the matrix pipe, as banded-Toeplitz products of v_mfma_f32_4x4x4_16b_bf16 -- one wave-instruction = 16
+// independent 4x4x4 products, one per CHANNEL (a depthwise conv mixes nothing across channels, which is why the big
+// MFMA shapes do not apply and why the VALU forms above pay one instruction per MAC).  Per block (= channel):
+//     D[i][j] += sum_k A[i][k] B[k][j]
+//       i = 4 output positions along x,  k = 4 consecutive INPUT slots along x,  j = 4 t-planes of a "t-quad"
+//       A = the (kt, ky) row of the channel's weights laid out as a band (Toeplitz) matrix: A[i][k] = w[kx(i, k)] or 0
+//       B = 4 input slots x 4 planes, read with ONE ds_read_b64 per lane from a planar image [channel][plane][row][slot]
+// 4 outputs x 3 taps need 6 inputs (stride 1) or 9 (stride 2), i.e. 2 or 3 k-steps: 12 of 32 / 48 products carry
+// data -- 37 % / 25 % of a pipe that does 1024 MACs per 8 cycles per SIMD, against 64 useful MACs per 4-cycle
+// v_dot2 of the slab kernel: ~3x the MACs per cycle, and no VALU work at all in the loop.
+//   * LDS image: slot = x + 1 (slot 0 and the slots past W hold zeros = the conv's zero padding in x), 16 slots = 32
+//     bytes per row, planes t = -1 .. T as zero halos (the 4 planes of a quad sit on different lanes, so the t boundary
+//     cannot be a uniform branch; the y boundary can: a whole (kt, ky) row is skipped), channel stride padded so that
+//     the 32 lanes of a ds_read_b64 half (8 channels x 4 planes) hit 32 different bank pairs.
+//   * fill = the transpose: a lane fetches the 8 channels of TWO x-neighbours (16 bytes each, zeros outside the row)
+//     and writes 8 dwords (x, x+1) -- slot pairs (2m, 2m+1) = x (2m-1, 2m), so the x halos are written by the fill.
+//   * a workgroup = one (batch, head, tensor, 16-channel block), 4 waves; a wave takes (t-quad, output row) units,
+//     keeps the Toeplitz fragments of all 9 (kt, ky) rows in 36 / 54 registers, and sends a finished unit through a
+//     2-KiB LDS transpose so that `pre` gets 16-byte stores.  LayerNorm stays pool_slab_ln_kernel.
+// Arithmetic: bf16 inputs and bf16-rounded weights (as the selector tables), fp32 accumulation in the order the
+// matrix pipe adds (k ascending inside a product, products in (kt, ky, k-step) order): the same values as the slab
+// kernel up to fp32 summation order.
+__device__ __forceinline__ f32x4_t mfma4(s16x4_t a, s16x4_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, c, 0, 0, 0);
+}
+constexpr int PM_SLOTS = 16, PM_ROWB = PM_SLOTS * 2;          // slots / bytes per image row
+__host__ __device__ inline int pm_plane_bytes(int H) { return H * PM_ROWB; }
+__host__ __device__ inline int pm_chan_bytes(int T, int H) { return (T + 2) * H * PM_ROWB + 8; }
+__host__ __device__ inline size_t pm_lds_bytes(int T, int H) { return (size_t)16 * pm_chan_bytes(T, H) + 4 * 2048 + 64; }
+
+// G = output groups of 4 along x that are computed (a group past the row multiplies zero slots; nothing of it is stored)
+template <int S, int G>
+__device__ __forceinline__ void pool_mfma_body(const svit_pool_args& a, int which, int bh, int cb, unsigned char* lds) {
+  constexpr int NA = S == 1 ? 2 : 3;                 // Toeplitz fragments per (kt, ky) row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = a.T, H = a.H, W = a.W;
+  const int Ho = pooled(H, S), Wo = pooled(W, S);
+  const int L = T * H * W, Lo = T * Ho * Wo;
+  const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
+  const int b = bh / a.heads, head = bh % a.heads;
+  const int PP = pm_plane_bytes(H), CS = pm_chan_bytes(T, H);
+  const size_t tok_stride = (size_t)3 * a.heads * HD;
+  const bf16_t* src = (const bf16_t*)a.qkv + (size_t)b * N * tok_stride + ((size_t)which * a.heads + head) * HD + cb * 16;
+  unsigned char* ostage = lds + 16 * CS;             // 4 x 2 KiB output transposes, then the object gains
+  float* g_lds = (float*)(ostage + 4 * 2048);
+#ifdef SVIT_POOL_STAMPS
+  const bool pst = which == 0 && cb == 0 && bh == 3 && tid == 0;
+#endif
+  PSTAMP(8);
+
+  // ---- zero halo planes t = -1 and t = T of the 16 channels -------------------------------------------
+  const int ppc = PP / 16;                           // 16-byte chunks per plane
+  for (int i = tid; i < 16 * 2 * ppc; i += blockDim.x) {
+    const int c = i / (2 * ppc), r = i % (2 * ppc);
+    *(uint4*)(lds + c * CS + (r < ppc ? 0 : (T + 1) * PP) + (r % ppc) * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  // ---- fill: task = (row of the volume, slot pair m, channel half); the loads of FB tasks per thread are requested
+  // together (one memory round trip per batch instead of one per task) ------------------------------------------
+  const int ntask = T * H * 16;
+  constexpr int FB = 4;
+  for (int q0 = tid; q0 < ntask; q0 += FB * (int)blockDim.x) {
+    uint4 v0[FB], v1[FB];
+#pragma unroll
+    for (int f = 0; f < FB; ++f) {
+      const int q = q0 + f * (int)blockDim.x;
+      const int half = q & 1, m = (q >> 1) & 7, row = q >> 4;
+      const int x0 = 2 * m - 1, x1 = 2 * m;
+      v0[f] = make_uint4(0u, 0u, 0u, 0u);
+      v1[f] = make_uint4(0u, 0u, 0u, 0u);
+      if (q < ntask && x0 >= 0 && x0 < W) v0[f] = *(const uint4*)(src + (size_t)(1 + row * W + x0) * tok_stride + half * 8);
+      if (q < ntask && x1 < W) v1[f] = *(const uint4*)(src + (size_t)(1 + row * W + x1) * tok_stride + half * 8);
+    }
+#pragma unroll
+    for (int f = 0; f < FB; ++f) {
+      const int q = q0 + f * (int)blockDim.x;
+      if (q >= ntask) break;
+      const int half = q & 1, m = (q >> 1) & 7, row = q >> 4;
+      const int t = row / H, y = row - t * H;
+      unsigned char* dst = lds + (half * 8) * CS + (t + 1) * PP + y * PM_ROWB + m * 4;
+      const uint32_t w0[4] = {v0[f].x, v0[f].y, v0[f].z, v0[f].w}, w1[4] = {v1[f].x, v1[f].y, v1[f].z, v1[f].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        *(uint32_t*)(dst + (2 * e) * CS) = (w0[e] & 0xffffu) | (w1[e] << 16);
+        *(uint32_t*)(dst + (2 * e + 1) * CS) = (w0[e] >> 16) | (w1[e] & 0xffff0000u);
+      }
+    }
+  }
+  PSTAMP(9);
+  // ---- object gain of the 16 channels (closed form of the cube branch) -------------
+  if (tid < 16) {
+    float nt3[3], nh3[3], ipt, iph;
+    obj_counts(1, nt3, &ipt);
+    obj_counts(S, nh3, &iph);
+    const float* cw = a.conv_w + (size_t)(cb * 16 + tid) * 27;
+    float gsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) gsum += cw[k] * nt3[k / 9] * nh3[(k / 3) % 3] * nh3[k % 3];
+    g_lds[tid] = gsum * ipt * iph * iph;
+  }
+  // ---- Toeplitz fragments: lane 4 blk + i holds row i of the band matrices of channel blk ----------------
+  const int blk = lane >> 2, li = lane & 3;
+  s16x4_t afr[9][NA];
+  {
+    const float* cw = a.conv_w + (size_t)(cb * 16 + blk) * 27;
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+      const bf16_t w3[3] = {f32_to_bf16(cw[p * 3]), f32_to_bf16(cw[p * 3 + 1]), f32_to_bf16(cw[p * 3 + 2])};
+#pragma unroll
+      for (int n = 0; n < NA; ++n)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          // input slot 4 (S g + n) + k against output position 4 g + li, whose first tap sits at slot S (4 g + li)
+          const int kx = 4 * n + k - S * li;
+          afr[p][n][k] = (short)((kx >= 0 && kx <= 2) ? w3[kx] : (bf16_t)0);
+        }
+    }
+  }
+  PSTAMP(10);
+  __syncthreads();
+  PSTAMP(11);
+
+  // ---- units: (t-quad, output row) ---------------------------------------------------------------------------
+  const unsigned lb = (unsigned)(blk * CS + li * PP);             // B operand: lane 4 blk + j reads plane j of the quad
+  unsigned char* ost = ostage + wave * 2048;
+  bf16_t* pre = (bf16_t*)a.pre + ((size_t)bh * Nout + 1) * HD + cb * 16;
+  const int nunit = (T >> 2) * Ho;
+  for (int u = wave; u < nunit; u += (int)(blockDim.x >> 6)) {
+    const int tq = u / Ho, yo = u - tq * Ho;
+    f32x4_t acc[G];
+#pragma unroll
+    for (int g2 = 0; g2 < G; ++g2) acc[g2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // all 36 fragment reads of the unit are independent of the MFMAs: one basic block, no branch -- a (kt, ky) row
+    // outside the plane (the conv's zero padding in y, uniform over the wave) reads the zero halo plane instead
+    s16x4_t bf[9][4];
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yi = S * yo + ky - 1;
+        const bool ok = yi >= 0 && yi < H;
+        const unsigned char* rowp = ok ? lds + lb + (4 * tq + kt) * PP + yi * PM_ROWB      // plane index = t + 1
+                                       : lds + blk * CS;                                     // plane t = -1: zeros
+#pragma unroll
+        for (int m = 0; m < 4; ++m) bf[kt * 3 + ky][m] = *(const s16x4_t*)(rowp + 8 * m);
+      }
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+      if constexpr (S == 1) {
+#pragma unroll
+        for (int g2 = 0; g2 < G; ++g2) acc[g2] = mfma4(afr[p][0], bf[p][g2], acc[g2]);
+#pragma unroll
+        for (int g2 = 0; g2 < G && g2 < 3; ++g2) acc[g2] = mfma4(afr[p][1], bf[p][g2 + 1], acc[g2]);
+      } else {
+#pragma unroll
+        for (int g2 = 0; g2 < G; ++g2) acc[g2] = mfma4(afr[p][0], bf[p][2 * g2], acc[g2]);
+#pragma unroll
+        for (int g2 = 0; g2 < G; ++g2) acc[g2] = mfma4(afr[p][1], bf[p][2 * g2 + 1], acc[g2]);
+        acc[0] = mfma4(afr[p][2], bf[p][2], acc[0]);
+      }
+    }
+    // D[i][j]: lane 4 blk + j holds the outputs x = 4 g + i (register i) of plane 4 tq + j, channel blk.
+    // Transpose through LDS: [plane j][x][channel] bf16, 32 bytes per token.
+#pragma unroll
+    for (int g2 = 0; g2 < G; ++g2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)        // (x positions past the row land in staging slots nobody reads)
+        *(bf16_t*)(ost + ((li * 16 + 4 * g2 + i) * 16 + blk) * 2) = f32_to_bf16(acc[g2][i]);
+    asm volatile("" ::: "memory");       // (the wave's own LDS operations complete in order; keep the compiler's order too)
+    for (int id = lane; id < 4 * Wo * 2; id += 64) {
+      const int tt = id >> 1, half = id & 1, jj = tt / Wo, xo = tt - jj * Wo;
+      const uint4 v = *(const uint4*)(ost + ((jj * 16 + xo) * 16 + half * 8) * 2);
+      *(uint4*)(pre + (size_t)(((4 * tq + jj) * Ho + yo) * Wo + xo) * HD + half * 8) = v;
+    }
+    asm volatile("" ::: "memory");
+  }
+  PSTAMP(12);
+  // ---- cls and object tokens: pre = x, x * g(w) ------------------------------------------------------------------
+  for (int i = tid; i < (1 + a.n_obj) * 2; i += blockDim.x) {
+    const int idx = i >> 1, half = i & 1;
+    const int tin = idx == 0 ? 0 : L + idx, tout = idx == 0 ? 0 : Lo + idx;
+    float f[8];
+    unpack8(*(const uint4*)(src + (size_t)tin * tok_stride + half * 8), f);
+    if (idx > 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] *= g_lds[half * 8 + e];
+    }
+    *(uint4*)((bf16_t*)a.pre + ((size_t)bh * Nout + tout) * HD + cb * 16 + half * 8) = pack8(f);
+  }
+  PSTAMP(13);
+}
+
+struct PoolMfma3 { svit_pool_args p[3]; };
+__global__ __launch_bounds__(256, 2) void pool_mfma_fwd_kernel(PoolMfma3 g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pm_lds[];
+  // 1-D grid, XCD-aware like the slab kernel: consecutive logical ids run on one XCD, and the six channel
+  // blocks of a (batch, head, tensor) are consecutive logical ids -- they read interleaved 32-byte pieces of
+  // the same lines.  Two kinds of workgroup: the q tensor (one fill, the long stride-1 sweep at blocks 4-13), and
+  // k followed by v (two fills, two short sweeps): 2 x 6 x B x heads workgroups -- 384 at the 14x14 stage, ONE
+  // round at two workgroups per CU (one workgroup per tensor gave 576: a second round for an eighth of them).
+  const int nwg = gridDim.x, lin = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+  int lg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  const int cb = lg % 6; lg /= 6;
+  const int nbh = g.p[0].B * g.p[0].heads;
+  const int bh = lg % nbh, kind = lg / nbh;
+  for (int which = kind; which <= 2 * kind; ++which) {         // kind 0: q; kind 1: k, v
+    const svit_pool_args& a = g.p[which];
+    if (which == 2) __syncthreads();                             // every wave is done with k's image
+    const int Wo = pooled(a.W, a.stride_hw);
+    if (a.stride_hw == 1) {
+      if (Wo > 8) pool_mfma_body<1, 4>(a, which, bh, cb, pm_lds);
+      else pool_mfma_body<1, 2>(a, which, bh, cb, pm_lds);
+    } else {
+      if (Wo > 4) pool_mfma_body<2, 2>(a, which, bh, cb, pm_lds);
+      else pool_mfma_body<2, 1>(a, which, bh, cb, pm_lds);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Slab stencils (round 3): the forward depthwise conv of one (batch, head, tensor) for ONE group of
 // 24 channels, with the input "slab" it needs (a range of t-planes and y-rows, every x; 48 bytes
@@ -1401,12 +1628,6 @@ __global__ __launch_bounds__(256) void relq_bwd_kernel(svit_relq_bwd_args a) {
 //     bf16 pre-LN value, saved for the backward anyway) and a second, row-wise launch
 //     (pool_slab_ln_kernel -> pool_ln_finish) normalises.  The tap order and the arithmetic are those
 //     of pool_ln_fwd_body: the results are bit-identical to the streaming kernel's.
-#ifdef SVIT_POOL_STAMPS
-__device__ unsigned long long g_slab_stamps[16];
-#define PSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (pst) g_slab_stamps[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define PSTAMP(i) do {} while (0)
-#endif
 struct SlabPlan { int on, TC, YC, nt, ny; };
 constexpr int SLAB_NT = 1024;                 // threads per slab workgroup: every wave does at most one 64-token unit
 // n / d for n < 65536 by one multiply-high with m = ceil(2^32 / d) (exact while n * d < 2^32)
@@ -1751,7 +1972,7 @@ static size_t tiled_lds_bytes(int W) {
 // fits SLAB_MAXTOK tokens; among those the one that re-reads the input least, then cut in t until the
 // launch has >= 256 workgroups.  Strides 1 and 2 only (a stride-4 / -8 stencil touches a small part
 // of the planes a slab would load), and only where `pre` is given (the LayerNorm launch reads it).
-static std::atomic<int> g_pool_slab{1};        // tuning knob (svit_debug_set_pool(0, v)): 0 = streaming kernels
+static std::atomic<int> g_pool_slab{getenv("SVIT_POOL_SLAB") ? atoi(getenv("SVIT_POOL_SLAB")) : 2};   // tuning knob (svit_debug_set_pool(0, v) / env for in-step A/Bs): 0 = streaming kernels, 1 = VALU slab conv, 2 = MFMA conv where its geometry holds
 static SlabPlan plan_slab(const svit_pool_args& a) {
   SlabPlan pl = {0, 0, 0, 0, 0};
   const int s = a.stride_hw;
@@ -1846,6 +2067,25 @@ static int pool_ln_fwd_qkv_kernels(const svit_pool_args* a3, const uint32_t* con
     }
   }
   if (n_slab) {
+    // round 4: the conv of the slab planes on the matrix pipe (pool_mfma_fwd_kernel) where its geometry holds for
+    // all three tensors: W <= 14 (16 slots per image row with both x halos), T a multiple of 4 (t-quads), the
+    // 16-channel image within the LDS of a CU; svit_debug_set_pool(0, 1) keeps the VALU slab kernel (A/B)
+    bool mfma = n_slab == 3 && g_pool_slab.load() != 1;
+    size_t mlds = 0;
+    for (int i = 0; i < 3 && mfma; ++i) {
+      mfma = a3[i].W <= 14 && a3[i].T % 4 == 0 && a3[i].T == a3[0].T && a3[i].H == a3[0].H;
+      mlds = std::max(mlds, pm_lds_bytes(a3[i].T, a3[i].H));
+    }
+    if (mfma && mlds > 160 * 1024) mfma = false;
+    if (mfma) {
+      static SvitOnce once_mfma;
+      if (int rc = svit_max_lds_once(once_mfma, (const void*)pool_mfma_fwd_kernel, 160 * 1024)) return rc;
+      PoolMfma3 mg;
+      for (int i = 0; i < 3; ++i) mg.p[i] = a3[i];
+      hipLaunchKernelGGL(pool_mfma_fwd_kernel, dim3(a3[0].B * a3[0].heads * 2 * 6), dim3(256), mlds,
+                         (hipStream_t)stream, mg);
+      SVIT_LAUNCH_CHECK();
+    } else {
     static SvitOnce once_slab;
     if (int rc = svit_max_lds_once(once_slab, (const void*)pool_slab_fwd_kernel, 80 * 1024)) return rc;
     sg.max_chunks = (int)sgx;
@@ -1853,6 +2093,7 @@ static int pool_ln_fwd_qkv_kernels(const svit_pool_args* a3, const uint32_t* con
     hipLaunchKernelGGL(pool_slab_fwd_kernel, dim3(sgx * a3[0].B * a3[0].heads * 12), dim3(SLAB_NT), slds,
                        (hipStream_t)stream, sg);
     SVIT_LAUNCH_CHECK();
+    }
     const size_t ln_lds = (sg.plan[0].on && sg.p[0].relq_R) ? (size_t)64 * SLN_QROW + (size_t)64 * a3[0].relq_lpad * 2 : 0;
     hipLaunchKernelGGL(pool_slab_ln_kernel, dim3(ln_blocks, a3[0].B * a3[0].heads, 3), dim3(256), ln_lds,
                        (hipStream_t)stream, sg);

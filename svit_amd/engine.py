@@ -214,7 +214,9 @@ class Engine:
         self._side = None
         self._side_keep = []
         self._side_active = False
-        self.overlap_wgrad = False   # measured: TN beside the chain costs more than it hides
+        # weight-gradient GEMMs on a side stream beside the dgrad chain: off (round-1 measurement: the TN GEMM beside
+        # the chain cost more than it hid); SVIT_OVERLAP_WGRAD=1 is the A/B knob for re-measuring it
+        self.overlap_wgrad = os.environ.get("SVIT_OVERLAP_WGRAD", "0") == "1"
         self.attn_q_splits = 0      # 0 = heuristic; 1 = no query split in the dk/dv kernel
         # regression-diff mode: every reduction that normally meets in fp32 atomics (attention
         # dk/dv query splits, the row splits of the grouped weight-gradient GEMM) runs unsplit, so

@@ -368,7 +368,7 @@ def test_pool_tiled_stride1_equals_streaming(ops, sq, skv, thw):
         assert rel_err(got[i][0][..., :96], ref[i][0][..., :96]) < 2e-2 and cos(got[i][0][..., :96], ref[i][0][..., :96]) > 0.9999, i
         assert torch.equal(got[i][0][..., 96:][..., cols if modes[i] else slice(0, 0)], ref[i][0][..., 96:][..., cols if modes[i] else slice(0, 0)]), i
         assert rel_err(got[i][1], ref[i][1]) < 2e-2 and cos(got[i][1], ref[i][1]) > 0.9999, i
-        assert rel_err(got[i][2], ref[i][2]) < 1e-4 and rel_err(got[i][3], ref[i][3]) < 1e-4, i
+        assert rel_err(got[i][2], ref[i][2]) < 2e-4 and rel_err(got[i][3], ref[i][3]) < 2e-4, i   # (another conv summation order on the slab planes since round 4)
     # backward: dgrad tiled vs streaming
     dpres = [rnd("td%d%d" % (i, thw[1]), tuple(ref[i][1].shape), 1.0, BF16) for i in range(3)]
     dws_a = [torch.zeros(96, 27, device=DEV) for _ in range(3)]
@@ -764,14 +764,14 @@ def test_pool_slab_forward_vs_conv3d(ops, B, h, thw, sq, skv, n_obj):
     da = 128 if J <= 32 else 160
     res = []
     try:
-        for on in (0, 1):
+        for on in (0, 1, 2):       # streaming kernels / VALU slab conv / MFMA conv (falls back to the slab where ineligible)
             lib.svit_debug_set_pool(0, on)
             r = ops.pool_ln_fwd_qkv(qkv, ws, g, b, B, h, thw, n_obj, (sq, skv, skv), (da, da, 96), (0, 1, 0),
                                     sels=sels, out_scales=(1.0, KSC, 1.0))
             torch.cuda.synchronize()
             res.append(r)
     finally:
-        lib.svit_debug_set_pool(0, 1)
+        lib.svit_debug_set_pool(0, 2)      # the library's default
     for which, s in ((0, sq), (1, skv), (2, skv)):
         x = qkv[:, 1:1 + L, which].float()
         vol = x.reshape(B, T, H, W, h, 96).permute(0, 4, 5, 1, 2, 3).reshape(B * h, 96, T, H, W)
@@ -779,16 +779,23 @@ def test_pool_slab_forward_vs_conv3d(ops, B, h, thw, sq, skv, n_obj):
         ref = F.conv3d(vol, w, None, stride=(1, s, s), padding=1, groups=96)
         Lo = ref.shape[2] * ref.shape[3] * ref.shape[4]
         ref = ref.reshape(B, h, 96, -1).transpose(2, 3)
-        out, pre, mean, rstd = res[1][which]
-        assert rel_err(pre[:, :, 1:1 + Lo], ref) < 1e-2          # bf16 rounding of the stored value
         gain = R.object_gain(ws[which].to(BF16).float().cpu().reshape(96, 1, 3, 3, 3), (1, s, s))
         obj = qkv[:, 1 + L:, which].float().cpu().permute(0, 2, 1, 3) * gain
-        assert rel_err(pre[:, :, 1 + Lo:], obj) < 2e-2
-        assert torch.equal(pre[:, :, 0].cpu(), qkv[:, 0, which].cpu())
         so, sp, sm, sr = res[0][which]
         cols = slice(0, 96) if which == 0 else slice(None)     # q's bias columns are the gather's to write
-        assert rel_err(out[..., cols], so[..., cols]) < 2e-2
-        assert rel_err(mean, sm) < 1e-3 and rel_err(rstd, sr) < 1e-3
+        for path in (1, 2):
+            out, pre, mean, rstd = res[path][which]
+            assert rel_err(pre[:, :, 1:1 + Lo], ref) < 1e-2          # bf16 rounding of the stored value
+            assert rel_err(pre[:, :, 1 + Lo:], obj) < 2e-2
+            assert torch.equal(pre[:, :, 0].cpu(), qkv[:, 0, which].cpu())
+            assert rel_err(out[..., cols], so[..., cols]) < 2e-2
+            assert rel_err(mean, sm) < 1e-3 and rel_err(rstd, sr) < 1e-3
+        # the MFMA conv (round 4: banded-Toeplitz v_mfma_f32_4x4x4_16b_bf16 products) against the VALU slab conv:
+        # the same bf16 operands and fp32 accumulation, another summation order -- the stored bf16 values may differ
+        # in the last place on a few elements, nothing more
+        pm, ps = res[2][which][1].float(), res[1][which][1].float()
+        assert rel_err(pm, ps) < 8e-3
+        assert float(((pm - ps).abs() > 0.02 * ps.abs().max()).float().mean()) == 0.0
 
 
 # -------------------------------------------------------------------- fused attention ----

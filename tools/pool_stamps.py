@@ -20,3 +20,6 @@ s = np.frombuffer(buf, dtype=np.uint64).astype(np.int64)
 us = lambda i, j: (s[j] - s[i]) / 100.0
 print("slab fwd WG (q, cg 0, chunk 0, bh 3): decode %.2f | fill issue %.2f | gain %.2f | dma wait %.2f | barrier %.2f | conv %.2f | special %.2f | total %.2f us"
       % (us(0, 1) * 0, us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6), us(0, 6)))
+if s[8] and s[13]:
+    print("mfma fwd WG (q, cb 0, bh 3): zero halos + fill %.2f | gains + Toeplitz fragments %.2f | barrier %.2f | units %.2f | cls / objects %.2f | total %.2f us"
+          % (us(8, 9), us(9, 10), us(10, 11), us(11, 12), us(12, 13), us(8, 13)))
