@@ -501,6 +501,25 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
     if (stages == 3) return launch_v2<RB, NB, WM, WN, 3, 32>(a, st);           \
     return launch_v2<RB, NB, WM, WN, 4, 32>(a, st);                            \
   } while (0)
+  // round 4: ONE-ROUND tiles for the wide short-K GEMMs of the 14x14 stage.  At M = 13064 the 128-row tiles above put
+  // 824 (128x192) or 1236 (128x128) workgroups on 512-768 slots: a second, part-filled round in which the chip mostly
+  // stores.  160x256 (1 x 4 waves of 160x64) covers 13064 x 1536 with 82 x 6 = 492 workgroups, 192x192 (2 x 2 waves of
+  // 96x96) covers 13064 x 1152 with 69 x 6 = 414: every workgroup resident at once (two per CU), more flops per LDS-fill
+  // byte (91 / 96 against 77 / 64).  force_cfg 9 / 10 force them (SVIT_NT_ONE_ROUND=0: never, for A/Bs); heuristic: only where the grid is one
+  // round and the 128-row grid is not.
+  {
+    static const int one_round = getenv("SVIT_NT_ONE_ROUND") ? atoi(getenv("SVIT_NT_ONE_ROUND")) : 1;   // (in-step A/B knob)
+    const long t160 = a.N % 256 == 0 ? (long)((a.M + 159) / 160) * (a.N / 256) : 0;
+    const long t192 = a.N % 192 == 0 ? (long)((a.M + 191) / 192) * (a.N / 192) : 0;
+    const long t128 = (long)((a.M + 127) / 128) * ((a.N + 191) / 192);
+    const bool auto_ok = force_cfg < 0 && one_round && !force_stages && !force_bk && a.K <= 512 && t128 > 512;
+    if (force_cfg == 9 || (auto_ok && t160 > 256 && t160 <= 512)) {
+      if (a.N % 256 == 0) return launch_v2<5, 2, 1, 4, 2, 32>(a, st);
+    }
+    if (force_cfg == 10 || (auto_ok && t192 > 256 && t192 <= 512)) {
+      if (a.N % 192 == 0) return launch_v2<3, 3, 2, 2, 2, 32>(a, st);
+    }
+  }
   if (sq) SVIT_NT_PICK(2, 2, 2, 2);
   if (big) SVIT_NT_PICK(2, 3, 2, 2);
   SVIT_NT_PICK(1, 3, 4, 1);

@@ -1384,7 +1384,11 @@ __global__ __launch_bounds__(256) void relq_bwd_kernel(svit_relq_bwd_args a) {
   for (int i = threadIdx.x; i < tab_n; i += blockDim.x) prow[i] = tabs[i];
 }
 
+// n / d for n < 65536 by one multiply-high with m = ceil(2^32 / d) (exact while n * d < 2^32)
+__device__ __forceinline__ int fdiv(int n, unsigned m) { return (int)__umulhi((unsigned)n, m); }
+__device__ __forceinline__ unsigned fdiv_magic_dev(int d) { return 0xFFFFFFFFu / (unsigned)d + 1u; }   // = ceil(2^32 / d)
 #ifdef SVIT_POOL_STAMPS
+__device__ unsigned long long g_pm_wg[4 * 2048];      // per workgroup of pool_mfma_fwd_kernel: start, end, kind, hw id
 __device__ unsigned long long g_slab_stamps[16];
 #define PSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (pst) g_slab_stamps[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -1418,9 +1422,10 @@ __device__ __forceinline__ f32x4_t mfma4(s16x4_t a, s16x4_t b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a, b, c, 0, 0, 0);
 }
 constexpr int PM_SLOTS = 16, PM_ROWB = PM_SLOTS * 2;          // slots / bytes per image row
+constexpr int PM_NT = 512, PM_NW = PM_NT / 64;                  // threads / waves per workgroup: 4 waves per SIMD at 2 per CU
 __host__ __device__ inline int pm_plane_bytes(int H) { return H * PM_ROWB; }
 __host__ __device__ inline int pm_chan_bytes(int T, int H) { return (T + 2) * H * PM_ROWB + 8; }
-__host__ __device__ inline size_t pm_lds_bytes(int T, int H) { return (size_t)16 * pm_chan_bytes(T, H) + 4 * 2048 + 64; }
+__host__ __device__ inline size_t pm_lds_bytes(int T, int H) { return (size_t)16 * pm_chan_bytes(T, H) + PM_NW * 1024 + 64 + 16 * 27 * 4; }
 
 // G = output groups of 4 along x that are computed (a group past the row multiplies zero slots; nothing of it is stored)
 template <int S, int G>
@@ -1435,28 +1440,33 @@ __device__ __forceinline__ void pool_mfma_body(const svit_pool_args& a, int whic
   const int PP = pm_plane_bytes(H), CS = pm_chan_bytes(T, H);
   const size_t tok_stride = (size_t)3 * a.heads * HD;
   const bf16_t* src = (const bf16_t*)a.qkv + (size_t)b * N * tok_stride + ((size_t)which * a.heads + head) * HD + cb * 16;
-  unsigned char* ostage = lds + 16 * CS;             // 4 x 2 KiB output transposes, then the object gains
-  float* g_lds = (float*)(ostage + 4 * 2048);
+  unsigned char* ostage = lds + 16 * CS;             // PM_NW x 1 KiB output transposes, then the object gains
+  float* g_lds = (float*)(ostage + PM_NW * 1024);
 #ifdef SVIT_POOL_STAMPS
   const bool pst = which == 0 && cb == 0 && bh == 3 && tid == 0;
 #endif
   PSTAMP(8);
 
+  // ---- requests first: the 16 x 27 weights of the channel block go to LDS (one coalesced load) while the image fills
+  const int blk = lane >> 2, li = lane & 3;
+  float* w_lds = g_lds + 16;
+  if (tid < 16 * 27) w_lds[tid] = a.conv_w[(size_t)cb * 16 * 27 + tid];
   // ---- zero halo planes t = -1 and t = T of the 16 channels -------------------------------------------
   const int ppc = PP / 16;                           // 16-byte chunks per plane
-  for (int i = tid; i < 16 * 2 * ppc; i += blockDim.x) {
+  for (int i = tid; i < 16 * 2 * ppc; i += PM_NT) {
     const int c = i / (2 * ppc), r = i % (2 * ppc);
     *(uint4*)(lds + c * CS + (r < ppc ? 0 : (T + 1) * PP) + (r % ppc) * 16) = make_uint4(0u, 0u, 0u, 0u);
   }
   // ---- fill: task = (row of the volume, slot pair m, channel half); the loads of FB tasks per thread are requested
   // together (one memory round trip per batch instead of one per task) ------------------------------------------
   const int ntask = T * H * 16;
+  const unsigned mH = fdiv_magic_dev(H);
   constexpr int FB = 4;
-  for (int q0 = tid; q0 < ntask; q0 += FB * (int)blockDim.x) {
+  for (int q0 = tid; q0 < ntask; q0 += FB * PM_NT) {
     uint4 v0[FB], v1[FB];
 #pragma unroll
     for (int f = 0; f < FB; ++f) {
-      const int q = q0 + f * (int)blockDim.x;
+      const int q = q0 + f * PM_NT;
       const int half = q & 1, m = (q >> 1) & 7, row = q >> 4;
       const int x0 = 2 * m - 1, x1 = 2 * m;
       v0[f] = make_uint4(0u, 0u, 0u, 0u);
@@ -1466,10 +1476,10 @@ __device__ __forceinline__ void pool_mfma_body(const svit_pool_args& a, int whic
     }
 #pragma unroll
     for (int f = 0; f < FB; ++f) {
-      const int q = q0 + f * (int)blockDim.x;
+      const int q = q0 + f * PM_NT;
       if (q >= ntask) break;
       const int half = q & 1, m = (q >> 1) & 7, row = q >> 4;
-      const int t = row / H, y = row - t * H;
+      const int t = fdiv(row, mH), y = row - t * H;
       unsigned char* dst = lds + (half * 8) * CS + (t + 1) * PP + y * PM_ROWB + m * 4;
       const uint32_t w0[4] = {v0[f].x, v0[f].y, v0[f].z, v0[f].w}, w1[4] = {v1[f].x, v1[f].y, v1[f].z, v1[f].w};
 #pragma unroll
@@ -1480,7 +1490,8 @@ __device__ __forceinline__ void pool_mfma_body(const svit_pool_args& a, int whic
     }
   }
   PSTAMP(9);
-  // ---- object gain of the 16 channels (closed form of the cube branch) -------------
+  // ---- object gain of the 16 channels (closed form of the cube branch), read by the cls /
+  // object pass at the end: written before the barrier -----------------------------------------------------------
   if (tid < 16) {
     float nt3[3], nh3[3], ipt, iph;
     obj_counts(1, nt3, &ipt);
@@ -1491,35 +1502,38 @@ __device__ __forceinline__ void pool_mfma_body(const svit_pool_args& a, int whic
     for (int k = 0; k < 27; ++k) gsum += cw[k] * nt3[k / 9] * nh3[(k / 3) % 3] * nh3[k % 3];
     g_lds[tid] = gsum * ipt * iph * iph;
   }
+  __syncthreads();
   // ---- Toeplitz fragments: lane 4 blk + i holds row i of the band matrices of channel blk ----------------
-  const int blk = lane >> 2, li = lane & 3;
   s16x4_t afr[9][NA];
-  {
-    const float* cw = a.conv_w + (size_t)(cb * 16 + blk) * 27;
 #pragma unroll
-    for (int p = 0; p < 9; ++p) {
-      const bf16_t w3[3] = {f32_to_bf16(cw[p * 3]), f32_to_bf16(cw[p * 3 + 1]), f32_to_bf16(cw[p * 3 + 2])};
+  for (int p = 0; p < 9; ++p) {
+    const bf16_t w3[3] = {f32_to_bf16(w_lds[blk * 27 + p * 3]), f32_to_bf16(w_lds[blk * 27 + p * 3 + 1]),
+                          f32_to_bf16(w_lds[blk * 27 + p * 3 + 2])};
 #pragma unroll
-      for (int n = 0; n < NA; ++n)
+    for (int n = 0; n < NA; ++n)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          // input slot 4 (S g + n) + k against output position 4 g + li, whose first tap sits at slot S (4 g + li)
-          const int kx = 4 * n + k - S * li;
-          afr[p][n][k] = (short)((kx >= 0 && kx <= 2) ? w3[kx] : (bf16_t)0);
-        }
-    }
+      for (int k = 0; k < 4; ++k) {
+        // input slot 4 (S g + n) + k against output position 4 g + li, whose first tap sits at slot S (4 g + li)
+        const int kx = 4 * n + k - S * li;
+        afr[p][n][k] = (short)((kx >= 0 && kx <= 2) ? w3[kx] : (bf16_t)0);
+      }
   }
   PSTAMP(10);
-  __syncthreads();
   PSTAMP(11);
 
   // ---- units: (t-quad, output row) ---------------------------------------------------------------------------
   const unsigned lb = (unsigned)(blk * CS + li * PP);             // B operand: lane 4 blk + j reads plane j of the quad
-  unsigned char* ost = ostage + wave * 2048;
-  bf16_t* pre = (bf16_t*)a.pre + ((size_t)bh * Nout + 1) * HD + cb * 16;
+  unsigned char* ost = ostage + wave * 1024;
+  // transposed staging: [plane j (4)][x (8)][channel (16)] bf16 = 1 KiB, two x phases per unit; on the way out lane
+  // (token = lane >> 1, half = lane & 1) owns one 16-byte chunk
+  unsigned char* owr = ost + ((li * 8) * 16 + blk) * 2;
+  const int o_tt = lane >> 1, o_half = lane & 1, o_jj = o_tt >> 3, o_x = o_tt & 7;
+  const unsigned char* ord = ost + (o_tt * 16 + o_half * 8) * 2;
+  bf16_t* pre = (bf16_t*)a.pre + ((size_t)bh * Nout + 1) * HD + cb * 16 + o_half * 8;
   const int nunit = (T >> 2) * Ho;
-  for (int u = wave; u < nunit; u += (int)(blockDim.x >> 6)) {
-    const int tq = u / Ho, yo = u - tq * Ho;
+  int tq = 0, yo = wave;
+  while (yo >= Ho) { yo -= Ho; ++tq; }
+  for (int u = wave; u < nunit; u += PM_NW) {
     f32x4_t acc[G];
 #pragma unroll
     for (int g2 = 0; g2 < G; ++g2) acc[g2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -1553,23 +1567,27 @@ __device__ __forceinline__ void pool_mfma_body(const svit_pool_args& a, int whic
       }
     }
     // D[i][j]: lane 4 blk + j holds the outputs x = 4 g + i (register i) of plane 4 tq + j, channel blk.
-    // Transpose through LDS: [plane j][x][channel] bf16, 32 bytes per token.
+    // Transpose through LDS, 8 x positions (two groups) per phase.
+    bf16_t* prow = pre + (size_t)(((4 * tq + o_jj) * Ho + yo) * Wo) * HD;
 #pragma unroll
-    for (int g2 = 0; g2 < G; ++g2)
+    for (int ph = 0; ph < (G + 1) / 2; ++ph) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)        // (x positions past the row land in staging slots nobody reads)
-        *(bf16_t*)(ost + ((li * 16 + 4 * g2 + i) * 16 + blk) * 2) = f32_to_bf16(acc[g2][i]);
-    asm volatile("" ::: "memory");       // (the wave's own LDS operations complete in order; keep the compiler's order too)
-    for (int id = lane; id < 4 * Wo * 2; id += 64) {
-      const int tt = id >> 1, half = id & 1, jj = tt / Wo, xo = tt - jj * Wo;
-      const uint4 v = *(const uint4*)(ost + ((jj * 16 + xo) * 16 + half * 8) * 2);
-      *(uint4*)(pre + (size_t)(((4 * tq + jj) * Ho + yo) * Wo + xo) * HD + half * 8) = v;
+      for (int g2 = 2 * ph; g2 < 2 * ph + 2 && g2 < G; ++g2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          *(bf16_t*)(owr + ((4 * (g2 - 2 * ph) + i) * 16) * 2) = f32_to_bf16(acc[g2][i]);
+      asm volatile("" ::: "memory");     // (the wave's own LDS operations complete in order; keep the compiler's order too)
+      const uint4 v = *(const uint4*)ord;
+      const int xo = 8 * ph + o_x;
+      if (xo < Wo) *(uint4*)(prow + (size_t)xo * HD) = v;
+      asm volatile("" ::: "memory");
     }
-    asm volatile("" ::: "memory");
+    yo += PM_NW;
+    while (yo >= Ho) { yo -= Ho; ++tq; }
   }
   PSTAMP(12);
   // ---- cls and object tokens: pre = x, x * g(w) ------------------------------------------------------------------
-  for (int i = tid; i < (1 + a.n_obj) * 2; i += blockDim.x) {
+  for (int i = tid; i < (1 + a.n_obj) * 2; i += PM_NT) {
     const int idx = i >> 1, half = i & 1;
     const int tin = idx == 0 ? 0 : L + idx, tout = idx == 0 ? 0 : Lo + idx;
     float f[8];
@@ -1584,7 +1602,7 @@ __device__ __forceinline__ void pool_mfma_body(const svit_pool_args& a, int whic
 }
 
 struct PoolMfma3 { svit_pool_args p[3]; };
-__global__ __launch_bounds__(256, 2) void pool_mfma_fwd_kernel(PoolMfma3 g) {
+__global__ __launch_bounds__(PM_NT, 4) void pool_mfma_fwd_kernel(PoolMfma3 g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pm_lds[];
   // 1-D grid, XCD-aware like the slab kernel: consecutive logical ids run on one XCD, and the six channel
   // blocks of a (batch, head, tensor) are consecutive logical ids -- they read interleaved 32-byte pieces of
@@ -1597,6 +1615,13 @@ __global__ __launch_bounds__(256, 2) void pool_mfma_fwd_kernel(PoolMfma3 g) {
   const int cb = lg % 6; lg /= 6;
   const int nbh = g.p[0].B * g.p[0].heads;
   const int bh = lg % nbh, kind = lg / nbh;
+#ifdef SVIT_POOL_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 2048) {
+    g_pm_wg[4 * blockIdx.x] = wall_clock64();
+    g_pm_wg[4 * blockIdx.x + 2] = kind;
+    g_pm_wg[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+  }
+#endif
   for (int which = kind; which <= 2 * kind; ++which) {         // kind 0: q; kind 1: k, v
     const svit_pool_args& a = g.p[which];
     if (which == 2) __syncthreads();                             // every wave is done with k's image
@@ -1609,6 +1634,10 @@ __global__ __launch_bounds__(256, 2) void pool_mfma_fwd_kernel(PoolMfma3 g) {
       else pool_mfma_body<2, 1>(a, which, bh, cb, pm_lds);
     }
   }
+#ifdef SVIT_POOL_STAMPS
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x < 2048) g_pm_wg[4 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1630,9 +1659,6 @@ __global__ __launch_bounds__(256, 2) void pool_mfma_fwd_kernel(PoolMfma3 g) {
 //     of pool_ln_fwd_body: the results are bit-identical to the streaming kernel's.
 struct SlabPlan { int on, TC, YC, nt, ny; };
 constexpr int SLAB_NT = 1024;                 // threads per slab workgroup: every wave does at most one 64-token unit
-// n / d for n < 65536 by one multiply-high with m = ceil(2^32 / d) (exact while n * d < 2^32)
-__device__ __forceinline__ int fdiv(int n, unsigned m) { return (int)__umulhi((unsigned)n, m); }
-__device__ __forceinline__ unsigned fdiv_magic_dev(int d) { return 0xFFFFFFFFu / (unsigned)d + 1u; }   // = ceil(2^32 / d)
 struct PoolSlab3 { svit_pool_args p[3]; SlabPlan plan[3]; const uint32_t* sel[3]; int max_chunks; };
 constexpr int SLAB_MAXTOK = 1600;
 
@@ -1781,6 +1807,9 @@ __global__ __launch_bounds__(SLAB_NT) void pool_slab_fwd_kernel(PoolSlab3 g) {
 #ifdef SVIT_POOL_STAMPS
 extern "C" int svit_debug_pool_stamps(unsigned long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_slab_stamps), sizeof(unsigned long long) * n);
+}
+extern "C" int svit_debug_pool_wg_times(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pm_wg), sizeof(unsigned long long) * n);
 }
 #endif
 
@@ -2077,12 +2106,16 @@ static int pool_ln_fwd_qkv_kernels(const svit_pool_args* a3, const uint32_t* con
       mlds = std::max(mlds, pm_lds_bytes(a3[i].T, a3[i].H));
     }
     if (mfma && mlds > 160 * 1024) mfma = false;
+    // measured (tools/diag/pool_fwd_ab.sh, profiles/r04_pool_mfma_stencil.txt): ahead of the VALU slab kernel where its
+    // 12 B heads workgroups are ONE round at two per CU (blocks 4-13 of 16x224^2: 24.6 against 28.4 us), level or
+    // behind with more (blocks 14 / 15, 8 heads); SVIT_POOL_SLAB=3 forces it everywhere its geometry holds
+    if (mfma && g_pool_slab.load() != 3 && ((long)a3[0].B * a3[0].heads * 12 > 512 || 2 * mlds > 160 * 1024)) mfma = false;
     if (mfma) {
       static SvitOnce once_mfma;
       if (int rc = svit_max_lds_once(once_mfma, (const void*)pool_mfma_fwd_kernel, 160 * 1024)) return rc;
       PoolMfma3 mg;
       for (int i = 0; i < 3; ++i) mg.p[i] = a3[i];
-      hipLaunchKernelGGL(pool_mfma_fwd_kernel, dim3(a3[0].B * a3[0].heads * 2 * 6), dim3(256), mlds,
+      hipLaunchKernelGGL(pool_mfma_fwd_kernel, dim3(a3[0].B * a3[0].heads * 2 * 6), dim3(PM_NT), mlds,
                          (hipStream_t)stream, mg);
       SVIT_LAUNCH_CHECK();
     } else {

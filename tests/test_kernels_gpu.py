@@ -77,7 +77,7 @@ def test_gemm_nt_epilogues(ops, M, K, N):
 
 
 @pytest.mark.parametrize("M,N,K", [(700, 384, 128), (1333, 1152, 384), (2049, 768, 192), (515, 384, 2304),
-                                   (20000, 576, 96), (130, 96, 64), (3001, 288, 448)])
+                                   (20000, 576, 96), (130, 96, 64), (3001, 288, 448), (1301, 1536, 384)])
 def test_gemm_nt_tile_variants(ops, M, N, K):
     """every (tile, pipeline depth, K-step) variant the heuristic can pick gives the same product"""
     import ctypes as C
@@ -110,6 +110,26 @@ def test_gemm_nt_tile_variants(ops, M, N, K):
                 assert rel_err(out, ref + resid) < 1e-3, (cfg, st, "resid")
                 out = ops.gemm_nt(a, w, bias, hip.EPI_BF16)
                 assert rel_err(out, ref) < 1e-2, (cfg, st, "bf16")
+        # round 4: the one-round tiles of the wide short-K GEMMs (160x256: N % 256 == 0, 192x192: N % 192 == 0), every
+        # epilogue family the 14x14 stage runs them with (bf16, GELU with both outputs, GELU-backward, fp32)
+        dact = rnd("vd%d" % M, (M, N), 1.0, BF16)
+        for cfg in (9, 10):
+            if (cfg == 9 and N % 256) or (cfg == 10 and N % 192):
+                continue
+            lib.svit_debug_set(0, 0), lib.svit_debug_set(1, cfg), lib.svit_debug_set(2, 0)
+            out = ops.gemm_nt(a, w, bias, hip.EPI_F32)
+            assert rel_err(out, ref) < 1e-3, cfg
+            out = ops.gemm_nt(a, w, bias, hip.EPI_BF16)
+            assert rel_err(out, ref) < 1e-2, (cfg, "bf16")
+            out2 = torch.empty(M, N, device=DEV, dtype=BF16)
+            res = ops.gemm_nt(a, w, bias, hip.EPI_GELU, out2=out2)
+            out = res[0] if isinstance(res, tuple) else res
+            assert rel_err(out, F.gelu(ref)) < 1e-2, (cfg, "gelu")
+            rg = ref.clone().requires_grad_(True)
+            F.gelu(rg).sum().backward()
+            assert rel_err(out2, rg.grad) < 1.5e-2, (cfg, "gelu'")
+            out = ops.gemm_nt(a, w, None, hip.EPI_DGELU, aux=dact)
+            assert rel_err(out, (ref - bias) * dact.float()) < 1e-2, (cfg, "dgelu")
     finally:
         lib.svit_debug_set(0, 0), lib.svit_debug_set(1, -1), lib.svit_debug_set(2, 0)
 
@@ -764,7 +784,7 @@ def test_pool_slab_forward_vs_conv3d(ops, B, h, thw, sq, skv, n_obj):
     da = 128 if J <= 32 else 160
     res = []
     try:
-        for on in (0, 1, 2):       # streaming kernels / VALU slab conv / MFMA conv (falls back to the slab where ineligible)
+        for on in (0, 1, 3):       # streaming kernels / VALU slab conv / MFMA conv wherever its geometry holds (else the slab)
             lib.svit_debug_set_pool(0, on)
             r = ops.pool_ln_fwd_qkv(qkv, ws, g, b, B, h, thw, n_obj, (sq, skv, skv), (da, da, 96), (0, 1, 0),
                                     sels=sels, out_scales=(1.0, KSC, 1.0))
