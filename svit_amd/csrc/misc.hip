@@ -292,8 +292,9 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
 // ---- second stage of the two-stage parameter-gradient reductions --------------------------
 // One job = column sums of `partial` [nblocks][n] added into up to six destination vectors.  Up
 // to SVIT_REDUCE_MAX_JOBS jobs share a launch (blockIdx.y = job): a transformer block's backward
-// produces four of them (two LayerNorms, pooled-LN, conv wgrad), each latency-bound alone.
-constexpr int SVIT_REDUCE_MAX_JOBS = 6;
+// produces four of them (two LayerNorms, pooled-LN, conv wgrad), each latency-bound alone; since round 4 the host
+// schedule keeps a group of four blocks' jobs in the queue (rotating scratch regions) and runs them as one launch.
+constexpr int SVIT_REDUCE_MAX_JOBS = 16;     // (round 4: four transformer blocks' jobs per launch; 16 x 88 bytes of kernel argument)
 struct SvitReduceJob {
   const float* partial;
   int nblocks, n;

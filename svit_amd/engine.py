@@ -203,8 +203,13 @@ class Engine:
         self._tn = []           # weight-gradient GEMMs queued by the running block backward
         # a block's four second-stage reductions (LN2, pooled LN, conv wgrad, LN1) run as one
         # deferred launch: each producer gets its own region of this scratch (floats)
-        self._red_ws = torch.empty(18 * 1024 * 1024, device=self.dev, dtype=F32)
+        # round 4: RED_GROUP consecutive blocks share ONE deferred launch (17 -> 5 reduce launches per step): every
+        # block of a group owns its own copy of the scratch, the queue is run when the group's last block is done --
+        # in front of the gradient-ready callback of the data-parallel buckets, which are four blocks wide as well
+        self.RED_GROUP = int(os.environ.get("SVIT_RED_GROUP", "4"))      # (1 = one launch per block, the round-3 schedule)
         M1 = 1024 * 1024
+        self._red_ws = torch.empty(self.RED_GROUP * 18 * M1, device=self.dev, dtype=F32)
+        self._red_slot = 0
         self._red_regions = {"ln2": (0, 4 * M1), "ln1": (4 * M1, 8 * M1), "pln": (8 * M1, 9 * M1),
                              "wgrad": (9 * M1, 18 * M1)}
         # the grouped weight-gradient GEMM leaves the dgrad chain: it runs on a second stream next
@@ -399,7 +404,8 @@ class Engine:
         def ready(rank):
             if on_ready is not None:
                 if ready_ranks is None or rank in ready_ranks:
-                    self._flush_tn()            # gradients must be final here
+                    ops.reduce_flush()          # gradients must be final here: queued second-stage reductions ...
+                    self._flush_tn()            # ... and queued weight-gradient GEMMs
                     self._join()
                 on_ready(rank)
         plan, f = self.plan, self.flat
@@ -414,7 +420,11 @@ class Engine:
         for blk in reversed(plan.blocks):
             below = st["blocks"][blk.index - 1] if blk.index > 0 else None
             try:
-                dx, dx16 = self._block_bwd(blk, st["blocks"][blk.index], dx, dx16, st["n_obj"], below)
+                # second-stage reductions: queued per group of RED_GROUP blocks, one launch when the group's last block is done
+                G = self.RED_GROUP
+                dx, dx16 = self._block_bwd(blk, st["blocks"][blk.index], dx, dx16, st["n_obj"], below,
+                                           red_begin=blk.index % G == G - 1 or blk.index == depth - 1,
+                                           red_end=blk.index % G == 0, red_slot=blk.index % G)
             except BaseException:
                 # a failed launch / allocation inside the bracket: the queued second-stage
                 # reductions and weight-gradient GEMMs hold pointers into this step's scratch
@@ -436,7 +446,8 @@ class Engine:
 
     def _rws(self, key):
         a, b = self._red_regions[key]
-        return self._red_ws[a:b]
+        o = self._red_slot * 18 * 1024 * 1024
+        return self._red_ws[o + a:o + b]
 
     def _fork(self, fn, keep):
         """run fn() on the side stream, after everything enqueued so far on the current one"""
@@ -485,7 +496,7 @@ class Engine:
             return None
         return ops.gemm_nt(dy16, f.wt(wname), None, epilogue, out=out, aux=aux, accumulate=accumulate)
 
-    def _block_bwd(self, blk, sv, dx2, dy, n_obj, below):
+    def _block_bwd(self, blk, sv, dx2, dy, n_obj, below, red_begin=True, red_end=True, red_slot=0):
         """dx2: f32 grad of the block output; dy: bf16(DropPath_mlp * dx2) from the producing
         LayerNorm backward; below: saved state of block index-1 (its MLP DropPath scales the bf16
         copy of this block's input grad) or None for block 0."""
@@ -497,7 +508,11 @@ class Engine:
         M, Mq = B * N, B * Nq
         sq, skv = blk.stride_q[1], blk.stride_kv[1]
         thw, q_thw, k_thw = sv["thw"], sv["q_thw"], sv["k_thw"]
-        ops.reduce_defer(True)      # this block's second-stage reductions: one launch at its end
+        # this block's second-stage reductions are queued (red_begin opens the queue, red_end runs it: backward() keeps
+        # a group of RED_GROUP blocks in one queue, each block on its own scratch slot; a stand-alone call does both)
+        self._red_slot = red_slot
+        if red_begin:
+            ops.reduce_defer(True)
         # ---- MLP branch: x2 = x1 + dp * fc2(gelu(fc1(LN2(x1)))) ------------------------------
         dy = dy.view(Mq, Co)
         dh = self._linear_bwd(dy, sv["act"], pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", True,
@@ -586,7 +601,8 @@ class Engine:
                                 want_bf16=below is not None,
                                 row_scale=below["dpm"] if below is not None else None,
                                 rows_per_sample=N, ws=self._rws("ln1"))
-        ops.reduce_defer(False)     # runs the queued reductions
+        if red_end:
+            ops.reduce_defer(False)     # runs the queued reductions (of the group)
         self._flush_tn(force=False)
         if below is None:
             return res.view(B, N, C), None

@@ -137,6 +137,11 @@ def reduce_defer(on):
     hip.call("svit_reduce_defer", int(on))
 
 
+def reduce_flush():
+    """run the current stream's queued second-stage reductions now (the stream stays in deferred mode)"""
+    hip.call("svit_reduce_flush")
+
+
 def reduce_reset():
     """error path: drop the current stream's queued reductions and leave deferred mode"""
     hip.call("svit_reduce_reset")

@@ -61,9 +61,15 @@ def test_against_reference_golden(name, manifest, golden_dir):
     got = P.digest(extra["obj_desc"].detach().cpu())
     assert abs(got["l2"] - d["l2"]) / d["l2"] < 2e-2
     np.testing.assert_allclose(got["head"], d["head"], atol=0.08)
-    np.testing.assert_allclose(extra["pred_bboxes"].detach().cpu().numpy(), arrays["pred_bboxes"], atol=3e-2)
-    np.testing.assert_allclose(extra["pred_contact_state"].detach().cpu().numpy(),
-                               arrays["pred_contact_state"], atol=5e-2)
+    for key, atol in (("pred_bboxes", 3e-2), ("pred_contact_state", 5e-2)):
+        got_t = extra[key].detach().cpu()
+        if key in arrays:
+            np.testing.assert_allclose(got_t.numpy(), arrays[key], atol=atol)
+        else:      # more than 1024 elements (the batch of 8): the fixture holds the reference's digest
+            dk, gk = case["digests"][key], P.digest(got_t)
+            assert abs(gk["l2"] - dk["l2"]) / dk["l2"] < 2e-2, key
+            np.testing.assert_allclose(gk["head"], dk["head"], atol=atol)
+            np.testing.assert_allclose(gk["strided"], dk["strided"], atol=atol)
     # eval mode: probabilities
     if "eval_probs" in arrays:
         model.eval()
