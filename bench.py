@@ -423,9 +423,15 @@ def main():
         args.no_cpu_baseline = True
     if rank == 0 and not args.no_kernel_trace:
         from svit_amd import hip
+        # per-kernel HIP events need eager launches.  An event pair brackets the launch's dispatch as well as its
+        # execution: against the rocprofv3 kernel trace of the same command every launch reads ~2 us long (sum of the
+        # event durations 13.6 ms for a 12.8 ms step; queueing the traced step behind a 120-ms GPU-side spin, so that the
+        # host cannot starve the device, changed nothing: profiles/r04 notes in DESIGN.md 5d) -- the fractions below are
+        # therefore slightly LOW; profiles/*_bench_kernel_stats.csv holds the trace's durations
         hip.start_trace()
-        step(args.warmup + args.steps, eager=True)   # per-kernel HIP events need eager launches
+        step(args.warmup + args.steps, eager=True)
         rows, total = kernel_report(hip.stop_trace(), args.batch)
+        out["kernel_timing"] = "HIP events around every launch of one eager step (dispatch included: ~2 us per launch above the rocprofv3 trace)"
         out["kernels"] = rows[:12]
         out["phases_ms"] = dict(kernel_report.phases)
         out["kernel_ms_total"] = round(total, 3)
