@@ -439,9 +439,10 @@ int svit_debug_set_tn_tile(int mode);
 /* pooling (csrc/pool.hip): key 0 = forward path of the small planes: 0 streaming kernels, 1 VALU slab conv, 2 (default)
  * MFMA conv where it is ahead (blocks 4-13 of 16x224^2) and the slab elsewhere, 3 MFMA conv wherever its geometry holds. */
 int svit_debug_set_pool(int key, int val);
-/* attention (csrc/attn_bwd.hip): key 0 = dkv kernel form (0 heuristic, 1 four waves, 2 eight waves with query
- * halves), key 2 = run only one of the backward's two kernels (0 both, 1 dkv only, 2 dq only; timing only -- the
- * skipped outputs are not written).  (The forward's 4- / 8-wave choice is the environment knob SVIT_ATTN_FWD_NW.) */
+/* attention: key 0 = dkv kernel form (0 heuristic, 1 four waves, 2 eight waves with query halves), key 1 = forward
+ * kernel form (0 the 128-query kernels, 1 the one-wave-per-SIMD 64-rows-per-wave kernel of csrc/attn_fwd64.hip), key 2 =
+ * run only one of the backward's two kernels (0 both, 1 dkv only, 2 dq only; timing only -- the skipped outputs are not
+ * written).  (The 4- / 8-wave choice among the 128-query kernels is the environment knob SVIT_ATTN_FWD_NW.) */
 int svit_attn_debug_set(int key, int val);
 #ifdef __cplusplus
 }

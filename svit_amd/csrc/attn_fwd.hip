@@ -16,6 +16,7 @@
 // exchange, and the exponentiated tile feeds the PV MFMA as its B operand without leaving
 // registers.  O^T accumulates as 3 x (32 dv x 32 query) blocks.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include "attn_common.h"
 #include "../../include/svit_hip.h"
@@ -375,6 +376,12 @@ int launch_fwd(const svit_attn_fwd_args& a, hipStream_t st) {
 }
 }  // namespace
 
+int attn_fwd_w64_launch(const svit_attn_fwd_args* a, int ksu, void* stream);      // attn_fwd64.hip
+// forward kernel form: 0 = the 128-query kernels (4 / 8 waves by shape), 1 = the 64-rows-per-wave kernel of
+// attn_fwd64.hip (measured 1.5x slower on every shape of the model, profiles/r04_attn_w64.txt: kept for the record and
+// for its parity tests).  svit_attn_debug_set(1, v) / SVIT_ATTN_FWD_W64 for A/Bs.
+std::atomic<int> g_attn_fwd_form{getenv("SVIT_ATTN_FWD_W64") ? atoi(getenv("SVIT_ATTN_FWD_W64")) : 0};
+
 extern "C" int svit_attn_fwd(const svit_attn_fwd_args* a, void* stream) {
   if (!a || !a->qa || !a->ka || !a->v || !a->ctx || !a->lse2) return SVIT_ERR_ARG;
   if (a->B <= 0 || a->heads <= 0 || a->Nq <= 0 || a->Nk <= 0) return SVIT_ERR_SHAPE;
@@ -386,6 +393,8 @@ extern "C" int svit_attn_fwd(const svit_attn_fwd_args* a, void* stream) {
   // wave per SIMD reaches half the VALU issue rate; it lives on as tools/diag/attn_fwd2_experiment.hip)
   const int extra = a->DA - 96;
   const int bias_cols = a->bias_cols > 0 ? a->bias_cols : extra;
+  // round 4: the one-wave-per-SIMD, 64-rows-per-wave form (attn_fwd64.hip), on request only
+  if (g_attn_fwd_form.load() == 1) return attn_fwd_w64_launch(a, 6 + (bias_cols + 15) / 16, stream);
   switch (6 + (bias_cols + 15) / 16) {
     case 7: return launch_fwd<7>(*a, (hipStream_t)stream);
     case 8: return launch_fwd<8>(*a, (hipStream_t)stream);

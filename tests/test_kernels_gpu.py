@@ -916,6 +916,41 @@ def test_attention_fwd_pipelined_kernel(ops, B, h, Nq, Nk, DA, J):
 
 
 
+@pytest.mark.parametrize("B,h,Nq,Nk,DA,J", [
+    (2, 4, 1633, 457, 128, 22),    # blocks 4-13: 7 workgroups of 256 rows per (batch, head), a ragged last tile of 9 keys
+    (1, 2, 700, 1633, 160, 36),    # long keys, 9 k-steps
+    (2, 2, 300, 54, 128, 15),      # a single ragged tile, 7 k-steps (two softmax steps without an MFMA to hide behind)
+    (1, 1, 70, 128, 160, 64),      # two tiles, 10 k-steps
+    (1, 1, 257, 192, 128, 0),      # three tiles, one row in the second workgroup
+    (1, 2, 129, 330, 128, 22),     # six tiles
+])
+def test_attention_fwd_one_wave_per_simd_kernel(ops, B, h, Nq, Nk, DA, J):
+    """Round 4: the 64-rows-per-wave, one-wave-per-SIMD forward (csrc/attn_fwd64.hip) against the
+    fp32 reference and against the 128-query kernels.  It is NOT the product path (1.5x slower on every shape of the
+    model, profiles/r04_attn_w64.txt); svit_attn_debug_set(1, 1) selects it."""
+    import ctypes as C
+    from svit_amd import hip
+    lib = hip.load()
+    scale = 96 ** -0.5
+    qa = rnd("wq%d_%d" % (Nq, DA), (B, h, Nq, DA), 1.0, BF16)
+    ka = rnd("wk%d_%d" % (Nk, DA), (B, h, Nk, DA), KSC, BF16)
+    v = rnd("wv%d" % Nk, (B, h, Nk, 96), 1.0, BF16)
+    if J:
+        qa[..., 96 + J:] = 0
+        ka[..., 96 + J:] = 0
+    ctx0, lse0 = ops.attn_fwd(qa, ka, v, scale, bias_cols=J)
+    try:
+        assert lib.svit_attn_debug_set(1, 1) == 0
+        ctx, lse2 = ops.attn_fwd(qa, ka, v, scale, bias_cols=J)
+        torch.cuda.synchronize()
+    finally:
+        lib.svit_attn_debug_set(1, 0)
+    ref, s = _attn_ref(qa.float().cpu(), ka.float().cpu(), v.float().cpu(), scale)
+    assert rel_err(ctx, ref) < 2e-2 and cos(ctx, ref) > 0.9999
+    assert rel_err(lse2, torch.logsumexp(s, dim=-1) * math.log2(math.e)) < 1e-3
+    assert rel_err(ctx, ctx0) < 1e-2 and rel_err(lse2, lse0) < 1e-3      # (row sums: fp32 adds here, bf16 P on the matrix pipe there)
+
+
 @pytest.mark.parametrize("Nk,DA", [(9, 128), (54, 128), (100, 160), (457, 128)])
 def test_attention_ragged_tile_reads_nothing_past_the_keys(ops, Nk, DA):
     """K and V are views into larger NaN-filled buffers (including behind the LAST (batch, head)):
