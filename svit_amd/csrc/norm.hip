@@ -1,6 +1,8 @@
 // LayerNorm forward/backward over the fp32 residual stream -- HBM-bound:
 // one wave per row, float4 accesses, fp32 statistics; backward accumulates dgamma/dbeta in
 // registers over a grid-stride loop and flushes them with one atomic per column per block.
+#include <algorithm>
+#include <cstdlib>
 #include "common.h"
 #include "../../include/svit_hip.h"
 
@@ -261,7 +263,8 @@ extern "C" int svit_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x
   if (rows <= 0 || C <= 0 || C % 4 != 0 || C > 768) return SVIT_ERR_SHAPE;
   // one partial row per block feeds the reduce launch: few rows for small inputs (the reduce
   // is latency-bound on its row count), up to 2048 blocks for the big ones (bandwidth)
-  int64_t blocks = (rows + 31) / 32;
+  static const int rpb = getenv("SVIT_LN_BWD_RPB") ? std::max(4, atoi(getenv("SVIT_LN_BWD_RPB"))) : 32;   // (in-step A/B knob)
+  int64_t blocks = (rows + rpb - 1) / rpb;
   if (blocks < 256) blocks = (rows + 3) / 4 < 256 ? (rows + 3) / 4 : 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks > workspace_floats / (2 * C)) blocks = workspace_floats / (2 * C);
