@@ -263,7 +263,11 @@ extern "C" int svit_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x
   if (rows <= 0 || C <= 0 || C % 4 != 0 || C > 768) return SVIT_ERR_SHAPE;
   // one partial row per block feeds the reduce launch: few rows for small inputs (the reduce
   // is latency-bound on its row count), up to 2048 blocks for the big ones (bandwidth)
-  static const int rpb = getenv("SVIT_LN_BWD_RPB") ? std::max(4, atoi(getenv("SVIT_LN_BWD_RPB"))) : 32;   // (in-step A/B knob)
+  // rows per workgroup: 16 (round 4).  At 32 the 13064-row launches of the 14x14 stage were 409 workgroups = 6 waves per
+  // CU, too few bytes in flight for the HBM rate; in the step 16 and 8 are level and 0.10 ms ahead of 32
+  // (12.70 / 12.71 vs 12.81 ms; an isolated loop, whose operands sit in the Infinity Cache, shows no difference --
+  // the round-3 sweep).  SVIT_LN_BWD_RPB is the A/B knob.
+  static const int rpb = getenv("SVIT_LN_BWD_RPB") ? std::max(4, atoi(getenv("SVIT_LN_BWD_RPB"))) : 16;
   int64_t blocks = (rows + rpb - 1) / rpb;
   if (blocks < 256) blocks = (rows + 3) / 4 < 256 ? (rows + 3) / 4 : 256;
   if (blocks > 2048) blocks = 2048;
