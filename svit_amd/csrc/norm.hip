@@ -235,7 +235,8 @@ extern "C" int svit_layernorm_fwd(const float* x, const float* gamma, const floa
                                   int64_t rows, int C, float eps, void* stream) {
   if (!x || !gamma || !beta || (!y_bf16 && !y_f32)) return SVIT_ERR_ARG;
   if (rows <= 0 || C <= 0 || C % 4 != 0 || C > 768) return SVIT_ERR_SHAPE;
-  int64_t blocks = (rows + 7) / 8;            // two rows in flight per (half-)wave
+  static const int rpb_f = getenv("SVIT_LN_FWD_RPB") ? std::max(4, atoi(getenv("SVIT_LN_FWD_RPB"))) : 8;     // (in-step A/B knob)
+  int64_t blocks = (rows + rpb_f - 1) / rpb_f;            // two rows in flight per (half-)wave
   if (blocks > 16384) blocks = 16384;
   if (blocks < 1) blocks = 1;
 #define SVIT_LN_FWD(NCH, HALF)                                                                \
