@@ -397,7 +397,8 @@ static void ring_choice(const svit_gemm_args& a, int* cfg, int* stages) {
   // few, long tiles: every 128x96 tile has a CU to itself -> 4-deep ring (3656 x 768 x 768..3072: -30 %)
   static const int k_min5 = getenv("SVIT_NT_RING_K5") ? atoi(getenv("SVIT_NT_RING_K5")) : 1024;     // (in-step A/B knobs)
   static const int t_max6 = getenv("SVIT_NT_RING_T6") ? atoi(getenv("SVIT_NT_RING_T6")) : 256;
-  if (t96 <= t_max6 && a.K >= 768) { *cfg = 6, *stages = 4; return; }
+  static const int s6 = getenv("SVIT_NT_RING_S6") ? atoi(getenv("SVIT_NT_RING_S6")) : 4;
+  if (t96 <= t_max6 && a.K >= 768) { *cfg = 6, *stages = (t96 > 256 ? 2 : s6); return; }   // (> 256 tiles: two workgroups per CU need the 2-stage ring)
   // long K, narrow output, enough 128x192 tiles for most CUs (13064 x 384 x 1152..2304: -6..-10 % in the
   // step, -15..-20 % isolated; on a par with hipBLASLt's 128x160x64 macro-tile)
   if (t192 >= 160 && a.N <= 768 && a.K >= k_min5) { *cfg = 5, *stages = 3; return; }
