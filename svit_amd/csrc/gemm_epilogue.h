@@ -1,6 +1,9 @@
 // Shared epilogue of the NT GEMM kernels (gemm.hip, gemm_v2.hip) -- gfx950.
 #pragma once
 #include "common.h"
+#ifndef SVIT_EPI_AHEAD      // slabs of epilogue operand lookahead: 1; 2 (a ring of three register sets) measured level in the step (round 4)
+#define SVIT_EPI_AHEAD 1
+#endif
 #include "../../include/svit_hip.h"
 
 // Each wave transposes its accumulators, 16 rows x (32*NB) columns at a time, through a
@@ -26,7 +29,10 @@ __device__ __forceinline__ void nt_epilogue_wide(const svit_gemm_args& p, f32x16
                                                  int lane, int wave) {
   constexpr int WN = 32 * NB, EP_LD = WN + 4, GPR = 4 * NB;     // 8-column groups per row
   float* stg = (float*)smem + wave * (16 * EP_LD);
-  uint4 aux_cur[NB], aux_nxt[NB];
+  // the saved gelu'(h) slabs are fetched SVIT_EPI_AHEAD 16-row slabs ahead through a ring of three register sets.  Two
+  // ahead was tried in round 4 (inside the step the slabs come from HBM, not from the Infinity Cache of an isolated
+  // loop): 12.66 / 12.68 vs 12.66 / 12.72 ms per step -- level; one stays (fewer live registers)
+  uint4 aux_ring[3][NB];
   auto fetch_aux = [&](int ih, uint4 (&dst)[NB]) {
     const int i = ih >> 1, half = ih & 1;
 #pragma unroll
@@ -47,7 +53,11 @@ __device__ __forceinline__ void nt_epilogue_wide(const svit_gemm_args& p, f32x16
       bias_r[it][1] = *(const float4*)(p.bias + col + 4);
     }
   }
-  if (EPI == SVIT_EPI_DGELU) fetch_aux(0, aux_cur);
+  constexpr int AHEAD = SVIT_EPI_AHEAD;
+  if (EPI == SVIT_EPI_DGELU) {
+    fetch_aux(0, aux_ring[0]);
+    if (AHEAD > 1 && 2 * RB > 1) fetch_aux(1, aux_ring[1]);
+  }
 #pragma unroll
   for (int ih = 0; ih < 2 * RB; ++ih) {
     const int i = ih >> 1, half = ih & 1;
@@ -57,7 +67,7 @@ __device__ __forceinline__ void nt_epilogue_wide(const svit_gemm_args& p, f32x16
       for (int rr = 0; rr < 8; ++rr)
         stg[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] =
             acc[i][j][half * 8 + rr];
-    if (EPI == SVIT_EPI_DGELU && ih + 1 < 2 * RB) fetch_aux(ih + 1, aux_nxt);
+    if (EPI == SVIT_EPI_DGELU && ih + AHEAD < 2 * RB) fetch_aux(ih + AHEAD, aux_ring[(ih + AHEAD) % 3]);
     nt_epi_sync<WAVE_PRIVATE>();
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
@@ -84,17 +94,13 @@ __device__ __forceinline__ void nt_epilogue_wide(const svit_gemm_args& p, f32x16
         o.x = pack_bf16x2(a[0], a[1]); o.y = pack_bf16x2(a[2], a[3]);
         o.z = pack_bf16x2(a[4], a[5]); o.w = pack_bf16x2(a[6], a[7]);
       } else {   // SVIT_EPI_DGELU: acc * saved gelu'(h)
-        const uint4 h = aux_cur[it];
+        const uint4 h = aux_ring[ih % 3][it];
         o.x = pack_bf16x2(v[0] * lo_bf16(h.x), v[1] * hi_bf16(h.x));
         o.y = pack_bf16x2(v[2] * lo_bf16(h.y), v[3] * hi_bf16(h.y));
         o.z = pack_bf16x2(v[4] * lo_bf16(h.z), v[5] * hi_bf16(h.z));
         o.w = pack_bf16x2(v[6] * lo_bf16(h.w), v[7] * hi_bf16(h.w));
       }
       *(uint4*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = o;
-    }
-    if (EPI == SVIT_EPI_DGELU) {
-#pragma unroll
-      for (int it = 0; it < NB; ++it) aux_cur[it] = aux_nxt[it];
     }
     if (ih + 1 < 2 * RB) nt_epi_sync<WAVE_PRIVATE>();
   }
@@ -184,7 +190,8 @@ __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&
   // staged / stored instead of exposing one memory round trip per 4 columns
   constexpr bool HAS_AUX = (EPI == SVIT_EPI_RESID || EPI == SVIT_EPI_DGELU || EPI == SVIT_EPI_F32);
   float* stg = (float*)smem + wave * (16 * EP_LD);
-  float4 aux_cur[NIT], aux_nxt[NIT];
+  float4 aux_ring[3][NIT];      // two slabs ahead, as in nt_epilogue_wide
+  constexpr int AHEAD = SVIT_EPI_AHEAD;
   const bool use_aux = HAS_AUX && (EPI != SVIT_EPI_F32 || p.accumulate);
   auto out_row = [&](int row) -> size_t {
     if (EPI == SVIT_EPI_F32 && p.remap_L > 0)
@@ -231,7 +238,10 @@ __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&
     rs_hi = p.row_scale[r_last / p.rows_per_sample];
     rs_boundary = (r_first / p.rows_per_sample + 1) * p.rows_per_sample;
   }
-  if (use_aux) fetch_aux(0, aux_cur);
+  if (use_aux) {
+    fetch_aux(0, aux_ring[0]);
+    if (AHEAD > 1 && 2 * RB > 1) fetch_aux(1, aux_ring[1]);
+  }
 #pragma unroll
   for (int ih = 0; ih < 2 * RB; ++ih) {
     const int i = ih >> 1, half = ih & 1;
@@ -241,7 +251,7 @@ __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&
       for (int rr = 0; rr < 8; ++rr)
         stg[((rr & 3) + 8 * (rr >> 2) + 4 * (lane >> 5)) * EP_LD + j * 32 + (lane & 31)] =
             acc[i][j][half * 8 + rr];
-    if (use_aux && ih + 1 < 2 * RB) fetch_aux(ih + 1, aux_nxt);
+    if (use_aux && ih + AHEAD < 2 * RB) fetch_aux(ih + AHEAD, aux_ring[(ih + AHEAD) % 3]);
     nt_epi_sync<WAVE_PRIVATE>();
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -276,28 +286,24 @@ __device__ __forceinline__ void nt_epilogue(const svit_gemm_args& p, f32x16_t (&
       } else if constexpr (EPI == SVIT_EPI_RESID) {
         const float s = rs_fast ? (row < rs_boundary ? rs_lo : rs_hi)
                                 : (p.row_scale ? p.row_scale[row / p.rows_per_sample] : 1.f);
-        const float4 res = aux_cur[it];
+        const float4 res = aux_ring[ih % 3][it];
         float4 o;
         o.x = res.x + s * v.x; o.y = res.y + s * v.y; o.z = res.z + s * v.z; o.w = res.w + s * v.w;
         *(float4*)((float*)p.out + (size_t)row * p.ldo + col) = o;
       } else if constexpr (EPI == SVIT_EPI_F32) {
         float4* o = (float4*)((float*)p.out + out_row(row) * p.ldo + col);
         if (p.accumulate) {
-          const float4 old = aux_cur[it];
+          const float4 old = aux_ring[ih % 3][it];
           v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
         }
         *o = v;
       } else if constexpr (EPI == SVIT_EPI_DGELU) {
-        const uint32_t hx = __float_as_uint(aux_cur[it].x), hy = __float_as_uint(aux_cur[it].y);
+        const uint32_t hx = __float_as_uint(aux_ring[ih % 3][it].x), hy = __float_as_uint(aux_ring[ih % 3][it].y);
         uint2 o;
         o.x = pack_bf16x2(v.x * lo_bf16(hx), v.y * hi_bf16(hx));
         o.y = pack_bf16x2(v.z * lo_bf16(hy), v.w * hi_bf16(hy));
         *(uint2*)((bf16_t*)p.out + (size_t)row * p.ldo + col) = o;
       }
-    }
-    if (use_aux) {
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) aux_cur[it] = aux_nxt[it];
     }
     if (ih + 1 < 2 * RB) nt_epi_sync<WAVE_PRIVATE>();
   }

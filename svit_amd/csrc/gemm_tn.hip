@@ -70,8 +70,11 @@ struct TnDma {
   __host__ __device__ static constexpr int swz_b(int row) { return ROWB == 384 ? ((row >> 1) & 1) : 0; }
 };
 using TnSmallD = TnDma<1, 4, 1, 64, 2>;     // 128 x 96 tiles, 64 rows per stage, 2 stages (56 KB)
-using TnBigD = TnDma<2, 2, 2, 32, 3>;       // 128 x 192 tiles, 32 rows per stage, 3 stages (60 KB)
-constexpr int TN_DMA_LDS = 2 * TnSmallD::STAGE > 3 * TnBigD::STAGE ? 2 * TnSmallD::STAGE : 3 * TnBigD::STAGE;
+#ifndef SVIT_TN_BIG_NS      // ring depth of the 128 x 192 tile (diagnostic builds: 4 = 80 KB, still two workgroups per CU)
+#define SVIT_TN_BIG_NS 3
+#endif
+using TnBigD = TnDma<2, 2, 2, 32, SVIT_TN_BIG_NS>;       // 128 x 192 tiles, 32 rows per stage, 3 stages (60 KB)
+constexpr int TN_DMA_LDS = 2 * TnSmallD::STAGE > SVIT_TN_BIG_NS * TnBigD::STAGE ? 2 * TnSmallD::STAGE : SVIT_TN_BIG_NS * TnBigD::STAGE;
 
 template <int OFF>
 __device__ __forceinline__ void tn_read_tr(s16x4_t& d, unsigned addr) {
