@@ -1929,8 +1929,9 @@ __global__ __launch_bounds__(256) void pool_slab_ln_kernel(PoolSlab3 g) {
 
 // grid.x of the persistent stencil kernels: token blocks are dealt round-robin to workgroups so
 // that about 1024 workgroups (2 per CU on two resident rounds) exist in total
-static unsigned persistent_x(int token_blocks, int other_dims) {
-  static const long want = getenv("SVIT_POOL_WGS") ? atol(getenv("SVIT_POOL_WGS")) : 1024;    // (in-step A/B knob)
+static unsigned persistent_x(int token_blocks, int other_dims, long want_override = 0) {
+  static const long want_env = getenv("SVIT_POOL_WGS") ? atol(getenv("SVIT_POOL_WGS")) : 1024;    // (in-step A/B knob)
+  const long want = want_override > 0 ? want_override : want_env;
   const long total = (long)token_blocks * other_dims;
   const long chunks = (total + want - 1) / want;
   long x = (token_blocks + chunks - 1) / chunks;
@@ -2091,7 +2092,8 @@ static int pool_ln_fwd_qkv_kernels(const svit_pool_args* a3, const uint32_t* con
       if (need > slds) slds = need;
       if ((unsigned)(pl.nt * pl.ny) > sgx) sgx = pl.nt * pl.ny;
       const int nout = 1 + a3[i].T * ((a3[i].H - 1) / s + 1) * ((a3[i].W - 1) / s + 1) + a3[i].n_obj;
-      ln_blocks = std::max(ln_blocks, (int)persistent_x((nout + 63) / 64, a3[0].B * a3[0].heads * 3));
+      static const long ln_want = getenv("SVIT_SLAB_LN_WGS") ? atol(getenv("SVIT_SLAB_LN_WGS")) : 2048;    // (in-step A/B: 1024 -> 2048 is -0.02..-0.04 ms)
+      ln_blocks = std::max(ln_blocks, (int)persistent_x((nout + 63) / 64, a3[0].B * a3[0].heads * 3, ln_want));
       ++n_slab;
     }
   }
