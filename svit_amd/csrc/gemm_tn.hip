@@ -235,7 +235,11 @@ __device__ __forceinline__ void tn_tile_dma(unsigned char* lds, const bf16_t* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = n0 + wn * 32 * RB + i * 32 + acc_row(r, lane);
+#ifdef SVIT_TN_FLUSH_PLAIN     // (diagnostic builds, TIMING ONLY: what the fp32 atomic flush costs against plain stores)
+        if (row < N) dW[(size_t)row * lddw + col] = acc[i][j][r];
+#else
         if (row < N) atomicAdd(dW + (size_t)row * lddw + col, acc[i][j][r]);
+#endif
       }
     }
   if (do_bias) {  // 16 threads share a column chunk: reduce through LDS, one atomic per column
