@@ -88,6 +88,11 @@ int svit_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
  * dgrad; ldd > R places a table inside a wider row, e.g. the concatenated rel-pos tables). */
 int svit_transpose_cast_batched(const float* src_base, void* dst_base, const int64_t* table,
                                 int n_mats, int max_tiles, void* stream);
+/* the same transposes, bf16 [R,C] -> bf16 [C,R], from the bf16 mirror of the weights (same table; offsets then index
+ * the mirror): what the step uses -- half the bytes of the fp32 form, 16-byte accesses both ways.  max_tiles counts
+ * 64 x 64 tiles here. */
+int svit_transpose_bf16_batched(const void* src_base, void* dst_base, const int64_t* table,
+                                int n_mats, int max_tiles, void* stream);
 /* dst(bf16)[R,ldd] = [src(f32)[R,C] | 0]: row-padded bf16 copy (patch-embed weight 441 -> 448). */
 int svit_pad_cast_rows(const float* src, void* dst, int R, int C, int ldd, void* stream);
 /* dst(bf16)[r,:] = scale[r/rows_per_sample] * src(f32)[row(r),:]   (DropPath backward).

@@ -50,6 +50,62 @@ __global__ void transpose_cast_kernel(const float* __restrict__ src_base,
   }
 }
 
+
+// the same batched transposes from the bf16 mirror (round 4: the fp32 form reads 137 MB for 69 MB of output with
+// 4-byte loads and 2-byte scattered stores; the mirror is written by the cast right before): 64 x 64 tiles, 16-byte
+// loads along source rows, 16-byte stores along destination rows where the run is whole and aligned, through an
+// LDS tile with odd-dword row pitch (the 8 two-byte column reads of a lane hit 8 different banks)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src_base,
+                                                             bf16_t* __restrict__ dst_base,
+                                                             const int64_t* __restrict__ table, int n_mats) {
+  constexpr int PITCH = 66;                                // bf16 elements per tile row (33 dwords)
+  __shared__ bf16_t tile[64 * PITCH];
+  const int mat = blockIdx.y;
+  if (mat >= n_mats) return;
+  const int64_t so = table[mat * 5 + 0], dof = table[mat * 5 + 1];
+  const int R = (int)table[mat * 5 + 2], C = (int)table[mat * 5 + 3];
+  const int64_t ldd = table[mat * 5 + 4];
+  const int tr = (R + 63) / 64, tc = (C + 63) / 64;
+  const int tid = threadIdx.x, ch = tid & 7, rr = tid >> 3;           // 8 chunks of 8 elements x 32 rows
+  const bool src_vec = ((so | C) & 7) == 0, dst_vec = ((dof | ldd) & 7) == 0;
+  for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+    const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int r = r0 + rr + 32 * pass, c = c0 + ch * 8;
+      alignas(16) bf16_t v[8];
+      if (src_vec && r < R && c + 8 <= C) {
+        *(uint4*)v = *(const uint4*)(src_base + so + (int64_t)r * C + c);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (r < R && c + e < C) ? src_base[so + (int64_t)r * C + c + e] : (bf16_t)0;
+      }
+      uint32_t* d = (uint32_t*)(tile + (rr + 32 * pass) * PITCH + ch * 8);    // 4-byte aligned (PITCH even)
+      const uint32_t* w = (const uint32_t*)v;
+      d[0] = w[0]; d[1] = w[1]; d[2] = w[2]; d[3] = w[3];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int cl = rr + 32 * pass, c = c0 + cl, r = r0 + ch * 8;     // destination row c, elements r .. r+7
+      alignas(16) bf16_t v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[(ch * 8 + e) * PITCH + cl];
+      if (c < C) {
+        bf16_t* o = dst_base + dof + (int64_t)c * ldd + r;
+        if (dst_vec && r + 8 <= R) {
+          *(uint4*)o = *(const uint4*)v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (r + e < R) o[e] = v[e];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void scale_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
                                   const float* __restrict__ row_scale, int rows_per_sample,
                                   int64_t rows, int cols, int gather_L, int gather_N,
@@ -421,6 +477,18 @@ extern "C" int svit_transpose_cast_batched(const float* src_base, void* dst_base
   int gx = max_tiles < 1 ? 1 : (max_tiles > 256 ? 256 : max_tiles);
   hipLaunchKernelGGL(transpose_cast_kernel, dim3(gx, n_mats), dim3(256), 0, (hipStream_t)stream,
                      src_base, (bf16_t*)dst_base, table, n_mats);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+
+extern "C" int svit_transpose_bf16_batched(const void* src_base, void* dst_base, const int64_t* table,
+                                           int n_mats, int max_tiles, void* stream) {
+  if (!src_base || !dst_base || !table || n_mats <= 0) return SVIT_ERR_ARG;
+  if (((uintptr_t)src_base | (uintptr_t)dst_base) & 15) return SVIT_ERR_ALIGN;
+  int gx = max_tiles < 1 ? 1 : (max_tiles > 256 ? 256 : max_tiles);
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3(gx, n_mats), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src_base, (bf16_t*)dst_base, table, n_mats);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }

@@ -156,8 +156,10 @@ class FlatParams:
         ops.cast_bf16(self.data, self.w16[:self.total])
         if self.pool_sel_index:
             ops.pool_weight_sel(self.data, self.pool_sel_off, self.pool_sel)
-        if self.n_t:
+        if self.n_t and os.environ.get("SVIT_TRANSPOSE_F32", "0") == "1":       # (in-step A/B knob: the round-3 form)
             ops.transpose_cast_batched(self.data, self.wT16, self.t_table, self.n_t, 256)
+        elif self.n_t:    # from the mirror the cast above just wrote: half the bytes of the fp32 source
+            ops.transpose_bf16_batched(self.w16, self.wT16, self.t_table, self.n_t, 256)
 
 
 def rel_sections(rows):

@@ -166,6 +166,14 @@ def transpose_cast_batched(src_flat, dst_flat, table, n_mats, max_tiles):
              max_tiles)
 
 
+def transpose_bf16_batched(src16_flat, dst_flat, table, n_mats, max_tiles):
+    """the same table of [R,C] -> [C,R] transposes, read from the bf16 mirror (offsets index the mirror)"""
+    _chk_dev(src16_flat, dst_flat, table)
+    assert src16_flat.dtype == BF16 and dst_flat.dtype == BF16
+    hip.call("svit_transpose_bf16_batched", ptr(src16_flat), ptr(dst_flat), ptr(table), n_mats,
+             max_tiles)
+
+
 def pad_cast_rows(src, dst):
     """dst bf16 [R,ldd] = [src f32 [R,C] | 0]."""
     _chk_dev(src, dst)

@@ -234,6 +234,34 @@ def test_transpose_cast_batched(ops):
         off += r * c
 
 
+def test_transpose_bf16_batched(ops):
+    """the step's form: from the bf16 mirror; odd shapes, a table placed inside a wider row (ldd > R), unaligned offsets"""
+    mats = [(96, 288, 96), (100, 37, 104), (768, 3072, 768), (27, 96, 64), (1536, 384, 1536)]
+    src_off, dst_off, so, do = [], [], 0, 3          # (dst base off by 3 elements: the scalar store path)
+    for r, c, ldd in mats:
+        src_off.append(so); dst_off.append(do)
+        so += (r * c + 7) // 8 * 8
+        do += c * ldd + 5
+    src = rnd("tpb", (so,), 1.0).to(BF16)
+    dst = torch.full((do + 8,), 7.0, device=DEV, dtype=BF16)
+    table = []
+    for (r, c, ldd), a, b in zip(mats, src_off, dst_off):
+        table += [a, b, r, c, ldd]
+    tab = torch.tensor(table, dtype=torch.int64, device=DEV)
+    ops.transpose_bf16_batched(src, dst, tab, len(mats), 256)
+    for (r, c, ldd), a, b in zip(mats, src_off, dst_off):
+        got = dst[b:b + c * ldd].reshape(c, ldd)
+        assert torch.equal(got[:, :r], src[a:a + r * c].reshape(r, c).t())
+        if ldd > r:
+            assert bool((got[:-1, r:] == 7.0).all())      # columns past R are not touched
+    # aligned destination (the product's layout): the 16-byte store path
+    dst2 = torch.zeros(so, device=DEV, dtype=BF16)
+    tab2 = torch.tensor(sum([[a, a, r, c, r] for (r, c, _), a in zip(mats, src_off)], []), dtype=torch.int64, device=DEV)
+    ops.transpose_bf16_batched(src, dst2, tab2, len(mats), 256)
+    for (r, c, _), a in zip(mats, src_off):
+        assert torch.equal(dst2[a:a + r * c].reshape(c, r), src[a:a + r * c].reshape(r, c).t())
+
+
 # -------------------------------------------------------------------------- LayerNorm ----
 @pytest.mark.parametrize("C", [96, 192, 384, 768])
 def test_layernorm(ops, C):
