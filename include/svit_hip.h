@@ -442,7 +442,8 @@ int svit_debug_set(int key, int val);
 int svit_debug_set_tn(int step_us_x100, int atomic_tbs_x100);
 int svit_debug_set_tn_tile(int mode);
 /* pooling (csrc/pool.hip): key 0 = forward path of the small planes: 0 streaming kernels, 1 VALU slab conv, 2 (default)
- * MFMA conv where it is ahead (blocks 4-13 of 16x224^2) and the slab elsewhere, 3 MFMA conv wherever its geometry holds. */
+ * MFMA conv where it is ahead (blocks 4-13 of 16x224^2) and the slab elsewhere, 3 MFMA conv wherever its geometry holds;
+ * key 1 = 1: planes up to 28x28 take the slab path too, cut in y (off by default: measured behind the streaming kernel). */
 int svit_debug_set_pool(int key, int val);
 /* attention: key 0 = dkv kernel form (0 heuristic, 1 four waves, 2 eight waves with query halves), key 1 = forward
  * kernel form (0 the 128-query kernels, 1 the one-wave-per-SIMD 64-rows-per-wave kernel of csrc/attn_fwd64.hip), key 2 =

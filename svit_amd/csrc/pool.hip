@@ -1385,8 +1385,11 @@ __global__ __launch_bounds__(256) void relq_bwd_kernel(svit_relq_bwd_args a) {
 }
 
 // n / d for n < 65536 by one multiply-high with m = ceil(2^32 / d) (exact while n * d < 2^32)
-__device__ __forceinline__ int fdiv(int n, unsigned m) { return (int)__umulhi((unsigned)n, m); }
-__device__ __forceinline__ unsigned fdiv_magic_dev(int d) { return 0xFFFFFFFFu / (unsigned)d + 1u; }   // = ceil(2^32 / d)
+// (d = 1: ceil(2^32 / 1) does not fit 32 bits and wraps to 0 -- fdiv takes m = 0 as "divide by one".  Round 3's y-chunked
+// slab planes divided by the rows of a chunk, which is 1 for a ragged last chunk: every output of that chunk landed in
+// its first t-plane -- the "wrong rows at stride 2" of DESIGN.md section 5c)
+__device__ __forceinline__ int fdiv(int n, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n; }
+__device__ __forceinline__ unsigned fdiv_magic_dev(int d) { return 0xFFFFFFFFu / (unsigned)d + 1u; }   // = ceil(2^32 / d); 0 for d = 1
 #ifdef SVIT_POOL_STAMPS
 __device__ unsigned long long g_pm_wg[4 * 2048];      // per workgroup of pool_mfma_fwd_kernel: start, end, kind, hw id
 __device__ unsigned long long g_slab_stamps[16];
@@ -2003,18 +2006,22 @@ static size_t tiled_lds_bytes(int W) {
 // launch has >= 256 workgroups.  Strides 1 and 2 only (a stride-4 / -8 stencil touches a small part
 // of the planes a slab would load), and only where `pre` is given (the LayerNorm launch reads it).
 static std::atomic<int> g_pool_slab{getenv("SVIT_POOL_SLAB") ? atoi(getenv("SVIT_POOL_SLAB")) : 2};   // tuning knob (svit_debug_set_pool(0, v) / env for in-step A/Bs): 0 = streaming kernels, 1 = VALU slab conv, 2 = MFMA conv where its geometry holds
+// key 1 of svit_debug_set_pool / SVIT_SLAB_YCHUNK: 1 = planes up to 28x28 take the slab path too, cut in y (round 3's
+// variant, off: measured below)
+static std::atomic<int> g_slab_ychunk{getenv("SVIT_SLAB_YCHUNK") ? atoi(getenv("SVIT_SLAB_YCHUNK")) : 0};
 static SlabPlan plan_slab(const svit_pool_args& a) {
   SlabPlan pl = {0, 0, 0, 0, 0};
   const int s = a.stride_hw;
+  const bool ychunk = g_slab_ychunk.load() == 1;
   // measured (tools/pool_one.py under rocprofv3, profiles/r03_pool_slab.txt): ahead of the streaming
   // kernel on the 14x14 and 7x7 planes (12 of 16 blocks), behind it on 28x28 and behind the tiled
   // stencil on 56x56 -- the conv phase is VALU-bound (27 v_dot2 per output channel) and a slab
   // workgroup serialises fill -> conv -> store with one 16-wave workgroup per CU (106 SGPRs)
-  if (!g_pool_slab.load() || s > 2 || !a.pre || a.H * a.W > 196) return pl;
+  if (!g_pool_slab.load() || s > 2 || !a.pre || a.H * a.W > (ychunk ? 784 : 196)) return pl;
   const int Ho = (a.H - 1) / s + 1;
   double best = 1e30;
   for (int tc = 1; tc <= a.T; ++tc)
-    for (int yc = Ho; yc <= Ho; ++yc) {     // whole planes only: the planes this path is used on (<= 14x14) fit
+    for (int yc = ychunk ? 1 : Ho; yc <= Ho; ++yc) {     // whole planes unless the y-chunk knob is on: the planes this path is used on (<= 14x14) fit
       const int pin = std::min(a.T, tc + 2), rin = std::min(a.H, s * (yc - 1) + 3);
       if ((long)pin * rin * a.W > SLAB_MAXTOK) continue;
       const double cost = ((double)pin / tc) * ((double)rin / (s * yc)) - 1e-6 * tc * yc;
@@ -2161,6 +2168,7 @@ static int pool_ln_fwd_qkv_kernels(const svit_pool_args* a3, const uint32_t* con
 
 extern "C" int svit_debug_set_pool(int key, int val) {   // tuning knob for tools/: 0 -> slab stencils on / off
   if (key == 0) g_pool_slab = val;
+  else if (key == 1) g_slab_ychunk = val;
   else return SVIT_ERR_ARG;
   return SVIT_OK;
 }

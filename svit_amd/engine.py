@@ -150,7 +150,8 @@ class FlatParams:
     TILED_MIN_PLANE = 2048
     # round 3: the slab stencil (csrc/pool.hip::pool_slab_fwd_kernel: input slab resident in LDS, scalar
     # weights, LayerNorm as a second row-wise launch) on the small planes -- 14x14 and 7x7, 12 of 16 blocks
-    SLAB_MAX_PLANE = 196
+    # (SVIT_SLAB_YCHUNK=1, the in-step A/B knob of the y-chunked 28x28 slab planes: csrc/pool.hip::plan_slab reads the same variable)
+    SLAB_MAX_PLANE = 784 if os.environ.get("SVIT_SLAB_YCHUNK", "0") == "1" else 196
 
     def refresh_low_precision(self):
         ops.cast_bf16(self.data, self.w16[:self.total])

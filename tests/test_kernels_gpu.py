@@ -780,15 +780,22 @@ def test_relpos_q(ops, q_thw, k_thw):
 
 
 
-@pytest.mark.parametrize("B,h,thw,sq,skv,n_obj", [
-    (2, 4, (8, 14, 14), 1, 2, 64),     # blocks 4-13 of 16x224^2
-    (1, 4, (16, 14, 14), 1, 2, 128),   # 32x224^2: three t-chunks per tensor
-    (1, 8, (16, 14, 14), 2, 1, 128),   # block 14 at 32 frames
-    (3, 4, (1, 14, 14), 1, 2, 4),      # frames pass (T' = 1)
-    (2, 8, (8, 7, 7), 1, 1, 64),       # block 15
-    (2, 2, (5, 9, 13), 2, 1, 8),       # odd plane, odd T
+@pytest.mark.parametrize("B,h,thw,sq,skv,n_obj,ychunk", [
+    (2, 4, (8, 14, 14), 1, 2, 64, False),     # blocks 4-13 of 16x224^2
+    (1, 4, (16, 14, 14), 1, 2, 128, False),   # 32x224^2: three t-chunks per tensor
+    (1, 8, (16, 14, 14), 2, 1, 128, False),   # block 14 at 32 frames
+    (3, 4, (1, 14, 14), 1, 2, 4, False),      # frames pass (T' = 1)
+    (2, 8, (8, 7, 7), 1, 1, 64, False),       # block 15
+    (2, 2, (5, 9, 13), 2, 1, 8, False),       # odd plane, odd T
+    # y-chunked planes (svit_debug_set_pool(1, 1); round 3's cut variant, its ragged-last-chunk division fixed in
+    # round 4 -- csrc/pool.hip::fdiv): 28x28 at strides 1 / 2 with T = 8 / 14 / 16, and a 14x14 plane cut in y
+    (2, 2, (8, 28, 28), 1, 2, 64, True),
+    (1, 2, (16, 28, 28), 2, 2, 128, True),
+    (1, 2, (14, 28, 28), 2, 2, 8, True),
+    (1, 4, (8, 14, 14), 1, 2, 64, True),
+    (1, 2, (3, 26, 22), 2, 2, 8, True),
 ])
-def test_pool_slab_forward_vs_conv3d(ops, B, h, thw, sq, skv, n_obj):
+def test_pool_slab_forward_vs_conv3d(ops, B, h, thw, sq, skv, n_obj, ychunk):
     """Round-3 slab stencil (csrc/pool.hip::pool_slab_fwd_kernel + pool_slab_ln_kernel; the path the
     engine takes on planes <= 14x14): pre-LN values against torch's depthwise conv3d on the same bf16
     operands, object / cls rows against the closed form, and out / mean / rstd against the streaming
@@ -812,6 +819,7 @@ def test_pool_slab_forward_vs_conv3d(ops, B, h, thw, sq, skv, n_obj):
     da = 128 if J <= 32 else 160
     res = []
     try:
+        lib.svit_debug_set_pool(1, 1 if ychunk else 0)
         for on in (0, 1, 3):       # streaming kernels / VALU slab conv / MFMA conv wherever its geometry holds (else the slab)
             lib.svit_debug_set_pool(0, on)
             r = ops.pool_ln_fwd_qkv(qkv, ws, g, b, B, h, thw, n_obj, (sq, skv, skv), (da, da, 96), (0, 1, 0),
@@ -819,7 +827,8 @@ def test_pool_slab_forward_vs_conv3d(ops, B, h, thw, sq, skv, n_obj):
             torch.cuda.synchronize()
             res.append(r)
     finally:
-        lib.svit_debug_set_pool(0, 2)      # the library's default
+        lib.svit_debug_set_pool(0, 2)      # the library's defaults
+        lib.svit_debug_set_pool(1, 0)
     for which, s in ((0, sq), (1, skv), (2, skv)):
         x = qkv[:, 1:1 + L, which].float()
         vol = x.reshape(B, T, H, W, h, 96).permute(0, 4, 5, 1, 2, 3).reshape(B * h, 96, T, H, W)
