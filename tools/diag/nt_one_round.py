@@ -8,22 +8,22 @@ import torch
 from svit_amd import hip, ops
 from tools.bench_kernels import rnd, timeit, DEV, BF16
 lib = hip.load()
-M = 13064
-for (N, K, epi, tag) in [(1536, 384, hip.EPI_GELU, "fc1+gelu"), (1536, 384, hip.EPI_DGELU, "fc2-dgrad"),
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 13064      # 25728 = the frames pass (128 frames x 201 tokens)
+for (N, K, epi, tag) in [(1536, 384, hip.EPI_GELU, "fc1+gelu"), (1536, 384, hip.EPI_GELU, "fc1 nosave"), (1536, 384, hip.EPI_DGELU, "fc2-dgrad"),
                          (1536, 384, hip.EPI_BF16, "bf16"), (1152, 384, hip.EPI_BF16, "qkv"),
                          (768, 384, hip.EPI_BF16, "N768"), (1536, 192, hip.EPI_GELU, "K192 gelu")]:
     a, w = rnd(M, K), rnd(N, K)
     bias = torch.zeros(N, device=DEV)
     aux = rnd(M, N) if epi == hip.EPI_DGELU else None
     out = torch.empty(M, N, device=DEV, dtype=BF16)
-    out2 = torch.empty(M, N, device=DEV, dtype=BF16) if epi == hip.EPI_GELU else None
+    out2 = torch.empty(M, N, device=DEV, dtype=BF16) if (epi == hip.EPI_GELU and tag != "fc1 nosave") else None
     res = []
     for cfg in (-1, 4, 0, 9, 10):
         if (cfg == 9 and N % 256) or (cfg in (0, 10) and N % 192) or (cfg == 4 and N % 128):
             res.append("cfg%d: -" % cfg)
             continue
         lib.svit_debug_set(1, cfg)
-        us = min(timeit(lambda: ops.gemm_nt(a, w, bias, epi, out=out, out2=out2, aux=aux), iters=40) for _ in range(3))
+        us = min(timeit(lambda: ops.gemm_nt(a, w, bias, epi, out=out, out2=out2, aux=aux, save=tag != "fc1 nosave"), iters=40) for _ in range(3))
         res.append("%s:%.1f" % ("auto" if cfg < 0 else "cfg%d" % cfg, us))
     lib.svit_debug_set(1, -1)
     wt = w.t().contiguous()
