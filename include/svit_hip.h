@@ -448,7 +448,8 @@ int svit_debug_set_pool(int key, int val);
 /* attention: key 0 = dkv kernel form (0 heuristic, 1 four waves, 2 eight waves with query halves), key 1 = forward
  * kernel form (0 the 128-query kernels, 1 the one-wave-per-SIMD 64-rows-per-wave kernel of csrc/attn_fwd64.hip), key 2 =
  * run only one of the backward's two kernels (0 both, 1 dkv only, 2 dq only; timing only -- the skipped outputs are not
- * written).  (The 4- / 8-wave choice among the 128-query kernels is the environment knob SVIT_ATTN_FWD_NW.) */
+ * written), key 3 = the forward's T' = 1 tile for Nk <= 64 (1 on (default), 0 the generic kernel).  (The 4- / 8-wave choice among
+ * the 128-query kernels is the environment knob SVIT_ATTN_FWD_NW.) */
 int svit_attn_debug_set(int key, int val);
 #ifdef __cplusplus
 }

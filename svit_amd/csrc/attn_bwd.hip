@@ -701,10 +701,12 @@ int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
 }  // namespace
 
 extern std::atomic<int> g_attn_fwd_form;      // attn_fwd.hip
+void attn_fwd_short_set(int v);               // attn_fwd.hip
 extern "C" int svit_attn_debug_set(int key, int val) {
   if (key == 0) g_dkv_halves = val;
   else if (key == 1) g_attn_fwd_form = val;
   else if (key == 2) g_bwd_skip = val;
+  else if (key == 3) attn_fwd_short_set(val);
   else return SVIT_ERR_ARG;
   return SVIT_OK;
 }

@@ -347,6 +347,215 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_kernel(svit
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------
+// T' = 1 tile (round 4): Nk <= 64 -- the single-frame passes (the reference's frames pass, tools/train_net.py:105-110, and
+// the image ranks: 7x7 pooled keys + cls + objects = 54 at every block).  One 64-key tile is the WHOLE key range, so there
+// is no ring, no online re-base and nothing for the waves of a workgroup to meet about after the K / V image has landed:
+//   * K and V of the (batch, head) arrive ONCE per workgroup (LDS-DMA, clamped rows past Nk) behind one barrier;
+//   * a workgroup is persistent over `tiles_per_wg` 128-query tiles; every wave walks its own 32-row sub-tiles with NO
+//     further barrier: Q fragments by row-per-lane loads issued ONE TILE AHEAD (the latency the generic kernel's prologue
+//     exposes per workgroup), scores, one exp2 per score relative to the tile's maximum, P.V, the row sum on the matrix
+//     pipe, output through a wave-private LDS region as whole 192-byte rows (+ the pooled-q residual);
+//   * the arithmetic is the generic kernel's first tile, operation for operation: results are bit-identical to it
+//     (tests/test_kernels_gpu.py::test_attention_fwd_short_key_tile).
+template <int KSU>
+__global__ __launch_bounds__(256, 2) void attn_fwd_short_kernel(svit_attn_fwd_args a, int tiles_per_wg) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int NP = (KSU + 1) / 2, KCOLS = NP * 32;
+  constexpr int K_BYTES = KT * KCOLS * 2, V_BYTES = KT * HD * 2, STAGE = K_BYTES + V_BYTES;
+  using KLoad = BufTile<KT, KCOLS, 4>;
+  using VLoad = BufTile<KT, HD, 4>;
+  constexpr int OROW = 208;            // bytes per staged output row (192 + pad: spreads the banks)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+  const int DA = a.DA;
+  const int wgid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int bh = wgid / gridDim.x, b = bh / a.heads, head = bh % a.heads;
+  const int ntiles = (a.Nq + 127) / 128;
+  const int t_begin = (wgid % gridDim.x) * tiles_per_wg, t_end = min(ntiles, t_begin + tiles_per_wg);
+  const bf16_t* qa = (const bf16_t*)a.qa + ((size_t)bh * a.Nq) * DA;
+  const bf16_t* ka = (const bf16_t*)a.ka + ((size_t)bh * a.Nk) * DA;
+  const bf16_t* vv = (const bf16_t*)a.v + ((size_t)bh * a.Nk) * HD;
+
+  KLoad kload;
+  VLoad vload;
+  kload.init(DA, wave, lane);
+  vload.init(HD, wave, lane);
+  const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)ka, 0, a.Nk * DA * 2, 0x00020000);
+  const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vv, 0, a.Nk * HD * 2, 0x00020000);
+  kload.issue_auto(krs, 0u, DA, a.Nk, smem, wave, lane);
+  vload.issue_auto(vrs, 0u, HD, a.Nk, smem + K_BYTES, wave, lane);
+  // the wave's Q fragments of its first tile (lane -> its own row, 16 bytes per k-step; rows past Nq re-read the last)
+  bf16x8_t qn[KSU];
+  auto load_q = [&](int tile) {
+    const int qc = min(tile * 128 + wave * 32 + (lane & 31), a.Nq - 1);
+#pragma unroll
+    for (int ks = 0; ks < KSU; ++ks) qn[ks] = *(const bf16x8_t*)(qa + (size_t)qc * DA + ks * 16 + hh * 8);
+  };
+  load_q(t_begin);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();        // the K / V image is complete; the only meeting point of the workgroup
+
+  bf16x8_t onesf;                      // A operand of the row-sum MFMA (row 0 = sum over the 16 keys of a P fragment)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) onesf[e] = (lane & 31) == 0 ? (__bf16)1.0f : (__bf16)0.0f;
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  unsigned kaddr[2], vaddr[2];
+  {
+    const int row = lane & 31, sw = (row >> 2) & 3;
+    kaddr[0] = lds0 + row * 64 + 16 * ((0 + hh) ^ sw);
+    kaddr[1] = lds0 + row * 64 + 16 * ((2 + hh) ^ sw);
+    const int cg = (lane >> 4) & 1, i = lane & 15, q = i >> 2, pp = i & 3;
+    const int r0 = 4 * hh, ch = 2 * cg + (pp >> 1);
+    const unsigned vb = lds0 + K_BYTES + 8 * (pp & 1);
+    vaddr[0] = vb + (r0 + q) * 64 + 16 * (ch ^ ((r0 >> 2) & 3));
+    vaddr[1] = vb + (r0 + 8 + q) * 64 + 16 * (ch ^ (((r0 + 8) >> 2) & 3));
+  }
+  unsigned char* ost = smem + STAGE + wave * (32 * OROW);      // wave-private output staging
+
+  auto walk = [&](auto HalfTag) {
+    constexpr bool HALF = decltype(HalfTag)::value == 1;       // Nk <= 32: only key block 0 is multiplied
+    constexpr int NKB = HALF ? 1 : 2;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      const int q0 = tile * 128 + wave * 32;
+      if (q0 >= a.Nq) break;                                   // (wave-uniform: this wave has no rows left)
+      const int qi = q0 + (lane & 31);
+      bf16x8_t qf[KSU];
+#pragma unroll
+      for (int ks = 0; ks < KSU; ++ks) qf[ks] = qn[ks];
+#pragma unroll
+      for (int ks = 0; ks < KSU; ++ks) asm volatile("" : "+v"(qf[ks]));
+      if (tile + 1 < t_end) load_q(tile + 1);                  // travels under this tile
+      // residual-pooling operand (the pooled q rows, in the row-major chunk order of the output stores)
+      uint4 qres[6];
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {
+        const int id = it * 64 + lane, row = id / 12, ch = id % 12;
+        const int q = min(q0 + row, a.Nq - 1);
+        qres[it] = *(const uint4*)(qa + (size_t)q * DA + ch * 8);
+      }
+      TrStream<6 * NKB, 3> vs;
+      auto rdv = [&](auto J, s16x4_t& lo, s16x4_t& hi) {
+        constexpr int i = decltype(J)::value, g = i / 3, j = i % 3;
+        lds_read_tr<g * 16 * 64 + j * KT * 64>(lo, vaddr[0]);
+        lds_read_tr<g * 16 * 64 + j * KT * 64>(hi, vaddr[1]);
+      };
+      vs.prologue(rdv);
+      f32x16_t s[2], zero;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+      RowStream<KSU * NKB, 4> ks_;
+      auto rdk = [&](auto J, bf16x8_t& d) {
+        constexpr int j = decltype(J)::value, kb = j / KSU, ks = j % KSU;
+        lds_read128<kb * 2048 + (ks >> 1) * KT * 64>(d, kaddr[ks & 1]);
+      };
+      ks_.prologue(rdk);
+      ks_.run(rdk, [&](auto J, const bf16x8_t& f) {
+        constexpr int j = decltype(J)::value, kb = j / KSU, ks = j % KSU;
+        s[kb] = mfma32(f, qf[ks], ks == 0 ? zero : s[kb]);
+      });
+      if (KT > a.Nk) {       // rows >= Nk hold re-read data (uniform branch)
+        asm volatile("; ragged key rows" ::: "memory");
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (kb * 32 + acc_row(r, lane) >= a.Nk) s[kb][r] = -INFINITY;
+      }
+      float mx;
+      if constexpr (HALF) {
+        mx = max3(s[0][0], s[0][1], s[0][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = max3(mx, s[0][r], s[0][r + 1]);
+        mx = fmaxf(mx, s[0][15]);
+      } else {
+        mx = max3(s[0][0], s[1][0], s[0][1]);
+        mx = max3(mx, s[1][1], s[0][2]);
+#pragma unroll
+        for (int r = 2; r < 15; ++r) mx = max3(mx, s[1][r], s[0][r + 1]);
+        mx = fmaxf(mx, s[1][15]);
+      }
+      mx = fmaxf(mx, other_half(mx));
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = fast_exp2(s[kb][r] - mx);
+      const bf16x8_t pf[4] = {acc_to_frag(s[0], 0), acc_to_frag(s[0], 1),
+                              HALF ? acc_to_frag(s[0], 0) : acc_to_frag(s[1], 0),
+                              HALF ? acc_to_frag(s[0], 1) : acc_to_frag(s[1], 1)};
+      f32x16_t o[3], lacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+      vs.run(rdv, [&](auto J, const bf16x8_t& f) {
+        constexpr int i = decltype(J)::value, g = i / 3, j = i % 3;
+        o[j] = mfma32(f, pf[g], o[j]);
+        if constexpr (j == 2) lacc = mfma32(onesf, pf[g], lacc);
+      });
+      // ---- normalise, stage the 32 x 96 tile, store whole rows with the pooled query added -------------------------
+      const float l_lo = __shfl(lacc[0], lane & 31, 64);
+      const float inv = 1.f / l_lo;
+      if (hh == 0 && qi < a.Nq) a.lse2[(size_t)bh * a.Nq + qi] = mx + log2f(l_lo);
+      {
+        unsigned char* orow = ost + (lane & 31) * OROW;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int dv = j * 32 + 8 * g + 4 * hh;
+            uint2 pk;
+            pk.x = pack_bf16x2(o[j][4 * g] * inv, o[j][4 * g + 1] * inv);
+            pk.y = pack_bf16x2(o[j][4 * g + 2] * inv, o[j][4 * g + 3] * inv);
+            *(uint2*)(orow + dv * 2) = pk;
+          }
+      }
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {
+        const int id = it * 64 + lane, row = id / 12, ch = id % 12;
+        const int q = q0 + row;
+        if (q < a.Nq) {
+          uint4 ov = *(const uint4*)(ost + row * OROW + ch * 16);
+          if (q > 0) {
+            const uint4 qq = qres[it];
+            ov.x = pack_bf16x2(lo_bf16(ov.x) + lo_bf16(qq.x), hi_bf16(ov.x) + hi_bf16(qq.x));
+            ov.y = pack_bf16x2(lo_bf16(ov.y) + lo_bf16(qq.y), hi_bf16(ov.y) + hi_bf16(qq.y));
+            ov.z = pack_bf16x2(lo_bf16(ov.z) + lo_bf16(qq.z), hi_bf16(ov.z) + hi_bf16(qq.z));
+            ov.w = pack_bf16x2(lo_bf16(ov.w) + lo_bf16(qq.w), hi_bf16(ov.w) + hi_bf16(qq.w));
+          }
+          *(uint4*)((bf16_t*)a.ctx + ((size_t)b * a.Nq + q) * a.heads * HD + head * HD + ch * 8) = ov;
+        }
+      }
+    }
+  };
+  if (a.Nk > 32) walk(Int<0>{});
+  else walk(Int<1>{});
+#endif
+}
+
+static std::atomic<int> g_attn_fwd_short{getenv("SVIT_ATTN_FWD_SHORT") ? atoi(getenv("SVIT_ATTN_FWD_SHORT")) : 1};   // tuning knob
+                                                                   // (svit_attn_debug_set(3, v)): 0 = Nk <= 64 runs the generic kernel too
+template <int KSU>
+int launch_short(const svit_attn_fwd_args& a, hipStream_t st) {
+  constexpr int NP = (KSU + 1) / 2;
+  const size_t lds = (size_t)(KT * NP * 32 * 2 + KT * HD * 2) + (size_t)4 * 32 * 208;
+  static SvitOnce once;
+  if (int rc = svit_max_lds_once(once, (const void*)attn_fwd_short_kernel<KSU>, lds)) return rc;
+  // ~two workgroups per CU in one round; a workgroup walks its share of the (batch, head)'s 128-query tiles
+  static const int want = getenv("SVIT_ATTN_SHORT_WGS") ? atoi(getenv("SVIT_ATTN_SHORT_WGS")) : 512;   // (in-step A/B knob)
+  const int ntiles = (a.Nq + 127) / 128, bh = a.B * a.heads;
+  int chunks = (want + bh - 1) / bh;
+  chunks = std::max(1, std::min(chunks, ntiles));
+  const int per = (ntiles + chunks - 1) / chunks;
+  chunks = (ntiles + per - 1) / per;
+  hipLaunchKernelGGL((attn_fwd_short_kernel<KSU>), dim3(chunks, bh), dim3(256), lds, st, a, per);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
 template <int KSU, int NW, int NS>
 int launch_cfg(const svit_attn_fwd_args& a, hipStream_t st) {
   constexpr int NP = (KSU + 1) / 2;
@@ -375,6 +584,8 @@ int launch_fwd(const svit_attn_fwd_args& a, hipStream_t st) {
   return wide ? launch_cfg<KSU, 8, 3>(a, st) : launch_cfg<KSU, 4, 2>(a, st);
 }
 }  // namespace
+static bool attn_fwd_short_on() { return g_attn_fwd_short.load() != 0; }
+void attn_fwd_short_set(int v) { g_attn_fwd_short = v; }      // svit_attn_debug_set(3, v), attn_bwd.hip
 
 int attn_fwd_w64_launch(const svit_attn_fwd_args* a, int ksu, void* stream);      // attn_fwd64.hip
 // forward kernel form: 0 = the 128-query kernels (4 / 8 waves by shape), 1 = the 64-rows-per-wave kernel of
@@ -395,6 +606,11 @@ extern "C" int svit_attn_fwd(const svit_attn_fwd_args* a, void* stream) {
   const int bias_cols = a->bias_cols > 0 ? a->bias_cols : extra;
   // round 4: the one-wave-per-SIMD, 64-rows-per-wave form (attn_fwd64.hip), on request only
   if (g_attn_fwd_form.load() == 1) return attn_fwd_w64_launch(a, 6 + (bias_cols + 15) / 16, stream);
+  // round 4: the T' = 1 tile -- the whole key range is one 64-key tile (frames pass, image ranks)
+  if (a->Nk <= KT && attn_fwd_short_on()) {
+    if (6 + (bias_cols + 15) / 16 == 7) return launch_short<7>(*a, (hipStream_t)stream);
+    if (6 + (bias_cols + 15) / 16 == 8) return launch_short<8>(*a, (hipStream_t)stream);
+  }
   switch (6 + (bias_cols + 15) / 16) {
     case 7: return launch_fwd<7>(*a, (hipStream_t)stream);
     case 8: return launch_fwd<8>(*a, (hipStream_t)stream);

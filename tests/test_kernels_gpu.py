@@ -988,6 +988,45 @@ def test_attention_fwd_one_wave_per_simd_kernel(ops, B, h, Nq, Nk, DA, J):
     assert rel_err(ctx, ctx0) < 1e-2 and rel_err(lse2, lse0) < 1e-3      # (row sums: fp32 adds here, bf16 P on the matrix pipe there)
 
 
+@pytest.mark.parametrize("B,h,Nq,Nk,J", [
+    (3, 2, 201, 54, 15),       # frames pass, 14x14 stage: two 128-query tiles per (batch, head)
+    (2, 1, 3141, 54, 15),      # frames pass, 56x56 stage: workgroups walk several tiles
+    (5, 8, 54, 54, 15),        # frames pass, last stage: one ragged tile
+    (2, 2, 130, 20, 9),        # at most 32 keys: half a tile
+    (1, 2, 789, 64, 0),        # exactly one full tile, every bias column carries data
+    (2, 3, 257, 33, 30),       # KSU = 8
+])
+def test_attention_fwd_short_key_tile(ops, B, h, Nq, Nk, J):
+    """Round 4, the T' = 1 tile (csrc/attn_fwd.hip::attn_fwd_short_kernel; VERDICT r3 item 8): Nk <= 64 runs a kernel of
+    its own -- K / V once per workgroup, waves persistent over 128-query tiles without further barriers.  Its arithmetic is
+    the generic kernel's first tile operation for operation: BIT-identical outputs (svit_attn_debug_set(3, 0) selects the
+    generic kernel), and the fp32 reference within the usual tolerance."""
+    from svit_amd import hip
+    lib = hip.load()
+    scale = 96 ** -0.5
+    DA = 128
+    qa = rnd("sq%d_%d" % (Nq, Nk), (B, h, Nq, DA), 1.0, BF16)
+    ka = rnd("sk%d_%d" % (Nq, Nk), (B, h, Nk, DA), KSC, BF16)
+    v = rnd("sv%d_%d" % (Nq, Nk), (B, h, Nk, 96), 1.0, BF16)
+    if J:
+        qa[..., 96 + J:] = 0
+        ka[..., 96 + J:] = 0
+    try:
+        assert lib.svit_attn_debug_set(3, 0) == 0
+        ctx0, lse0 = ops.attn_fwd(qa, ka, v, scale, bias_cols=J)
+        torch.cuda.synchronize()
+        assert lib.svit_attn_debug_set(3, 1) == 0
+        ctx = torch.full_like(ctx0, float("nan"))
+        ctx, lse2 = ops.attn_fwd(qa, ka, v, scale, bias_cols=J)
+        torch.cuda.synchronize()
+    finally:
+        lib.svit_attn_debug_set(3, 1)
+    assert torch.equal(ctx, ctx0) and torch.equal(lse2, lse0)
+    ref, s = _attn_ref(qa.float().cpu(), ka.float().cpu(), v.float().cpu(), scale)
+    assert rel_err(ctx, ref) < 2e-2 and cos(ctx, ref) > 0.9999
+    assert rel_err(lse2, torch.logsumexp(s, dim=-1) * math.log2(math.e)) < 1e-3
+
+
 @pytest.mark.parametrize("Nk,DA", [(9, 128), (54, 128), (100, 160), (457, 128)])
 def test_attention_ragged_tile_reads_nothing_past_the_keys(ops, Nk, DA):
     """K and V are views into larger NaN-filled buffers (including behind the LAST (batch, head)):

@@ -24,4 +24,4 @@ for blk, h, thw, sq, skv in [(0, 1, (1, 56, 56), 1, 8), (1, 2, (1, 56, 56), 2, 4
     Nk = 1 + ops.pooled(thw[1], skv) * ops.pooled(thw[2], skv) + n_obj
     mb = (qkv.numel() * 2 + Bf * h * (Nq * da + Nk * da + Nk * 96) * 2) / 1e6
     print("blk%-2d h=%d N=%5d Nq=%5d Nk=%3d | q %6.1f k %6.1f v %6.1f | fused no-save %6.1f  save %6.1f us | %.0f MB -> %.2f TB/s" %
-          (blk, h, N, Nq, Nk, t1[0], t1[1], t1[2], tf, ts, mb, mb / tf / 1e6 * 1e6 / 1e6), flush=True)
+          (blk, h, N, Nq, Nk, t1[0], t1[1], t1[2], tf, ts, mb, mb / tf), flush=True)      # MB / us = TB/s
