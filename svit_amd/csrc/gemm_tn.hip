@@ -64,16 +64,25 @@ struct TnDma {
   static constexpr int ROWA = TN * 2, ROWB = TK * 2;             // 256 B; 192 / 384 B
   static constexpr int A_BYTES = BM * ROWA, B_BYTES = BM * ROWB, STAGE = A_BYTES + B_BYTES;
   static constexpr int A_INSTR = A_BYTES / 1024, B_INSTR = B_BYTES / 1024;
-  static constexpr int PER = (A_INSTR + B_INSTR) / 4;            // DMA instructions per wave and stage
-  static_assert((A_INSTR + B_INSTR) % 4 == 0, "every wave issues the same number of pieces");
+  static constexpr int NW = WN * WK, NT = NW * 64;               // waves / threads of a workgroup
+  static constexpr int PER = (A_INSTR + B_INSTR) / NW;           // DMA instructions per wave and stage
+  static_assert((A_INSTR + B_INSTR) % NW == 0, "every wave issues the same number of pieces");
   __host__ __device__ static constexpr int swz_a(int row) { return row & 3; }
-  __host__ __device__ static constexpr int swz_b(int row) { return ROWB == 384 ? ((row >> 1) & 1) : 0; }
+  // 384-byte rows alternate between two bank offsets (one swizzle bit), rows that are a multiple of 256 bytes all
+  // start on the same bank (two bits, like A), 192-byte rows skew by themselves
+  __host__ __device__ static constexpr int swz_b(int row) { return ROWB == 384 ? ((row >> 1) & 1) : (ROWB % 256 == 0 ? (row & 3) : 0); }
 };
 using TnSmallD = TnDma<1, 4, 1, 64, 2>;     // 128 x 96 tiles, 64 rows per stage, 2 stages (56 KB)
 #ifndef SVIT_TN_BIG_NS      // ring depth of the 128 x 192 tile (diagnostic builds: 4 = 80 KB, still two workgroups per CU)
 #define SVIT_TN_BIG_NS 3
 #endif
 using TnBigD = TnDma<2, 2, 2, 32, SVIT_TN_BIG_NS>;       // 128 x 192 tiles, 32 rows per stage, 3 stages (60 KB)
+#ifndef SVIT_TN_WIDE_NS
+#define SVIT_TN_WIDE_NS 4
+#endif
+// round 4: 128 x 384 tiles, EIGHT waves (2 x 4 of 64 x 96), 32 rows per stage (8 + 24 KB), one workgroup per CU: 48 flop per
+// staged byte against 38 (128 x 192) -- for the K % 384 == 0 problems (every Linear of the 14x14 and 7x7 stages)
+using TnWideD = TnDma<2, 2, 4, 32, SVIT_TN_WIDE_NS>;
 constexpr int TN_DMA_LDS = 2 * TnSmallD::STAGE > SVIT_TN_BIG_NS * TnBigD::STAGE ? 2 * TnSmallD::STAGE : SVIT_TN_BIG_NS * TnBigD::STAGE;
 
 template <int OFF>
@@ -94,11 +103,12 @@ __device__ __forceinline__ void tn_tile_dma(unsigned char* lds, const bf16_t* __
   if (m_begin >= m_end) return;
   // ---- per-lane source offsets of this wave's DMA pieces (stage-invariant)
   // (a wave's first A_INSTR / 4 pieces are A pieces wave, wave + 4, ...; the rest B pieces)
-  constexpr int PA = C::A_INSTR / 4;
-  static_assert(C::A_INSTR % 4 == 0 && C::B_INSTR % 4 == 0, "pieces split evenly over the four waves");
+  constexpr int NW = C::NW, NT = C::NT;
+  constexpr int PA = C::A_INSTR / NW;
+  static_assert(C::A_INSTR % NW == 0 && C::B_INSTR % NW == 0, "pieces split evenly over the waves");
   unsigned voff[PER];
   const int na8 = (N - n0 + 7) / 8, nb8 = (K - k0 + 7) / 8;     // valid 16-byte column chunks of this tile
-  auto piece = [&](int i, bool a) { return wave + 4 * (a ? i : i - PA); };
+  auto piece = [&](int i, bool a) { return wave + NW * (a ? i : i - PA); };
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const bool a = i < PA;
@@ -175,14 +185,15 @@ __device__ __forceinline__ void tn_tile_dma(unsigned char* lds, const bf16_t* __
     const unsigned so = (unsigned)((s % NS) * C::STAGE);
     if (m_begin + (s + 1) * BM > m_end) {      // ragged last stage: the re-read rows count nothing
       const int valid = m_end - (m_begin + s * BM);
-      for (int c = tid; c < (BM - valid) * (C::ROWA / 16); c += 256)
+      for (int c = tid; c < (BM - valid) * (C::ROWA / 16); c += NT)
         *(uint4*)(lds + so + valid * C::ROWA + c * 16) = make_uint4(0, 0, 0, 0);
       __syncthreads();
     }
     if (do_bias) {
+      constexpr int CPR = C::TN / 8, RP = NT / CPR;       // 16-byte chunks per A row; rows per pass of the workgroup
 #pragma unroll
-      for (int r0 = 0; r0 < BM; r0 += 16) {
-        const int row = r0 + (tid >> 4), lc = tid & 15;
+      for (int r0 = 0; r0 < BM; r0 += RP) {
+        const int row = r0 + tid / CPR, lc = tid % CPR;
         uint4 u;    // (asm: a compiler-visible LDS load behind an LDS-DMA draws an s_waitcnt vmcnt(0))
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(u)
                      : "v"(lds0 + so + row * C::ROWA + ((((lc >> 2) ^ C::swz_a(row))) << 6) + (lc & 3) * 16) : "memory");
@@ -242,16 +253,18 @@ __device__ __forceinline__ void tn_tile_dma(unsigned char* lds, const bf16_t* __
 #endif
       }
     }
-  if (do_bias) {  // 16 threads share a column chunk: reduce through LDS, one atomic per column
+  if (do_bias) {  // RP threads share a column chunk: reduce through LDS, one atomic per column
+    constexpr int CPR = C::TN / 8, RP = NT / CPR;
+    static_assert(BM % RP == 0, "whole passes over a stage");
     __syncthreads();                  // (the ring is read by nobody any more)
-    float* red = (float*)lds;  // [16][128]
+    float* red = (float*)lds;  // [RP][TN]
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[(tid >> 4) * C::TN + (tid & 15) * 8 + e] = bsum[e];
+    for (int e = 0; e < 8; ++e) red[(tid / CPR) * C::TN + (tid % CPR) * 8 + e] = bsum[e];
     __syncthreads();
     if (tid < C::TN && n0 + tid < N) {
       float sum = 0.f;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) sum += red[g * C::TN + tid];
+      for (int g = 0; g < RP; ++g) sum += red[g * C::TN + tid];
       atomicAdd(dbias + n0 + tid, sum);
     }
   }
@@ -312,6 +325,26 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup g) {
     tn_tile_dma<TnSmallD>(lds, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.dW, p.lddw, p.M, p.N, p.K,
                           tn * TnSmall::TN, tk * TnSmall::TK, m_begin, min(p.M, m_begin + g.rows_per_split[pi]),
                           p.dbias, tk == 0);
+}
+
+// the same grid logic for groups whose problems all take 128 x 384 tiles (8 waves, dynamic LDS: NS x 32 KB)
+__global__ __launch_bounds__(512) void gemm_tn_grouped_wide_kernel(const TnGroup g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_w[];
+  const int nwg = gridDim.x, lin = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+  const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < SVIT_TN_GROUP_MAX; ++i)
+    if (i < g.count && bid >= g.first_block[i]) pi = i;
+  const svit_tn_problem& p = g.p[pi];
+  const int local = bid - g.first_block[pi];
+  const int tile = local % g.tiles[pi], split = local / g.tiles[pi];
+  const int tn = tile % g.tiles_n[pi], tk = tile / g.tiles_n[pi];
+  const int m_begin = split * g.rows_per_split[pi];
+  tn_tile_dma<TnWideD>(lds_w, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.dW, p.lddw, p.M, p.N, p.K,
+                       tn * TnWideD::TN, tk * TnWideD::TK, m_begin, min(p.M, m_begin + g.rows_per_split[pi]),
+                       p.dbias, tk == 0);
 }
 
 __global__ void colsum_kernel(const bf16_t* __restrict__ A, int lda, float* __restrict__ out,
@@ -392,9 +425,11 @@ static std::atomic<double> g_tn_atomic_tbs{tn_env("SVIT_TN_ATOMIC_TBS", 0.75)}; 
 // operands come from HBM, not from the Infinity Cache an isolated loop keeps them in, and fewer, fatter tiles
 // re-read less), 3: 128x192 where K % 192 == 0
 static std::atomic<int> g_tn_big{(int)tn_env("SVIT_TN_TILE", 2)};
+static std::atomic<int> g_tn_wide{(int)tn_env("SVIT_TN_WIDE", 0)};      // 1: 128 x 384 / 8-wave tiles for the groups whose K are all multiples of 384
 extern "C" int svit_debug_set_tn_tile(int mode) {
-  if (mode < 0 || mode > 3) return SVIT_ERR_ARG;
-  g_tn_big = mode;
+  if (mode < 0 || mode > 7) return SVIT_ERR_ARG;
+  g_tn_big = mode & 3;
+  g_tn_wide = (mode >> 2) & 1;
   return SVIT_OK;
 }
 extern "C" int svit_debug_set_tn(int step_us_x100, int atomic_tbs_x100) {
@@ -437,6 +472,12 @@ static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void
     g.count = count - base < SVIT_TN_GROUP_MAX ? count - base : SVIT_TN_GROUP_MAX;
     long max_steps = 1;
     const int big_mode = g_tn_big.load();
+    // round 4: 128 x 384 / 8-wave tiles where EVERY problem of the group has K % 384 == 0 and N >= 128 (one launch = one
+    // block size); SVIT_TN_WIDE / svit_debug_set_tn_tile(4 | mode): A/B knob
+    bool wide = g_tn_wide.load() != 0;
+    for (int i = 0; i < g.count && wide; ++i)
+      wide = probs[base + i].K % TnWideD::TK == 0 && probs[base + i].N >= 128;
+    const long slots = wide ? 256 : 512;
     int bm[SVIT_TN_GROUP_MAX];
     double tile_bytes[SVIT_TN_GROUP_MAX];
     for (int i = 0; i < g.count; ++i) {
@@ -450,8 +491,9 @@ static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void
                                   (g.p[i].M <= 4096 || (g.p[i].M >= 32768 && g.p[i].M < 131072)))
                  : big_mode == 3 ? (g.p[i].K % TnBig::TK == 0 && g.p[i].N >= 128)
                                  : (big_mode == 2);
-      const int tn = g.big[i] ? TnBig::TN : TnSmall::TN, tk = g.big[i] ? TnBig::TK : TnSmall::TK;
-      bm[i] = g.big[i] ? TnBig::BM : TnSmall::BM;
+      if (wide) g.big[i] = 1;
+      const int tn = wide ? TnWideD::TN : g.big[i] ? TnBig::TN : TnSmall::TN, tk = wide ? TnWideD::TK : g.big[i] ? TnBig::TK : TnSmall::TK;
+      bm[i] = wide ? TnWideD::BM : g.big[i] ? TnBig::BM : TnSmall::BM;
       tile_bytes[i] = (double)tn * tk * 4.0;
       g.tiles_n[i] = (g.p[i].N + tn - 1) / tn;
       g.tiles[i] = g.tiles_n[i] * ((g.p[i].K + tk - 1) / tk);
@@ -473,7 +515,7 @@ static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void
         blocks += nb;
         flush += (double)nb * tile_bytes[i];
       }
-      const double t = (double)((blocks + 511) / 512) * steps * g_tn_step_us +
+      const double t = (double)((blocks + slots - 1) / slots) * steps * g_tn_step_us +
                        flush / (g_tn_atomic_tbs * 1e6);
       if (t < best) { best = t; best_steps = steps; }
     }
@@ -486,7 +528,14 @@ static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void
       total += g.tiles[i] * splits;
     }
     for (int i = g.count; i <= SVIT_TN_GROUP_MAX; ++i) g.first_block[i] = total;
-    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, g);
+    if (wide) {
+      static SvitOnce once_wide;
+      constexpr size_t wlds = (size_t)TnWideD::NS * TnWideD::STAGE;
+      if (int rc = svit_max_lds_once(once_wide, (const void*)gemm_tn_grouped_wide_kernel, wlds)) return rc;
+      hipLaunchKernelGGL(gemm_tn_grouped_wide_kernel, dim3(total), dim3(512), wlds, (hipStream_t)stream, g);
+    } else {
+      hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, g);
+    }
     SVIT_LAUNCH_CHECK();
   }
   return SVIT_OK;

@@ -175,13 +175,30 @@ def test_gemm_tn_grouped(ops, count, tile_mode):
     try:
         _tn_grouped_case(ops, count)
     finally:
-        lib.svit_debug_set_tn_tile(1)
+        lib.svit_debug_set_tn_tile(2)      # the library's default
 
 
-def _tn_grouped_case(ops, count):
-    shapes = [(1000, 288, 96), (4100, 384, 1536), (70, 96, 441), (13064, 384, 384), (333, 40, 96),
+def test_gemm_tn_grouped_wide_tiles(ops):
+    """Round 4: 128 x 384 tiles on 8-wave workgroups (svit_debug_set_tn_tile(4 | mode)) for groups whose problems all have
+    K % 384 == 0 and N >= 128 -- ragged rows (M % 32 != 0), a ragged N tile, row-strided A, with and without bias -- and a
+    group with one K = 96 problem, which must fall back to the 4-wave kernel."""
+    import ctypes as C
+    from svit_amd import hip
+    lib = hip.load()
+    lib.svit_debug_set_tn_tile.restype, lib.svit_debug_set_tn_tile.argtypes = C.c_int32, [C.c_int32]
+    assert lib.svit_debug_set_tn_tile(6) == 0
+    try:
+        _tn_grouped_case(ops, 8, [(4100, 384, 1536), (13064, 384, 384), (64, 3072, 768), (2000, 1152, 384),
+                                  (700, 768, 768), (3001, 1536, 384), (129, 128, 384), (500, 200, 384)])
+        _tn_grouped_case(ops, 3, [(4100, 384, 1536), (1000, 288, 96), (2000, 1152, 384)])
+    finally:
+        lib.svit_debug_set_tn_tile(2)
+
+
+def _tn_grouped_case(ops, count, shapes=None):
+    shapes = (shapes or [(1000, 288, 96), (4100, 384, 1536), (70, 96, 441), (13064, 384, 384), (333, 40, 96),
               (64, 3072, 768), (2000, 1152, 384), (5000, 96, 96), (129, 128, 96), (8000, 64, 96),
-              (700, 768, 768)][:count]
+              (700, 768, 768)])[:count]
     probs, refs = [], []
     for i, (M, N, K) in enumerate(shapes):
         wide = rnd("ga%d" % i, (M, N + 16), 1.0, BF16)
