@@ -76,7 +76,10 @@ using TnSmallD = TnDma<1, 4, 1, 64, 2>;     // 128 x 96 tiles, 64 rows per stage
 #ifndef SVIT_TN_BIG_NS      // ring depth of the 128 x 192 tile (diagnostic builds: 4 = 80 KB, still two workgroups per CU)
 #define SVIT_TN_BIG_NS 3
 #endif
-using TnBigD = TnDma<2, 2, 2, 32, SVIT_TN_BIG_NS>;       // 128 x 192 tiles, 32 rows per stage, 3 stages (60 KB)
+#ifndef SVIT_TN_BIG_BM      // reduction rows per stage of the 128 x 192 tile (diagnostic builds: 64 with 2 stages = half the barriers)
+#define SVIT_TN_BIG_BM 32
+#endif
+using TnBigD = TnDma<2, 2, 2, SVIT_TN_BIG_BM, SVIT_TN_BIG_NS>;       // 128 x 192 tiles, 32 rows per stage, 3 stages (60 KB)
 #ifndef SVIT_TN_WIDE_NS
 #define SVIT_TN_WIDE_NS 4
 #endif
@@ -493,7 +496,7 @@ static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void
                                  : (big_mode == 2);
       if (wide) g.big[i] = 1;
       const int tn = wide ? TnWideD::TN : g.big[i] ? TnBig::TN : TnSmall::TN, tk = wide ? TnWideD::TK : g.big[i] ? TnBig::TK : TnSmall::TK;
-      bm[i] = wide ? TnWideD::BM : g.big[i] ? TnBig::BM : TnSmall::BM;
+      bm[i] = wide ? TnWideD::BM : g.big[i] ? TnBigD::BM : TnSmall::BM;
       tile_bytes[i] = (double)tn * tk * 4.0;
       g.tiles_n[i] = (g.p[i].N + tn - 1) / tn;
       g.tiles[i] = g.tiles_n[i] * ((g.p[i].K + tk - 1) / tk);
