@@ -86,6 +86,8 @@ using TnBigD = TnDma<2, 2, 2, SVIT_TN_BIG_BM, SVIT_TN_BIG_NS>;       // 128 x 19
 // round 4: 128 x 384 tiles, EIGHT waves (2 x 4 of 64 x 96), 32 rows per stage (8 + 24 KB), one workgroup per CU: 48 flop per
 // staged byte against 38 (128 x 192) -- for the K % 384 == 0 problems (every Linear of the 14x14 and 7x7 stages)
 using TnWideD = TnDma<2, 2, 4, 32, SVIT_TN_WIDE_NS>;
+// the same tile on FOUR waves of 128 x 96 (one wave per SIMD): 14 transposed reads per 12 MFMAs instead of 10 per 6
+using TnWide4D = TnDma<4, 1, 4, 32, SVIT_TN_WIDE_NS>;
 constexpr int TN_DMA_LDS = 2 * TnSmallD::STAGE > SVIT_TN_BIG_NS * TnBigD::STAGE ? 2 * TnSmallD::STAGE : SVIT_TN_BIG_NS * TnBigD::STAGE;
 
 template <int OFF>
@@ -331,7 +333,8 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup g) {
 }
 
 // the same grid logic for groups whose problems all take 128 x 384 tiles (8 waves, dynamic LDS: NS x 32 KB)
-__global__ __launch_bounds__(512) void gemm_tn_grouped_wide_kernel(const TnGroup g) {
+template <class CFG>
+__global__ __launch_bounds__(CFG::NT, 1) void gemm_tn_grouped_wide_kernel(const TnGroup g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_w[];
   const int nwg = gridDim.x, lin = blockIdx.x;
   const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
@@ -345,9 +348,9 @@ __global__ __launch_bounds__(512) void gemm_tn_grouped_wide_kernel(const TnGroup
   const int tile = local % g.tiles[pi], split = local / g.tiles[pi];
   const int tn = tile % g.tiles_n[pi], tk = tile / g.tiles_n[pi];
   const int m_begin = split * g.rows_per_split[pi];
-  tn_tile_dma<TnWideD>(lds_w, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.dW, p.lddw, p.M, p.N, p.K,
-                       tn * TnWideD::TN, tk * TnWideD::TK, m_begin, min(p.M, m_begin + g.rows_per_split[pi]),
-                       p.dbias, tk == 0);
+  tn_tile_dma<CFG>(lds_w, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.dW, p.lddw, p.M, p.N, p.K,
+                   tn * CFG::TN, tk * CFG::TK, m_begin, min(p.M, m_begin + g.rows_per_split[pi]),
+                   p.dbias, tk == 0);
 }
 
 __global__ void colsum_kernel(const bf16_t* __restrict__ A, int lda, float* __restrict__ out,
@@ -430,9 +433,9 @@ static std::atomic<double> g_tn_atomic_tbs{tn_env("SVIT_TN_ATOMIC_TBS", 0.75)}; 
 static std::atomic<int> g_tn_big{(int)tn_env("SVIT_TN_TILE", 2)};
 static std::atomic<int> g_tn_wide{(int)tn_env("SVIT_TN_WIDE", 0)};      // 1: 128 x 384 / 8-wave tiles for the groups whose K are all multiples of 384
 extern "C" int svit_debug_set_tn_tile(int mode) {
-  if (mode < 0 || mode > 7) return SVIT_ERR_ARG;
+  if (mode < 0 || mode > 11) return SVIT_ERR_ARG;
   g_tn_big = mode & 3;
-  g_tn_wide = (mode >> 2) & 1;
+  g_tn_wide = (mode >> 2) & 3;       // 1: eight waves of 64 x 96, 2: four waves of 128 x 96
   return SVIT_OK;
 }
 extern "C" int svit_debug_set_tn(int step_us_x100, int atomic_tbs_x100) {
@@ -532,10 +535,15 @@ static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void
     }
     for (int i = g.count; i <= SVIT_TN_GROUP_MAX; ++i) g.first_block[i] = total;
     if (wide) {
-      static SvitOnce once_wide;
+      static SvitOnce once_wide, once_wide4;
       constexpr size_t wlds = (size_t)TnWideD::NS * TnWideD::STAGE;
-      if (int rc = svit_max_lds_once(once_wide, (const void*)gemm_tn_grouped_wide_kernel, wlds)) return rc;
-      hipLaunchKernelGGL(gemm_tn_grouped_wide_kernel, dim3(total), dim3(512), wlds, (hipStream_t)stream, g);
+      if (g_tn_wide.load() == 2) {      // (the four-wave form of the same tile)
+        if (int rc = svit_max_lds_once(once_wide4, (const void*)gemm_tn_grouped_wide_kernel<TnWide4D>, wlds)) return rc;
+        hipLaunchKernelGGL(gemm_tn_grouped_wide_kernel<TnWide4D>, dim3(total), dim3(256), wlds, (hipStream_t)stream, g);
+      } else {
+        if (int rc = svit_max_lds_once(once_wide, (const void*)gemm_tn_grouped_wide_kernel<TnWideD>, wlds)) return rc;
+        hipLaunchKernelGGL(gemm_tn_grouped_wide_kernel<TnWideD>, dim3(total), dim3(512), wlds, (hipStream_t)stream, g);
+      }
     } else {
       hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, g);
     }
