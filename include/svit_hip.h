@@ -438,8 +438,8 @@ int svit_debug_set(int key, int val);
 /* grouped TN GEMM (csrc/gemm_tn.hip): cost-model constants of the row-chunk planner (x 0.01: microseconds per
  * k-step, TB/s of the fp32-atomic flush; <= 0 leaves a constant unchanged), and the tile mode (0: 128x96 only,
  * 1: per-problem heuristic fitted on isolated launches, 2: 128x192 everywhere (default), 3: 128x192 where
- * K % 192 == 0; + 4 / + 8: 128x384 tiles on 8-wave (64x96 per wave) / 4-wave (128x96 per wave) workgroups for the groups whose
- * problems all have K % 384 == 0). */
+ * K % 192 == 0; + 4 / + 8 / + 12: 128x384 tiles on 8-wave (64x96 per wave) / 4-wave (128x96 per wave) workgroups / the ring form (8 MFMA
+ * waves + 4 loader waves) for the groups whose problems all have K % 384 == 0). */
 int svit_debug_set_tn(int step_us_x100, int atomic_tbs_x100);
 int svit_debug_set_tn_tile(int mode);
 /* pooling (csrc/pool.hip): key 0 = forward path of the small planes: 0 streaming kernels, 1 VALU slab conv, 2 (default)

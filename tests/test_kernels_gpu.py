@@ -187,11 +187,12 @@ def test_gemm_tn_grouped_wide_tiles(ops):
     lib = hip.load()
     lib.svit_debug_set_tn_tile.restype, lib.svit_debug_set_tn_tile.argtypes = C.c_int32, [C.c_int32]
     try:
-        for mode in (6, 10):       # eight waves of 64 x 96 / four waves of 128 x 96
+        for mode in (6, 10, 14):       # eight waves of 64 x 96 / four waves of 128 x 96 / ring form (8 MFMA + 4 loader waves)
             assert lib.svit_debug_set_tn_tile(mode) == 0
             _tn_grouped_case(ops, 8, [(4100, 384, 1536), (13064, 384, 384), (64, 3072, 768), (2000, 1152, 384),
                                       (700, 768, 768), (3001, 1536, 384), (129, 128, 384), (500, 200, 384)])
             _tn_grouped_case(ops, 3, [(4100, 384, 1536), (1000, 288, 96), (2000, 1152, 384)])
+        _tn_grouped_case(ops, 11)          # (mode 14 still set: a mixed group is split into a ring launch and a 4-wave launch)
     finally:
         lib.svit_debug_set_tn_tile(2)
 
