@@ -501,7 +501,10 @@ struct TnGroup {
   int count;
 };
 
-__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup g) {
+#ifndef SVIT_TN_WPE         // waves per SIMD the grouped kernel is compiled for (diagnostic builds: 3 with SVIT_TN_BIG_NS=2 = three workgroups per CU)
+#define SVIT_TN_WPE 2
+#endif
+__global__ __launch_bounds__(256, SVIT_TN_WPE) void gemm_tn_grouped_kernel(const TnGroup g) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[TN_DMA_LDS];
   // Logical ids are (problem, split)-major, tile-minor: the tiles of one split walk the SAME
   // rows in lock-step and re-read each other's A / B column panels (A once per k-tile, B once
@@ -717,7 +720,8 @@ static int tn_grouped_launch(const svit_tn_problem* probs, int count, int ordere
     bool wide = g_tn_wide.load() >= 1 && g_tn_wide.load() <= 3;
     for (int i = 0; i < g.count && wide; ++i)
       wide = probs[base + i].K % TnWideD::TK == 0 && probs[base + i].N >= 128;
-    const long slots = wide ? 256 : 512;
+    static const long slots4 = (long)tn_env("SVIT_TN_SLOTS", 512);      // resident 4-wave workgroups the planner counts on (A/B knob)
+    const long slots = wide ? 256 : slots4;
     int bm[SVIT_TN_GROUP_MAX];
     double tile_bytes[SVIT_TN_GROUP_MAX];
     for (int i = 0; i < g.count; ++i) {
