@@ -237,19 +237,28 @@ __global__ void special_grads_kernel(const float* __restrict__ dx, float* __rest
   const int n_out = C + O * C + (add_pos ? Tx * C : 0);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_out) return;
+  // (round 4: the B*Tx / B*O terms of an element are summed in FIXED order, but their loads leave in batches of eight --
+  // as a plain loop the launch was a chain of 128 dependent-latency loads on eight CUs: 35 us)
   float acc = 0.f;
+  auto sum_terms = [&](int n_terms, auto&& addr) {
+    for (int j0 = 0; j0 < n_terms; j0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = j0 + e < n_terms ? dx[addr(j0 + e)] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += v[e];
+    }
+  };
   if (i < C) {
-    for (int b = 0; b < B; ++b) acc += dx[(int64_t)b * N * C + i];
+    sum_terms(B, [&](int b) { return (int64_t)b * N * C + i; });
     g_cls[i] += acc;
   } else if (i < C + O * C) {
     const int o = (i - C) / C, c = (i - C) % C;
-    for (int b = 0; b < B; ++b)
-      for (int t = 0; t < Tx; ++t) acc += dx[((int64_t)b * N + 1 + L + t * O + o) * C + c];
+    sum_terms(B * Tx, [&](int j) { const int b = j / Tx, t = j % Tx; return ((int64_t)b * N + 1 + L + t * O + o) * C + c; });
     g_obj[o * C + c] += acc;
   } else {
     const int t = (i - C - O * C) / C, c = (i - C - O * C) % C;
-    for (int b = 0; b < B; ++b)
-      for (int o = 0; o < O; ++o) acc += dx[((int64_t)b * N + 1 + L + t * O + o) * C + c];
+    sum_terms(B * O, [&](int j) { const int b = j / O, o = j % O; return ((int64_t)b * N + 1 + L + t * O + o) * C + c; });
     g_pos[t * C + c] += acc;
   }
 }
