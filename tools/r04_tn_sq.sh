@@ -1,5 +1,5 @@
-# SQ counter passes over the grouped TN weight-gradient launches INSIDE one eager training step (GPU box):
-#   bash tools/r04_tn_sq.sh   -> gpurun_out/r04_tn_sq.txt
+# SQ counter passes over EVERY kernel of one eager training step (GPU box), summarised per family:
+#   bash tools/r04_tn_sq.sh   -> gpurun_out/r04_tn_sq.txt (grouped TN), r04_nt_sq.txt (NT GEMMs), r04_pool_sq.txt, r04_ln_sq.txt
 # (counters only with --kernel-trace; the program directly after `--`)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -14,6 +14,8 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
 done
 cd $R
 python3 tools/pmc_sq.py $(ls gpurun_out/pmc_tnsq?/*/*counter_collection.csv) --match gemm_tn_grouped > gpurun_out/r04_tn_sq.txt
-python3 tools/pmc_sq.py $(ls gpurun_out/pmc_tnsq?/*/*counter_collection.csv) --match gemm_nt_ring_kernel > gpurun_out/r04_ntring_sq.txt
+python3 tools/pmc_sq.py $(ls gpurun_out/pmc_tnsq?/*/*counter_collection.csv) --match gemm_nt_ > gpurun_out/r04_nt_sq.txt
+python3 tools/pmc_sq.py $(ls gpurun_out/pmc_tnsq?/*/*counter_collection.csv) --match pool_ > gpurun_out/r04_pool_sq.txt
+python3 tools/pmc_sq.py $(ls gpurun_out/pmc_tnsq?/*/*counter_collection.csv) --match ln_ > gpurun_out/r04_ln_sq.txt
 rm -rf gpurun_out/pmc_tnsq?
 cat gpurun_out/r04_tn_sq.txt
