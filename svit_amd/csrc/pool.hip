@@ -516,11 +516,19 @@ __device__ __forceinline__ void pool_ln_bwd_body(const svit_pool_ln_bwd_args& a,
   __shared__ float red[2][HD];
   for (int i = threadIdx.x; i < 2 * HD; i += blockDim.x) (&red[0][0])[i] = 0.f;
   __syncthreads();
-  const int sub = threadIdx.x & 3, c0 = sub * 24;
+  // channel map of a thread's 24 values: SVIT_POOL_LNB_MAP 1 (round 4) = three groups of 8 at 32 v + 8 sub -- the four lanes of a token
+  // read 64 contiguous bytes (bf16) / 128 (fp32) per instruction; 0 = one run of 24 at 24 sub (four 16-byte pieces 48 bytes apart)
+#ifndef SVIT_POOL_LNB_MAP
+#define SVIT_POOL_LNB_MAP 1
+#endif
+  const int sub = threadIdx.x & 3;
+  constexpr int GS = SVIT_POOL_LNB_MAP ? 32 : 8;          // element stride between a thread's groups of 8
+  const int c0 = SVIT_POOL_LNB_MAP ? sub * 8 : sub * 24;
+  auto chan = [&](int i) { return c0 + (i >> 3) * GS + (i & 7); };
   const int64_t total = (int64_t)a.B * a.heads * a.Nout;
   float gam[24], dg[24], db[24];
 #pragma unroll
-  for (int i = 0; i < 24; ++i) { gam[i] = a.gamma[c0 + i]; dg[i] = 0.f; db[i] = 0.f; }
+  for (int i = 0; i < 24; ++i) { gam[i] = a.gamma[chan(i)]; dg[i] = 0.f; db[i] = 0.f; }
   const int64_t iters = (total + (int64_t)gridDim.x * 64 - 1) / ((int64_t)gridDim.x * 64);
   for (int64_t it = 0; it < iters; ++it) {
     const int64_t row = (it * gridDim.x + blockIdx.x) * 64 + (threadIdx.x >> 2);
@@ -540,7 +548,7 @@ __device__ __forceinline__ void pool_ln_bwd_body(const svit_pool_ln_bwd_args& a,
           for (int part = 0; part < (a.main_parts > 1 ? a.main_parts : 1); ++part, p += a.main_part_stride) {
 #pragma unroll
             for (int v = 0; v < 6; ++v) {
-              const float4 f = *(const float4*)(p + v * 4);
+              const float4 f = *(const float4*)(p + (v >> 1) * GS + (v & 1) * 4);
               d[v * 4] += f.x; d[v * 4 + 1] += f.y; d[v * 4 + 2] += f.z; d[v * 4 + 3] += f.w;
             }
           }
@@ -549,7 +557,7 @@ __device__ __forceinline__ void pool_ln_bwd_body(const svit_pool_ln_bwd_args& a,
 #pragma unroll
           for (int v = 0; v < 3; ++v) {
             float f[8];
-            unpack8(*(const uint4*)(p + v * 8), f);
+            unpack8(*(const uint4*)(p + v * GS), f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) d[v * 8 + e] += f[e];
           }
@@ -560,7 +568,7 @@ __device__ __forceinline__ void pool_ln_bwd_body(const svit_pool_ln_bwd_args& a,
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
           float f[8];
-          unpack8(*(const uint4*)(p + v * 8), f);
+          unpack8(*(const uint4*)(p + v * GS), f);
 #pragma unroll
           for (int e = 0; e < 8; ++e) d[v * 8 + e] += f[e];
         }
@@ -569,7 +577,7 @@ __device__ __forceinline__ void pool_ln_bwd_body(const svit_pool_ln_bwd_args& a,
         const float* p = a.d_extra + row * HD + c0;
 #pragma unroll
         for (int v = 0; v < 6; ++v) {
-          const float4 f = *(const float4*)(p + v * 4);
+          const float4 f = *(const float4*)(p + (v >> 1) * GS + (v & 1) * 4);
           d[v * 4] += f.x; d[v * 4 + 1] += f.y; d[v * 4 + 2] += f.z; d[v * 4 + 3] += f.w;
         }
       }
@@ -577,7 +585,7 @@ __device__ __forceinline__ void pool_ln_bwd_body(const svit_pool_ln_bwd_args& a,
 #pragma unroll
       for (int v = 0; v < 3; ++v) {
         float f[8];
-        unpack8(*(const uint4*)(pp + v * 8), f);
+        unpack8(*(const uint4*)(pp + v * GS), f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) xh[v * 8 + e] = (f[e] - mean) * rstd;
       }
@@ -600,7 +608,7 @@ __device__ __forceinline__ void pool_ln_bwd_body(const svit_pool_ln_bwd_args& a,
         float f[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = rstd * (d[v * 8 + e] - s1 - xh[v * 8 + e] * s2);
-        *(uint4*)(o + v * 8) = pack8(f);
+        *(uint4*)(o + v * GS) = pack8(f);
       }
     }
   }
@@ -618,8 +626,8 @@ __device__ __forceinline__ void pool_ln_bwd_body(const svit_pool_ln_bwd_args& a,
   if ((threadIdx.x & 63) < 4) {
 #pragma unroll
     for (int i = 0; i < 24; ++i) {
-      wred[threadIdx.x >> 6][0][c0 + i] = dg[i];
-      wred[threadIdx.x >> 6][1][c0 + i] = db[i];
+      wred[threadIdx.x >> 6][0][chan(i)] = dg[i];
+      wred[threadIdx.x >> 6][1][chan(i)] = db[i];
     }
   }
   __syncthreads();
