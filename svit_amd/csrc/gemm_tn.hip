@@ -4,6 +4,7 @@
 // (the forward / dgrad kernel svit_gemm_nt lives in gemm_nt.hip)
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 #include <cstdlib>
@@ -499,6 +500,10 @@ struct TnGroup {
   int rows_per_split[SVIT_TN_GROUP_MAX];
   int big[SVIT_TN_GROUP_MAX];          // 1: 128 x 192 tiles (TnBig), 0: 128 x 96 (TnSmall)
   int count;
+  // round 4 (SVIT_TN_PACK): explicit placement -- entry [xcd * cap + pos] = problem << 24 | split << 12 | tile, -1 = empty slot.
+  // The tiles of one (problem, split) walk the same rows; packed so that no such set straddles two XCDs (two L2s fetching it)
+  const int* table;
+  int cap;
 };
 
 #ifndef SVIT_TN_WPE         // waves per SIMD the grouped kernel is compiled for (diagnostic builds: 3 with SVIT_TN_BIG_NS=2 = three workgroups per CU)
@@ -513,14 +518,20 @@ __global__ __launch_bounds__(256, SVIT_TN_WPE) void gemm_tn_grouped_kernel(const
   // against ~230 MB of operands -- the kernel ran at HBM speed).
   const int nwg = gridDim.x, lin = blockIdx.x;
   const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
-  const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
-  int pi = 0;
+  int pi = 0, tile, split;
+  if (g.table) {
+    const int e = g.table[xcd * g.cap + (lin >> 3)];
+    if (e < 0) return;                     // (padding slot)
+    pi = e >> 24; split = (e >> 12) & 0xfff; tile = e & 0xfff;
+  } else {
+    const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
 #pragma unroll
-  for (int i = 1; i < SVIT_TN_GROUP_MAX; ++i)
-    if (i < g.count && bid >= g.first_block[i]) pi = i;
+    for (int i = 1; i < SVIT_TN_GROUP_MAX; ++i)
+      if (i < g.count && bid >= g.first_block[i]) pi = i;
+    const int local = bid - g.first_block[pi];
+    tile = local % g.tiles[pi]; split = local / g.tiles[pi];
+  }
   const svit_tn_problem& p = g.p[pi];
-  const int local = bid - g.first_block[pi];
-  const int tile = local % g.tiles[pi], split = local / g.tiles[pi];
   const int tn = tile % g.tiles_n[pi], tk = tile / g.tiles_n[pi];
   const int m_begin = split * g.rows_per_split[pi];
   if (g.big[pi])
@@ -675,6 +686,78 @@ static int tn_check(const svit_tn_problem& p) {
   return SVIT_OK;
 }
 
+
+// ---- XCD-aligned placement of the grouped launch (round 4, SVIT_TN_PACK) ---------------------------------------------
+// Workgroups are dealt to the 8 XCDs round-robin (blockIdx & 7); the tiles of one (problem, split) read the same reduction rows
+// and share them through ONE L2 only if they sit on one XCD.  With plain consecutive ids about a third of those sets straddle
+// two XCDs and both L2s fetch the rows (TCC counters: 1.45x the operand bytes over the fabric).  Here the sets are packed into
+// eight bins (first-fit decreasing, capacity grown until everything fits); the table lives in device memory, built once per
+// distinct group geometry (the geometries of a training step are static) and cached.
+static std::atomic<int> g_tn_pack{(int)tn_env("SVIT_TN_PACK", 0)};
+struct TnPackEntry { std::vector<int> key; int* dev; int cap; };
+static std::mutex g_tn_pack_mu;
+static std::vector<TnPackEntry> g_tn_pack_cache;
+static const int* tn_pack_table(const TnGroup& g, int total, int* cap_out) {
+  std::vector<int> key;
+  int dev_id = 0;
+  if (hipGetDevice(&dev_id) != hipSuccess) dev_id = 0;
+  key.push_back(dev_id);
+  struct Set { int pi, split, n; };
+  std::vector<Set> sets;
+  for (int i = 0; i < g.count; ++i) {
+    const int splits = (g.p[i].M + g.rows_per_split[i] - 1) / g.rows_per_split[i];
+    key.push_back(g.tiles[i]); key.push_back(splits);
+    if (g.tiles[i] > 0xfff || splits > 0xfff) return nullptr;
+    for (int sp = 0; sp < splits; ++sp) sets.push_back({i, sp, g.tiles[i]});
+  }
+  std::lock_guard<std::mutex> lk(g_tn_pack_mu);
+  for (const auto& e : g_tn_pack_cache)
+    if (e.key == key) { *cap_out = e.cap; return e.dev; }
+  // sets larger than a bin are cut into bin-sized pieces first (block 0: hundreds of tiles per split)
+  std::vector<int> order(sets.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sets[a].n > sets[b].n; });
+  int cap = (total + 7) / 8;
+  std::vector<std::vector<int>> bins;
+  for (;; cap += std::max(1, cap / 32)) {
+    bins.assign(8, {});
+    std::vector<int> used(8, 0);
+    bool ok = true;
+    for (int si : order) {
+      const Set& st = sets[si];
+      int done = 0;
+      while (done < st.n) {
+        // whole remainder into the first bin that takes it, else the emptiest bin takes what it can
+        int b = -1;
+        for (int x = 0; x < 8; ++x)
+          if (cap - used[x] >= st.n - done) { b = x; break; }
+        int take = st.n - done;
+        if (b < 0) {
+          if (st.n - done <= cap) { ok = false; break; }       // would fit an empty bin: grow the capacity instead of cutting
+          b = (int)(std::min_element(used.begin(), used.end()) - used.begin());
+          take = cap - used[b];
+          if (take <= 0) { ok = false; break; }
+        }
+        for (int t = 0; t < take; ++t) bins[b].push_back(st.pi << 24 | st.split << 12 | (done + t));
+        used[b] += take;
+        done += take;
+      }
+      if (!ok) break;
+    }
+    if (ok) break;
+    if (cap > total) return nullptr;
+  }
+  std::vector<int> host((size_t)8 * cap, -1);
+  for (int x = 0; x < 8; ++x)
+    for (size_t j = 0; j < bins[x].size(); ++j) host[(size_t)x * cap + j] = bins[x][j];
+  int* dev = nullptr;
+  if (hipMalloc((void**)&dev, host.size() * sizeof(int)) != hipSuccess) return nullptr;
+  if (hipMemcpy(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); return nullptr; }
+  g_tn_pack_cache.push_back({key, dev, cap});
+  *cap_out = cap;
+  return dev;
+}
+
 static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void* stream);
 
 extern "C" int svit_gemm_tn_grouped(const svit_tn_problem* probs, int count, void* stream) {
@@ -772,6 +855,14 @@ static int tn_grouped_launch(const svit_tn_problem* probs, int count, int ordere
       total += g.tiles[i] * splits;
     }
     for (int i = g.count; i <= SVIT_TN_GROUP_MAX; ++i) g.first_block[i] = total;
+    g.table = nullptr;
+    g.cap = 0;
+    int launch_total = total;
+    if (!wide && !ordered && g_tn_pack.load() != 0 && total >= 64) {
+      int cap = 0;
+      g.table = tn_pack_table(g, total, &cap);
+      if (g.table) { g.cap = cap; launch_total = 8 * cap; }
+    }
     if (wide) {
       static SvitOnce once_wide, once_wide4;
       constexpr size_t wlds = (size_t)TnWideD::NS * TnWideD::STAGE;
@@ -787,7 +878,7 @@ static int tn_grouped_launch(const svit_tn_problem* probs, int count, int ordere
         hipLaunchKernelGGL(gemm_tn_grouped_wide_kernel<TnWideD>, dim3(total), dim3(512), wlds, (hipStream_t)stream, g);
       }
     } else {
-      hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, g);
+      hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(launch_total), dim3(256), 0, (hipStream_t)stream, g);
     }
     SVIT_LAUNCH_CHECK();
   }
