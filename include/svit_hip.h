@@ -428,30 +428,33 @@ int svit_ensemble_update(const float* preds, const int64_t* labels, const int64_
 int svit_topk_correct(const float* video_preds, const int64_t* video_labels, int V, int C,
                       const int* ks, int nk, int* counts, int* err, void* stream);
 /* ------------------------------------------------ diagnostics (tools/ only) ------------------ */
-/* Process-wide tuning knobs for the measurement scripts under tools/ (A/B runs of kernel variants inside one
- * process).  NOT part of the drop-in surface: the product path (svit_amd/engine.py, bench.py) never calls them,
- * their defaults are the measured heuristics, and every one takes effect for launches issued after the call.
- * They replace nothing in the reference (it has no native code).  Return 0 or SVIT_ERR_ARG. */
+/* Process-wide tuning knobs for the measurement scripts under tools/ and for the variant-parity tests (A/B runs of
+ * kernel variants inside one process).  NOT part of the drop-in surface: the product path (svit_amd/engine.py,
+ * bench.py) never calls them.  They are the ONLY way to change a heuristic: the library reads no environment
+ * variable; all of them write one table (csrc/common.h SvitKnob, csrc/misc.hip), every selectable variant computes the
+ * same results (none skips work), out-of-range values return SVIT_ERR_ARG, and svit_debug_reset() restores every
+ * default -- tests and tools call it in their `finally`.  They replace nothing in the reference (it has no native
+ * code). */
 /* NT GEMM (csrc/gemm_nt.hip): key 0 = pipeline stages (2..4, 0 = heuristic), key 1 = forced tile/ring
- * configuration (-1 = heuristic, 8 = the pre-ring v2 heuristic), key 2 = forced K-step (32 / 64, 0 = heuristic). */
+ * configuration (-1 = heuristic, 0..10; 8 = the pre-ring v2 heuristic), key 2 = forced K-step (32 / 64, 0 = heuristic). */
 int svit_debug_set(int key, int val);
 /* grouped TN GEMM (csrc/gemm_tn.hip): cost-model constants of the row-chunk planner (x 0.01: microseconds per
  * k-step, TB/s of the fp32-atomic flush; <= 0 leaves a constant unchanged), and the tile mode (0: 128x96 only,
  * 1: per-problem heuristic fitted on isolated launches, 2: 128x192 everywhere (default), 3: 128x192 where
- * K % 192 == 0; + 4 / + 8 / + 12: 128x384 tiles on 8-wave (64x96 per wave) / 4-wave (128x96 per wave) workgroups / the ring form (8 MFMA
- * waves + 4 loader waves) for the groups whose problems all have K % 384 == 0). */
+ * K % 192 == 0). */
 int svit_debug_set_tn(int step_us_x100, int atomic_tbs_x100);
 int svit_debug_set_tn_tile(int mode);
 /* pooling (csrc/pool.hip): key 0 = forward path of the small planes: 0 streaming kernels, 1 VALU slab conv, 2 (default)
  * MFMA conv where it is ahead (blocks 4-13 of 16x224^2) and the slab elsewhere, 3 MFMA conv wherever its geometry holds;
- * key 1 = 1: planes up to 28x28 take the slab path too, cut in y (off by default: measured behind the streaming kernel). */
+ * key 1 = backward path of the small planes: 1 (default) the fused plane-walk kernel (LayerNorm backward + conv dgrad +
+ * conv wgrad in one launch) where it fits, 0 the three streaming launches. */
 int svit_debug_set_pool(int key, int val);
-/* attention: key 0 = dkv kernel form (0 heuristic, 1 four waves, 2 eight waves with query halves), key 1 = forward
- * kernel form (0 the 128-query kernels, 1 the one-wave-per-SIMD 64-rows-per-wave kernel of csrc/attn_fwd64.hip), key 2 =
- * run only one of the backward's two kernels (0 both, 1 dkv only, 2 dq only; timing only -- the skipped outputs are not
- * written), key 3 = the forward's T' = 1 tile for Nk <= 64 (1 on (default), 0 the generic kernel).  (The 4- / 8-wave choice among
- * the 128-query kernels is the environment knob SVIT_ATTN_FWD_NW.) */
+/* attention: key 0 = dkv kernel form (0 heuristic, 1 four waves, 2 eight waves with query halves), key 1 = backward
+ * launch form (0 heuristic, 1 two launches: dq then dkv, 2 one launch with both kinds of workgroup), key 3 = the
+ * forward's T' = 1 tile for Nk <= 64 (1 on (default), 0 the generic kernel). */
 int svit_attn_debug_set(int key, int val);
+/* every knob above back to its default */
+int svit_debug_reset(void);
 #ifdef __cplusplus
 }
 #endif

@@ -32,8 +32,6 @@
 // addressed by buffer descriptor + scalar offset (no per-piece address arithmetic); the dkv kernel
 // consumes 64 queries per barrier (was 32); dQa leaves through LDS as whole rows in 16-byte stores.
 #include <algorithm>
-#include <atomic>
-#include <cstdlib>
 #include "attn_common.h"
 #include "../../include/svit_hip.h"
 
@@ -636,10 +634,15 @@ __global__ __launch_bounds__(256 * NH, NH == 2 ? 1 : 2) void attn_bwd_dkv_kernel
 #endif
 }
 
-static int dkv_env(const char* n, int d) { const char* e = getenv(n); return e ? atoi(e) : d; }
-static std::atomic<int> g_dkv_halves{dkv_env("SVIT_DKV_HALVES", 0)};   // tuning knob (svit_attn_debug_set(0, n) / env for in-step A/Bs): 1 / 2, 0 = heuristic
-static const int g_dkv_target = dkv_env("SVIT_DKV_TARGET", 256);      // workgroups the query split aims at
-static std::atomic<int> g_bwd_skip{0};     // tools only (svit_attn_debug_set(2, m)): bit 0 skips the dq launch, bit 1 the dkv launch
+#ifndef SVIT_DKV_TARGET       // workgroups the query split of the dkv kernel aims at (swept inside the step in round 4)
+#define SVIT_DKV_TARGET 256
+#endif
+constexpr int g_dkv_target = SVIT_DKV_TARGET;
+// (timing-only "run one of the two kernels" switch of the diagnostic builds, -DSVIT_DIAG_BWD_ONLY=1 dq / 2 dkv: the skipped
+// outputs are NOT written, so it cannot exist in the product library -- tools/diag/build_variant.py)
+#ifndef SVIT_DIAG_BWD_ONLY
+#define SVIT_DIAG_BWD_ONLY 0
+#endif
 
 // how the query range of the dkv kernel is cut: (dkv waves / 4, effective number of parts)
 struct DkvPlan { int halves, splits, tiles_per_split; };
@@ -648,7 +651,7 @@ static DkvPlan dkv_plan(const svit_attn_bwd_args& a) {
   const int base = key_blocks * a.B * a.heads;
   // two query halves (8 waves) where the launch leaves one 4-wave workgroup per CU anyway: the
   // short-key blocks (tools/bench_kernels.py attn)
-  int halves = g_dkv_halves.load();
+  int halves = svit_knob(SVIT_K_ATTN_DKV_FORM);
   if (halves != 1 && halves != 2) halves = (a.DA == 128 && base <= 256) ? 2 : 1;
   const int nqt = (a.Nq + QR - 1) / QR;
   int splits = a.q_splits;
@@ -683,7 +686,7 @@ int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
   const DkvPlan pl = dkv_plan(a);
   const int key_blocks = (a.Nk + 127) / 128;
   if (((uintptr_t)a.dk | (uintptr_t)a.dv) & 15) return SVIT_ERR_ALIGN;
-  const int skip = g_bwd_skip.load();
+  constexpr int skip = SVIT_DIAG_BWD_ONLY == 1 ? 2 : SVIT_DIAG_BWD_ONLY == 2 ? 1 : 0;
   if (!(skip & 1))
     hipLaunchKernelGGL((attn_bwd_dq_kernel<DA, KSU>), dim3((a.Nq + 127) / 128, a.B * a.heads), dim3(256),
                        lds_dq, st, a);
@@ -699,17 +702,6 @@ int launch_bwd(const svit_attn_bwd_args& a, hipStream_t st) {
   return SVIT_OK;
 }
 }  // namespace
-
-extern std::atomic<int> g_attn_fwd_form;      // attn_fwd.hip
-void attn_fwd_short_set(int v);               // attn_fwd.hip
-extern "C" int svit_attn_debug_set(int key, int val) {
-  if (key == 0) g_dkv_halves = val;
-  else if (key == 1) g_attn_fwd_form = val;
-  else if (key == 2) g_bwd_skip = val;
-  else if (key == 3) attn_fwd_short_set(val);
-  else return SVIT_ERR_ARG;
-  return SVIT_OK;
-}
 
 static int check_bwd_args(const svit_attn_bwd_args* a) {
   if (!a) return SVIT_ERR_ARG;

@@ -16,8 +16,6 @@
 // exchange, and the exponentiated tile feeds the PV MFMA as its B operand without leaving
 // registers.  O^T accumulates as 3 x (32 dv x 32 query) blocks.
 #include <algorithm>
-#include <atomic>
-#include <cstdlib>
 #include "attn_common.h"
 #include "../../include/svit_hip.h"
 
@@ -536,8 +534,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_short_kernel(svit_attn_fwd_ar
 #endif
 }
 
-static std::atomic<int> g_attn_fwd_short{getenv("SVIT_ATTN_FWD_SHORT") ? atoi(getenv("SVIT_ATTN_FWD_SHORT")) : 1};   // tuning knob
-                                                                   // (svit_attn_debug_set(3, v)): 0 = Nk <= 64 runs the generic kernel too
+#ifndef SVIT_ATTN_SHORT_WGS     // workgroups the T' = 1 launch aims at (swept inside the frames-pass step in round 4)
+#define SVIT_ATTN_SHORT_WGS 512
+#endif
 template <int KSU>
 int launch_short(const svit_attn_fwd_args& a, hipStream_t st) {
   constexpr int NP = (KSU + 1) / 2;
@@ -545,7 +544,7 @@ int launch_short(const svit_attn_fwd_args& a, hipStream_t st) {
   static SvitOnce once;
   if (int rc = svit_max_lds_once(once, (const void*)attn_fwd_short_kernel<KSU>, lds)) return rc;
   // ~two workgroups per CU in one round; a workgroup walks its share of the (batch, head)'s 128-query tiles
-  static const int want = getenv("SVIT_ATTN_SHORT_WGS") ? atoi(getenv("SVIT_ATTN_SHORT_WGS")) : 512;   // (in-step A/B knob)
+  constexpr int want = SVIT_ATTN_SHORT_WGS;
   const int ntiles = (a.Nq + 127) / 128, bh = a.B * a.heads;
   int chunks = (want + bh - 1) / bh;
   chunks = std::max(1, std::min(chunks, ntiles));
@@ -575,24 +574,16 @@ int launch_cfg(const svit_attn_fwd_args& a, hipStream_t st) {
 
 template <int KSU>
 int launch_fwd(const svit_attn_fwd_args& a, hipStream_t st) {
-  // 8-wave workgroups once they still cover the chip (one per CU); SVIT_ATTN_FWD_NW forces 4 / 8
-  static const int force = getenv("SVIT_ATTN_FWD_NW") ? atoi(getenv("SVIT_ATTN_FWD_NW")) : 0;
+  // 8-wave workgroups once they still cover the chip (one per CU)
   // measured (tools/bench_kernels.py attn): the 8-wave form wins 3-4 % on the long-key blocks
   // (Nk = 1633, DA = 160) and loses on the short ones, where the 8-wave barrier dominates
   const long wg8 = (long)((a.Nq + 255) / 256) * a.B * a.heads;
-  const bool wide = force ? force == 8 : (a.DA == 160 && wg8 >= 200);
+  const bool wide = a.DA == 160 && wg8 >= 200;
   return wide ? launch_cfg<KSU, 8, 3>(a, st) : launch_cfg<KSU, 4, 2>(a, st);
 }
 }  // namespace
-static bool attn_fwd_short_on() { return g_attn_fwd_short.load() != 0; }
-void attn_fwd_short_set(int v) { g_attn_fwd_short = v; }      // svit_attn_debug_set(3, v), attn_bwd.hip
-
-int attn_fwd_w64_launch(const svit_attn_fwd_args* a, int ksu, void* stream);      // attn_fwd64.hip
-// forward kernel form: 0 = the 128-query kernels (4 / 8 waves by shape), 1 = the 64-rows-per-wave kernel of
-// attn_fwd64.hip (measured 1.5x slower on every shape of the model, profiles/r04_attn_w64.txt: kept for the record and
-// for its parity tests).  svit_attn_debug_set(1, v) / SVIT_ATTN_FWD_W64 for A/Bs.
-std::atomic<int> g_attn_fwd_form{getenv("SVIT_ATTN_FWD_W64") ? atoi(getenv("SVIT_ATTN_FWD_W64")) : 0};
-
+// (the one-wave-per-SIMD, 64-rows-per-wave forward of round 4 measured 1.5x slower on every shape of the model --
+// profiles/r04_attn_w64.txt -- and lives on as tools/diag/variants/attn_fwd64.hip, no longer part of the library)
 extern "C" int svit_attn_fwd(const svit_attn_fwd_args* a, void* stream) {
   if (!a || !a->qa || !a->ka || !a->v || !a->ctx || !a->lse2) return SVIT_ERR_ARG;
   if (a->B <= 0 || a->heads <= 0 || a->Nq <= 0 || a->Nk <= 0) return SVIT_ERR_SHAPE;
@@ -604,10 +595,8 @@ extern "C" int svit_attn_fwd(const svit_attn_fwd_args* a, void* stream) {
   // wave per SIMD reaches half the VALU issue rate; it lives on as tools/diag/attn_fwd2_experiment.hip)
   const int extra = a->DA - 96;
   const int bias_cols = a->bias_cols > 0 ? a->bias_cols : extra;
-  // round 4: the one-wave-per-SIMD, 64-rows-per-wave form (attn_fwd64.hip), on request only
-  if (g_attn_fwd_form.load() == 1) return attn_fwd_w64_launch(a, 6 + (bias_cols + 15) / 16, stream);
   // round 4: the T' = 1 tile -- the whole key range is one 64-key tile (frames pass, image ranks)
-  if (a->Nk <= KT && attn_fwd_short_on()) {
+  if (a->Nk <= KT && svit_knob(SVIT_K_ATTN_FWD_SHORT) != 0) {
     if (6 + (bias_cols + 15) / 16 == 7) return launch_short<7>(*a, (hipStream_t)stream);
     if (6 + (bias_cols + 15) / 16 == 8) return launch_short<8>(*a, (hipStream_t)stream);
   }

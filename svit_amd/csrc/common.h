@@ -34,6 +34,30 @@ static inline int svit_max_lds_once(SvitOnce& once, const void* fn, size_t bytes
   return 0;
 }
 
+// ---- tuning knobs (diagnostics) ----------------------------------------------------------------
+// ONE process-wide table, defined in misc.hip.  It is written only through the svit_debug_* entry points
+// declared in include/svit_hip.h ("diagnostics": tools/ and the variant-parity tests call them, the product path
+// never does) and svit_debug_reset() restores every default.  The library reads NO environment variable: geometry
+// constants that earlier rounds swept through getenv() are now compile-time macros (tools/diag/build_variant.py
+// rebuilds one source with a different -D for an A/B).
+enum SvitKnob {
+  SVIT_K_NT_STAGES = 0,     // NT GEMM pipeline stages: 2..4, 0 = heuristic
+  SVIT_K_NT_CFG,            // NT GEMM forced tile / ring configuration, -1 = heuristic, 8 = the pre-ring v2 heuristic
+  SVIT_K_NT_BK,             // NT GEMM forced K-step: 32 / 64, 0 = heuristic
+  SVIT_K_TN_STEP_US_X100,   // grouped TN planner: microseconds per k-step x 100
+  SVIT_K_TN_ATOMIC_TBS_X100,  // grouped TN planner: TB/s of the fp32-atomic flush x 100
+  SVIT_K_TN_TILE,           // grouped TN tile mode: 0 128x96 only, 1 isolated-launch heuristic, 2 128x192 everywhere, 3 128x192 where K % 192 == 0
+  SVIT_K_POOL_FWD,          // small-plane pooling forward: 0 streaming, 1 VALU slab conv, 2 MFMA conv where ahead (default), 3 MFMA conv wherever it fits
+  SVIT_K_POOL_BWD,          // small-plane pooling backward: 0 the three streaming launches, 1 (default) the fused plane-walk kernel where it fits
+  SVIT_K_ATTN_DKV_FORM,     // attention dkv kernel: 0 heuristic, 1 four waves, 2 eight waves with query halves
+  SVIT_K_ATTN_FWD_SHORT,    // attention forward T' = 1 tile for Nk <= 64: 1 on (default), 0 generic kernel
+  SVIT_K_ATTN_BWD_FORM,     // attention backward: 0 heuristic, 1 two launches (dq, dkv), 2 one launch with both roles
+  SVIT_K_COUNT
+};
+int svit_knob(int k);                 // misc.hip
+int svit_knob_set(int k, int v);      // 0 or SVIT_ERR_ARG
+void svit_knob_reset();
+
 #define SVIT_LAUNCH_CHECK()                       \
   do {                                            \
     hipError_t e__ = hipGetLastError();           \

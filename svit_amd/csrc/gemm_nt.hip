@@ -14,8 +14,6 @@
 // (wave-uniform base + lane*16); the four 16-B chunks of a row are XOR-swizzled with
 // ((row>>2)&3) on the per-lane SOURCE address, and the same XOR is applied on the fragment
 // reads -> ds_read_b128 of 16 consecutive rows hits 16 distinct slots of the 256-B bank row.
-#include <atomic>
-#include <cstdlib>
 #include "gemm_epilogue.h"
 #include "attn_common.h"   // Int / static_for / lds_read128 / lgkm_release1
 
@@ -374,17 +372,7 @@ int launch_ring(const svit_gemm_args& a, hipStream_t st) {
 }
 }  // namespace
 
-static std::atomic<int> g_nt_stages{getenv("SVIT_NT_STAGES") ? atoi(getenv("SVIT_NT_STAGES")) : 0};     // tuning knob (svit_debug_set(0, n) or env for in-step A/Bs); 2..4, 0 = heuristic
-static std::atomic<int> g_nt_force_cfg{-1}; // tuning knob (svit_debug_set(1, c)); -1 = heuristic
-static std::atomic<int> g_nt_force_bk{0};   // tuning knob (svit_debug_set(2, bk)); 32 / 64, 0 = heuristic
-extern "C" int svit_debug_set(int key, int val) {
-  if (key == 0) g_nt_stages = val;
-  else if (key == 1) g_nt_force_cfg = val;
-  else if (key == 2) g_nt_force_bk = val;
-  else return SVIT_ERR_ARG;
-  return SVIT_OK;
-}
-
+// tuning knobs: SVIT_K_NT_STAGES / _CFG / _BK of the table in common.h (svit_debug_set, tools and variant-parity tests only)
 // Which ring kernel, if any.  Two sets of measurements on MI355X decide (profiles/r03_nt_ring.txt):
 // isolated loops per epilogue family (tools/bench_kernels.py ntring <epilogue>), where the ring kernels win
 // almost everywhere K % 64 == 0, and the replayed training step with every NT launch matched by position
@@ -395,9 +383,7 @@ static void ring_choice(const svit_gemm_args& a, int* cfg, int* stages) {
   const long tm = (a.M + 127) / 128;
   const long t192 = a.N % 192 == 0 ? tm * (a.N / 192) : 0, t96 = tm * ((a.N + 95) / 96);
   // few, long tiles: every 128x96 tile has a CU to itself -> 4-deep ring (3656 x 768 x 768..3072: -30 %)
-  static const int k_min5 = getenv("SVIT_NT_RING_K5") ? atoi(getenv("SVIT_NT_RING_K5")) : 1024;     // (in-step A/B knobs)
-  static const int t_max6 = getenv("SVIT_NT_RING_T6") ? atoi(getenv("SVIT_NT_RING_T6")) : 256;
-  static const int s6 = getenv("SVIT_NT_RING_S6") ? atoi(getenv("SVIT_NT_RING_S6")) : 4;
+  constexpr int k_min5 = 1024, t_max6 = 256, s6 = 4;     // (swept inside the step in round 4: profiles/r04_in_step_sweeps.txt)
   if (t96 <= t_max6 && a.K >= 768) { *cfg = 6, *stages = (t96 > 256 ? 2 : s6); return; }   // (> 256 tiles: two workgroups per CU need the 2-stage ring)
   // long K, narrow output, enough 128x192 tiles for most CUs (13064 x 384 x 1152..2304: -6..-10 % in the
   // step, -15..-20 % isolated; on a par with hipBLASLt's 128x160x64 macro-tile)
@@ -449,8 +435,8 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
   // 0.6-0.9x the speed of these tiles on every shape of the model: one barrier-locked workgroup
   // per CU leaves nothing to overlap its epilogues and barriers with.
   // force_cfg: 0 / 2 / 4 = v2 tiles, 5 / 6 / 7 = ring tiles, 8 = the v2 heuristic (no ring), -1 = heuristic
-  const int force_raw = g_nt_force_cfg.load(), force_stages = g_nt_stages.load();
-  const bool no_ring = force_raw == 8 || g_nt_force_bk.load() != 0;
+  const int force_raw = svit_knob(SVIT_K_NT_CFG), force_stages = svit_knob(SVIT_K_NT_STAGES);
+  const bool no_ring = force_raw == 8 || svit_knob(SVIT_K_NT_BK) != 0;
   const int force_cfg = force_raw == 8 ? -1 : force_raw;
   // Ring kernels (loader waves + MFMA waves, K-steps of 64; tools/bench_kernels.py ntring, profiles/
   // r03_nt_ring.txt): see ring_choice().
@@ -487,7 +473,7 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
   // for the narrow-output, long-K GEMMs (fc2, proj, qkv dgrad: N <= 768, K >= 384) as 128x96
   // blocks at depth 2, and slower elsewhere -- the 2x LDS per stage costs a resident workgroup
   // (tools/bench_kernels.py ntstages, profiles/r02_nt_tile_sweep.txt)
-  const int force_bk = g_nt_force_bk.load();
+  const int force_bk = svit_knob(SVIT_K_NT_BK);
   bool bk64 = a.K % 64 == 0 && a.N <= 768 && a.K >= 384;
   if (force_bk) bk64 = force_bk == 64 && a.K % 64 == 0;
   if (bk64 && force_cfg < 0 && !force_stages) return launch_v2<1, 3, 4, 1, 2, 64>(a, st);
@@ -506,10 +492,10 @@ extern "C" int svit_gemm_nt(const svit_gemm_args* args, void* stream) {
   // 824 (128x192) or 1236 (128x128) workgroups on 512-768 slots: a second, part-filled round in which the chip mostly
   // stores.  160x256 (1 x 4 waves of 160x64) covers 13064 x 1536 with 82 x 6 = 492 workgroups, 192x192 (2 x 2 waves of
   // 96x96) covers 13064 x 1152 with 69 x 6 = 414: every workgroup resident at once (two per CU), more flops per LDS-fill
-  // byte (91 / 96 against 77 / 64).  force_cfg 9 / 10 force them (SVIT_NT_ONE_ROUND=0: never, for A/Bs); heuristic: only where the grid is one
+  // byte (91 / 96 against 77 / 64).  force_cfg 9 / 10 force them; heuristic: only where the grid is one
   // round and the 128-row grid is not.
   {
-    static const int one_round = getenv("SVIT_NT_ONE_ROUND") ? atoi(getenv("SVIT_NT_ONE_ROUND")) : 1;   // (in-step A/B knob)
+    constexpr int one_round = 1;
     const long t160 = a.N % 256 == 0 ? (long)((a.M + 159) / 160) * (a.N / 256) : 0;
     const long t192 = a.N % 192 == 0 ? (long)((a.M + 191) / 192) * (a.N / 192) : 0;
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 191) / 192);

@@ -480,6 +480,48 @@ inline unsigned grid_for(int64_t work_items, int block, unsigned cap = 8192) {
 }  // namespace
 
 extern "C" int svit_version(void) { return 1; }
+
+// ---- the knob table (common.h: SvitKnob) -----------------------------------------------------------------------
+static const int k_knob_default[SVIT_K_COUNT] = {
+    /* NT_STAGES */ 0, /* NT_CFG */ -1, /* NT_BK */ 0, /* TN_STEP_US_X100 */ 85, /* TN_ATOMIC_TBS_X100 */ 75, /* TN_TILE */ 2,
+    /* POOL_FWD */ 2, /* POOL_BWD */ 1, /* ATTN_DKV_FORM */ 0, /* ATTN_FWD_SHORT */ 1, /* ATTN_BWD_FORM */ 0};
+static int g_knob[SVIT_K_COUNT] = {0, -1, 0, 85, 75, 2, 2, 1, 0, 1, 0};     // (= k_knob_default; accessed through __atomic builtins)
+int svit_knob(int k) { return __atomic_load_n(&g_knob[k], __ATOMIC_RELAXED); }
+int svit_knob_set(int k, int v) {
+  if (k < 0 || k >= SVIT_K_COUNT) return SVIT_ERR_ARG;
+  __atomic_store_n(&g_knob[k], v, __ATOMIC_RELAXED);
+  return SVIT_OK;
+}
+void svit_knob_reset() {
+  for (int k = 0; k < SVIT_K_COUNT; ++k) __atomic_store_n(&g_knob[k], k_knob_default[k], __ATOMIC_RELAXED);
+}
+// The declared diagnostics entry points (include/svit_hip.h).  Out-of-range values are refused, not clamped.
+extern "C" int svit_debug_set(int key, int val) {
+  if (key == 0) return (val == 0 || (val >= 2 && val <= 4)) ? svit_knob_set(SVIT_K_NT_STAGES, val) : SVIT_ERR_ARG;
+  if (key == 1) return (val >= -1 && val <= 10) ? svit_knob_set(SVIT_K_NT_CFG, val) : SVIT_ERR_ARG;
+  if (key == 2) return (val == 0 || val == 32 || val == 64) ? svit_knob_set(SVIT_K_NT_BK, val) : SVIT_ERR_ARG;
+  return SVIT_ERR_ARG;
+}
+extern "C" int svit_debug_set_tn(int step_us_x100, int atomic_tbs_x100) {
+  if (step_us_x100 > 0) svit_knob_set(SVIT_K_TN_STEP_US_X100, step_us_x100);
+  if (atomic_tbs_x100 > 0) svit_knob_set(SVIT_K_TN_ATOMIC_TBS_X100, atomic_tbs_x100);
+  return SVIT_OK;
+}
+extern "C" int svit_debug_set_tn_tile(int mode) {
+  return (mode >= 0 && mode <= 3) ? svit_knob_set(SVIT_K_TN_TILE, mode) : SVIT_ERR_ARG;
+}
+extern "C" int svit_debug_set_pool(int key, int val) {
+  if (key == 0) return (val >= 0 && val <= 3) ? svit_knob_set(SVIT_K_POOL_FWD, val) : SVIT_ERR_ARG;
+  if (key == 1) return (val == 0 || val == 1) ? svit_knob_set(SVIT_K_POOL_BWD, val) : SVIT_ERR_ARG;
+  return SVIT_ERR_ARG;
+}
+extern "C" int svit_attn_debug_set(int key, int val) {
+  if (key == 0) return (val >= 0 && val <= 2) ? svit_knob_set(SVIT_K_ATTN_DKV_FORM, val) : SVIT_ERR_ARG;
+  if (key == 1) return (val >= 0 && val <= 2) ? svit_knob_set(SVIT_K_ATTN_BWD_FORM, val) : SVIT_ERR_ARG;
+  if (key == 3) return (val == 0 || val == 1) ? svit_knob_set(SVIT_K_ATTN_FWD_SHORT, val) : SVIT_ERR_ARG;
+  return SVIT_ERR_ARG;
+}
+extern "C" int svit_debug_reset(void) { svit_knob_reset(); return SVIT_OK; }
 extern "C" const char* svit_arch(void) { return "gfx950"; }
 
 extern "C" int svit_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {

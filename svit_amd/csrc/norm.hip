@@ -235,7 +235,7 @@ extern "C" int svit_layernorm_fwd(const float* x, const float* gamma, const floa
                                   int64_t rows, int C, float eps, void* stream) {
   if (!x || !gamma || !beta || (!y_bf16 && !y_f32)) return SVIT_ERR_ARG;
   if (rows <= 0 || C <= 0 || C % 4 != 0 || C > 768) return SVIT_ERR_SHAPE;
-  static const int rpb_f = getenv("SVIT_LN_FWD_RPB") ? std::max(4, atoi(getenv("SVIT_LN_FWD_RPB"))) : 8;     // (in-step A/B knob)
+  constexpr int rpb_f = 8;
   int64_t blocks = (rows + rpb_f - 1) / rpb_f;            // two rows in flight per (half-)wave
   if (blocks > 16384) blocks = 16384;
   if (blocks < 1) blocks = 1;
@@ -267,8 +267,8 @@ extern "C" int svit_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x
   // rows per workgroup: 16 (round 4).  At 32 the 13064-row launches of the 14x14 stage were 409 workgroups = 6 waves per
   // CU, too few bytes in flight for the HBM rate; in the step 16 and 8 are level and 0.10 ms ahead of 32
   // (12.70 / 12.71 vs 12.81 ms; an isolated loop, whose operands sit in the Infinity Cache, shows no difference --
-  // the round-3 sweep).  SVIT_LN_BWD_RPB is the A/B knob.
-  static const int rpb = getenv("SVIT_LN_BWD_RPB") ? std::max(4, atoi(getenv("SVIT_LN_BWD_RPB"))) : 16;
+  // the round-3 sweep).
+  constexpr int rpb = 16;
   int64_t blocks = (rows + rpb - 1) / rpb;
   if (blocks < 256) blocks = (rows + 3) / 4 < 256 ? (rows + 3) / 4 : 256;
   if (blocks > 2048) blocks = 2048;

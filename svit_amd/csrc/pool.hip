@@ -1038,7 +1038,7 @@ static WgradPlan plan_wgrad(const svit_pool_wgrad_args& a, int Ho, int Wo) {
   // (round 3: 768 -> 224.  Every t chunk re-fetches two halo planes and writes its own 31-KB partial row;
   // un-chunked walks were 20-35 % faster wherever (y, x, batch, head) alone gives ~1 workgroup per CU:
   // tools/_run_pool2.sh sweep, profiles/r03_pool_slab.txt)
-  static const long want = [] { const char* e = getenv("SVIT_WGRAD_TILES"); return e ? atol(e) : 224L; }();
+  constexpr long want = 224;
   while (t_chunks < a.T && (long)pl.tiles_x * pl.tiles_y * a.B * a.heads * t_chunks < want &&
          a.T / (t_chunks * 2) >= 2)
     t_chunks *= 2;
@@ -1941,8 +1941,7 @@ __global__ __launch_bounds__(256) void pool_slab_ln_kernel(PoolSlab3 g) {
 // grid.x of the persistent stencil kernels: token blocks are dealt round-robin to workgroups so
 // that about 1024 workgroups (2 per CU on two resident rounds) exist in total
 static unsigned persistent_x(int token_blocks, int other_dims, long want_override = 0) {
-  static const long want_env = getenv("SVIT_POOL_WGS") ? atol(getenv("SVIT_POOL_WGS")) : 1024;    // (in-step A/B knob)
-  const long want = want_override > 0 ? want_override : want_env;
+  const long want = want_override > 0 ? want_override : 1024;      // (512 / 1024 / 2048 swept inside the step in round 4)
   const long total = (long)token_blocks * other_dims;
   const long chunks = (total + want - 1) / want;
   long x = (token_blocks + chunks - 1) / chunks;
@@ -2013,23 +2012,21 @@ static size_t tiled_lds_bytes(int W) {
 // fits SLAB_MAXTOK tokens; among those the one that re-reads the input least, then cut in t until the
 // launch has >= 256 workgroups.  Strides 1 and 2 only (a stride-4 / -8 stencil touches a small part
 // of the planes a slab would load), and only where `pre` is given (the LayerNorm launch reads it).
-static std::atomic<int> g_pool_slab{getenv("SVIT_POOL_SLAB") ? atoi(getenv("SVIT_POOL_SLAB")) : 2};   // tuning knob (svit_debug_set_pool(0, v) / env for in-step A/Bs): 0 = streaming kernels, 1 = VALU slab conv, 2 = MFMA conv where its geometry holds
-// key 1 of svit_debug_set_pool / SVIT_SLAB_YCHUNK: 1 = planes up to 28x28 take the slab path too, cut in y (round 3's
-// variant, off: measured below)
-static std::atomic<int> g_slab_ychunk{getenv("SVIT_SLAB_YCHUNK") ? atoi(getenv("SVIT_SLAB_YCHUNK")) : 0};
+// SVIT_K_POOL_FWD of the knob table (common.h): 0 = streaming kernels, 1 = VALU slab conv, 2 = MFMA conv where it is ahead,
+// 3 = MFMA conv wherever its geometry holds.  Whole planes only: the y-chunked planner for 28x28 planes (rounds 3-4)
+// measured level with the streaming kernel inside the step (profiles/r04_in_step_sweeps.txt) and was removed in round 5.
 static SlabPlan plan_slab(const svit_pool_args& a) {
   SlabPlan pl = {0, 0, 0, 0, 0};
   const int s = a.stride_hw;
-  const bool ychunk = g_slab_ychunk.load() == 1;
   // measured (tools/pool_one.py under rocprofv3, profiles/r03_pool_slab.txt): ahead of the streaming
   // kernel on the 14x14 and 7x7 planes (12 of 16 blocks), behind it on 28x28 and behind the tiled
   // stencil on 56x56 -- the conv phase is VALU-bound (27 v_dot2 per output channel) and a slab
   // workgroup serialises fill -> conv -> store with one 16-wave workgroup per CU (106 SGPRs)
-  if (!g_pool_slab.load() || s > 2 || !a.pre || a.H * a.W > (ychunk ? 784 : 196)) return pl;
+  if (!svit_knob(SVIT_K_POOL_FWD) || s > 2 || !a.pre || a.H * a.W > 196) return pl;
   const int Ho = (a.H - 1) / s + 1;
   double best = 1e30;
   for (int tc = 1; tc <= a.T; ++tc)
-    for (int yc = ychunk ? 1 : Ho; yc <= Ho; ++yc) {     // whole planes unless the y-chunk knob is on: the planes this path is used on (<= 14x14) fit
+    for (int yc = Ho; yc <= Ho; ++yc) {     // whole planes: the planes this path is used on (<= 14x14) fit
       const int pin = std::min(a.T, tc + 2), rin = std::min(a.H, s * (yc - 1) + 3);
       if ((long)pin * rin * a.W > SLAB_MAXTOK) continue;
       const double cost = ((double)pin / tc) * ((double)rin / (s * yc)) - 1e-6 * tc * yc;
@@ -2093,9 +2090,7 @@ static int pool_ln_fwd_qkv_kernels(const svit_pool_args* a3, const uint32_t* con
     sg.plan[i] = sel3 ? plan_slab(a3[i]) : SlabPlan{0, 0, 0, 0, 0};
     g.skip[i] = sg.plan[i].on;
     if (i == 0) {
-      // (A/B knob for in-step measurements: SVIT_SLAB_RELQ=0 keeps the rel-pos product as its own GEMM launch)
-      static const bool fuse_env = !(getenv("SVIT_SLAB_RELQ") && atoi(getenv("SVIT_SLAB_RELQ")) == 0);
-      const bool fuse = fuse_env && a3[0].relq_lpad <= 288;       // (the product tile of 64 tokens must fit LDS)
+      const bool fuse = a3[0].relq_lpad <= 288;       // (the product tile of 64 tokens must fit LDS)
       if (!fuse) sg.p[0].relq_R = nullptr;
       *q_on_slab = sg.plan[0].on && fuse;
     }
@@ -2107,7 +2102,7 @@ static int pool_ln_fwd_qkv_kernels(const svit_pool_args* a3, const uint32_t* con
       if (need > slds) slds = need;
       if ((unsigned)(pl.nt * pl.ny) > sgx) sgx = pl.nt * pl.ny;
       const int nout = 1 + a3[i].T * ((a3[i].H - 1) / s + 1) * ((a3[i].W - 1) / s + 1) + a3[i].n_obj;
-      static const long ln_want = getenv("SVIT_SLAB_LN_WGS") ? atol(getenv("SVIT_SLAB_LN_WGS")) : 2048;    // (in-step A/B: 1024 -> 2048 is -0.02..-0.04 ms)
+      constexpr long ln_want = 2048;    // (in-step A/B of round 4: 1024 -> 2048 is -0.02..-0.04 ms)
       ln_blocks = std::max(ln_blocks, (int)persistent_x((nout + 63) / 64, a3[0].B * a3[0].heads * 3, ln_want));
       ++n_slab;
     }
@@ -2116,7 +2111,7 @@ static int pool_ln_fwd_qkv_kernels(const svit_pool_args* a3, const uint32_t* con
     // round 4: the conv of the slab planes on the matrix pipe (pool_mfma_fwd_kernel) where its geometry holds for
     // all three tensors: W <= 14 (16 slots per image row with both x halos), T a multiple of 4 (t-quads), the
     // 16-channel image within the LDS of a CU; svit_debug_set_pool(0, 1) keeps the VALU slab kernel (A/B)
-    bool mfma = n_slab == 3 && g_pool_slab.load() != 1;
+    bool mfma = n_slab == 3 && svit_knob(SVIT_K_POOL_FWD) != 1;
     size_t mlds = 0;
     for (int i = 0; i < 3 && mfma; ++i) {
       mfma = a3[i].W <= 14 && a3[i].T % 4 == 0 && a3[i].T == a3[0].T && a3[i].H == a3[0].H;
@@ -2125,8 +2120,8 @@ static int pool_ln_fwd_qkv_kernels(const svit_pool_args* a3, const uint32_t* con
     if (mfma && mlds > 160 * 1024) mfma = false;
     // measured (tools/diag/pool_fwd_ab.sh, profiles/r04_pool_mfma_stencil.txt): ahead of the VALU slab kernel where its
     // 12 B heads workgroups are ONE round at two per CU (blocks 4-13 of 16x224^2: 24.6 against 28.4 us), level or
-    // behind with more (blocks 14 / 15, 8 heads); SVIT_POOL_SLAB=3 forces it everywhere its geometry holds
-    if (mfma && g_pool_slab.load() != 3 && ((long)a3[0].B * a3[0].heads * 12 > 512 || 2 * mlds > 160 * 1024)) mfma = false;
+    // behind with more (blocks 14 / 15, 8 heads); svit_debug_set_pool(0, 3) forces it everywhere its geometry holds
+    if (mfma && svit_knob(SVIT_K_POOL_FWD) != 3 && ((long)a3[0].B * a3[0].heads * 12 > 512 || 2 * mlds > 160 * 1024)) mfma = false;
     if (mfma) {
       static SvitOnce once_mfma;
       if (int rc = svit_max_lds_once(once_mfma, (const void*)pool_mfma_fwd_kernel, 160 * 1024)) return rc;
@@ -2139,7 +2134,6 @@ static int pool_ln_fwd_qkv_kernels(const svit_pool_args* a3, const uint32_t* con
     static SvitOnce once_slab;
     if (int rc = svit_max_lds_once(once_slab, (const void*)pool_slab_fwd_kernel, 80 * 1024)) return rc;
     sg.max_chunks = (int)sgx;
-    if (getenv("SVIT_SLAB_LDS_MIN")) slds = std::max(slds, (size_t)atoi(getenv("SVIT_SLAB_LDS_MIN")));
     hipLaunchKernelGGL(pool_slab_fwd_kernel, dim3(sgx * a3[0].B * a3[0].heads * 12), dim3(SLAB_NT), slds,
                        (hipStream_t)stream, sg);
     SVIT_LAUNCH_CHECK();
@@ -2171,13 +2165,6 @@ static int pool_ln_fwd_qkv_kernels(const svit_pool_args* a3, const uint32_t* con
   hipLaunchKernelGGL(pool_ln_fwd3_kernel, dim3(gx, a3[0].B * a3[0].heads, 3), dim3(256), lds,
                      (hipStream_t)stream, g);
   SVIT_LAUNCH_CHECK();
-  return SVIT_OK;
-}
-
-extern "C" int svit_debug_set_pool(int key, int val) {   // tuning knob for tools/: 0 -> slab stencils on / off
-  if (key == 0) g_pool_slab = val;
-  else if (key == 1) g_slab_ychunk = val;
-  else return SVIT_ERR_ARG;
   return SVIT_OK;
 }
 
@@ -2219,7 +2206,7 @@ extern "C" int svit_pool_ln_bwd_qkv(const svit_pool_ln_bwd_args* a3, void* strea
     const int64_t total = (int64_t)a3[i].B * a3[i].heads * a3[i].Nout;
     if (total > max_total) max_total = total;
   }
-  static const int tpb = getenv("SVIT_POOL_LNB_TPB") ? atoi(getenv("SVIT_POOL_LNB_TPB")) : 256;   // (in-step A/B knob)
+  constexpr int tpb = 256;
   int64_t blocks = (max_total + tpb - 1) / tpb;
   if (blocks < 128) blocks = (max_total + 63) / 64 < 128 ? (max_total + 63) / 64 : 128;
   if (blocks > 1024) blocks = 1024;

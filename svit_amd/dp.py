@@ -38,7 +38,7 @@ class DataParallel(nn.Module):
     `.device`, `train()/eval()`, `parameters()` (checkpoint.py:140,236; train_net.py:117-118)."""
 
     def __init__(self, module, device_ids=None, output_device=None, find_unused_parameters=False,
-                 process_group=None, bucket_ranks=4, average=True):
+                 process_group=None, bucket_ranks=4, average=True, force_collectives=False):
         super().__init__()
         self.module = module
         self.device = module.cls_token.device
@@ -46,11 +46,14 @@ class DataParallel(nn.Module):
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.bucket_ranks = max(1, bucket_ranks)
         self.average = average
+        # test / rehearsal switch: run the whole exchange (broadcast, bucketed async all-reduce, finish) even when the
+        # process group has ONE rank -- the production branch (backend "nccl" = RCCL, ReduceOp.AVG) on a one-GPU box
+        self.force_collectives = bool(force_collectives) and dist.is_initialized()
         self._works = []
         self._pending = []
         module._grad_ready_hook = self._on_ready
         module._grad_ready_ranks = self.launch_ranks()
-        if self.world_size > 1:
+        if self.world_size > 1 or self.force_collectives:
             self._broadcast_parameters()
 
     def _broadcast_parameters(self):
@@ -80,7 +83,7 @@ class DataParallel(nn.Module):
 
     def _on_ready(self, rank):
         """engine callback: gradients of readiness rank `rank` are final on this GPU."""
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.force_collectives:
             return
         flat = self.module.flat
         self._pending.extend(flat.ready_ranges[rank])

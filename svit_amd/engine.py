@@ -10,8 +10,6 @@ memory, streams and a handful of O(B*65*C) index/reduction ops on the special to
 """
 import math
 
-import os
-
 import torch
 
 from . import arch, hip, ops
@@ -150,16 +148,15 @@ class FlatParams:
     TILED_MIN_PLANE = 2048
     # round 3: the slab stencil (csrc/pool.hip::pool_slab_fwd_kernel: input slab resident in LDS, scalar
     # weights, LayerNorm as a second row-wise launch) on the small planes -- 14x14 and 7x7, 12 of 16 blocks
-    # (SVIT_SLAB_YCHUNK=1, the in-step A/B knob of the y-chunked 28x28 slab planes: csrc/pool.hip::plan_slab reads the same variable)
-    SLAB_MAX_PLANE = 784 if os.environ.get("SVIT_SLAB_YCHUNK", "0") == "1" else 196
+    SLAB_MAX_PLANE = 196
 
     def refresh_low_precision(self):
         ops.cast_bf16(self.data, self.w16[:self.total])
         if self.pool_sel_index:
+            # selector tables = the SCALAR weight operands (s_load) of the forward stencils: pool_tiled_body<.., SW = true>
+            # (56x56 stride-1 planes), pool_slab_fwd_kernel (blocks 14 / 15) -- csrc/pool.hip
             ops.pool_weight_sel(self.data, self.pool_sel_off, self.pool_sel)
-        if self.n_t and os.environ.get("SVIT_TRANSPOSE_F32", "0") == "1":       # (in-step A/B knob: the round-3 form)
-            ops.transpose_cast_batched(self.data, self.wT16, self.t_table, self.n_t, 256)
-        elif self.n_t:    # from the mirror the cast above just wrote: half the bytes of the fp32 source
+        if self.n_t:    # from the mirror the cast above just wrote: half the bytes of the fp32 source
             ops.transpose_bf16_batched(self.w16, self.wT16, self.t_table, self.n_t, 256)
 
 
@@ -196,12 +193,12 @@ def _resize_matrix(rows_have, rows_need):
 
 
 class Engine:
-    def __init__(self, plan: arch.Plan, flat: FlatParams):
+    def __init__(self, plan: arch.Plan, flat: FlatParams, red_group=4):
         self.plan, self.flat = plan, flat
         self.dev = flat.data.device
         self._rel_cache = {}
         self._relq_cache = {}
-        self.fused_scatter = os.environ.get("SVIT_FUSED_SCATTER", "1") != "0"
+        self.fused_scatter = True     # (False = the stand-alone rel-pos scatter launch; tests / tools flip the attribute)
         self.patch_w16 = torch.zeros((plan.embed_dim, 448), device=self.dev, dtype=BF16)
         self._tn = []           # weight-gradient GEMMs queued by the running block backward
         # a block's four second-stage reductions (LN2, pooled LN, conv wgrad, LN1) run as one
@@ -209,7 +206,8 @@ class Engine:
         # round 4: RED_GROUP consecutive blocks share ONE deferred launch (17 -> 5 reduce launches per step): every
         # block of a group owns its own copy of the scratch, the queue is run when the group's last block is done --
         # in front of the gradient-ready callback of the data-parallel buckets, which are four blocks wide as well
-        self.RED_GROUP = int(os.environ.get("SVIT_RED_GROUP", "4"))      # (1 = one launch per block, the round-3 schedule)
+        # (1 = one launch per block, the round-3 schedule).  Scratch: RED_GROUP x 72 MB of fp32 partial rows.
+        self.RED_GROUP = max(1, int(red_group))
         M1 = 1024 * 1024
         self._red_ws = torch.empty(self.RED_GROUP * 18 * M1, device=self.dev, dtype=F32)
         self._red_slot = 0
@@ -224,7 +222,7 @@ class Engine:
         self._side_active = False
         # weight-gradient GEMMs on a side stream beside the dgrad chain: off (round-1 measurement: the TN GEMM beside
         # the chain cost more than it hid); SVIT_OVERLAP_WGRAD=1 is the A/B knob for re-measuring it
-        self.overlap_wgrad = os.environ.get("SVIT_OVERLAP_WGRAD", "0") == "1"
+        self.overlap_wgrad = False
         self.attn_q_splits = 0      # 0 = heuristic; 1 = no query split in the dk/dv kernel
         # regression-diff mode: every reduction that normally meets in fp32 atomics (attention
         # dk/dv query splits, the row splits of the grouped weight-gradient GEMM) runs unsplit, so

@@ -178,6 +178,7 @@ _SIGS = {
     "svit_debug_set_tn_tile": (i32, [i32]),
     "svit_debug_set_pool": (i32, [i32, i32]),
     "svit_attn_debug_set": (i32, [i32, i32]),
+    "svit_debug_reset": (i32, []),
 }
 EXPORTS = tuple(sorted(_SIGS))
 

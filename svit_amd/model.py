@@ -10,7 +10,6 @@ launch schedules of svit_amd/engine.py.  There is no PyTorch fallback for the ba
 a GPU or without libsvit_hip.so the forward raises.
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -191,7 +190,7 @@ class SViT(nn.Module):
                 _trunc_normal_(m.weight)
                 nn.init.constant_(m.bias, 0)
         self.engine = None
-        self.fused_head = os.environ.get("SVIT_FUSED_HEAD", "1") != "0"   # A/B knob: 0 = ATen head in training too
+        self.fused_head = True      # (False = the ATen head in training too; tests / tools flip the attribute)
         self._head_ones = None
         self.flat = None
         self._grad_ready_hook = None   # set by the data-parallel wrapper (svit_amd/dp.py)

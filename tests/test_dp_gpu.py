@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out, graphed=False, backend="gloo"):
+def _worker(rank, world, port, out, graphed=False, backend="gloo", force=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -31,6 +31,8 @@ def _worker(rank, world, port, out, graphed=False, backend="gloo"):
         torch.cuda.set_device(rank)
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", rank))
+    elif backend == "none":      # plain single process, no process group at all
+        torch.cuda.set_device(0)
     else:
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -47,7 +49,11 @@ def _worker(rank, world, port, out, graphed=False, backend="gloo"):
     sd = P.state_dict(R.param_shapes(spec))
     if rank == 0:
         model.load_state_dict(sd)          # rank 1 keeps its random init: must be overwritten
-    dp = DataParallel(model, bucket_ranks=4) if world > 1 else model
+    if force or backend == "none":
+        # bit-equality test: every reduction that normally meets in fp32 atomics runs unsplit (Engine.deterministic), so the
+        # different grouping of the weight-gradient launches around the collective launch points cannot show
+        model.engine.deterministic = True
+    dp = DataParallel(model, bucket_ranks=4, force_collectives=force) if (world > 1 or force) else model
     opt = optim.construct_optimizer(dp, cfg)
     optim.set_lr(opt, 1e-3)
     x_all, y_all = P.frames(4, 4, 64), P.labels(4)
@@ -58,7 +64,7 @@ def _worker(rank, world, port, out, graphed=False, backend="gloo"):
     if graphed:
         from svit_amd.graph import GraphedTrainStep
         step = GraphedTrainStep(dp, lambda p, e, l: torch.nn.functional.cross_entropy(p, l), [x], y)
-        assert sum(1 for k, _ in step.segments if k == "ready") == (len(dp.launch_ranks()) if world > 1 else 0)
+        assert sum(1 for k, _ in step.segments if k == "ready") == (len(dp.launch_ranks()) if (world > 1 or force) else 0)
     for _ in range(2):
         if step is not None:
             step([x], y)
@@ -71,6 +77,8 @@ def _worker(rank, world, port, out, graphed=False, backend="gloo"):
         opt.step()
     torch.cuda.synchronize()
     flat = model.flat.data.detach().cpu()
+    if force:       # the forced one-rank exchange really went through the collective path
+        assert dist.get_backend() == backend and dp.force_collectives and not dp._works
     if world > 1:
         both = [torch.zeros_like(flat) for _ in range(world)]
         dist.all_gather(both, flat)
@@ -78,14 +86,15 @@ def _worker(rank, world, port, out, graphed=False, backend="gloo"):
             (both[0] - both[1]).abs().max())
     if rank == 0:
         torch.save(flat, out)
-    dist.barrier()
-    dist.destroy_process_group()
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
-def _run(world, out, graphed=False, backend="gloo"):
+def _run(world, out, graphed=False, backend="gloo", force=False):
     port = _free_port()
     ctx = mp.get_context("spawn")      # fresh children, started before this process touches a GPU
-    procs = [ctx.Process(target=_worker, args=(r, world, port, out, graphed, backend))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out, graphed, backend, force))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -116,6 +125,20 @@ def test_graphed_two_ranks_equal_eager_one_rank(tmp_path):
     assert cos > 0.999999
 
 
+@pytest.mark.parametrize("graphed", [False, True])
+def test_rccl_production_branch_with_one_rank(tmp_path, graphed):
+    """The production exchange executed on the ONE GPU of the test box: init_process_group("nccl", world_size=1,
+    device_id=...) in a child process, DataParallel(force_collectives=True) so that `_on_ready` takes the
+    backend == "nccl" / ReduceOp.AVG / async_op path (svit_amd/dp.py) and `finish()` orders the current stream behind
+    RCCL's -- eager and between HIP-graph segments.  An all-reduce(AVG) over one rank is the identity, so the weights after
+    two optimiser steps must be BIT-equal to the same steps with no process group at all.  Proves that RCCL loads beside
+    libsvit_hip.so, that AVG is accepted, and that the hook / graph-segment / finish order works on the real backend;
+    it says nothing about N > 1 (xGMI), which only the driver's multi-GPU node can run."""
+    plain = _run(1, str(tmp_path / "w1.pt"), graphed=graphed, backend="none")
+    rccl = _run(1, str(tmp_path / "w1r.pt"), graphed=graphed, backend="nccl", force=True)
+    assert torch.equal(plain, rccl), float((plain - rccl).abs().max())
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
 @pytest.mark.parametrize("graphed", [False, True])
 def test_rccl_two_gpus_equal_one_rank(tmp_path, graphed):
@@ -128,6 +151,26 @@ def test_rccl_two_gpus_equal_one_rank(tmp_path, graphed):
     assert (one - two).abs().max().item() < 2e-3 * one.abs().max().item()
     cos = torch.dot(one.double(), two.double()) / (one.double().norm() * two.double().norm())
     assert cos > 0.999999
+
+
+def test_bench_forced_dp_on_one_gpu_reports_rccl():
+    """`SVIT_BENCH_FORCE_DP=1 python bench.py --gpus 1`: the bench's training step over a one-rank RCCL process group
+    (hip-graph segments cut at the collective launch points, all-reduce(AVG) between them) -- the line must say so."""
+    import json
+    import subprocess
+    env = dict(os.environ, SVIT_BENCH_FORCE_DP="1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SVIT_BENCH_BACKEND", "SVIT_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
+                        "--warmup", "1", "--batch", "1", "--frames", "4", "--crop", "64",
+                        "--no-cpu-baseline", "--no-kernel-trace"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["config"]["backend"] == "rccl" and out["config"]["ranks_seen"] == 1 and out["config"]["forced_dp"]
+    assert out["n_gpus"] == 1 and out["value"] > 0 and "hip-graph" in out["config"]["launch"]
 
 
 @pytest.mark.parametrize("n", [2, 5])
@@ -175,7 +218,7 @@ def _hetero_worker(rank, world, port, out, graphed):
     model = MODEL_REGISTRY.get("SViT")(cfg).cuda()
     model.load_state_dict(P.state_dict(R.param_shapes(R.make_spec(4, 64, drop_path_rate=0.0,
                                                                   dropout_rate=0.0))))
-    dp = DataParallel(model, bucket_ranks=4) if world > 1 else model
+    dp = DataParallel(model, bucket_ranks=4, force_collectives=force) if (world > 1 or force) else model
 
     def batch(role):
         if role.is_image:

@@ -175,26 +175,7 @@ def test_gemm_tn_grouped(ops, count, tile_mode):
     try:
         _tn_grouped_case(ops, count)
     finally:
-        lib.svit_debug_set_tn_tile(2)      # the library's default
-
-
-def test_gemm_tn_grouped_wide_tiles(ops):
-    """Round 4: 128 x 384 tiles on 8-wave workgroups (svit_debug_set_tn_tile(4 | mode)) for groups whose problems all have
-    K % 384 == 0 and N >= 128 -- ragged rows (M % 32 != 0), a ragged N tile, row-strided A, with and without bias -- and a
-    group with one K = 96 problem, which must fall back to the 4-wave kernel."""
-    import ctypes as C
-    from svit_amd import hip
-    lib = hip.load()
-    lib.svit_debug_set_tn_tile.restype, lib.svit_debug_set_tn_tile.argtypes = C.c_int32, [C.c_int32]
-    try:
-        for mode in (6, 10, 14):       # eight waves of 64 x 96 / four waves of 128 x 96 / ring form (8 MFMA + 4 loader waves)
-            assert lib.svit_debug_set_tn_tile(mode) == 0
-            _tn_grouped_case(ops, 8, [(4100, 384, 1536), (13064, 384, 384), (64, 3072, 768), (2000, 1152, 384),
-                                      (700, 768, 768), (3001, 1536, 384), (129, 128, 384), (500, 200, 384)])
-            _tn_grouped_case(ops, 3, [(4100, 384, 1536), (1000, 288, 96), (2000, 1152, 384)])
-        _tn_grouped_case(ops, 11)          # (mode 14 still set: a mixed group is split into a ring launch and a 4-wave launch)
-    finally:
-        lib.svit_debug_set_tn_tile(2)
+        lib.svit_debug_reset()
 
 
 def _tn_grouped_case(ops, count, shapes=None):
@@ -799,22 +780,15 @@ def test_relpos_q(ops, q_thw, k_thw):
 
 
 
-@pytest.mark.parametrize("B,h,thw,sq,skv,n_obj,ychunk", [
-    (2, 4, (8, 14, 14), 1, 2, 64, False),     # blocks 4-13 of 16x224^2
-    (1, 4, (16, 14, 14), 1, 2, 128, False),   # 32x224^2: three t-chunks per tensor
-    (1, 8, (16, 14, 14), 2, 1, 128, False),   # block 14 at 32 frames
-    (3, 4, (1, 14, 14), 1, 2, 4, False),      # frames pass (T' = 1)
-    (2, 8, (8, 7, 7), 1, 1, 64, False),       # block 15
-    (2, 2, (5, 9, 13), 2, 1, 8, False),       # odd plane, odd T
-    # y-chunked planes (svit_debug_set_pool(1, 1); round 3's cut variant, its ragged-last-chunk division fixed in
-    # round 4 -- csrc/pool.hip::fdiv): 28x28 at strides 1 / 2 with T = 8 / 14 / 16, and a 14x14 plane cut in y
-    (2, 2, (8, 28, 28), 1, 2, 64, True),
-    (1, 2, (16, 28, 28), 2, 2, 128, True),
-    (1, 2, (14, 28, 28), 2, 2, 8, True),
-    (1, 4, (8, 14, 14), 1, 2, 64, True),
-    (1, 2, (3, 26, 22), 2, 2, 8, True),
+@pytest.mark.parametrize("B,h,thw,sq,skv,n_obj", [
+    (2, 4, (8, 14, 14), 1, 2, 64),     # blocks 4-13 of 16x224^2
+    (1, 4, (16, 14, 14), 1, 2, 128),   # 32x224^2: three t-chunks per tensor
+    (1, 8, (16, 14, 14), 2, 1, 128),   # block 14 at 32 frames
+    (3, 4, (1, 14, 14), 1, 2, 4),      # frames pass (T' = 1)
+    (2, 8, (8, 7, 7), 1, 1, 64),       # block 15
+    (2, 2, (5, 9, 13), 2, 1, 8),       # odd plane, odd T
 ])
-def test_pool_slab_forward_vs_conv3d(ops, B, h, thw, sq, skv, n_obj, ychunk):
+def test_pool_slab_forward_vs_conv3d(ops, B, h, thw, sq, skv, n_obj):
     """Round-3 slab stencil (csrc/pool.hip::pool_slab_fwd_kernel + pool_slab_ln_kernel; the path the
     engine takes on planes <= 14x14): pre-LN values against torch's depthwise conv3d on the same bf16
     operands, object / cls rows against the closed form, and out / mean / rstd against the streaming
@@ -838,7 +812,6 @@ def test_pool_slab_forward_vs_conv3d(ops, B, h, thw, sq, skv, n_obj, ychunk):
     da = 128 if J <= 32 else 160
     res = []
     try:
-        lib.svit_debug_set_pool(1, 1 if ychunk else 0)
         for on in (0, 1, 3):       # streaming kernels / VALU slab conv / MFMA conv wherever its geometry holds (else the slab)
             lib.svit_debug_set_pool(0, on)
             r = ops.pool_ln_fwd_qkv(qkv, ws, g, b, B, h, thw, n_obj, (sq, skv, skv), (da, da, 96), (0, 1, 0),
@@ -846,8 +819,7 @@ def test_pool_slab_forward_vs_conv3d(ops, B, h, thw, sq, skv, n_obj, ychunk):
             torch.cuda.synchronize()
             res.append(r)
     finally:
-        lib.svit_debug_set_pool(0, 2)      # the library's defaults
-        lib.svit_debug_set_pool(1, 0)
+        lib.svit_debug_reset()
     for which, s in ((0, sq), (1, skv), (2, skv)):
         x = qkv[:, 1:1 + L, which].float()
         vol = x.reshape(B, T, H, W, h, 96).permute(0, 4, 5, 1, 2, 3).reshape(B * h, 96, T, H, W)
@@ -970,41 +942,6 @@ def test_attention_fwd_pipelined_kernel(ops, B, h, Nq, Nk, DA, J):
     assert rel_err(ctx, ref) < 2e-2 and cos(ctx, ref) > 0.9999
     assert rel_err(lse2, torch.logsumexp(s, dim=-1) * math.log2(math.e)) < 1e-3
 
-
-
-@pytest.mark.parametrize("B,h,Nq,Nk,DA,J", [
-    (2, 4, 1633, 457, 128, 22),    # blocks 4-13: 7 workgroups of 256 rows per (batch, head), a ragged last tile of 9 keys
-    (1, 2, 700, 1633, 160, 36),    # long keys, 9 k-steps
-    (2, 2, 300, 54, 128, 15),      # a single ragged tile, 7 k-steps (two softmax steps without an MFMA to hide behind)
-    (1, 1, 70, 128, 160, 64),      # two tiles, 10 k-steps
-    (1, 1, 257, 192, 128, 0),      # three tiles, one row in the second workgroup
-    (1, 2, 129, 330, 128, 22),     # six tiles
-])
-def test_attention_fwd_one_wave_per_simd_kernel(ops, B, h, Nq, Nk, DA, J):
-    """Round 4: the 64-rows-per-wave, one-wave-per-SIMD forward (csrc/attn_fwd64.hip) against the
-    fp32 reference and against the 128-query kernels.  It is NOT the product path (1.5x slower on every shape of the
-    model, profiles/r04_attn_w64.txt); svit_attn_debug_set(1, 1) selects it."""
-    import ctypes as C
-    from svit_amd import hip
-    lib = hip.load()
-    scale = 96 ** -0.5
-    qa = rnd("wq%d_%d" % (Nq, DA), (B, h, Nq, DA), 1.0, BF16)
-    ka = rnd("wk%d_%d" % (Nk, DA), (B, h, Nk, DA), KSC, BF16)
-    v = rnd("wv%d" % Nk, (B, h, Nk, 96), 1.0, BF16)
-    if J:
-        qa[..., 96 + J:] = 0
-        ka[..., 96 + J:] = 0
-    ctx0, lse0 = ops.attn_fwd(qa, ka, v, scale, bias_cols=J)
-    try:
-        assert lib.svit_attn_debug_set(1, 1) == 0
-        ctx, lse2 = ops.attn_fwd(qa, ka, v, scale, bias_cols=J)
-        torch.cuda.synchronize()
-    finally:
-        lib.svit_attn_debug_set(1, 0)
-    ref, s = _attn_ref(qa.float().cpu(), ka.float().cpu(), v.float().cpu(), scale)
-    assert rel_err(ctx, ref) < 2e-2 and cos(ctx, ref) > 0.9999
-    assert rel_err(lse2, torch.logsumexp(s, dim=-1) * math.log2(math.e)) < 1e-3
-    assert rel_err(ctx, ctx0) < 1e-2 and rel_err(lse2, lse0) < 1e-3      # (row sums: fp32 adds here, bf16 P on the matrix pipe there)
 
 
 @pytest.mark.parametrize("B,h,Nq,Nk,J", [

@@ -314,3 +314,30 @@ def test_full_size_properties_of_the_bench_workload():
         opt.step()
         losses.append(float(loss))
     assert all(l == l for l in losses) and losses[-1] < losses[0] - 0.05, losses
+
+
+def test_grouped_second_stage_reductions_equal_ungrouped():
+    """Engine.RED_GROUP (second-stage reductions of 4 blocks in one launch, rotating scratch slots)
+    against RED_GROUP = 1 (one launch per block), with the gradient-ready hook firing INSIDE a group (ranks 2 and 6 of
+    a depth-16 model = after blocks 14 and 10, both mid-group) so that `ready()` flushes a part-filled queue: flat.grad
+    must be bit-equal (deterministic mode: no fp32 atomics meet anywhere)."""
+    from svit_amd.engine import Engine
+    grads = []
+    for rg in (1, 4, 0):
+        cfg, model, spec, sd = S.build_hip_model(4, 64)
+        model.engine = Engine(model.plan, model.flat, red_group=rg)
+        assert model.engine.RED_GROUP == max(1, rg)
+        model.engine.deterministic = True
+        model.engine.refresh_weights()
+        fired = []
+        model._grad_ready_hook = fired.append
+        model._grad_ready_ranks = {2, 6, model.flat.n_ranks - 1}
+        x = P.frames(2, 4, 64).cuda()
+        logits, _ = model([x], {})
+        model.flat.grad.zero_()
+        torch.nn.functional.cross_entropy(logits, P.labels(2).cuda()).backward()
+        torch.cuda.synchronize()
+        assert fired == list(range(model.flat.n_ranks))
+        grads.append(model.flat.grad.clone())
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+    assert float(grads[0].abs().max()) > 0

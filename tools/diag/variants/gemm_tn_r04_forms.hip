@@ -3,7 +3,11 @@
 //                  through ds_read_b64_tr_b16 transposed LDS reads; fused bias gradient)
 // (the forward / dgrad kernel svit_gemm_nt lives in gemm_nt.hip)
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <type_traits>
+#include <vector>
+#include <cstdlib>
 #include "common.h"
 #include "../../include/svit_hip.h"
 
@@ -78,6 +82,14 @@ using TnSmallD = TnDma<1, 4, 1, 64, 2>;     // 128 x 96 tiles, 64 rows per stage
 #define SVIT_TN_BIG_BM 32
 #endif
 using TnBigD = TnDma<2, 2, 2, SVIT_TN_BIG_BM, SVIT_TN_BIG_NS>;       // 128 x 192 tiles, 32 rows per stage, 3 stages (60 KB)
+#ifndef SVIT_TN_WIDE_NS
+#define SVIT_TN_WIDE_NS 4
+#endif
+// round 4: 128 x 384 tiles, EIGHT waves (2 x 4 of 64 x 96), 32 rows per stage (8 + 24 KB), one workgroup per CU: 48 flop per
+// staged byte against 38 (128 x 192) -- for the K % 384 == 0 problems (every Linear of the 14x14 and 7x7 stages)
+using TnWideD = TnDma<2, 2, 4, 32, SVIT_TN_WIDE_NS>;
+// the same tile on FOUR waves of 128 x 96 (one wave per SIMD): 14 transposed reads per 12 MFMAs instead of 10 per 6
+using TnWide4D = TnDma<4, 1, 4, 32, SVIT_TN_WIDE_NS>;
 constexpr int TN_DMA_LDS = 2 * TnSmallD::STAGE > SVIT_TN_BIG_NS * TnBigD::STAGE ? 2 * TnSmallD::STAGE : SVIT_TN_BIG_NS * TnBigD::STAGE;
 
 template <int OFF>
@@ -267,6 +279,202 @@ __device__ __forceinline__ void tn_tile_dma(unsigned char* lds, const bf16_t* __
 }
 
 
+// ---------------------------------------------------------------------------------------
+// Ring form of the same tile walk (late round 4): LOADER waves + MFMA waves, as in gemm_nt_ring_kernel.  SQ counters of the
+// grouped launches inside the step (profiles/r04_tn_sq_counters.txt): matrix pipe 40 % busy, waves 41 % stalled at issue, and
+// five loops that differ in tile, wave count, ring depth, rows per stage and flush all land on 1.42 ms -- what they share is that
+// a wave ISSUES its LDS-DMA pieces (60-185 cycles each, MI355X guide) in the same instruction stream as its 12 MFMAs per stage.
+// Here waves NM .. NM+NL-1 only issue pieces, wait for them (counted vmcnt), zero a ragged last stage and sum the bias columns;
+// waves 0 .. NM-1 only read fragments and multiply.  One s_barrier per stage joins them: "stage s has landed" (loaders arrive
+// behind their vmcnt) and "stage s-1 is read" (MFMA waves arrive behind the lgkmcnt(0) of its last fragments).
+template <class C, int NL>
+__device__ __forceinline__ void tn_tile_ring(unsigned char* lds, const bf16_t* __restrict__ A, int lda,
+                                             const bf16_t* __restrict__ B, int ldb,
+                                             float* __restrict__ dW, int lddw, int M, int N, int K, int n0,
+                                             int k0, int m_begin, int m_end,
+                                             float* __restrict__ dbias, bool bias_tile) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int RB = C::RB, BM = C::BM, NS = C::NS, NM = C::NW;
+  constexpr int PIECES = C::A_INSTR + C::B_INSTR, PER = PIECES / NL, PA = C::A_INSTR / NL;
+  static_assert(C::A_INSTR % NL == 0 && C::B_INSTR % NL == 0, "pieces split evenly over the loader waves");
+  static_assert(NS >= 2 && NS <= 5, "ring depth");
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (m_begin >= m_end) return;
+  const int nsteps = (m_end - m_begin + BM - 1) / BM;
+  const bool do_bias = (dbias != nullptr) && bias_tile;
+  const unsigned lds0 = (unsigned)(size_t)lds;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  constexpr int LT = NL * 64;                                  // loader threads
+  const int ltid = tid - NM * 64;
+
+  if (wave >= NM) {
+    // ================================================================ loader waves
+    const int lw = wave - NM;
+    unsigned voff[PER];
+    const int na8 = (N - n0 + 7) / 8, nb8 = (K - k0 + 7) / 8;
+    auto piece = [&](int i, bool a) { return lw + NL * (a ? i : i - PA); };
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const bool a = i < PA;
+      const int o = piece(i, a) * 1024 + lane * 16;
+      const int rowb = a ? C::ROWA : C::ROWB;
+      const int row = o / rowb, inrow = o % rowb;
+      const int pb = inrow >> 6, c16 = (inrow >> 4) & 3;
+      const int lb = pb ^ (a ? C::swz_a(row) : C::swz_b(row));
+      const int ch = min(lb * 4 + c16, (a ? na8 : nb8) - 1);
+      voff[i] = (unsigned)(row * (a ? lda : ldb) + (a ? n0 : k0) + ch * 8) * 2u;
+    }
+    const auto ars = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)std::min<size_t>((size_t)M * lda * 2, 0x7fffffffu), 0x00020000);
+    const auto brs = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)std::min<size_t>((size_t)M * ldb * 2, 0x7fffffffu), 0x00020000);
+    auto issue = [&](int s) {
+      unsigned char* st = lds + (s % NS) * C::STAGE;
+      const int m0 = m_begin + s * BM;
+      const int valid = m_end - m0;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const bool a = i < PA;
+        unsigned vo = voff[i];
+        if (valid < BM) {
+          const int row = (piece(i, a) * 1024 + lane * 16) / (a ? C::ROWA : C::ROWB);
+          vo -= (unsigned)(row - min(row, valid - 1)) * (a ? lda : ldb) * 2u;
+        }
+        unsigned char* dst = st + (a ? 0 : C::A_BYTES) + piece(i, a) * 1024;
+        if (a)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)dst, 16, vo,
+                                                   (unsigned)m0 * lda * 2u, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void*)dst, 16, vo,
+                                                   (unsigned)m0 * ldb * 2u, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < nsteps) issue(s);
+    for (int s = 0; s < nsteps; ++s) {
+      // stages issued after stage s so far: the prologue's, then one per passed barrier
+      const int younger = min(NS - 2, nsteps - 1 - s);
+      if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
+      else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned so = (unsigned)((s % NS) * C::STAGE);
+      __builtin_amdgcn_s_barrier();      // B(s): stage s has landed; everyone is done with stage s-1
+      if (m_begin + (s + 1) * BM > m_end) {      // ragged last stage (uniform): the re-read rows count nothing --
+        const int valid = m_end - (m_begin + s * BM);      // zeroed once EVERY loader's pieces are in, behind a barrier of their own
+        for (int c = ltid; c < (BM - valid) * (C::ROWA / 16); c += LT)
+          *(uint4*)(lds + so + valid * C::ROWA + c * 16) = make_uint4(0, 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      if (s + NS - 1 < nsteps) issue(s + NS - 1);
+      if (do_bias) {
+        constexpr int CPR = C::TN / 8, RP = LT / CPR;
+        static_assert(BM % RP == 0, "whole passes over a stage");
+#pragma unroll
+        for (int r0 = 0; r0 < BM; r0 += RP) {
+          const int row = r0 + ltid / CPR, lc = ltid % CPR;
+          uint4 u;
+          asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(u)
+                       : "v"(lds0 + so + row * C::ROWA + ((((lc >> 2) ^ C::swz_a(row))) << 6) + (lc & 3) * 16) : "memory");
+          bsum[0] += lo_bf16(u.x); bsum[1] += hi_bf16(u.x);
+          bsum[2] += lo_bf16(u.y); bsum[3] += hi_bf16(u.y);
+          bsum[4] += lo_bf16(u.z); bsum[5] += hi_bf16(u.z);
+          bsum[6] += lo_bf16(u.w); bsum[7] += hi_bf16(u.w);
+        }
+      }
+    }
+  } else {
+    // ================================================================ MFMA waves
+    const int wn = wave / C::WK, wk = wave % C::WK;
+    f32x16_t acc[RB][3];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int hh = lane >> 5, cg = (lane >> 4) & 1, ii = lane & 15, q = ii >> 2, pp = ii & 3;
+    unsigned a_addr[RB], b_addr[3];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int col = wn * 32 * RB + i * 32 + 16 * cg + 4 * pp;
+      a_addr[i] = lds0 + (8 * hh + q) * C::ROWA + (((col >> 5) ^ C::swz_a(q)) << 6) + (col & 31) * 2;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int col = wk * 96 + j * 32 + 16 * cg + 4 * pp;
+      b_addr[j] = lds0 + C::A_BYTES + (8 * hh + q) * C::ROWB + (((col >> 5) ^ C::swz_b(q)) << 6) + (col & 31) * 2;
+    }
+    constexpr int KS = BM / 16;
+    for (int s = 0; s < nsteps; ++s) {
+      __builtin_amdgcn_s_barrier();      // B(s)
+      if (m_begin + (s + 1) * BM > m_end) __builtin_amdgcn_s_barrier();     // (the loaders zero the ragged rows in between)
+      const unsigned so = (unsigned)((s % NS) * C::STAGE);
+      s16x4_t fl[2][RB + 3], fh[2][RB + 3];
+      auto rd = [&](auto KS_, auto BUF_) {
+        constexpr int ks = decltype(KS_)::value, buf = decltype(BUF_)::value;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          tn_read_tr<ks * 16 * C::ROWA>(fl[buf][i], a_addr[i] + so);
+          tn_read_tr<(ks * 16 + 4) * C::ROWA>(fh[buf][i], a_addr[i] + so);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          tn_read_tr<ks * 16 * C::ROWB>(fl[buf][RB + j], b_addr[j] + so);
+          tn_read_tr<(ks * 16 + 4) * C::ROWB>(fh[buf][RB + j], b_addr[j] + so);
+        }
+      };
+      rd(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+      tn_static_for<0, KS>([&](auto KS_) {
+        constexpr int ks = decltype(KS_)::value, cur = ks & 1;
+        if constexpr (ks + 1 < KS) {
+          rd(std::integral_constant<int, ks + 1>{}, std::integral_constant<int, (cur ^ 1)>{});
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (RB + 3)) : "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int f = 0; f < RB + 3; ++f) asm volatile("" : "+v"(fl[cur][f]), "+v"(fh[cur][f]));
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int i = 0; i < RB; ++i)
+            acc[i][j] = mfma32(make_bf16x8(fl[cur][i], fh[cur][i]), make_bf16x8(fl[cur][RB + j], fh[cur][RB + j]), acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int col = k0 + wk * 96 + j * 32 + (lane & 31);
+        if (col >= K) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = n0 + wn * 32 * RB + i * 32 + acc_row(r, lane);
+          if (row < N) atomicAdd(dW + (size_t)row * lddw + col, acc[i][j][r]);
+        }
+      }
+  }
+  if (do_bias) {  // the loaders' column sums: reduce through LDS, one atomic per column
+    constexpr int CPR = C::TN / 8, RP = LT / CPR;
+    __syncthreads();                  // (the ring is read by nobody any more)
+    float* red = (float*)lds;  // [RP][TN]
+    if (wave >= NM) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[(ltid / CPR) * C::TN + (ltid % CPR) * 8 + e] = bsum[e];
+    }
+    __syncthreads();
+    if (tid < C::TN && n0 + tid < N) {
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < RP; ++g) sum += red[g * C::TN + tid];
+      atomicAdd(dbias + n0 + tid, sum);
+    }
+  }
+#endif
+}
+
 constexpr int TN_BM = TnSmall::BM, TN_TN = TnSmall::TN, TN_TK = TnSmall::TK;   // the single-GEMM entry point
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ A, int lda,
@@ -292,6 +500,10 @@ struct TnGroup {
   int rows_per_split[SVIT_TN_GROUP_MAX];
   int big[SVIT_TN_GROUP_MAX];          // 1: 128 x 192 tiles (TnBig), 0: 128 x 96 (TnSmall)
   int count;
+  // round 4 (SVIT_TN_PACK): explicit placement -- entry [xcd * cap + pos] = problem << 24 | split << 12 | tile, -1 = empty slot.
+  // The tiles of one (problem, split) walk the same rows; packed so that no such set straddles two XCDs (two L2s fetching it)
+  const int* table;
+  int cap;
 };
 
 #ifndef SVIT_TN_WPE         // waves per SIMD the grouped kernel is compiled for (diagnostic builds: 3 with SVIT_TN_BIG_NS=2 = three workgroups per CU)
@@ -306,13 +518,19 @@ __global__ __launch_bounds__(256, SVIT_TN_WPE) void gemm_tn_grouped_kernel(const
   // against ~230 MB of operands -- the kernel ran at HBM speed).
   const int nwg = gridDim.x, lin = blockIdx.x;
   const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
-  int pi = 0;
-  const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  int pi = 0, tile, split;
+  if (g.table) {
+    const int e = g.table[xcd * g.cap + (lin >> 3)];
+    if (e < 0) return;                     // (padding slot)
+    pi = e >> 24; split = (e >> 12) & 0xfff; tile = e & 0xfff;
+  } else {
+    const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
 #pragma unroll
-  for (int i = 1; i < SVIT_TN_GROUP_MAX; ++i)
-    if (i < g.count && bid >= g.first_block[i]) pi = i;
-  const int local = bid - g.first_block[pi];
-  const int tile = local % g.tiles[pi], split = local / g.tiles[pi];
+    for (int i = 1; i < SVIT_TN_GROUP_MAX; ++i)
+      if (i < g.count && bid >= g.first_block[i]) pi = i;
+    const int local = bid - g.first_block[pi];
+    tile = local % g.tiles[pi]; split = local / g.tiles[pi];
+  }
   const svit_tn_problem& p = g.p[pi];
   const int tn = tile % g.tiles_n[pi], tk = tile / g.tiles_n[pi];
   const int m_begin = split * g.rows_per_split[pi];
@@ -324,6 +542,48 @@ __global__ __launch_bounds__(256, SVIT_TN_WPE) void gemm_tn_grouped_kernel(const
     tn_tile_dma<TnSmallD>(lds, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.dW, p.lddw, p.M, p.N, p.K,
                           tn * TnSmall::TN, tk * TnSmall::TK, m_begin, min(p.M, m_begin + g.rows_per_split[pi]),
                           p.dbias, tk == 0);
+}
+
+// the same grid logic for groups whose problems all take 128 x 384 tiles (8 waves, dynamic LDS: NS x 32 KB)
+template <class CFG>
+__global__ __launch_bounds__(CFG::NT, 1) void gemm_tn_grouped_wide_kernel(const TnGroup g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_w[];
+  const int nwg = gridDim.x, lin = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+  const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < SVIT_TN_GROUP_MAX; ++i)
+    if (i < g.count && bid >= g.first_block[i]) pi = i;
+  const svit_tn_problem& p = g.p[pi];
+  const int local = bid - g.first_block[pi];
+  const int tile = local % g.tiles[pi], split = local / g.tiles[pi];
+  const int tn = tile % g.tiles_n[pi], tk = tile / g.tiles_n[pi];
+  const int m_begin = split * g.rows_per_split[pi];
+  tn_tile_dma<CFG>(lds_w, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.dW, p.lddw, p.M, p.N, p.K,
+                   tn * CFG::TN, tk * CFG::TK, m_begin, min(p.M, m_begin + g.rows_per_split[pi]),
+                   p.dbias, tk == 0);
+}
+
+// ring form: the 128 x 384 tile, eight MFMA waves + four loader waves, one workgroup per CU
+constexpr int TN_RING_NL = 4;
+__global__ __launch_bounds__((TnWideD::NW + TN_RING_NL) * 64, 1) void gemm_tn_grouped_ring_kernel(const TnGroup g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_r[];
+  const int nwg = gridDim.x, lin = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+  const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < SVIT_TN_GROUP_MAX; ++i)
+    if (i < g.count && bid >= g.first_block[i]) pi = i;
+  const svit_tn_problem& p = g.p[pi];
+  const int local = bid - g.first_block[pi];
+  const int tile = local % g.tiles[pi], split = local / g.tiles[pi];
+  const int tn = tile % g.tiles_n[pi], tk = tile / g.tiles_n[pi];
+  const int m_begin = split * g.rows_per_split[pi];
+  tn_tile_ring<TnWideD, TN_RING_NL>(lds_r, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.dW, p.lddw, p.M, p.N, p.K,
+                                    tn * TnWideD::TN, tk * TnWideD::TK, m_begin, min(p.M, m_begin + g.rows_per_split[pi]),
+                                    p.dbias, tk == 0);
 }
 
 __global__ void colsum_kernel(const bf16_t* __restrict__ A, int lda, float* __restrict__ out,
@@ -390,13 +650,33 @@ extern "C" int svit_gemm_tn(const void* A, int lda, const void* B, int ldb, floa
   return SVIT_OK;
 }
 
-// cost-model constants of the grouped launch: SVIT_K_TN_STEP_US_X100 (one 64-row step of a workgroup, 512 resident),
-// SVIT_K_TN_ATOMIC_TBS_X100 (effective fp32 atomic flush rate) and the tile mode SVIT_K_TN_TILE of the knob table in
-// common.h -- 2 = 128x192 everywhere since the in-step A/B of round 3 (13.46 -> 13.30 ms per step,
-// profiles/r03_tn_tile_modes.txt: inside the step the operands come from HBM, not from the Infinity Cache an isolated
-// loop keeps them in, and fewer, fatter tiles re-read less).  The 128x384 forms (eight waves, four waves, ring with loader
-// waves) and the XCD-packed placement table of round 4 measured level or behind (profiles/r04_tn_l2_counters.txt) and
-// live on only as tools/diag/variants/gemm_tn_r04_forms.hip.
+// cost-model constants of the grouped launch (svit_debug_set_tn / svit_debug_set_tn_tile for sweeps)
+// (environment overrides for in-step A/B runs -- isolated loops keep the operands in the Infinity Cache and
+// hide what the planner costs in HBM re-reads: SVIT_TN_STEP_US, SVIT_TN_ATOMIC_TBS, SVIT_TN_TILE)
+static double tn_env(const char* name, double dflt) {
+  const char* e = getenv(name);
+  return e ? atof(e) : dflt;
+}
+static std::atomic<double> g_tn_step_us{tn_env("SVIT_TN_STEP_US", 0.85)};      // one 64-row step of a workgroup, 512 resident
+static std::atomic<double> g_tn_atomic_tbs{tn_env("SVIT_TN_ATOMIC_TBS", 0.75)};   // effective fp32 atomic flush rate, TB/s
+// 0: 128x96 tiles only, 1: the per-problem heuristic fitted on ISOLATED launches, 2: 128x192 everywhere (default since
+// the in-step A/B of round 3: 13.46 -> 13.30 ms per step, profiles/r03_tn_tile_modes.txt -- inside the step the
+// operands come from HBM, not from the Infinity Cache an isolated loop keeps them in, and fewer, fatter tiles
+// re-read less), 3: 128x192 where K % 192 == 0
+static std::atomic<int> g_tn_big{(int)tn_env("SVIT_TN_TILE", 2)};
+static std::atomic<int> g_tn_wide{(int)tn_env("SVIT_TN_WIDE", 0)};      // 1: 128 x 384 / 8-wave tiles for the groups whose K are all multiples of 384
+extern "C" int svit_debug_set_tn_tile(int mode) {
+  if (mode < 0 || mode > 15) return SVIT_ERR_ARG;
+  g_tn_big = mode & 3;
+  g_tn_wide = (mode >> 2) & 3;       // 1: eight waves of 64 x 96, 2: four waves of 128 x 96, 3: ring form (8 MFMA + 4 loader waves)       // 1: eight waves of 64 x 96, 2: four waves of 128 x 96, 3: ring form (8 MFMA + 4 loader waves)
+  return SVIT_OK;
+}
+extern "C" int svit_debug_set_tn(int step_us_x100, int atomic_tbs_x100) {
+  if (step_us_x100 > 0) g_tn_step_us = step_us_x100 * 0.01;
+  if (atomic_tbs_x100 > 0) g_tn_atomic_tbs = atomic_tbs_x100 * 0.01;
+  return SVIT_OK;
+}
+
 static int tn_check(const svit_tn_problem& p) {
   if (!p.A || !p.B || !p.dW) return SVIT_ERR_ARG;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return SVIT_ERR_SHAPE;
@@ -406,6 +686,77 @@ static int tn_check(const svit_tn_problem& p) {
   return SVIT_OK;
 }
 
+
+// ---- XCD-aligned placement of the grouped launch (round 4, SVIT_TN_PACK) ---------------------------------------------
+// Workgroups are dealt to the 8 XCDs round-robin (blockIdx & 7); the tiles of one (problem, split) read the same reduction rows
+// and share them through ONE L2 only if they sit on one XCD.  With plain consecutive ids about a third of those sets straddle
+// two XCDs and both L2s fetch the rows (TCC counters: 1.45x the operand bytes over the fabric).  Here the sets are packed into
+// eight bins (first-fit decreasing, capacity grown until everything fits); the table lives in device memory, built once per
+// distinct group geometry (the geometries of a training step are static) and cached.
+static std::atomic<int> g_tn_pack{(int)tn_env("SVIT_TN_PACK", 0)};
+struct TnPackEntry { std::vector<int> key; int* dev; int cap; };
+static std::mutex g_tn_pack_mu;
+static std::vector<TnPackEntry> g_tn_pack_cache;
+static const int* tn_pack_table(const TnGroup& g, int total, int* cap_out) {
+  std::vector<int> key;
+  int dev_id = 0;
+  if (hipGetDevice(&dev_id) != hipSuccess) dev_id = 0;
+  key.push_back(dev_id);
+  struct Set { int pi, split, n; };
+  std::vector<Set> sets;
+  for (int i = 0; i < g.count; ++i) {
+    const int splits = (g.p[i].M + g.rows_per_split[i] - 1) / g.rows_per_split[i];
+    key.push_back(g.tiles[i]); key.push_back(splits);
+    if (g.tiles[i] > 0xfff || splits > 0xfff) return nullptr;
+    for (int sp = 0; sp < splits; ++sp) sets.push_back({i, sp, g.tiles[i]});
+  }
+  std::lock_guard<std::mutex> lk(g_tn_pack_mu);
+  for (const auto& e : g_tn_pack_cache)
+    if (e.key == key) { *cap_out = e.cap; return e.dev; }
+  // sets larger than a bin are cut into bin-sized pieces first (block 0: hundreds of tiles per split)
+  std::vector<int> order(sets.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sets[a].n > sets[b].n; });
+  int cap = (total + 7) / 8;
+  std::vector<std::vector<int>> bins;
+  for (;; cap += std::max(1, cap / 32)) {
+    bins.assign(8, {});
+    std::vector<int> used(8, 0);
+    bool ok = true;
+    for (int si : order) {
+      const Set& st = sets[si];
+      int done = 0;
+      while (done < st.n) {
+        // whole remainder into the first bin that takes it, else the emptiest bin takes what it can
+        int b = -1;
+        for (int x = 0; x < 8; ++x)
+          if (cap - used[x] >= st.n - done) { b = x; break; }
+        int take = st.n - done;
+        if (b < 0) {
+          if (st.n - done <= cap) { ok = false; break; }       // would fit an empty bin: grow the capacity instead of cutting
+          b = (int)(std::min_element(used.begin(), used.end()) - used.begin());
+          take = cap - used[b];
+          if (take <= 0) { ok = false; break; }
+        }
+        for (int t = 0; t < take; ++t) bins[b].push_back(st.pi << 24 | st.split << 12 | (done + t));
+        used[b] += take;
+        done += take;
+      }
+      if (!ok) break;
+    }
+    if (ok) break;
+    if (cap > total) return nullptr;
+  }
+  std::vector<int> host((size_t)8 * cap, -1);
+  for (int x = 0; x < 8; ++x)
+    for (size_t j = 0; j < bins[x].size(); ++j) host[(size_t)x * cap + j] = bins[x][j];
+  int* dev = nullptr;
+  if (hipMalloc((void**)&dev, host.size() * sizeof(int)) != hipSuccess) return nullptr;
+  if (hipMemcpy(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); return nullptr; }
+  g_tn_pack_cache.push_back({key, dev, cap});
+  *cap_out = cap;
+  return dev;
+}
 
 static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void* stream);
 
@@ -421,19 +772,39 @@ extern "C" int svit_gemm_tn_grouped_ex(const svit_tn_problem* probs, int count, 
   return tn_grouped(probs, count, ordered, stream);
 }
 
+static int tn_grouped_launch(const svit_tn_problem* probs, int count, int ordered, void* stream);
 static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void* stream) {
   if (!probs || count <= 0) return SVIT_ERR_ARG;
   for (int i = 0; i < count; ++i) {
     const int rc = tn_check(probs[i]);
     if (rc) return rc;
   }
+  if (g_tn_wide.load() >= 1 && g_tn_wide.load() <= 3 && !ordered) {
+    // the wide / ring kernels are launches of their own (one launch = one block size): the K % 384 == 0 problems -- the Linears of
+    // the 14x14 and 7x7 stages -- go there, the rest (the K = 96 rel-pos table gradients, narrow stages) stay on the 4-wave kernel
+    std::vector<svit_tn_problem> w, r;
+    for (int i = 0; i < count; ++i)
+      (probs[i].K % TnWideD::TK == 0 && probs[i].N >= 128 ? w : r).push_back(probs[i]);
+    if (!w.empty() && !r.empty()) {
+      if (int rc = tn_grouped_launch(w.data(), (int)w.size(), ordered, stream)) return rc;
+      return tn_grouped_launch(r.data(), (int)r.size(), ordered, stream);
+    }
+  }
+  return tn_grouped_launch(probs, count, ordered, stream);
+}
+static int tn_grouped_launch(const svit_tn_problem* probs, int count, int ordered, void* stream) {
   for (int base = 0; base < count; base += SVIT_TN_GROUP_MAX) {
     TnGroup g;
     g.count = count - base < SVIT_TN_GROUP_MAX ? count - base : SVIT_TN_GROUP_MAX;
     long max_steps = 1;
-    const int big_mode = svit_knob(SVIT_K_TN_TILE);
-    const double step_us = svit_knob(SVIT_K_TN_STEP_US_X100) * 0.01, atomic_tbs = svit_knob(SVIT_K_TN_ATOMIC_TBS_X100) * 0.01;
-    constexpr long slots = 512;      // resident 4-wave workgroups the planner counts on
+    const int big_mode = g_tn_big.load();
+    // round 4: 128 x 384 / 8-wave tiles where EVERY problem of the group has K % 384 == 0 and N >= 128 (one launch = one
+    // block size); SVIT_TN_WIDE / svit_debug_set_tn_tile(4 | mode): A/B knob
+    bool wide = g_tn_wide.load() >= 1 && g_tn_wide.load() <= 3;
+    for (int i = 0; i < g.count && wide; ++i)
+      wide = probs[base + i].K % TnWideD::TK == 0 && probs[base + i].N >= 128;
+    static const long slots4 = (long)tn_env("SVIT_TN_SLOTS", 512);      // resident 4-wave workgroups the planner counts on (A/B knob)
+    const long slots = wide ? 256 : slots4;
     int bm[SVIT_TN_GROUP_MAX];
     double tile_bytes[SVIT_TN_GROUP_MAX];
     for (int i = 0; i < g.count; ++i) {
@@ -447,8 +818,9 @@ static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void
                                   (g.p[i].M <= 4096 || (g.p[i].M >= 32768 && g.p[i].M < 131072)))
                  : big_mode == 3 ? (g.p[i].K % TnBig::TK == 0 && g.p[i].N >= 128)
                                  : (big_mode == 2);
-      const int tn = g.big[i] ? TnBig::TN : TnSmall::TN, tk = g.big[i] ? TnBig::TK : TnSmall::TK;
-      bm[i] = g.big[i] ? TnBigD::BM : TnSmall::BM;
+      if (wide) g.big[i] = 1;
+      const int tn = wide ? TnWideD::TN : g.big[i] ? TnBig::TN : TnSmall::TN, tk = wide ? TnWideD::TK : g.big[i] ? TnBig::TK : TnSmall::TK;
+      bm[i] = wide ? TnWideD::BM : g.big[i] ? TnBigD::BM : TnSmall::BM;
       tile_bytes[i] = (double)tn * tk * 4.0;
       g.tiles_n[i] = (g.p[i].N + tn - 1) / tn;
       g.tiles[i] = g.tiles_n[i] * ((g.p[i].K + tk - 1) / tk);
@@ -470,8 +842,8 @@ static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void
         blocks += nb;
         flush += (double)nb * tile_bytes[i];
       }
-      const double t = (double)((blocks + slots - 1) / slots) * steps * step_us +
-                       flush / (atomic_tbs * 1e6);
+      const double t = (double)((blocks + slots - 1) / slots) * steps * g_tn_step_us +
+                       flush / (g_tn_atomic_tbs * 1e6);
       if (t < best) { best = t; best_steps = steps; }
     }
     if (ordered) best_steps = max_steps;
@@ -483,7 +855,31 @@ static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void
       total += g.tiles[i] * splits;
     }
     for (int i = g.count; i <= SVIT_TN_GROUP_MAX; ++i) g.first_block[i] = total;
-    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, g);
+    g.table = nullptr;
+    g.cap = 0;
+    int launch_total = total;
+    if (!wide && !ordered && g_tn_pack.load() != 0 && total >= 64) {
+      int cap = 0;
+      g.table = tn_pack_table(g, total, &cap);
+      if (g.table) { g.cap = cap; launch_total = 8 * cap; }
+    }
+    if (wide) {
+      static SvitOnce once_wide, once_wide4;
+      constexpr size_t wlds = (size_t)TnWideD::NS * TnWideD::STAGE;
+      if (g_tn_wide.load() == 3) {      // (ring form: eight MFMA waves + four loader waves)
+        static SvitOnce once_ring;
+        if (int rc = svit_max_lds_once(once_ring, (const void*)gemm_tn_grouped_ring_kernel, wlds)) return rc;
+        hipLaunchKernelGGL(gemm_tn_grouped_ring_kernel, dim3(total), dim3((TnWideD::NW + TN_RING_NL) * 64), wlds, (hipStream_t)stream, g);
+      } else if (g_tn_wide.load() == 2) {      // (the four-wave form of the same tile)
+        if (int rc = svit_max_lds_once(once_wide4, (const void*)gemm_tn_grouped_wide_kernel<TnWide4D>, wlds)) return rc;
+        hipLaunchKernelGGL(gemm_tn_grouped_wide_kernel<TnWide4D>, dim3(total), dim3(256), wlds, (hipStream_t)stream, g);
+      } else {
+        if (int rc = svit_max_lds_once(once_wide, (const void*)gemm_tn_grouped_wide_kernel<TnWideD>, wlds)) return rc;
+        hipLaunchKernelGGL(gemm_tn_grouped_wide_kernel<TnWideD>, dim3(total), dim3(512), wlds, (hipStream_t)stream, g);
+      }
+    } else {
+      hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(launch_total), dim3(256), 0, (hipStream_t)stream, g);
+    }
     SVIT_LAUNCH_CHECK();
   }
   return SVIT_OK;
