@@ -16,6 +16,13 @@ constexpr int HD = 96;
 
 __device__ __forceinline__ int pooled(int n, int s) { return (n - 1) / s + 1; }
 
+// n / d for n < 65536 by one multiply-high with m = ceil(2^32 / d) (exact while n * d < 2^32)
+// (d = 1: ceil(2^32 / 1) does not fit 32 bits and wraps to 0 -- fdiv takes m = 0 as "divide by one".  Round 3's y-chunked
+// slab planes divided by the rows of a chunk, which is 1 for a ragged last chunk: every output of that chunk landed in
+// its first t-plane -- the "wrong rows at stride 2" of DESIGN.md section 5c)
+__device__ __forceinline__ int fdiv(int n, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n; }
+__device__ __forceinline__ unsigned fdiv_magic_dev(int d) { return 0xFFFFFFFFu / (unsigned)d + 1u; }   // = ceil(2^32 / d); 0 for d = 1
+
 // per-axis tap counts of the object branch: how many output positions of a zero-padded 3-cube
 // see tap i in range, and the number of output positions (attention.py:45-53)
 __device__ __forceinline__ void obj_counts(int s, float n[3], float* inv_p) {
@@ -1247,6 +1254,290 @@ __global__ __launch_bounds__(192) void pool_bwd_small_kernel(PoolBwdSmall g) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Fused conv backward of the small planes (round 5): conv dgrad AND conv wgrad of q, k, v in ONE
+// launch for every block whose POOLED planes fit LDS (output planes <= 14x14: blocks 3-15 of 16x224^2), replacing
+// pool_dgrad3 (27-tap gather of dpre through L2: 5x its bytes fetched) + pool_wgrad3 (x halo ring + dpre re-read).
+//   * A workgroup owns (batch*head, tensor, 32-CHANNEL group, t-chunk): 32 channels = 64 bytes = exactly one cache line of
+//     every token row it touches in dpre, qkv and dqkv -- no line is shared between workgroups, every byte of x is read
+//     once and every byte of dqkv written once.
+//   * dpre of the chunk's output planes (+ one halo plane each side in t) is staged ONCE in LDS, zero-padded in y and x:
+//     cell(yo, xo) = (yo + 1) * P + xo + 1 with pitch P = Wo + 1 (the right halo of a row is the left halo of the next),
+//     planes outside [0, T) are zero planes.  Every tap of every token is then an unconditional LDS read: no bounds
+//     tests, no clamped addresses.
+//   * The workgroup walks its INPUT tokens once (gather form).  Thread = (channel pair, token slot); per tap ONE
+//     ds_read_b32 (the pair's two bf16 dpre values) feeds dx += w * dpre (dgrad) and dw += x * dpre (wgrad) as four
+//     v_dot2_f32_bf16 against "selector" operands (the other half of the pair zero): no bf16 unpacking.  The 27 weights
+//     and 27 weight-gradient sums of both channels live in registers.  Stride 2: tokens are walked parity class by parity
+//     class ((y + 1) & 1, (x + 1) & 1) in groups of 4, so a wave's tap set is compile-time (4 / 2 / 2 / 1 (ky, kx) pairs).
+//   * x of the next token group is fetched while the current one is computed; dx leaves as 4-byte stores that fill whole
+//     64-byte lines per token.
+//   * dw: token slots meet through shuffles + LDS, one partial row [32 channels][27] per workgroup, summed by the
+//     second-stage reduce (fixed order: bit-reproducible).  cls / object rows (dx = dpre, dx = dpre * g(w), the closed-form
+//     object share of dw) ride on chunk 0.
+// The host planner cuts T per tensor so that the items are about equally long and fill the chip once, two workgroups per CU.
+constexpr int PF_NT = 256, PF_ROWB = 64, PF_SLOTS = PF_NT / 16;
+#ifdef SVIT_POOL_STAMPS
+__device__ unsigned long long g_pf_wg[8 * 2048];      // per workgroup of pool_bwd_fused_kernel: start, staged, walked, end, which, chunk, hw id
+#define PFSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x < 2048) g_pf_wg[8 * blockIdx.x + (i)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PFSTAMP(i) do {} while (0)
+#endif
+struct PoolBwdFused {
+  svit_pool_dgrad_args d[3];
+  const void* qkv;
+  float* partial;            // [B*heads * max_chunks][3][96][27]
+  int n_per[3], n_chunks[3]; // input planes per chunk / chunks, per tensor
+  int order[3];              // tensors in launch order (longest items first)
+  int first_item[4];         // item ranges of order[0..2]
+  int max_chunks;
+};
+
+__host__ __device__ inline int pf_plane_bytes(int Ho, int Wo) { return ((Ho + 2) * (Wo + 1) + 1) * PF_ROWB; }
+
+// One UNIT of the walk = what shares a neighbourhood of dpre cells:
+//   stride 1: one input token; its 27 taps read the 3 x 3 cells around (y, x) in planes t+1, t, t-1;
+//   stride 2: the 2 x 2 input tokens (2a .. 2a+1, 2b .. 2b+1).  Even coordinates are hit by tap 1 only (cell a), odd
+//     ones by tap 0 (cell a + 1) and tap 2 (cell a): the four tokens together use every (ky, kx) exactly once per plane
+//     on the 2 x 2 cells (a .. a+1, b .. b+1) -- 12 reads and 27 taps per unit, the same arithmetic per step as stride 1.
+// lb = LDS byte address of the unit's base cell (stride 1: cell (y, x); stride 2: cell (a, b)) in the slot of plane t.
+// ALL reads of the unit are issued before the first dot2 (a scheduling barrier keeps hipcc from sinking each read next
+// to its use, which exposed one LDS round trip per tap with only two waves per SIMD to hide it).
+template <int S>
+__device__ __forceinline__ void pf_unit(unsigned lb, int plane_b, int rowb, const uint32_t (&xs0)[S * S], const uint32_t (&xs1)[S * S],
+                                        const uint32_t (&w0)[27], const uint32_t (&w1)[27], float (&dw0)[27],
+                                        float (&dw1)[27], float (&a0)[S * S], float (&a1)[S * S]) {
+  constexpr int NR = S == 1 ? 3 : 2;              // cell rows / columns read per plane
+  uint32_t v[3][NR * NR];
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int cidx = 0; cidx < NR; ++cidx) {
+        const int dr = S == 1 ? r - 1 : r, dc = S == 1 ? cidx - 1 : cidx;     // stride 1: rows y-1 .. y+1; stride 2: rows a, a+1
+        v[kt][r * NR + cidx] = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(
+            lb + (1 - kt) * plane_b + dr * rowb + dc * PF_ROWB);
+      }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int k = (kt * 3 + ky) * 3 + kx;
+        // stride 1: output (y + 1 - ky, x + 1 - kx) = cell row 2 - ky of the 3 read.  stride 2: tap 0 -> odd token, cell + 1;
+        // tap 1 -> even token, cell + 0; tap 2 -> odd token, cell + 0
+        const int r = S == 1 ? 2 - ky : (ky == 0 ? 1 : 0), cidx = S == 1 ? 2 - kx : (kx == 0 ? 1 : 0);
+        const int tok = S == 1 ? 0 : (ky == 1 ? 0 : 2) + (kx == 1 ? 0 : 1);
+        const uint32_t d = v[kt][r * NR + cidx];
+        a0[tok] = dot2_sel(d, w0[k], a0[tok]);
+        a1[tok] = dot2_sel(d, w1[k], a1[tok]);
+        dw0[k] = dot2_sel(d, xs0[tok], dw0[k]);
+        dw1[k] = dot2_sel(d, xs1[tok], dw1[k]);
+      }
+}
+
+template <int S>
+__device__ __forceinline__ void pool_bwd_fused_body(const PoolBwdFused& g, int which, int bh, int group, int chunk,
+                                                    unsigned char* smem) {
+  const svit_pool_dgrad_args& a = g.d[which];
+  const int tid = threadIdx.x, cp = tid & 15, ts = tid >> 4, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), k4 = ts & 3;
+  const int c = group * 32 + 2 * cp;
+  const int s = S;
+  const int T = a.T, H = a.H, W = a.W;
+  const int Ho = pooled(H, s), Wo = pooled(W, s);
+  const int L = T * H * W, Lo = T * Ho * Wo;
+  const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
+  const int b = bh / a.heads, head = bh % a.heads;
+  const int P = Wo + 1, rows = (Ho + 2) * P + 1, plane_b = rows * PF_ROWB, rowb = P * PF_ROWB;
+  const int n_per = g.n_per[which];
+  const int t0 = chunk * n_per, t1 = min(T, t0 + n_per), np = t1 - t0;
+  const bf16_t* dsrc = (const bf16_t*)a.dpre + (size_t)bh * Nout * HD + group * 32;
+  PFSTAMP(0);
+  // ---- stage dpre planes t0-1 .. t1 (slot sl holds output plane t0 - 1 + sl) by LDS-DMA: the whole image is cut into
+  // 1-KiB pieces, a lane's 16 bytes come from its cell's row of dpre, or -- halo cells, planes outside [0, T), the tail
+  // of the last piece -- from past the end of the buffer descriptor, which reads as zeros.  All pieces of a wave are in
+  // flight at once: one memory round trip for the whole prologue.
+  {
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)dsrc, 0, (int)((size_t)Nout * HD * 2), 0x00020000);
+    const unsigned mP = fdiv_magic_dev(P), mR = fdiv_magic_dev(rows);
+    const int pieces = ((np + 2) * plane_b + 1023) >> 10;
+    for (int q = wave; q < pieces; q += PF_NT / 64) {
+      const int o = q * 1024 + lane * 16;
+      const int cell = o >> 6, part = (o >> 4) & 3;
+      const int sl = fdiv(cell, mR), cr = cell - sl * rows;
+      const int yy = fdiv(cr, mP), xx = cr - yy * P;
+      const int to = t0 - 1 + sl;
+      const bool ok = sl < np + 2 && to >= 0 && to < T && yy >= 1 && yy <= Ho && xx >= 1 && xx <= Wo;
+      const unsigned voff = ok ? (unsigned)((1 + (to * Ho + yy - 1) * Wo + xx - 1) * (HD * 2) + part * 16) : 0x7ffffff0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + q * 1024), 16, voff, 0, 0, 0);
+    }
+  }
+  // ---- this thread's weights (bf16-rounded selectors, like every stencil of this file) and accumulators
+  uint32_t w0[27], w1[27];
+  float dw0[27], dw1[27];
+  float nt[3], nh[3], ipt, iph;
+  obj_counts(1, nt, &ipt);
+  obj_counts(s, nh, &iph);
+  const float onorm = ipt * iph * iph;
+  float g0 = 0.f, g1 = 0.f;                   // object gains g(w) of the two channels, from the fp32 weights (as the forward)
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const float f0 = a.conv_w[(size_t)c * 27 + k], f1 = a.conv_w[(size_t)(c + 1) * 27 + k];
+    const float coef = nt[k / 9] * nh[(k / 3) % 3] * nh[k % 3] * onorm;
+    g0 += f0 * coef; g1 += f1 * coef;
+    w0[k] = (uint32_t)f32_to_bf16(f0);
+    w1[k] = (uint32_t)f32_to_bf16(f1) << 16;
+    dw0[k] = 0.f; dw1[k] = 0.f;
+  }
+  const size_t tok_stride = (size_t)3 * a.heads * HD;
+  const size_t col = ((size_t)which * a.heads + head) * HD + c;
+  const bf16_t* xin = (const bf16_t*)g.qkv + (size_t)b * N * tok_stride + col;
+  bf16_t* dxo = (bf16_t*)a.dqkv + (size_t)b * N * tok_stride + col;
+  // ---- the walk: units (see pf_unit) of the chunk's planes, unit f = slot + 16 i of thread slot ts.  x (qkv) and dx
+  // (dqkv) go through buffer descriptors with a per-lane byte offset: an invalid token (past the last unit, or the
+  // odd row / column a 2 x 2 unit hangs over the plane's edge) carries an offset past the descriptor's end -- its x reads
+  // as zero (nothing enters dw) and its dx store is dropped, so the loop has no per-token branches.  x of the unit D
+  // steps ahead is fetched into the ring slot just consumed; a unit's offsets ride in the ring with it.
+  {
+    constexpr int D = 4, NT = S * S;
+    const int UR = S == 1 ? H : (H + 1) >> 1, UC = S == 1 ? W : (W + 1) >> 1;     // units per plane: rows x columns
+    const int U = UR * UC, total = np * U;
+    const unsigned mU = fdiv_magic_dev(U), mC = fdiv_magic_dev(UC);
+    const unsigned stride_b = (unsigned)(tok_stride * 2);
+    const size_t span = (size_t)N * tok_stride * 2;                                 // bytes of one clip in qkv / dqkv
+    const unsigned col_b = (unsigned)((((size_t)which * a.heads + head) * HD + c) * 2);
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)g.qkv + (size_t)b * span), 0, (int)span, 0x00020000);
+    const auto drs = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)a.dqkv + (size_t)b * span), 0, (int)span, 0x00020000);
+    constexpr unsigned OOB = 0x7ffffff0u;
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    // unit f of this thread -> byte offsets of its tokens, LDS address of its base cell
+    auto locate = [&](int f, unsigned (&off)[NT], unsigned* lb) {
+      const bool live = f < total;
+      const int fc = live ? f : 0;
+      const int pl = fdiv(fc, mU), u = fc - pl * U;
+      const int ur = fdiv(u, mC), uc = u - ur * UC;
+      const int y = S * ur, x = S * uc;
+      const unsigned o = (unsigned)(1 + ((t0 + pl) * H + y) * W + x) * stride_b + col_b;
+      *lb = lds0 + (unsigned)((pl + 1) * plane_b + ((ur + 1) * P + uc + 1) * PF_ROWB + cp * 4);
+      off[0] = live ? o : OOB;
+      if (S == 2) {
+        const bool vx = live && x + 1 < W, vy = live && y + 1 < H;
+        off[1] = vx ? o + stride_b : OOB;
+        off[2] = vy ? o + (unsigned)W * stride_b : OOB;
+        off[3] = vx && vy ? o + (unsigned)(W + 1) * stride_b : OOB;
+      }
+    };
+    uint32_t xq[D][NT];
+    unsigned oq[D][NT], lq[D];
+    int f = ts;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      locate(f + j * PF_SLOTS, oq[j], &lq[j]);
+#pragma unroll
+      for (int e = 0; e < NT; ++e) xq[j][e] = __builtin_amdgcn_raw_buffer_load_b32(xrs, oq[j][e], 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * NT) : "memory");      // the staged planes (everything but the x ring) have landed
+    __syncthreads();
+    PFSTAMP(1);
+    const int steps = (total + PF_SLOTS - 1) / PF_SLOTS;               // (uniform: every thread walks the same number of steps)
+    for (int i = 0; i < steps; i += D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        if (i + j < steps) {
+          uint32_t xs0[NT], xs1[NT];
+          unsigned off[NT];
+          float a0[NT], a1[NT];
+#pragma unroll
+          for (int e = 0; e < NT; ++e) {
+            xs0[e] = xq[j][e] & 0xffffu; xs1[e] = xq[j][e] & 0xffff0000u;
+            off[e] = oq[j][e];
+            a0[e] = 0.f; a1[e] = 0.f;
+          }
+          const unsigned lb = lq[j];
+          locate(f + D * PF_SLOTS, oq[j], &lq[j]);
+#pragma unroll
+          for (int e = 0; e < NT; ++e) xq[j][e] = __builtin_amdgcn_raw_buffer_load_b32(xrs, oq[j][e], 0, 0);
+          pf_unit<S>(lb, plane_b, rowb, xs0, xs1, w0, w1, dw0, dw1, a0, a1);
+#pragma unroll
+          for (int e = 0; e < NT; ++e) __builtin_amdgcn_raw_buffer_store_b32(pack_bf16x2(a0[e], a1[e]), drs, off[e], 0, 0);
+          f += PF_SLOTS;
+        }
+      }
+    }
+  }
+  PFSTAMP(2);
+  // ---- cls / object rows ride on chunk 0: dx[cls] = dpre[cls], dx[obj] = dpre[obj] * g(w), dw += coef * sum dpre * x
+  if (chunk == 0) {
+    float go0 = 0.f, go1 = 0.f;
+    for (int i = ts; i <= a.n_obj; i += PF_SLOTS) {        // i = 0: cls, i >= 1: object i - 1
+      const int tin = i == 0 ? 0 : L + i, tout = i == 0 ? 0 : Lo + i;
+      const uint32_t dv = *(const uint32_t*)(dsrc + (size_t)tout * HD + 2 * cp);
+      float d0 = lo_bf16(dv), d1 = hi_bf16(dv);
+      if (i > 0) {
+        const uint32_t xv = *(const uint32_t*)(xin + (size_t)tin * tok_stride);
+        go0 += d0 * lo_bf16(xv); go1 += d1 * hi_bf16(xv);
+        d0 *= g0; d1 *= g1;
+      }
+      *(uint32_t*)(dxo + (size_t)tin * tok_stride) = pack_bf16x2(d0, d1);
+    }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const float coef = nt[k / 9] * nh[(k / 3) % 3] * nh[k % 3] * onorm;
+      dw0[k] += go0 * coef; dw1[k] += go1 * coef;
+    }
+  }
+  // ---- the 16 token slots meet: 4 per wave through shuffles, the 4 waves through LDS
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    dw0[k] += __shfl_xor(dw0[k], 16, 64); dw0[k] += __shfl_xor(dw0[k], 32, 64);
+    dw1[k] += __shfl_xor(dw1[k], 16, 64); dw1[k] += __shfl_xor(dw1[k], 32, 64);
+  }
+  __syncthreads();                              // everyone is done reading the planes
+  float* red = (float*)smem;                    // [4 waves][16 pairs][54]
+  if ((tid & 63) < 16) {
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      red[(wave * 16 + cp) * 54 + k] = dw0[k];
+      red[(wave * 16 + cp) * 54 + 27 + k] = dw1[k];
+    }
+  }
+  __syncthreads();
+  // one partial row per (batch*head, chunk): [which][c][tap], this workgroup's 32 channels of it
+  float* prow = g.partial + (((size_t)bh * g.max_chunks + chunk) * 3 + which) * (27 * HD) + group * 32 * 27;
+  for (int o = tid; o < 16 * 54; o += PF_NT)
+    prow[o] = red[o] + red[864 + o] + red[2 * 864 + o] + red[3 * 864 + o];     // ([pair][ch 0 taps | ch 1 taps] = [c][tap])
+  // rows of chunks this tensor does not have must read as zero in the second-stage sum
+  if (chunk == 0)
+    for (int ch = g.n_chunks[which]; ch < g.max_chunks; ++ch) {
+      float* z = g.partial + (((size_t)bh * g.max_chunks + ch) * 3 + which) * (27 * HD) + group * 32 * 27;
+      for (int o = tid; o < 32 * 27; o += PF_NT) z[o] = 0.f;
+    }
+#ifdef SVIT_POOL_STAMPS
+  __syncthreads();
+  PFSTAMP(3);
+  if (threadIdx.x == 0 && blockIdx.x < 2048) {
+    g_pf_wg[8 * blockIdx.x + 4] = which; g_pf_wg[8 * blockIdx.x + 5] = chunk;
+    g_pf_wg[8 * blockIdx.x + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+  }
+#endif
+}
+
+__global__ __launch_bounds__(PF_NT, 2) void pool_bwd_fused_kernel(PoolBwdFused g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_pf[];
+  const int item = blockIdx.x;
+  const int j = (item >= g.first_item[1]) + (item >= g.first_item[2]);
+  const int which = g.order[j];
+  const int local = item - g.first_item[j];
+  const int BH = g.d[0].B * g.d[0].heads;
+  const int bh = local % BH, rest = local / BH, group = rest % 3, chunk = rest / 3;
+  if (g.d[which].stride_hw == 1) pool_bwd_fused_body<1>(g, which, bh, group, chunk, smem_pf);
+  else pool_bwd_fused_body<2>(g, which, bh, group, chunk, smem_pf);
+}
+
+// ---------------------------------------------------------------------------------------
 // query side of the decomposed relative-position bias
 __global__ __launch_bounds__(256) void relq_fwd_kernel(svit_relq_args a) {
   const int extra = a.ld - HD;               // 32 or 64 columns
@@ -1392,12 +1683,6 @@ __global__ __launch_bounds__(256) void relq_bwd_kernel(svit_relq_bwd_args a) {
   for (int i = threadIdx.x; i < tab_n; i += blockDim.x) prow[i] = tabs[i];
 }
 
-// n / d for n < 65536 by one multiply-high with m = ceil(2^32 / d) (exact while n * d < 2^32)
-// (d = 1: ceil(2^32 / 1) does not fit 32 bits and wraps to 0 -- fdiv takes m = 0 as "divide by one".  Round 3's y-chunked
-// slab planes divided by the rows of a chunk, which is 1 for a ragged last chunk: every output of that chunk landed in
-// its first t-plane -- the "wrong rows at stride 2" of DESIGN.md section 5c)
-__device__ __forceinline__ int fdiv(int n, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n; }
-__device__ __forceinline__ unsigned fdiv_magic_dev(int d) { return 0xFFFFFFFFu / (unsigned)d + 1u; }   // = ceil(2^32 / d); 0 for d = 1
 #ifdef SVIT_POOL_STAMPS
 __device__ unsigned long long g_pm_wg[4 * 2048];      // per workgroup of pool_mfma_fwd_kernel: start, end, kind, hw id
 __device__ unsigned long long g_slab_stamps[16];
@@ -1821,6 +2106,9 @@ extern "C" int svit_debug_pool_stamps(unsigned long long* host, int n) {
 }
 extern "C" int svit_debug_pool_wg_times(unsigned long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pm_wg), sizeof(unsigned long long) * n);
+}
+extern "C" int svit_debug_pool_bwd_wg_times(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pf_wg), sizeof(unsigned long long) * n);
 }
 #endif
 
@@ -2314,11 +2602,76 @@ extern "C" int svit_pool_conv_bwd_qkv_sel(const svit_pool_dgrad_args* d3, const 
   if (!sel3) return SVIT_ERR_ARG;
   return pool_conv_bwd_qkv_impl(d3, w3, sel3, stream);
 }
+// Planner of the fused conv backward: input planes per chunk for each tensor, so that the items (one per batch*head,
+// tensor, 32-channel group, chunk) are about equally long and fill the chip's slots (two workgroups per CU) once.
+// cost of an item = planes x (tokens of an input plane x taps per token) + what staging its (planes + 2) dpre planes
+// costs; estimate of the launch = the longest item, or the average load of a slot plus half an item when the items
+// outnumber the slots.  Returns false where a tensor's three padded planes do not fit.
+static bool plan_bwd_fused(const svit_pool_dgrad_args* d3, PoolBwdFused* g, size_t* lds_out) {
+  constexpr size_t LDS_MAX = 79 * 1024;       // two workgroups per CU (the image is staged in whole 1-KiB pieces)
+  constexpr double SLOTS = 512.0;
+  const int T = d3[0].T, BH = d3[0].B * d3[0].heads;
+  double unit[3], stage[3];
+  int nmax[3];
+  for (int i = 0; i < 3; ++i) {
+    const int s = d3[i].stride_hw;
+    if (s < 1 || s > 2) return false;
+    const int Ho = (d3[i].H - 1) / s + 1, Wo = (d3[i].W - 1) / s + 1;
+    const size_t pb = (size_t)pf_plane_bytes(Ho, Wo);
+    if (3 * pb > LDS_MAX) return false;
+    nmax[i] = (int)std::min<size_t>((size_t)T, LDS_MAX / pb - 2);
+    unit[i] = (double)d3[i].H * d3[i].W * (s == 1 ? 27.0 : 6.75);
+    stage[i] = (double)(Ho + 2) * (Wo + 1) * 2.0;
+  }
+  // tensors with the same stride take the same chunking (k and v always do): search (n for tensor 0, n for tensors 1 / 2)
+  double best = 1e300;
+  int bn0 = 1, bn1 = 1;
+  const bool same12 = d3[1].stride_hw == d3[2].stride_hw;
+  for (int n0 = 1; n0 <= nmax[0]; ++n0)
+    for (int n1 = 1; n1 <= std::min(nmax[1], nmax[2]); ++n1) {
+      const int n[3] = {n0, n1, n1};
+      double items = 0, sum = 0, longest = 0;
+      for (int i = 0; i < 3; ++i) {
+        const int chunks = (T + n[i] - 1) / n[i];
+        const double cost = n[i] * unit[i] + (n[i] + 2) * stage[i] + 400.0;
+        items += 3.0 * BH * chunks;
+        sum += 3.0 * BH * (T * unit[i] + chunks * ((n[i] + 2) * stage[i] + 400.0));
+        longest = std::max(longest, cost);
+      }
+      const double est = items <= SLOTS ? std::max(longest, sum / SLOTS) : sum / SLOTS + 0.5 * longest;
+      if (est < best) { best = est; bn0 = n0; bn1 = n1; }
+    }
+  (void)same12;
+  const int n[3] = {bn0, bn1, bn1};
+  size_t lds = 4 * 16 * 54 * sizeof(float);
+  double len[3];
+  g->max_chunks = 1;
+  for (int i = 0; i < 3; ++i) {
+    const int s = d3[i].stride_hw;
+    const int Ho = (d3[i].H - 1) / s + 1, Wo = (d3[i].W - 1) / s + 1;
+    g->n_per[i] = n[i];
+    g->n_chunks[i] = (T + n[i] - 1) / n[i];
+    g->max_chunks = std::max(g->max_chunks, g->n_chunks[i]);
+    lds = std::max(lds, ((size_t)(n[i] + 2) * pf_plane_bytes(Ho, Wo) + 1023) / 1024 * 1024);
+    len[i] = n[i] * unit[i];
+  }
+  // launch order: longest items first (the dispatcher fills the second slot of every CU with the shorter ones)
+  int ord[3] = {0, 1, 2};
+  std::sort(ord, ord + 3, [&](int x, int y) { return len[x] > len[y] || (len[x] == len[y] && x < y); });
+  int first = 0;
+  for (int j = 0; j < 3; ++j) {
+    g->order[j] = ord[j];
+    g->first_item[j] = first;
+    first += 3 * BH * g->n_chunks[ord[j]];
+  }
+  g->first_item[3] = first;
+  *lds_out = lds;
+  return true;
+}
+
 static int pool_conv_bwd_qkv_impl(const svit_pool_dgrad_args* d3, const svit_pool_wgrad_args* w3,
                                   const uint32_t* const* sel3, void* stream) {
   if (!d3 || !w3) return SVIT_ERR_ARG;
-  bool small = true;
-  size_t lds = 16 * 648 * sizeof(float);
   for (int i = 0; i < 3; ++i) {
     const svit_pool_dgrad_args& d = d3[i];
     const svit_pool_wgrad_args& w = w3[i];
@@ -2327,38 +2680,30 @@ static int pool_conv_bwd_qkv_impl(const svit_pool_dgrad_args* d3, const svit_poo
     const int rc = check_pool_dims(d.B, d.heads, d.T, d.H, d.W, d.n_obj, d.stride_hw);
     if (rc) return rc;
     if (w.dpre != d.dpre || w.stride_hw != d.stride_hw || w.qkv != w3[0].qkv) return SVIT_ERR_ARG;
-    const int Ho = (d.H - 1) / d.stride_hw + 1, Wo = (d.W - 1) / d.stride_hw + 1;
-    const size_t need = (size_t)(1 + d.T * Ho * Wo + d.n_obj) * 48;
-    if (need > lds) lds = need;
-    if (d.stride_hw > 2) small = false;
+    if (d.B != d3[0].B || d.heads != d3[0].heads || d.T != d3[0].T || d.H != d3[0].H || d.W != d3[0].W ||
+        d.n_obj != d3[0].n_obj)
+      return SVIT_ERR_SHAPE;
   }
-  const int N = 1 + d3[0].T * d3[0].H * d3[0].W + d3[0].n_obj;
-  // measured (tools/bench_kernels.py poolbwd): the fused kernel wins at the 7x7 stage (78 vs
-  // 126 us) and loses from 14x14 on (155 vs 108 us: two channels per thread do not amortise
-  // the tap addressing the way the streaming dgrad's 24 channels per lane do)
-  if (lds > 112 * 1024 || N > 1024) small = false;
-  if (!small) {   // large planes: the streaming / tiled kernels
+  PoolBwdFused g;
+  size_t lds = 0;
+  bool fused = svit_knob(SVIT_K_POOL_BWD) != 0 && plan_bwd_fused(d3, &g, &lds);
+  const int64_t prows = fused ? (int64_t)d3[0].B * d3[0].heads * g.max_chunks : 0;
+  if (fused && (!w3[0].workspace || w3[0].workspace_floats < prows * 3 * 27 * HD || prows > 4096)) fused = false;
+  if (!fused) {   // large planes (pooled planes past 14x14, strides > 2): the streaming / tiled kernels
     int rc = pool_conv_dgrad_qkv_impl(d3, sel3, stream);
     if (rc) return rc;
     return svit_pool_conv_wgrad_qkv(w3, stream);
   }
-  PoolBwdSmall g;
-  for (int i = 0; i < 3; ++i) {
-    g.d[i] = d3[i];
-    g.nsplit[i] = d3[i].stride_hw == 1 ? 2 : 1;     // 27 taps per token vs <= 12
-  }
+  for (int i = 0; i < 3; ++i) g.d[i] = d3[i];
   g.qkv = w3[0].qkv;
-  const int prows = d3[0].B * d3[0].heads * 2;
-  if (!w3[0].workspace || w3[0].workspace_floats < (int64_t)prows * 3 * 27 * HD) return SVIT_ERR_ARG;
   g.partial = w3[0].workspace;
   static SvitOnce once;
-  if (int rc = svit_max_lds_once(once, (const void*)pool_bwd_small_kernel, 112 * 1024)) return rc;
-  hipLaunchKernelGGL(pool_bwd_small_kernel, dim3(d3[0].B * d3[0].heads, 3, 8), dim3(192), lds,
-                     (hipStream_t)stream, g);
+  if (int rc = svit_max_lds_once(once, (const void*)pool_bwd_fused_kernel, 80 * 1024)) return rc;
+  hipLaunchKernelGGL(pool_bwd_fused_kernel, dim3((unsigned)g.first_item[3]), dim3(PF_NT), lds, (hipStream_t)stream, g);
   SVIT_LAUNCH_CHECK();
   SvitReduceDst dst = {{w3[0].dw, w3[1].dw, w3[2].dw, w3[2].dw, w3[2].dw, w3[2].dw},
                        {27 * HD, 2 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD}};
-  svit_launch_reduce(w3[0].workspace, prows, 3 * 27 * HD, dst, (hipStream_t)stream);
+  svit_launch_reduce(w3[0].workspace, (int)prows, 3 * 27 * HD, dst, (hipStream_t)stream);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }

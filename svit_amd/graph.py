@@ -46,7 +46,8 @@ class GraphedTrainStep:
         if not self.core.training:
             raise RuntimeError("GraphedTrainStep captures the training step: call model.train() first")
         self.loss_fun = loss_fun
-        self.dp = model if hasattr(model, "_on_ready") and getattr(model, "world_size", 1) > 1 else None
+        self.dp = model if hasattr(model, "_on_ready") and (getattr(model, "world_size", 1) > 1 or
+                                                           getattr(model, "force_collectives", False)) else None
         self.x = inputs[0].detach().clone().contiguous()
         self.labels = _tree_map(lambda t: t.detach().clone(), labels)
         self.segments = []          # replay items: ("graph", CUDAGraph) | ("side", fn) | ("join", None) | ("ready", ranks)

@@ -218,7 +218,7 @@ def _hetero_worker(rank, world, port, out, graphed):
     model = MODEL_REGISTRY.get("SViT")(cfg).cuda()
     model.load_state_dict(P.state_dict(R.param_shapes(R.make_spec(4, 64, drop_path_rate=0.0,
                                                                   dropout_rate=0.0))))
-    dp = DataParallel(model, bucket_ranks=4, force_collectives=force) if (world > 1 or force) else model
+    dp = DataParallel(model, bucket_ranks=4) if world > 1 else model
 
     def batch(role):
         if role.is_image:

@@ -475,10 +475,22 @@ def test_pool_qkv_fused_equals_single(ops, sq, skv, thw):
 
 @pytest.mark.parametrize("sq,skv,thw,B,h", [(1, 2, (4, 14, 14), 2, 4), (2, 1, (2, 14, 14), 2, 8),
                                              (1, 1, (3, 7, 7), 3, 2), (2, 2, (2, 9, 11), 2, 2),
-                                             (1, 4, (2, 16, 16), 2, 2)])
+                                             (1, 4, (2, 16, 16), 2, 2),
+                                             (1, 2, (8, 14, 14), 2, 4),      # blocks 4-13 of 16x224^2 (chunked in t)
+                                             (2, 2, (8, 28, 28), 1, 4),      # block 3: 28x28 planes pooled to 14x14
+                                             (2, 1, (8, 14, 14), 1, 8),      # block 14
+                                             (1, 1, (8, 7, 7), 2, 8),        # block 15
+                                             (1, 2, (16, 14, 14), 1, 4),     # 32x224^2
+                                             (1, 2, (1, 14, 14), 3, 4),      # frames pass / image ranks (T' = 1)
+                                             (1, 2, (5, 13, 9), 2, 1),       # odd planes, odd T
+                                             (2, 2, (3, 20, 20), 1, 2)])     # 312^2 crop, block 4 (20x20 -> 10x10)
 def test_pool_conv_bwd_fused_small_planes(ops, sq, skv, thw, B, h):
-    """dgrad + wgrad in one kernel (dpre in LDS) == the two streaming launches; the last case
-    (stride 4) must take the fall-through path"""
+    """Round 5: conv dgrad + conv wgrad of q, k, v in ONE launch with the dpre halo staged once in LDS
+    (csrc/pool.hip::pool_bwd_fused_kernel) == the streaming launches it replaces (svit_debug_set_pool(1, 0) runs them
+    through the same entry point); the stride-4 case must take the fall-through path by itself"""
+    import ctypes as C
+    from svit_amd import hip
+    lib = hip.load()
     O = 5
     qkv = _qkv(B, h, thw, O, "s%d%d" % (sq, skv))
     ws = [rnd("sw%d" % i, (96, 27), 0.3) for i in range(3)]
@@ -495,8 +507,60 @@ def test_pool_conv_bwd_fused_small_planes(ops, sq, skv, thw, B, h):
     dw_got = [torch.full((96, 27), 0.5, device=DEV) for _ in range(3)]
     ops.pool_conv_bwd_qkv(dpres, ws, d_got, qkv, dw_got, B, h, thw, O, strides)
     assert rel_err(d_got.float(), d_ref.float()) < 1e-2
+    assert float((d_got.float() - d_ref.float()).abs().max()) < 0.05 * float(d_ref.float().abs().max())
     for i in range(3):
         assert rel_err(dw_got[i] - 0.5, dw_ref[i]) < 2e-4
+    # and the same entry point with the fused kernel switched off: the two paths stay interchangeable
+    try:
+        assert lib.svit_debug_set_pool(1, 0) == 0
+        d_off = torch.full_like(qkv, 7.0)
+        dw_off = [torch.zeros((96, 27), device=DEV) for _ in range(3)]
+        ops.pool_conv_bwd_qkv(dpres, ws, d_off, qkv, dw_off, B, h, thw, O, strides)
+        assert torch.equal(d_off, d_ref)
+    finally:
+        lib.svit_debug_reset()
+
+
+@pytest.mark.parametrize("sq,skv,thw,h", [(2, 2, (8, 28, 28), 1),       # block 3
+                                           (1, 2, (8, 14, 14), 2),       # blocks 4-13
+                                           (2, 1, (8, 14, 14), 2),       # block 14
+                                           (1, 1, (8, 7, 7), 2),         # block 15
+                                           (1, 2, (1, 14, 14), 2)])      # T' = 1
+def test_pool_backward_vs_oracle_at_the_step_shapes(ops, sq, skv, thw, h):
+    """The pooling backward as the engine runs it at every (stride, plane) of blocks 3-15 -- svit_pool_ln_bwd_qkv then
+    the fused conv backward -- against autograd of the oracle's attention_pool restatement (oracle.svit_ref.pool_tokens,
+    attention.py:13-65): d(qkv), d(conv weight), d(gamma), d(beta) of q, k and v."""
+    B, O = 1, 8
+    qkv = _qkv(B, h, thw, O, "o%d%d%d" % (sq, skv, thw[1]))
+    strides = (sq, skv, skv)
+    ws = [rnd("ow%d" % i, (96, 27), 0.3) for i in range(3)]
+    gs = [rnd("og%d" % i, (96,), 0.2) + 1.0 for i in range(3)]
+    bs = [rnd("ob%d" % i, (96,), 0.1) for i in range(3)]
+    entries, refs = [], []
+    for i, s in enumerate(strides):
+        Ho, Wo = ops.pooled(thw[1], s), ops.pooled(thw[2], s)
+        out, pre, mean, rstd = ops.pool_ln_fwd(qkv, i, ws[i], gs[i], bs[i], B, h, thw, O, s, ld_out=96, mode=0)
+        x = qkv[:, :, i].permute(0, 2, 1, 3).float().cpu().requires_grad_(True)
+        wc = ws[i].cpu().reshape(96, 1, 3, 3, 3).clone().requires_grad_(True)
+        gc, bc = gs[i].cpu().clone().requires_grad_(True), bs[i].cpu().clone().requires_grad_(True)
+        ref, _ = R.pool_tokens(x, thw, (1, s, s), wc, gc, bc, O)
+        assert rel_err(out, ref) < 2e-2
+        Nout = ref.shape[2]
+        dout = rnd("od%d%d" % (i, s), (B, h, Nout, 96), 1.0, BF16)
+        ref.backward(dout.float().cpu())
+        refs.append((x.grad, wc.grad.reshape(96, 27), gc.grad, bc.grad))
+        dg, db = torch.zeros(96, device=DEV), torch.zeros(96, device=DEV)
+        entries.append(((pre, mean, rstd, gs[i], dg, db, B, h, Nout), dict(d_main=dout, ld_main=96)))
+    dpres = ops.pool_ln_bwd_qkv(entries)
+    dqkv = torch.full_like(qkv, 7.0)
+    dws = [torch.zeros((96, 27), device=DEV) for _ in range(3)]
+    ops.pool_conv_bwd_qkv(dpres, ws, dqkv, qkv, dws, B, h, thw, O, strides)
+    for i in range(3):
+        gx, gw, gg, gb = refs[i]
+        got = dqkv[:, :, i].permute(0, 2, 1, 3)
+        assert cos(got, gx) > 0.9995 and rel_err(got, gx) < 3e-2, i
+        assert cos(dws[i], gw) > 0.9995 and rel_err(dws[i], gw) < 3e-2, i
+        assert rel_err(entries[i][0][4], gg) < 2e-2 and rel_err(entries[i][0][5], gb) < 2e-2, i
 
 
 def test_pool_ln_bwd_three_inputs(ops):
