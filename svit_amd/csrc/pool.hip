@@ -6,6 +6,7 @@
 // the 27-tap stencil reads the qkv GEMM output in place, the object-token branch is the closed
 // form obj*g(w), and LayerNorm(96) is fused (4-lane shuffle reduce).
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <atomic>
 #include "common.h"
@@ -1472,16 +1473,29 @@ __device__ __forceinline__ void pool_bwd_fused_body(const PoolBwdFused& g, int w
   // ---- cls / object rows ride on chunk 0: dx[cls] = dpre[cls], dx[obj] = dpre[obj] * g(w), dw += coef * sum dpre * x
   if (chunk == 0) {
     float go0 = 0.f, go1 = 0.f;
-    for (int i = ts; i <= a.n_obj; i += PF_SLOTS) {        // i = 0: cls, i >= 1: object i - 1
-      const int tin = i == 0 ? 0 : L + i, tout = i == 0 ? 0 : Lo + i;
-      const uint32_t dv = *(const uint32_t*)(dsrc + (size_t)tout * HD + 2 * cp);
-      float d0 = lo_bf16(dv), d1 = hi_bf16(dv);
-      if (i > 0) {
-        const uint32_t xv = *(const uint32_t*)(xin + (size_t)tin * tok_stride);
-        go0 += d0 * lo_bf16(xv); go1 += d1 * hi_bf16(xv);
-        d0 *= g0; d1 *= g1;
+    // (four rows per thread in flight: the loads of a row depend on nothing, only their round trips would add up)
+    for (int i0 = ts; i0 <= a.n_obj; i0 += 4 * PF_SLOTS) {        // i = 0: cls, i >= 1: object i - 1
+      uint32_t dv[4], xv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = i0 + e * PF_SLOTS;
+        dv[e] = 0u; xv[e] = 0u;
+        if (i <= a.n_obj) {
+          dv[e] = *(const uint32_t*)(dsrc + (size_t)(i == 0 ? 0 : Lo + i) * HD + 2 * cp);
+          if (i > 0) xv[e] = *(const uint32_t*)(xin + (size_t)(L + i) * tok_stride);
+        }
       }
-      *(uint32_t*)(dxo + (size_t)tin * tok_stride) = pack_bf16x2(d0, d1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = i0 + e * PF_SLOTS;
+        if (i > a.n_obj) continue;
+        float d0 = lo_bf16(dv[e]), d1 = hi_bf16(dv[e]);
+        if (i > 0) {
+          go0 += d0 * lo_bf16(xv[e]); go1 += d1 * hi_bf16(xv[e]);
+          d0 *= g0; d1 *= g1;
+        }
+        *(uint32_t*)(dxo + (size_t)(i == 0 ? 0 : L + i) * tok_stride) = pack_bf16x2(d0, d1);
+      }
     }
 #pragma unroll
     for (int k = 0; k < 27; ++k) {
@@ -2604,44 +2618,47 @@ extern "C" int svit_pool_conv_bwd_qkv_sel(const svit_pool_dgrad_args* d3, const 
 }
 // Planner of the fused conv backward: input planes per chunk for each tensor, so that the items (one per batch*head,
 // tensor, 32-channel group, chunk) are about equally long and fill the chip's slots (two workgroups per CU) once.
-// cost of an item = planes x (tokens of an input plane x taps per token) + what staging its (planes + 2) dpre planes
-// costs; estimate of the launch = the longest item, or the average load of a slot plus half an item when the items
-// outnumber the slots.  Returns false where a tensor's three padded planes do not fit.
+// Item time, from the in-kernel stamps of round 5 (profiles/r05_pool_bwd_stamps.txt, MI355X): 4.5 us of staging, then
+// ceil(planes x units per plane / 16 thread slots) steps of 0.47 us (stride 1: one token per unit) or 0.96 us (stride 2:
+// four tokens -- four loads and four stores -- per unit), 2.5 us of tail (+ 1.5 us for the cls / object rows of chunk 0).
+// Estimate of the launch = the longest item if everything is resident at once, else the average load of a slot plus
+// half an item.  Returns false where a tensor's three padded planes do not fit.
 static bool plan_bwd_fused(const svit_pool_dgrad_args* d3, PoolBwdFused* g, size_t* lds_out) {
   constexpr size_t LDS_MAX = 79 * 1024;       // two workgroups per CU (the image is staged in whole 1-KiB pieces)
   constexpr double SLOTS = 512.0;
   const int T = d3[0].T, BH = d3[0].B * d3[0].heads;
-  double unit[3], stage[3];
+  double units[3], step_us[3];
   int nmax[3];
   for (int i = 0; i < 3; ++i) {
     const int s = d3[i].stride_hw;
     if (s < 1 || s > 2) return false;
     const int Ho = (d3[i].H - 1) / s + 1, Wo = (d3[i].W - 1) / s + 1;
     const size_t pb = (size_t)pf_plane_bytes(Ho, Wo);
-    if (3 * pb > LDS_MAX) return false;
-    nmax[i] = (int)std::min<size_t>((size_t)T, LDS_MAX / pb - 2);
-    unit[i] = (double)d3[i].H * d3[i].W * (s == 1 ? 27.0 : 6.75);
-    stage[i] = (double)(Ho + 2) * (Wo + 1) * 2.0;
+    if (3 * pb + 1023 > LDS_MAX) return false;
+    nmax[i] = (int)std::min<size_t>((size_t)T, (LDS_MAX - 1023) / pb - 2);
+    units[i] = s == 1 ? (double)d3[i].H * d3[i].W : (double)((d3[i].H + 1) / 2) * ((d3[i].W + 1) / 2);
+    step_us[i] = s == 1 ? 0.47 : 0.96;
   }
-  // tensors with the same stride take the same chunking (k and v always do): search (n for tensor 0, n for tensors 1 / 2)
+  auto item_us = [&](int i, int n, bool first) {
+    return 4.5 + std::ceil(n * units[i] / PF_SLOTS) * step_us[i] + 2.5 + (first ? 1.5 : 0.0);
+  };
+  // k and v share a chunking (same stride in every block of the model); search (n for q, n for k / v)
   double best = 1e300;
   int bn0 = 1, bn1 = 1;
-  const bool same12 = d3[1].stride_hw == d3[2].stride_hw;
   for (int n0 = 1; n0 <= nmax[0]; ++n0)
     for (int n1 = 1; n1 <= std::min(nmax[1], nmax[2]); ++n1) {
       const int n[3] = {n0, n1, n1};
       double items = 0, sum = 0, longest = 0;
       for (int i = 0; i < 3; ++i) {
         const int chunks = (T + n[i] - 1) / n[i];
-        const double cost = n[i] * unit[i] + (n[i] + 2) * stage[i] + 400.0;
+        const int last = T - (chunks - 1) * n[i];
         items += 3.0 * BH * chunks;
-        sum += 3.0 * BH * (T * unit[i] + chunks * ((n[i] + 2) * stage[i] + 400.0));
-        longest = std::max(longest, cost);
+        sum += 3.0 * BH * ((chunks - 1) * item_us(i, n[i], false) + item_us(i, last, false) + 1.5);
+        longest = std::max(longest, item_us(i, n[i], chunks == 1));
       }
       const double est = items <= SLOTS ? std::max(longest, sum / SLOTS) : sum / SLOTS + 0.5 * longest;
       if (est < best) { best = est; bn0 = n0; bn1 = n1; }
     }
-  (void)same12;
   const int n[3] = {bn0, bn1, bn1};
   size_t lds = 4 * 16 * 54 * sizeof(float);
   double len[3];
@@ -2653,7 +2670,7 @@ static bool plan_bwd_fused(const svit_pool_dgrad_args* d3, PoolBwdFused* g, size
     g->n_chunks[i] = (T + n[i] - 1) / n[i];
     g->max_chunks = std::max(g->max_chunks, g->n_chunks[i]);
     lds = std::max(lds, ((size_t)(n[i] + 2) * pf_plane_bytes(Ho, Wo) + 1023) / 1024 * 1024);
-    len[i] = n[i] * unit[i];
+    len[i] = item_us(i, n[i], false);
   }
   // launch order: longest items first (the dispatcher fills the second slot of every CU with the shorter ones)
   int ord[3] = {0, 1, 2};

@@ -7,12 +7,12 @@ import sys
 
 src = sys.argv[1]
 git_head = sys.argv[2] if len(sys.argv) > 2 else None
-fam_of = lambda k: ("svit_gemm_nt" if "gemm_nt_v2" in k else
+fam_of = lambda k: ("svit_gemm_nt" if "gemm_nt_v2" in k or "gemm_nt_ring" in k else
                     "svit_attn_fwd" if "attn_fwd_kernel" in k or "attn_fwd2_kernel" in k else
                     "svit_attn_bwd" if "attn_bwd_" in k else
                     "svit_gemm_tn_grouped" if "gemm_tn_grouped" in k else
                     "svit_pool_ln_fwd_qkv" if "pool_ln_fwd3" in k else
-                    "svit_pool_conv_bwd_qkv" if "pool_dgrad3" in k or "pool_wgrad3" in k or "pool_bwd_small" in k else None)
+                    "svit_pool_conv_bwd_qkv" if "pool_dgrad3" in k or "pool_wgrad3" in k or "pool_bwd_fused" in k else None)
 agg = {}
 for line in open(src):
     m = re.match(r"(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)", line)
