@@ -235,31 +235,42 @@ __global__ void special_grads_kernel(const float* __restrict__ dx, float* __rest
                                      float* __restrict__ g_obj, float* __restrict__ g_pos, int B, int N, int L,
                                      int Tx, int O, int C, int add_pos) {
   const int n_out = C + O * C + (add_pos ? Tx * C : 0);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_out) return;
-  // (round 4: the B*Tx / B*O terms of an element are summed in FIXED order, but their loads leave in batches of eight --
-  // as a plain loop the launch was a chain of 128 dependent-latency loads on eight CUs: 35 us)
+  // EIGHT lanes per output element (round 5): lane part p sums terms p, p + 8, ... in batches of eight independent loads,
+  // the eight partial sums meet in a fixed shuffle tree -- bit-reproducible, and the launch is two or three memory round
+  // trips deep instead of sixteen (33 us -> a few: one thread per element walked 128 terms in sixteen dependent batches)
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gid >> 3, part = gid & 7;
+  const bool live = i < n_out;
   float acc = 0.f;
   auto sum_terms = [&](int n_terms, auto&& addr) {
-    for (int j0 = 0; j0 < n_terms; j0 += 8) {
+    for (int j0 = part; j0 < n_terms; j0 += 64) {
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = j0 + e < n_terms ? dx[addr(j0 + e)] : 0.f;
+      for (int e = 0; e < 8; ++e) v[e] = j0 + 8 * e < n_terms ? dx[addr(j0 + 8 * e)] : 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc += v[e];
     }
   };
-  if (i < C) {
-    sum_terms(B, [&](int b) { return (int64_t)b * N * C + i; });
-    g_cls[i] += acc;
-  } else if (i < C + O * C) {
-    const int o = (i - C) / C, c = (i - C) % C;
-    sum_terms(B * Tx, [&](int j) { const int b = j / Tx, t = j % Tx; return ((int64_t)b * N + 1 + L + t * O + o) * C + c; });
-    g_obj[o * C + c] += acc;
-  } else {
-    const int t = (i - C - O * C) / C, c = (i - C - O * C) % C;
-    sum_terms(B * O, [&](int j) { const int b = j / O, o = j % O; return ((int64_t)b * N + 1 + L + t * O + o) * C + c; });
-    g_pos[t * C + c] += acc;
+  int kind = 3, o = 0, c = 0, t = 0;
+  if (live) {
+    if (i < C) {
+      kind = 0;
+      sum_terms(B, [&](int b) { return (int64_t)b * N * C + i; });
+    } else if (i < C + O * C) {
+      kind = 1; o = (i - C) / C; c = (i - C) % C;
+      sum_terms(B * Tx, [&](int j) { const int b = j / Tx, tt = j % Tx; return ((int64_t)b * N + 1 + L + tt * O + o) * C + c; });
+    } else {
+      kind = 2; t = (i - C - O * C) / C; c = (i - C - O * C) % C;
+      sum_terms(B * O, [&](int j) { const int b = j / O, oo = j % O; return ((int64_t)b * N + 1 + L + t * O + oo) * C + c; });
+    }
+  }
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  acc += __shfl_xor(acc, 4, 64);
+  if (part == 0) {
+    if (kind == 0) g_cls[i] += acc;
+    else if (kind == 1) g_obj[o * C + c] += acc;
+    else if (kind == 2) g_pos[t * C + c] += acc;
   }
 }
 
@@ -604,7 +615,7 @@ extern "C" int svit_special_token_grads(const float* dx, float* g_cls, float* g_
   if (!dx || !g_cls || !g_obj || (add_pos && !g_pos)) return SVIT_ERR_ARG;
   if (N != 1 + L + Tx * O || B <= 0 || C <= 0) return SVIT_ERR_SHAPE;
   const int n_out = C + O * C + (add_pos ? Tx * C : 0);
-  hipLaunchKernelGGL(special_grads_kernel, dim3((n_out + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx, g_cls,
+  hipLaunchKernelGGL(special_grads_kernel, dim3((n_out * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx, g_cls,
                      g_obj, g_pos, B, N, L, Tx, O, C, add_pos);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;

@@ -6,6 +6,8 @@
 // the 27-tap stencil reads the qkv GEMM output in place, the object-token branch is the closed
 // form obj*g(w), and LayerNorm(96) is fused (4-lane shuffle reduce).
 #include <algorithm>
+#include <mutex>
+#include <vector>
 #include <cmath>
 #include <cstdlib>
 #include <atomic>
@@ -1255,27 +1257,34 @@ __global__ __launch_bounds__(192) void pool_bwd_small_kernel(PoolBwdSmall g) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Fused conv backward of the small planes (round 5): conv dgrad AND conv wgrad of q, k, v in ONE
-// launch for every block whose POOLED planes fit LDS (output planes <= 14x14: blocks 3-15 of 16x224^2), replacing
+// Fused conv backward (round 5): conv dgrad AND conv wgrad of q, k, v in ONE launch, replacing
 // pool_dgrad3 (27-tap gather of dpre through L2: 5x its bytes fetched) + pool_wgrad3 (x halo ring + dpre re-read).
-//   * A workgroup owns (batch*head, tensor, 32-CHANNEL group, t-chunk): 32 channels = 64 bytes = exactly one cache line of
-//     every token row it touches in dpre, qkv and dqkv -- no line is shared between workgroups, every byte of x is read
-//     once and every byte of dqkv written once.
-//   * dpre of the chunk's output planes (+ one halo plane each side in t) is staged ONCE in LDS, zero-padded in y and x:
-//     cell(yo, xo) = (yo + 1) * P + xo + 1 with pitch P = Wo + 1 (the right halo of a row is the left halo of the next),
-//     planes outside [0, T) are zero planes.  Every tap of every token is then an unconditional LDS read: no bounds
-//     tests, no clamped addresses.
-//   * The workgroup walks its INPUT tokens once (gather form).  Thread = (channel pair, token slot); per tap ONE
-//     ds_read_b32 (the pair's two bf16 dpre values) feeds dx += w * dpre (dgrad) and dw += x * dpre (wgrad) as four
-//     v_dot2_f32_bf16 against "selector" operands (the other half of the pair zero): no bf16 unpacking.  The 27 weights
-//     and 27 weight-gradient sums of both channels live in registers.  Stride 2: tokens are walked parity class by parity
-//     class ((y + 1) & 1, (x + 1) & 1) in groups of 4, so a wave's tap set is compile-time (4 / 2 / 2 / 1 (ky, kx) pairs).
-//   * x of the next token group is fetched while the current one is computed; dx leaves as 4-byte stores that fill whole
-//     64-byte lines per token.
-//   * dw: token slots meet through shuffles + LDS, one partial row [32 channels][27] per workgroup, summed by the
+//   * A workgroup owns (batch*head, tensor, 32-CHANNEL group, t-chunk, y-chunk): 32 channels = 64 bytes = exactly one
+//     cache line of every token row it touches in dpre, qkv and dqkv -- no line is shared between workgroups, every byte
+//     of x is read once and every byte of dqkv written once.
+//   * dpre of the chunk's output planes and rows (+ the halo plane each side in t and, at stride 1, the halo row each
+//     side in y) is staged ONCE in LDS by LDS-DMA, zero-padded: image row = output row - ybase, cell(row, xo) =
+//     row * P + xo + 1 with pitch P = Wo + 1 (the right halo of a row is the left halo of the next); halo cells, rows
+//     outside [0, Ho) and planes outside [0, T) come from past the end of the buffer descriptor = zeros.  Every tap of
+//     every token is then an unconditional LDS read: no bounds tests, no clamped addresses.
+//   * The workgroup walks its INPUT tokens once (gather form), in UNITS that share a neighbourhood of dpre cells:
+//       stride 1: one token; its 27 taps read the 3 x 3 cells around (y, x) in planes t+1, t, t-1;
+//       stride 2: the 2 x 2 tokens (2a .. 2a+1, 2b .. 2b+1).  Even coordinates are hit by tap 1 only (cell a), odd ones by
+//         tap 0 (cell a + 1) and tap 2 (cell a): together the four tokens use every (ky, kx) exactly once per plane on
+//         the 2 x 2 cells (a .. a+1, b .. b+1) -- 12 reads and 27 taps per unit, the same arithmetic per step as stride 1;
+//       stride >= 3: the 3 x 3 tokens under ONE output cell (windows do not overlap): 3 reads and 27 taps per unit;
+//         the tokens between the windows get their zeros from a 16-byte-store pass in front of the walk.
+//     Thread = (channel pair, unit slot); per tap ONE ds_read_b32 (the pair's two bf16 dpre values) feeds
+//     dx += w * dpre (dgrad) and dw += x * dpre (wgrad) as four v_dot2_f32_bf16 against "selector" operands (the other
+//     half of the pair zero): no bf16 unpacking.  The 27 weights and 27 weight-gradient sums of both channels live in
+//     registers.  The walk is bound by VALU issue (in-kernel stamps: 0.47 us per 16-unit step at two workgroups per CU).
+//   * x (qkv) and dx (dqkv) go through buffer descriptors with per-lane byte offsets: an invalid token (past the last unit,
+//     or hanging over the plane's edge) carries an offset past the end -- its x reads as zero, its dx store is dropped:
+//     the loop has no per-token branches.  x of the unit D steps ahead is fetched into the ring slot just consumed.
+//   * dw: unit slots meet through shuffles + LDS, one partial row [32 channels][27] per workgroup, summed by the
 //     second-stage reduce (fixed order: bit-reproducible).  cls / object rows (dx = dpre, dx = dpre * g(w), the closed-form
 //     object share of dw) ride on chunk 0.
-// The host planner cuts T per tensor so that the items are about equally long and fill the chip once, two workgroups per CU.
+// The host planner cuts T and the unit rows per tensor so that the items are about equally long and fill the chip.
 constexpr int PF_NT = 256, PF_ROWB = 64, PF_SLOTS = PF_NT / 16;
 #ifdef SVIT_POOL_STAMPS
 __device__ unsigned long long g_pf_wg[8 * 2048];      // per workgroup of pool_bwd_fused_kernel: start, staged, walked, end, which, chunk, hw id
@@ -1287,27 +1296,26 @@ struct PoolBwdFused {
   svit_pool_dgrad_args d[3];
   const void* qkv;
   float* partial;            // [B*heads * max_chunks][3][96][27]
-  int n_per[3], n_chunks[3]; // input planes per chunk / chunks, per tensor
+  int n_per[3], t_chunks[3]; // input planes per chunk / chunks along t, per tensor
+  int r_per[3], y_chunks[3]; // unit rows per chunk / chunks along y
   int order[3];              // tensors in launch order (longest items first)
   int first_item[4];         // item ranges of order[0..2]
-  int max_chunks;
+  int max_chunks;            // max over the tensors of t_chunks * y_chunks
 };
+// stride class (1, 2, 3 = any stride >= 3) -> rows / columns of units of a plane, image rows of a chunk of R unit rows
+__host__ __device__ inline int pf_class(int s) { return s >= 3 ? 3 : s; }
+__host__ __device__ inline int pf_unit_rows(int sc, int H, int Ho) { return sc == 1 ? H : sc == 2 ? (H + 1) >> 1 : Ho; }
+__host__ __device__ inline int pf_image_rows(int sc, int R) { return sc == 1 ? R + 2 : sc == 2 ? R + 1 : R; }
+__host__ __device__ inline int pf_plane_bytes(int image_rows, int Wo) { return (image_rows * (Wo + 1) + 1) * PF_ROWB; }
 
-__host__ __device__ inline int pf_plane_bytes(int Ho, int Wo) { return ((Ho + 2) * (Wo + 1) + 1) * PF_ROWB; }
-
-// One UNIT of the walk = what shares a neighbourhood of dpre cells:
-//   stride 1: one input token; its 27 taps read the 3 x 3 cells around (y, x) in planes t+1, t, t-1;
-//   stride 2: the 2 x 2 input tokens (2a .. 2a+1, 2b .. 2b+1).  Even coordinates are hit by tap 1 only (cell a), odd
-//     ones by tap 0 (cell a + 1) and tap 2 (cell a): the four tokens together use every (ky, kx) exactly once per plane
-//     on the 2 x 2 cells (a .. a+1, b .. b+1) -- 12 reads and 27 taps per unit, the same arithmetic per step as stride 1.
-// lb = LDS byte address of the unit's base cell (stride 1: cell (y, x); stride 2: cell (a, b)) in the slot of plane t.
-// ALL reads of the unit are issued before the first dot2 (a scheduling barrier keeps hipcc from sinking each read next
-// to its use, which exposed one LDS round trip per tap with only two waves per SIMD to hide it).
-template <int S>
-__device__ __forceinline__ void pf_unit(unsigned lb, int plane_b, int rowb, const uint32_t (&xs0)[S * S], const uint32_t (&xs1)[S * S],
+// lb = LDS byte address of the unit's base cell in the slot of plane t.  ALL reads of the unit are issued before the first
+// dot2 (a scheduling barrier keeps hipcc from sinking each read next to its use, which exposed one LDS round trip per tap
+// with only two waves per SIMD to hide it).
+template <int SC, int NT>
+__device__ __forceinline__ void pf_unit(unsigned lb, int plane_b, int rowb, const uint32_t (&xs0)[NT], const uint32_t (&xs1)[NT],
                                         const uint32_t (&w0)[27], const uint32_t (&w1)[27], float (&dw0)[27],
-                                        float (&dw1)[27], float (&a0)[S * S], float (&a1)[S * S]) {
-  constexpr int NR = S == 1 ? 3 : 2;              // cell rows / columns read per plane
+                                        float (&dw1)[27], float (&a0)[NT], float (&a1)[NT]) {
+  constexpr int NR = SC == 1 ? 3 : SC == 2 ? 2 : 1;              // cell rows / columns read per plane
   uint32_t v[3][NR * NR];
 #pragma unroll
   for (int kt = 0; kt < 3; ++kt)
@@ -1315,7 +1323,7 @@ __device__ __forceinline__ void pf_unit(unsigned lb, int plane_b, int rowb, cons
     for (int r = 0; r < NR; ++r)
 #pragma unroll
       for (int cidx = 0; cidx < NR; ++cidx) {
-        const int dr = S == 1 ? r - 1 : r, dc = S == 1 ? cidx - 1 : cidx;     // stride 1: rows y-1 .. y+1; stride 2: rows a, a+1
+        const int dr = SC == 1 ? r - 1 : r, dc = SC == 1 ? cidx - 1 : cidx;     // stride 1: rows y-1 .. y+1; stride 2: rows a, a+1
         v[kt][r * NR + cidx] = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(
             lb + (1 - kt) * plane_b + dr * rowb + dc * PF_ROWB);
       }
@@ -1328,9 +1336,9 @@ __device__ __forceinline__ void pf_unit(unsigned lb, int plane_b, int rowb, cons
       for (int kx = 0; kx < 3; ++kx) {
         const int k = (kt * 3 + ky) * 3 + kx;
         // stride 1: output (y + 1 - ky, x + 1 - kx) = cell row 2 - ky of the 3 read.  stride 2: tap 0 -> odd token, cell + 1;
-        // tap 1 -> even token, cell + 0; tap 2 -> odd token, cell + 0
-        const int r = S == 1 ? 2 - ky : (ky == 0 ? 1 : 0), cidx = S == 1 ? 2 - kx : (kx == 0 ? 1 : 0);
-        const int tok = S == 1 ? 0 : (ky == 1 ? 0 : 2) + (kx == 1 ? 0 : 1);
+        // tap 1 -> even token, cell + 0; tap 2 -> odd token, cell + 0.  stride >= 3: token (ky, kx) of the window, its one cell
+        const int r = SC == 1 ? 2 - ky : SC == 2 ? (ky == 0 ? 1 : 0) : 0, cidx = SC == 1 ? 2 - kx : SC == 2 ? (kx == 0 ? 1 : 0) : 0;
+        const int tok = SC == 1 ? 0 : SC == 2 ? (ky == 1 ? 0 : 2) + (kx == 1 ? 0 : 1) : ky * 3 + kx;
         const uint32_t d = v[kt][r * NR + cidx];
         a0[tok] = dot2_sel(d, w0[k], a0[tok]);
         a1[tok] = dot2_sel(d, w1[k], a1[tok]);
@@ -1339,28 +1347,33 @@ __device__ __forceinline__ void pf_unit(unsigned lb, int plane_b, int rowb, cons
       }
 }
 
-template <int S>
-__device__ __forceinline__ void pool_bwd_fused_body(const PoolBwdFused& g, int which, int bh, int group, int chunk,
-                                                    unsigned char* smem) {
+template <int SC>
+__device__ __forceinline__ void pool_bwd_fused_body(const PoolBwdFused& g, int which, int bh, int group, int tchunk,
+                                                    int ychunk, unsigned char* smem) {
   const svit_pool_dgrad_args& a = g.d[which];
   const int tid = threadIdx.x, cp = tid & 15, ts = tid >> 4, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), k4 = ts & 3;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = group * 32 + 2 * cp;
-  const int s = S;
+  const int s = a.stride_hw;
   const int T = a.T, H = a.H, W = a.W;
   const int Ho = pooled(H, s), Wo = pooled(W, s);
   const int L = T * H * W, Lo = T * Ho * Wo;
   const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
   const int b = bh / a.heads, head = bh % a.heads;
-  const int P = Wo + 1, rows = (Ho + 2) * P + 1, plane_b = rows * PF_ROWB, rowb = P * PF_ROWB;
+  const int chunk = tchunk * g.y_chunks[which] + ychunk;
   const int n_per = g.n_per[which];
-  const int t0 = chunk * n_per, t1 = min(T, t0 + n_per), np = t1 - t0;
+  const int t0 = tchunk * n_per, t1 = min(T, t0 + n_per), np = t1 - t0;
+  // unit rows [ur0, ur1) of this chunk; image row 0 = output row ybase
+  const int UR = pf_unit_rows(SC, H, Ho), UC = SC == 1 ? W : SC == 2 ? (W + 1) >> 1 : Wo;
+  const int ur0 = ychunk * g.r_per[which], ur1 = min(UR, ur0 + g.r_per[which]), Rc = ur1 - ur0;
+  const int ybase = SC == 1 ? ur0 - 1 : ur0, RR = pf_image_rows(SC, Rc);
+  const int P = Wo + 1, rows = RR * P + 1, plane_b = rows * PF_ROWB, rowb = P * PF_ROWB;
   const bf16_t* dsrc = (const bf16_t*)a.dpre + (size_t)bh * Nout * HD + group * 32;
   PFSTAMP(0);
   // ---- stage dpre planes t0-1 .. t1 (slot sl holds output plane t0 - 1 + sl) by LDS-DMA: the whole image is cut into
-  // 1-KiB pieces, a lane's 16 bytes come from its cell's row of dpre, or -- halo cells, planes outside [0, T), the tail
-  // of the last piece -- from past the end of the buffer descriptor, which reads as zeros.  All pieces of a wave are in
-  // flight at once: one memory round trip for the whole prologue.
+  // 1-KiB pieces, a lane's 16 bytes come from its cell's row of dpre, or -- halo cells, rows / planes outside the volume, the
+  // tail of the last piece -- from past the end of the buffer descriptor, which reads as zeros.  All pieces of a wave are
+  // in flight at once: one memory round trip for the whole prologue.
   {
     const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)dsrc, 0, (int)((size_t)Nout * HD * 2), 0x00020000);
     const unsigned mP = fdiv_magic_dev(P), mR = fdiv_magic_dev(rows);
@@ -1369,10 +1382,10 @@ __device__ __forceinline__ void pool_bwd_fused_body(const PoolBwdFused& g, int w
       const int o = q * 1024 + lane * 16;
       const int cell = o >> 6, part = (o >> 4) & 3;
       const int sl = fdiv(cell, mR), cr = cell - sl * rows;
-      const int yy = fdiv(cr, mP), xx = cr - yy * P;
-      const int to = t0 - 1 + sl;
-      const bool ok = sl < np + 2 && to >= 0 && to < T && yy >= 1 && yy <= Ho && xx >= 1 && xx <= Wo;
-      const unsigned voff = ok ? (unsigned)((1 + (to * Ho + yy - 1) * Wo + xx - 1) * (HD * 2) + part * 16) : 0x7ffffff0u;
+      const int rr = fdiv(cr, mP), xx = cr - rr * P;
+      const int to = t0 - 1 + sl, yo = ybase + rr;
+      const bool ok = sl < np + 2 && to >= 0 && to < T && rr < RR && yo >= 0 && yo < Ho && xx >= 1 && xx <= Wo;
+      const unsigned voff = ok ? (unsigned)((1 + (to * Ho + yo) * Wo + xx - 1) * (HD * 2) + part * 16) : 0x7ffffff0u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + q * 1024), 16, voff, 0, 0, 0);
     }
   }
@@ -1397,15 +1410,23 @@ __device__ __forceinline__ void pool_bwd_fused_body(const PoolBwdFused& g, int w
   const size_t col = ((size_t)which * a.heads + head) * HD + c;
   const bf16_t* xin = (const bf16_t*)g.qkv + (size_t)b * N * tok_stride + col;
   bf16_t* dxo = (bf16_t*)a.dqkv + (size_t)b * N * tok_stride + col;
-  // ---- the walk: units (see pf_unit) of the chunk's planes, unit f = slot + 16 i of thread slot ts.  x (qkv) and dx
-  // (dqkv) go through buffer descriptors with a per-lane byte offset: an invalid token (past the last unit, or the
-  // odd row / column a 2 x 2 unit hangs over the plane's edge) carries an offset past the descriptor's end -- its x reads
-  // as zero (nothing enters dw) and its dx store is dropped, so the loop has no per-token branches.  x of the unit D
-  // steps ahead is fetched into the ring slot just consumed; a unit's offsets ride in the ring with it.
+  // ---- stride >= 3: the tokens between the 3 x 3 windows get zeros.  The chunk's input rows (the windows of its unit
+  // rows and the gap below each; the last chunk runs to the plane's end) are contiguous tokens: 16-byte stores, 4 lanes
+  // per token.  They are complete (s_waitcnt below) before any wave stores a window's dx over them.
+  if (SC == 3) {
+    const int ylo = max(0, s * ur0 - 1), yhi = ur1 == UR ? H : min(H, s * ur1 - 1);
+    const int cnt4 = (yhi - ylo) * W * 4;
+    char* zb = (char*)a.dqkv + ((size_t)b * N * tok_stride + ((size_t)which * a.heads + head) * HD + group * 32) * 2;
+    for (int pl = 0; pl < np; ++pl) {
+      const size_t tok0 = 1 + (size_t)((t0 + pl) * H + ylo) * W;
+      for (int i = tid; i < cnt4; i += PF_NT)
+        *(uint4*)(zb + (tok0 + (i >> 2)) * tok_stride * 2 + (i & 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  // ---- the walk: unit f = slot + 16 i of thread slot ts
   {
-    constexpr int D = 4, NT = S * S;
-    const int UR = S == 1 ? H : (H + 1) >> 1, UC = S == 1 ? W : (W + 1) >> 1;     // units per plane: rows x columns
-    const int U = UR * UC, total = np * U;
+    constexpr int NT = SC == 1 ? 1 : SC == 2 ? 4 : 9, D = SC == 3 ? 2 : 4;
+    const int U = Rc * UC, total = np * U;
     const unsigned mU = fdiv_magic_dev(U), mC = fdiv_magic_dev(UC);
     const unsigned stride_b = (unsigned)(tok_stride * 2);
     const size_t span = (size_t)N * tok_stride * 2;                                 // bytes of one clip in qkv / dqkv
@@ -1420,27 +1441,46 @@ __device__ __forceinline__ void pool_bwd_fused_body(const PoolBwdFused& g, int w
       const int fc = live ? f : 0;
       const int pl = fdiv(fc, mU), u = fc - pl * U;
       const int ur = fdiv(u, mC), uc = u - ur * UC;
-      const int y = S * ur, x = S * uc;
-      const unsigned o = (unsigned)(1 + ((t0 + pl) * H + y) * W + x) * stride_b + col_b;
-      *lb = lds0 + (unsigned)((pl + 1) * plane_b + ((ur + 1) * P + uc + 1) * PF_ROWB + cp * 4);
-      off[0] = live ? o : OOB;
-      if (S == 2) {
+      const int gr = ur0 + ur;                                                      // unit row in the plane
+      const int y = SC == 1 ? gr : SC == 2 ? 2 * gr : s * gr - 1, x = SC == 1 ? uc : SC == 2 ? 2 * uc : s * uc - 1;
+      const int tokidx = 1 + ((t0 + pl) * H + y) * W + x;                           // (y, x = -1: the window hangs over the edge)
+      const unsigned o = (unsigned)tokidx * stride_b + col_b;
+      *lb = lds0 + (unsigned)((pl + 1) * plane_b + ((SC == 1 ? ur + 1 : ur) * P + uc + 1) * PF_ROWB + cp * 4);
+      if (SC == 1) {
+        off[0] = live ? o : OOB;
+      } else if (SC == 2) {
         const bool vx = live && x + 1 < W, vy = live && y + 1 < H;
+        off[0] = live ? o : OOB;
         off[1] = vx ? o + stride_b : OOB;
         off[2] = vy ? o + (unsigned)W * stride_b : OOB;
         off[3] = vx && vy ? o + (unsigned)(W + 1) * stride_b : OOB;
+      } else {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const bool v = live && y + ky >= 0 && y + ky < H && x + kx >= 0 && x + kx < W;
+            off[ky * 3 + kx] = v ? o + (unsigned)(ky * W + kx) * stride_b : OOB;
+          }
       }
     };
+    // (stride >= 3: nine offsets per unit -- they are recomputed at the unit's turn instead of riding in the ring)
+    constexpr int NO = SC == 3 ? 1 : NT;
     uint32_t xq[D][NT];
-    unsigned oq[D][NT], lq[D];
+    unsigned oq[D][NO], lq[D];
     int f = ts;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      locate(f + j * PF_SLOTS, oq[j], &lq[j]);
+      unsigned off[NT];
+      locate(f + j * PF_SLOTS, off, &lq[j]);
 #pragma unroll
-      for (int e = 0; e < NT; ++e) xq[j][e] = __builtin_amdgcn_raw_buffer_load_b32(xrs, oq[j][e], 0, 0);
+      for (int e = 0; e < NT; ++e) xq[j][e] = __builtin_amdgcn_raw_buffer_load_b32(xrs, off[e], 0, 0);
+      if constexpr (SC != 3) {
+#pragma unroll
+        for (int e = 0; e < NT; ++e) oq[j][e] = off[e];
+      }
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * NT) : "memory");      // the staged planes (everything but the x ring) have landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D * NT) : "memory");      // the staged planes, the zero pass (everything but the x ring) are complete
     __syncthreads();
     PFSTAMP(1);
     const int steps = (total + PF_SLOTS - 1) / PF_SLOTS;               // (uniform: every thread walks the same number of steps)
@@ -1449,19 +1489,28 @@ __device__ __forceinline__ void pool_bwd_fused_body(const PoolBwdFused& g, int w
       for (int j = 0; j < D; ++j) {
         if (i + j < steps) {
           uint32_t xs0[NT], xs1[NT];
-          unsigned off[NT];
+          unsigned off[NT], lb = lq[j];
           float a0[NT], a1[NT];
 #pragma unroll
           for (int e = 0; e < NT; ++e) {
             xs0[e] = xq[j][e] & 0xffffu; xs1[e] = xq[j][e] & 0xffff0000u;
-            off[e] = oq[j][e];
             a0[e] = 0.f; a1[e] = 0.f;
           }
-          const unsigned lb = lq[j];
-          locate(f + D * PF_SLOTS, oq[j], &lq[j]);
+          {
+            unsigned offn[NT];
+            locate(f + D * PF_SLOTS, offn, &lq[j]);
 #pragma unroll
-          for (int e = 0; e < NT; ++e) xq[j][e] = __builtin_amdgcn_raw_buffer_load_b32(xrs, oq[j][e], 0, 0);
-          pf_unit<S>(lb, plane_b, rowb, xs0, xs1, w0, w1, dw0, dw1, a0, a1);
+            for (int e = 0; e < NT; ++e) xq[j][e] = __builtin_amdgcn_raw_buffer_load_b32(xrs, offn[e], 0, 0);
+            if constexpr (SC != 3) {
+#pragma unroll
+              for (int e = 0; e < NT; ++e) { off[e] = oq[j][e]; oq[j][e] = offn[e]; }
+            }
+          }
+          pf_unit<SC, NT>(lb, plane_b, rowb, xs0, xs1, w0, w1, dw0, dw1, a0, a1);
+          if constexpr (SC == 3) {
+            unsigned lb2;
+            locate(f, off, &lb2);
+          }
 #pragma unroll
           for (int e = 0; e < NT; ++e) __builtin_amdgcn_raw_buffer_store_b32(pack_bf16x2(a0[e], a1[e]), drs, off[e], 0, 0);
           f += PF_SLOTS;
@@ -1503,7 +1552,7 @@ __device__ __forceinline__ void pool_bwd_fused_body(const PoolBwdFused& g, int w
       dw0[k] += go0 * coef; dw1[k] += go1 * coef;
     }
   }
-  // ---- the 16 token slots meet: 4 per wave through shuffles, the 4 waves through LDS
+  // ---- the 16 unit slots meet: 4 per wave through shuffles, the 4 waves through LDS
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
     dw0[k] += __shfl_xor(dw0[k], 16, 64); dw0[k] += __shfl_xor(dw0[k], 32, 64);
@@ -1525,7 +1574,7 @@ __device__ __forceinline__ void pool_bwd_fused_body(const PoolBwdFused& g, int w
     prow[o] = red[o] + red[864 + o] + red[2 * 864 + o] + red[3 * 864 + o];     // ([pair][ch 0 taps | ch 1 taps] = [c][tap])
   // rows of chunks this tensor does not have must read as zero in the second-stage sum
   if (chunk == 0)
-    for (int ch = g.n_chunks[which]; ch < g.max_chunks; ++ch) {
+    for (int ch = g.t_chunks[which] * g.y_chunks[which]; ch < g.max_chunks; ++ch) {
       float* z = g.partial + (((size_t)bh * g.max_chunks + ch) * 3 + which) * (27 * HD) + group * 32 * 27;
       for (int o = tid; o < 32 * 27; o += PF_NT) z[o] = 0.f;
     }
@@ -1546,9 +1595,12 @@ __global__ __launch_bounds__(PF_NT, 2) void pool_bwd_fused_kernel(PoolBwdFused g
   const int which = g.order[j];
   const int local = item - g.first_item[j];
   const int BH = g.d[0].B * g.d[0].heads;
-  const int bh = local % BH, rest = local / BH, group = rest % 3, chunk = rest / 3;
-  if (g.d[which].stride_hw == 1) pool_bwd_fused_body<1>(g, which, bh, group, chunk, smem_pf);
-  else pool_bwd_fused_body<2>(g, which, bh, group, chunk, smem_pf);
+  const int bh = local % BH, rest = local / BH, group = rest % 3, ch = rest / 3;
+  const int ychunk = ch % g.y_chunks[which], tchunk = ch / g.y_chunks[which];
+  const int s = g.d[which].stride_hw;
+  if (s == 1) pool_bwd_fused_body<1>(g, which, bh, group, tchunk, ychunk, smem_pf);
+  else if (s == 2) pool_bwd_fused_body<2>(g, which, bh, group, tchunk, ychunk, smem_pf);
+  else pool_bwd_fused_body<3>(g, which, bh, group, tchunk, ychunk, smem_pf);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2616,61 +2668,94 @@ extern "C" int svit_pool_conv_bwd_qkv_sel(const svit_pool_dgrad_args* d3, const 
   if (!sel3) return SVIT_ERR_ARG;
   return pool_conv_bwd_qkv_impl(d3, w3, sel3, stream);
 }
-// Planner of the fused conv backward: input planes per chunk for each tensor, so that the items (one per batch*head,
-// tensor, 32-channel group, chunk) are about equally long and fill the chip's slots (two workgroups per CU) once.
-// Item time, from the in-kernel stamps of round 5 (profiles/r05_pool_bwd_stamps.txt, MI355X): 4.5 us of staging, then
-// ceil(planes x units per plane / 16 thread slots) steps of 0.47 us (stride 1: one token per unit) or 0.96 us (stride 2:
-// four tokens -- four loads and four stores -- per unit), 2.5 us of tail (+ 1.5 us for the cls / object rows of chunk 0).
-// Estimate of the launch = the longest item if everything is resident at once, else the average load of a slot plus
-// half an item.  Returns false where a tensor's three padded planes do not fit.
+// Planner of the fused conv backward: input planes (n) and unit rows (R) per chunk for each tensor, so that the items (one per
+// batch*head, tensor, 32-channel group, t-chunk, y-chunk) are about equally long and fill the chip's slots (two workgroups
+// per CU).  Item time, from the in-kernel stamps of round 5 (profiles/r05_pool_bwd_stamps.txt, MI355X): staging 3 us + 0.08 us
+// per 1-KiB piece and wave, then ceil(planes x units / 16 thread slots) steps of 0.47 us (stride 1: one token per unit), 0.96 us
+// (stride 2: four tokens -- four loads and four stores -- per unit) or ~2 us (stride >= 3: nine), 2.5 us of tail (+ 1.5 us for
+// the cls / object rows of chunk 0).  Estimate of the launch = the longest item if everything is resident at once, else the
+// average load of a slot plus half an item.  Returns false where not even one unit row of three planes fits.
+struct PfTensorPlan { int n, r; };
 static bool plan_bwd_fused(const svit_pool_dgrad_args* d3, PoolBwdFused* g, size_t* lds_out) {
   constexpr size_t LDS_MAX = 79 * 1024;       // two workgroups per CU (the image is staged in whole 1-KiB pieces)
   constexpr double SLOTS = 512.0;
   const int T = d3[0].T, BH = d3[0].B * d3[0].heads;
-  double units[3], step_us[3];
-  int nmax[3];
+  int sc[3], UR[3], UC[3], Wo[3];
+  double step_us[3];
   for (int i = 0; i < 3; ++i) {
     const int s = d3[i].stride_hw;
-    if (s < 1 || s > 2) return false;
-    const int Ho = (d3[i].H - 1) / s + 1, Wo = (d3[i].W - 1) / s + 1;
-    const size_t pb = (size_t)pf_plane_bytes(Ho, Wo);
-    if (3 * pb + 1023 > LDS_MAX) return false;
-    nmax[i] = (int)std::min<size_t>((size_t)T, (LDS_MAX - 1023) / pb - 2);
-    units[i] = s == 1 ? (double)d3[i].H * d3[i].W : (double)((d3[i].H + 1) / 2) * ((d3[i].W + 1) / 2);
-    step_us[i] = s == 1 ? 0.47 : 0.96;
+    if (s < 1) return false;
+    const int Ho = (d3[i].H - 1) / s + 1;
+    Wo[i] = (d3[i].W - 1) / s + 1;
+    sc[i] = pf_class(s);
+    UR[i] = pf_unit_rows(sc[i], d3[i].H, Ho);
+    UC[i] = sc[i] == 1 ? d3[i].W : sc[i] == 2 ? (d3[i].W + 1) / 2 : Wo[i];
+    step_us[i] = sc[i] == 1 ? 0.47 : sc[i] == 2 ? 0.96 : 2.0;
+    if (3 * (size_t)pf_plane_bytes(pf_image_rows(sc[i], 1), Wo[i]) + 1023 > LDS_MAX) return false;
   }
-  auto item_us = [&](int i, int n, bool first) {
-    return 4.5 + std::ceil(n * units[i] / PF_SLOTS) * step_us[i] + 2.5 + (first ? 1.5 : 0.0);
+  auto lds_of = [&](int i, int n, int r) { return ((size_t)(n + 2) * pf_plane_bytes(pf_image_rows(sc[i], r), Wo[i]) + 1023) / 1024 * 1024; };
+  auto item_us = [&](int i, int n, int r, bool first) {
+    return 3.0 + 0.08 * (double)(lds_of(i, n, r) / 1024) / 4.0 + std::ceil((double)n * r * UC[i] / PF_SLOTS) * step_us[i] + 2.5 +
+           (first ? 1.5 : 0.0);
   };
-  // k and v share a chunking (same stride in every block of the model); search (n for q, n for k / v)
-  double best = 1e300;
-  int bn0 = 1, bn1 = 1;
-  for (int n0 = 1; n0 <= nmax[0]; ++n0)
-    for (int n1 = 1; n1 <= std::min(nmax[1], nmax[2]); ++n1) {
-      const int n[3] = {n0, n1, n1};
-      double items = 0, sum = 0, longest = 0;
-      for (int i = 0; i < 3; ++i) {
-        const int chunks = (T + n[i] - 1) / n[i];
-        const int last = T - (chunks - 1) * n[i];
-        items += 3.0 * BH * chunks;
-        sum += 3.0 * BH * ((chunks - 1) * item_us(i, n[i], false) + item_us(i, last, false) + 1.5);
-        longest = std::max(longest, item_us(i, n[i], chunks == 1));
+  // candidate (n, r) per tensor: every n, r = ceil(UR / k); k and v share a choice (same stride in every block of the model)
+  auto candidates = [&](int i, std::vector<PfTensorPlan>* out) {
+    for (int n = 1; n <= T; ++n) {
+      int last_r = -1;
+      for (int k = 1; k <= UR[i]; ++k) {
+        const int r = (UR[i] + k - 1) / k;
+        if (r == last_r) continue;
+        last_r = r;
+        if (lds_of(i, n, r) <= LDS_MAX) out->push_back({n, r});
       }
-      const double est = items <= SLOTS ? std::max(longest, sum / SLOTS) : sum / SLOTS + 0.5 * longest;
-      if (est < best) { best = est; bn0 = n0; bn1 = n1; }
     }
-  const int n[3] = {bn0, bn1, bn1};
+  };
+  std::vector<PfTensorPlan> cq, ckv;
+  candidates(0, &cq);
+  {
+    std::vector<PfTensorPlan> c1, c2;
+    candidates(1, &c1);
+    candidates(2, &c2);
+    for (const auto& x : c1)
+      for (const auto& y : c2)
+        if (x.n == y.n && x.r == y.r) ckv.push_back(x);
+    if (sc[1] != sc[2] || UR[1] != UR[2]) ckv = c1.size() < c2.size() ? c1 : c2;      // (not the model's case: take the tighter list)
+  }
+  if (cq.empty() || ckv.empty()) return false;
+  double best = 1e300;
+  PfTensorPlan bq = cq[0], bkv = ckv[0];
+  for (const auto& pq : cq)
+    for (const auto& pkv : ckv) {
+      const PfTensorPlan pl[3] = {pq, pkv, pkv};
+      double items = 0, sum = 0, longest = 0;
+      bool fits = true;
+      for (int i = 0; i < 3 && fits; ++i) {
+        if (lds_of(i, pl[i].n, pl[i].r) > LDS_MAX) { fits = false; break; }
+        const int tc = (T + pl[i].n - 1) / pl[i].n, yc = (UR[i] + pl[i].r - 1) / pl[i].r;
+        const int nl = T - (tc - 1) * pl[i].n, rl = UR[i] - (yc - 1) * pl[i].r;
+        items += 3.0 * BH * tc * yc;
+        sum += 3.0 * BH * ((tc - 1) * (yc - 1) * item_us(i, pl[i].n, pl[i].r, false) + (tc - 1) * item_us(i, pl[i].n, rl, false) +
+                           (yc - 1) * item_us(i, nl, pl[i].r, false) + item_us(i, nl, rl, false) + 1.5);
+        longest = std::max(longest, item_us(i, pl[i].n, pl[i].r, tc * yc == 1));
+      }
+      if (!fits || (long)BH * std::max((T + pq.n - 1) / pq.n * ((UR[0] + pq.r - 1) / pq.r),
+                                      (T + pkv.n - 1) / pkv.n * ((UR[1] + pkv.r - 1) / pkv.r)) > 4096) continue;
+      const double est = items <= SLOTS ? std::max(longest, sum / SLOTS) : sum / SLOTS + 0.5 * longest;
+      if (est < best) { best = est; bq = pq; bkv = pkv; }
+    }
+  if (best >= 1e300) return false;
+  const PfTensorPlan pl[3] = {bq, bkv, bkv};
   size_t lds = 4 * 16 * 54 * sizeof(float);
   double len[3];
   g->max_chunks = 1;
   for (int i = 0; i < 3; ++i) {
-    const int s = d3[i].stride_hw;
-    const int Ho = (d3[i].H - 1) / s + 1, Wo = (d3[i].W - 1) / s + 1;
-    g->n_per[i] = n[i];
-    g->n_chunks[i] = (T + n[i] - 1) / n[i];
-    g->max_chunks = std::max(g->max_chunks, g->n_chunks[i]);
-    lds = std::max(lds, ((size_t)(n[i] + 2) * pf_plane_bytes(Ho, Wo) + 1023) / 1024 * 1024);
-    len[i] = item_us(i, n[i], false);
+    g->n_per[i] = pl[i].n;
+    g->r_per[i] = pl[i].r;
+    g->t_chunks[i] = (T + pl[i].n - 1) / pl[i].n;
+    g->y_chunks[i] = (UR[i] + pl[i].r - 1) / pl[i].r;
+    g->max_chunks = std::max(g->max_chunks, g->t_chunks[i] * g->y_chunks[i]);
+    lds = std::max(lds, lds_of(i, pl[i].n, pl[i].r));
+    len[i] = item_us(i, pl[i].n, pl[i].r, false);
   }
   // launch order: longest items first (the dispatcher fills the second slot of every CU with the shorter ones)
   int ord[3] = {0, 1, 2};
@@ -2679,11 +2764,36 @@ static bool plan_bwd_fused(const svit_pool_dgrad_args* d3, PoolBwdFused* g, size
   for (int j = 0; j < 3; ++j) {
     g->order[j] = ord[j];
     g->first_item[j] = first;
-    first += 3 * BH * g->n_chunks[ord[j]];
+    first += 3 * BH * g->t_chunks[ord[j]] * g->y_chunks[ord[j]];
   }
   g->first_item[3] = first;
   *lds_out = lds;
   return true;
+}
+
+// The search above costs ~1 ms of host time: its result is a pure function of the geometry, so it is memoised (a training
+// step has at most 16 distinct geometries; the table is append-only, mutex-guarded, and holds no device state).
+struct PfPlanKey { int v[8]; bool operator==(const PfPlanKey& o) const { for (int i = 0; i < 8; ++i) if (v[i] != o.v[i]) return false; return true; } };
+struct PfPlanEntry { PfPlanKey key; bool ok; PoolBwdFused plan; size_t lds; };
+static std::mutex g_pf_plan_mu;
+static std::vector<PfPlanEntry> g_pf_plans;
+static bool plan_bwd_fused_cached(const svit_pool_dgrad_args* d3, PoolBwdFused* g, size_t* lds_out) {
+  const PfPlanKey key = {{d3[0].B * d3[0].heads, d3[0].T, d3[0].H, d3[0].W, d3[0].stride_hw, d3[1].stride_hw, d3[2].stride_hw, 0}};
+  {
+    std::lock_guard<std::mutex> lk(g_pf_plan_mu);
+    for (const auto& e : g_pf_plans)
+      if (e.key == key) { *g = e.plan; *lds_out = e.lds; return e.ok; }
+  }
+  PfPlanEntry e;
+  e.key = key;
+  e.lds = 0;
+  e.ok = plan_bwd_fused(d3, &e.plan, &e.lds);
+  {
+    std::lock_guard<std::mutex> lk(g_pf_plan_mu);
+    if (g_pf_plans.size() < 256) g_pf_plans.push_back(e);
+  }
+  *g = e.plan; *lds_out = e.lds;
+  return e.ok;
 }
 
 static int pool_conv_bwd_qkv_impl(const svit_pool_dgrad_args* d3, const svit_pool_wgrad_args* w3,
@@ -2703,7 +2813,7 @@ static int pool_conv_bwd_qkv_impl(const svit_pool_dgrad_args* d3, const svit_poo
   }
   PoolBwdFused g;
   size_t lds = 0;
-  bool fused = svit_knob(SVIT_K_POOL_BWD) != 0 && plan_bwd_fused(d3, &g, &lds);
+  bool fused = svit_knob(SVIT_K_POOL_BWD) != 0 && plan_bwd_fused_cached(d3, &g, &lds);
   const int64_t prows = fused ? (int64_t)d3[0].B * d3[0].heads * g.max_chunks : 0;
   if (fused && (!w3[0].workspace || w3[0].workspace_floats < prows * 3 * 27 * HD || prows > 4096)) fused = false;
   if (!fused) {   // large planes (pooled planes past 14x14, strides > 2): the streaming / tiled kernels

@@ -483,11 +483,16 @@ def test_pool_qkv_fused_equals_single(ops, sq, skv, thw):
                                              (1, 2, (16, 14, 14), 1, 4),     # 32x224^2
                                              (1, 2, (1, 14, 14), 3, 4),      # frames pass / image ranks (T' = 1)
                                              (1, 2, (5, 13, 9), 2, 1),       # odd planes, odd T
-                                             (2, 2, (3, 20, 20), 1, 2)])     # 312^2 crop, block 4 (20x20 -> 10x10)
+                                             (2, 2, (3, 20, 20), 1, 2),      # 312^2 crop, block 4 (20x20 -> 10x10)
+                                             (1, 8, (2, 56, 56), 1, 1),      # block 0: 56x56 planes cut in y, k / v at stride 8
+                                             (2, 4, (3, 56, 56), 1, 2),      # block 1: 56x56 -> 28x28 (q), stride 4 (k, v)
+                                             (1, 4, (3, 28, 28), 2, 2),      # block 2
+                                             (1, 8, (2, 30, 23), 1, 1),      # ragged windows at stride 8 (the last one runs to the edge)
+                                             (2, 3, (2, 19, 26), 1, 2)])     # stride 3
 def test_pool_conv_bwd_fused_small_planes(ops, sq, skv, thw, B, h):
     """Round 5: conv dgrad + conv wgrad of q, k, v in ONE launch with the dpre halo staged once in LDS
-    (csrc/pool.hip::pool_bwd_fused_kernel) == the streaming launches it replaces (svit_debug_set_pool(1, 0) runs them
-    through the same entry point); the stride-4 case must take the fall-through path by itself"""
+    (csrc/pool.hip::pool_bwd_fused_kernel; every stride, planes cut in t and y) == the streaming launches it replaces
+    (svit_debug_set_pool(1, 0) runs them through the same entry point)"""
     import ctypes as C
     from svit_amd import hip
     lib = hip.load()
@@ -521,14 +526,17 @@ def test_pool_conv_bwd_fused_small_planes(ops, sq, skv, thw, B, h):
         lib.svit_debug_reset()
 
 
-@pytest.mark.parametrize("sq,skv,thw,h", [(2, 2, (8, 28, 28), 1),       # block 3
+@pytest.mark.parametrize("sq,skv,thw,h", [(1, 8, (2, 56, 56), 1),       # block 0 (two of its eight planes)
+                                           (2, 4, (2, 56, 56), 2),       # block 1
+                                           (1, 4, (3, 28, 28), 2),       # block 2
+                                           (2, 2, (8, 28, 28), 1),       # block 3
                                            (1, 2, (8, 14, 14), 2),       # blocks 4-13
                                            (2, 1, (8, 14, 14), 2),       # block 14
                                            (1, 1, (8, 7, 7), 2),         # block 15
                                            (1, 2, (1, 14, 14), 2)])      # T' = 1
 def test_pool_backward_vs_oracle_at_the_step_shapes(ops, sq, skv, thw, h):
     """The pooling backward as the engine runs it at every (stride, plane) of blocks 3-15 -- svit_pool_ln_bwd_qkv then
-    the fused conv backward -- against autograd of the oracle's attention_pool restatement (oracle.svit_ref.pool_tokens,
+    the fused conv backward (blocks 0-15: every stride of the model) -- against autograd of the oracle's attention_pool restatement (oracle.svit_ref.pool_tokens,
     attention.py:13-65): d(qkv), d(conv weight), d(gamma), d(beta) of q, k and v."""
     B, O = 1, 8
     qkv = _qkv(B, h, thw, O, "o%d%d%d" % (sq, skv, thw[1]))

@@ -14,7 +14,8 @@ DEV = torch.device("cuda")
 BF16 = torch.bfloat16
 lib = hip.load()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-SHAPES = [("blk3", 4, (8, 28, 28), 2, 2), ("blk4-13", 4, (8, 14, 14), 1, 2), ("blk14", 8, (8, 14, 14), 2, 1),
+SHAPES = [("blk0", 1, (8, 56, 56), 1, 8), ("blk1", 2, (8, 56, 56), 2, 4), ("blk2", 2, (8, 28, 28), 1, 4),
+          ("blk3", 4, (8, 28, 28), 2, 2), ("blk4-13", 4, (8, 14, 14), 1, 2), ("blk14", 8, (8, 14, 14), 2, 1),
           ("blk15", 8, (8, 7, 7), 1, 1), ("c4 blk4-13", 4, (16, 14, 14), 1, 2), ("frames blk4-13 (B*16)", 4, (1, 14, 14), 1, 2)]
 
 
@@ -46,7 +47,7 @@ for name, h, thw, sq, skv in SHAPES:
         dpres.append(torch.randn((b, h, nout, 96), generator=g).to(DEV, BF16))
     dqkv = torch.empty_like(qkv)
     dws = [torch.zeros((96, 27), device=DEV) for _ in range(3)]
-    ws_buf = torch.empty(9 * 1024 * 1024, device=DEV)
+    ws_buf = torch.empty(18 * 1024 * 1024, device=DEV)
     run = lambda: ops.pool_conv_bwd_qkv(dpres, ws, dqkv, qkv, dws, b, h, thw, n_obj, strides, ws=ws_buf)
     try:
         lib.svit_debug_set_pool(1, 1)

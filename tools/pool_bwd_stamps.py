@@ -18,7 +18,7 @@ from svit_amd import hip, ops
 
 DEV = torch.device("cuda")
 lib = hip.load()
-SH = {"blk3": (4, (8, 28, 28), 2, 2), "blk4": (4, (8, 14, 14), 1, 2), "blk14": (8, (8, 14, 14), 2, 1), "blk15": (8, (8, 7, 7), 1, 1)}
+SH = {"blk0": (1, (8, 56, 56), 1, 8), "blk1": (2, (8, 56, 56), 2, 4), "blk2": (2, (8, 28, 28), 1, 4), "blk3": (4, (8, 28, 28), 2, 2), "blk4": (4, (8, 14, 14), 1, 2), "blk14": (8, (8, 14, 14), 2, 1), "blk15": (8, (8, 7, 7), 1, 1)}
 name = sys.argv[1] if len(sys.argv) > 1 else "blk4"
 h, thw, sq, skv = SH[name]
 B, n_obj = 8, 64
