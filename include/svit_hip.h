@@ -225,7 +225,7 @@ int svit_pool_ln_fwd_qkv(const svit_pool_args* args3, void* stream);
 /* Stride-1 stencils that keep their input in LDS.  svit_pool_weight_sel turns a list of depthwise weights
  * (fp32 [96][27] each, at src_base + src_off[i]) into "selector" tables dst[i][27][96] (uint32:
  * bf16(w) in the half of the dword that matches the channel's position in a packed bf16 pair); run
- * once per step for all blocks.  The *_sel entry points take the three tables of a block.  Who reads
+ * once per step for all blocks.  The *_sel entry point takes the three tables of a block.  Who reads
  * them: the SLAB forward (round 3; planes of <= 196 tokens, i.e. the 14x14 and 7x7 stages) fetches a
  * channel group's 27 x 24 entries as SCALAR operands (s_load) -- its stencil has no vector weight loads
  * at all; the LDS-tiled kernels of round 2 (56x56 planes; halo ring in LDS) build their own LDS weight
@@ -237,14 +237,15 @@ int svit_pool_ln_fwd_qkv_sel(const svit_pool_args* args3, const uint32_t* const*
 int svit_pool_ln_bwd_qkv(const svit_pool_ln_bwd_args* args3, void* stream);
 int svit_pool_conv_dgrad_qkv(const svit_pool_dgrad_args* args3, void* stream);
 int svit_pool_conv_wgrad_qkv(const svit_pool_wgrad_args* args3, void* stream);
-/* Steps 2 + 3 together (what the engine calls): for the small planes (14x14 / 7x7 stages, strides
- * 1 or 2) ONE kernel walks the input tokens once with dpre in LDS and produces dqkv and the
- * three dw (fp32 atomics); larger planes fall through to the two streaming launches above.
- * dgrad3[i] / wgrad3[i] describe the same `which` = i (same dpre, stride, dims). */
+/* Steps 2 + 3 together (what the engine calls; round 5): conv dgrad AND conv wgrad of q, k, v in ONE launch for every
+ * stride and plane of the model (csrc/pool.hip::pool_bwd_fused_kernel: a workgroup stages the dpre halo of its chunk of
+ * planes / rows once in LDS and walks its input tokens once, producing dqkv and per-workgroup partial rows of the three dw
+ * that the second-stage reduce sums in a fixed order); where not even one unit row of three padded planes fits LDS, or
+ * with svit_debug_set_pool(1, 0), it falls through to the two streaming launches above.
+ * dgrad3[i] / wgrad3[i] describe the same `which` = i (same dpre, stride, dims); wgrad3[0].workspace >=
+ * B * heads * chunks * 3 * 27 * 96 floats. */
 int svit_pool_conv_bwd_qkv(const svit_pool_dgrad_args* dgrad3, const svit_pool_wgrad_args* wgrad3,
                            void* stream);
-int svit_pool_conv_bwd_qkv_sel(const svit_pool_dgrad_args* dgrad3, const svit_pool_wgrad_args* wgrad3,
-                               const uint32_t* const* sel3, void* stream);
 
 /* ------------------------------------------- decomposed rel-pos bias, query side (K9/K10) */
 /* cal_rel_pos_spatial / cal_rel_pos_temporal (attention.py:84-183) restated as

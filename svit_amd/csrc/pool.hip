@@ -239,8 +239,8 @@ __device__ __forceinline__ void pool_ln_fwd_body(const svit_pool_args& a, const 
 //     ds_read_b128 group are 16 consecutive tokens and hit 16 distinct slots of the bank row.
 //   * LayerNorm(96) spans the four waves: two tiny exchanges (sum, then squared deviations)
 //     through LDS per plane.
-//   * FLIP selects the transposed stencil (conv dgrad of a stride-1 conv = correlation with the
-//     flipped kernel), DGRAD the epilogue: bf16 rows of dqkv instead of LayerNorm + out/pre.
+//   (forward only since round 5: the dgrad form of this body -- flipped kernel, dqkv rows instead of LayerNorm -- went
+//    with the fused conv backward further down)
 constexpr int TL_ROW = 208;       // LDS bytes per token row (192 + 16 pad)
 
 struct PoolTilePlan {
@@ -264,14 +264,14 @@ __device__ __forceinline__ int b128_group_order(int lane) {
   return (lane & 32) + g * 16 + k;
 }
 
-template <int TX, int TY, bool DGRAD, bool SW>
+template <int TX, int TY, bool SW>
 __device__ __forceinline__ void pool_tiled_body(
     const bf16_t* __restrict__ in_base, size_t in_tok_stride /* elements */, int in_first /* token index of patch 0 */,
     const float* __restrict__ w_lds /* [27][96] selector dwords in LDS (!SW) */,
     const uint32_t* __restrict__ sel /* the same table in global memory (SW: read as scalar operands) */,
     int T, int H, int W, int wg,
     const PoolTilePlan& pl, unsigned char* ring, float* xch /* [2][4][64] */,
-    const svit_pool_args* fa, const svit_pool_dgrad_args* da, int bh) {
+    const svit_pool_args* fa, int bh) {
   constexpr int HX = TX + 2, HY = TY + 2, HTOK = HX * HY, PLANE_B = HTOK * TL_ROW;
   constexpr int CH = HTOK * 12, PER = (CH + 255) / 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -332,7 +332,7 @@ __device__ __forceinline__ void pool_tiled_body(
           const int tap0 = (kt * 3 + ky) * 3;
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
-            const cptr_t w = selw + (DGRAD ? 26 - (tap0 + kx) : tap0 + kx) * HD;
+            const cptr_t w = selw + (tap0 + kx) * HD;
             const unsigned char* p = pl_base + (ky * HX + kx) * TL_ROW;
             const uint4 v0 = *(const uint4*)(p), v1 = *(const uint4*)(p + 16), v2 = *(const uint4*)(p + 32);
             acc[0] = dot2_sel(v0.x, w[0], acc[0]);   acc[1] = dot2_sel(v0.x, w[1], acc[1]);
@@ -359,7 +359,7 @@ __device__ __forceinline__ void pool_tiled_body(
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           const int tap = (kt * 3 + ky) * 3 + kx;
-          const float* wt = wsel + (DGRAD ? 26 - tap : tap) * HD;   // wave-uniform: broadcast LDS reads
+          const float* wt = wsel + tap * HD;   // wave-uniform: broadcast LDS reads
           const unsigned char* p = pl_base + (ky * HX + kx) * TL_ROW;
 #pragma unroll
           for (int u = 0; u < 3; ++u) fma8_sel(acc, u, *(const uint4*)(p + u * 16), wt);
@@ -367,17 +367,7 @@ __device__ __forceinline__ void pool_tiled_body(
     }
     }
     const int y = y0 + ty, x = x0 + tx;
-    if constexpr (DGRAD) {
-      if (live) {
-        const int b = bh / da->heads, head = bh % da->heads;
-        const int N = 1 + T * H * W + da->n_obj;
-        const size_t ts = (size_t)3 * da->heads * HD;
-        bf16_t* o = (bf16_t*)da->dqkv + ((size_t)b * N + 1 + (t * H + y) * W + x) * ts +
-                    ((size_t)da->which * da->heads + head) * HD + wave * 24;
-#pragma unroll
-        for (int v = 0; v < 3; ++v) *(uint4*)(o + v * 8) = pack8(&acc[v * 8]);
-      }
-    } else {
+    {
       // LayerNorm over the 96 channels of the token = over the four waves
 #pragma unroll
       for (int i = 0; i < 24; ++i) acc[i] = bf16_to_f32(f32_to_bf16(acc[i]));   // what backward sees
@@ -495,9 +485,9 @@ __global__ __launch_bounds__(256) void pool_ln_fwd3_kernel(PoolFwd3 g) {
     unsigned char* ring = pool_dyn + 512 * sizeof(float);
     const uint32_t* sel = g.sel[blockIdx.z];      // scalar weights: nothing to stage in LDS
     if (a.W > 8)
-      pool_tiled_body<16, 4, false, true>(base, ts, 1, w_lds, sel, a.T, a.H, a.W, wg, pl, ring, xch, &a, nullptr, bh);
+      pool_tiled_body<16, 4, true>(base, ts, 1, w_lds, sel, a.T, a.H, a.W, wg, pl, ring, xch, &a, bh);
     else
-      pool_tiled_body<8, 8, false, true>(base, ts, 1, w_lds, sel, a.T, a.H, a.W, wg, pl, ring, xch, &a, nullptr, bh);
+      pool_tiled_body<8, 8, true>(base, ts, 1, w_lds, sel, a.T, a.H, a.W, wg, pl, ring, xch, &a, bh);
     return;
   }
   const int Nout = 1 + a.T * pooled(a.H, a.stride_hw) * pooled(a.W, a.stride_hw) + a.n_obj;
@@ -787,57 +777,11 @@ __global__ __launch_bounds__(256) void pool_dgrad_kernel(svit_pool_dgrad_args a)
   __shared__ __attribute__((aligned(16))) float g_lds[HD];
   pool_dgrad_loop<S>(a, w_lds, g_lds);
 }
-// cls and object rows of a tiled dgrad tensor: dx[cls] = dpre[cls], dx[obj] = dpre[obj] * g(w)
-__device__ __forceinline__ void pool_dgrad_special_body(const svit_pool_dgrad_args& a, const float* g_lds, int blk) {
-  const int L = a.T * a.H * a.W, N = 1 + L + a.n_obj;     // stride 1: Nout == N
-  const int bh = blockIdx.y, b = bh / a.heads, head = bh % a.heads;
-  const int idx = blk * 64 + (threadIdx.x >> 2);
-  const int sub = threadIdx.x & 3, c0 = sub * 24;
-  if (idx > a.n_obj) return;
-  const int tok = idx == 0 ? 0 : L + idx;
-  const bf16_t* dp = (const bf16_t*)a.dpre + ((size_t)bh * N + tok) * HD + c0;
-  const size_t ts = (size_t)3 * a.heads * HD;
-  bf16_t* o = (bf16_t*)a.dqkv + ((size_t)b * N + tok) * ts + ((size_t)a.which * a.heads + head) * HD + c0;
-#pragma unroll
-  for (int v = 0; v < 3; ++v) {
-    float f[8];
-    unpack8(*(const uint4*)(dp + v * 8), f);
-    if (tok != 0) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] *= g_lds[c0 + v * 8 + e];
-    }
-    *(uint4*)(o + v * 8) = pack8(f);
-  }
-}
-
-struct PoolDgrad3 { svit_pool_dgrad_args p[3]; PoolTilePlan plan[3]; const uint32_t* sel[3]; };
+struct PoolDgrad3 { svit_pool_dgrad_args p[3]; };
 __global__ __launch_bounds__(256) void pool_dgrad3_kernel(PoolDgrad3 g) {
   __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];
   __shared__ __attribute__((aligned(16))) float g_lds[HD];
-  extern __shared__ __attribute__((aligned(16))) unsigned char pool_dyn[];
   const svit_pool_dgrad_args& a = g.p[blockIdx.z];
-  const PoolTilePlan& pl = g.plan[blockIdx.z];
-  if (pl.tiled) {
-    const int wg = blockIdx.x;
-    if (wg >= pl.n_wgs + pl.n_special) return;
-    if (wg >= pl.n_wgs) {
-      load_weights(a.conv_w, w_lds, g_lds, a.stride_hw);
-      pool_dgrad_special_body(a, g_lds, wg - pl.n_wgs);
-      return;
-    }
-    const int bh = blockIdx.y;
-    const int N = 1 + a.T * a.H * a.W + a.n_obj;
-    const bf16_t* base = (const bf16_t*)a.dpre + (size_t)bh * N * HD;
-    float* xch = (float*)pool_dyn;
-    unsigned char* ring = pool_dyn + 512 * sizeof(float);
-    // (weights from LDS here: as scalar operands -- the forward's way -- the dgrad measured no faster in the step)
-    load_weights(a.conv_w, w_lds, nullptr, a.stride_hw);
-    if (a.W > 8)
-      pool_tiled_body<16, 4, true, false>(base, HD, 1, w_lds, nullptr, a.T, a.H, a.W, wg, pl, ring, xch, nullptr, &a, bh);
-    else
-      pool_tiled_body<8, 8, true, false>(base, HD, 1, w_lds, nullptr, a.T, a.H, a.W, wg, pl, ring, xch, nullptr, &a, bh);
-    return;
-  }
   if (a.stride_hw == 1) pool_dgrad_loop<1>(a, w_lds, g_lds);
   else if (a.stride_hw == 2) pool_dgrad_loop<2>(a, w_lds, g_lds);
   else pool_dgrad_loop<3>(a, w_lds, g_lds);
@@ -1076,184 +1020,6 @@ static int launch_wgrad(const svit_pool_wgrad_args& a, int Ho, int Wo, hipStream
   svit_launch_reduce(a.workspace, (int)blocks, 27 * HD, dst, st);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
-}
-
-// ---------------------------------------------------------------------------------------
-// Small-plane pooling backward (the 14x14 / 7x7 stages, 12 of 16 blocks): conv dgrad AND conv
-// wgrad of q, k, v in ONE launch.  Both consume the same 3x3x3 neighbourhood of dpre, so a
-// workgroup keeps dpre of one (batch, head) for a 24-channel group in LDS (<= ~100 KB), walks
-// the INPUT tokens once and, per valid tap, does  dx[in] += w[tap] * dpre[out]  and
-// dw[tap] += x[in] * dpre[out]  from the same LDS read.  Thread = (channel pair, token lane);
-// the 27 weights and 27 weight-gradient accumulators of both channels live in registers (tap
-// indices are compile-time: stride 2 dispatches on the input parity).  dw leaves through fp32
-// atomics (<= 64 adders per address).  Replaces pool_dgrad3 + pool_wgrad3 + a reduce launch
-// (~110 us -> one latency-light kernel) where the planes are small.
-struct PoolBwdSmall {
-  svit_pool_dgrad_args d[3];
-  const void* qkv;
-  float* partial;     // [B*heads * 2 (split)][3 (which)][96][27] partial weight gradients
-  int nsplit[3];
-};
-
-template <int S, int PY, int PX>
-__device__ __forceinline__ void pbs_taps(const bf16_t* dp, int cp, int t, int y, int x, int T,
-                                         int Ho, int Wo, float x0, float x1, const float (&w0)[27],
-                                         const float (&w1)[27], float (&dw0)[27], float (&dw1)[27],
-                                         float& a0, float& a1) {
-  // branch-free: every candidate tap reads LDS (row 0 when it falls outside the volume) and an
-  // invalid tap contributes zeros -- all reads are in flight before the first FMA
-  int rowb[3][3];
-  bool rv[3][3], xv[3];
-  int xo[3];
-#pragma unroll
-  for (int kx = 0; kx < 3; ++kx) {
-    const int xn = x + 1 - kx;
-    xo[kx] = S == 2 ? (xn >> 1) : xn;
-    xv[kx] = xn >= 0 && xo[kx] < Wo;
-  }
-#pragma unroll
-  for (int kt = 0; kt < 3; ++kt) {
-    const int to = t + 1 - kt;
-    const bool tv = to >= 0 && to < T;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int yn = y + 1 - ky;
-      const int yo = S == 2 ? (yn >> 1) : yn;
-      rv[kt][ky] = tv && yn >= 0 && yo < Ho;
-      rowb[kt][ky] = 1 + (to * Ho + yo) * Wo;
-    }
-  }
-  uint32_t v[27];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    const int kt = k / 9, ky = (k / 3) % 3, kx = k % 3;
-    v[k] = 0u;
-    if (S == 2 && ((ky & 1) != PY || (kx & 1) != PX)) continue;       // compile-time
-    const bool ok = rv[kt][ky] && xv[kx];
-    const int row = ok ? rowb[kt][ky] + xo[kx] : 0;
-    const uint32_t r = *(const uint32_t*)(dp + (size_t)row * 24 + 2 * cp);
-    v[k] = ok ? r : 0u;
-  }
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    const int ky = (k / 3) % 3, kx = k % 3;
-    if (S == 2 && ((ky & 1) != PY || (kx & 1) != PX)) continue;       // compile-time
-    const float d0 = lo_bf16(v[k]), d1 = hi_bf16(v[k]);
-    a0 += w0[k] * d0; a1 += w1[k] * d1;
-    dw0[k] += x0 * d0; dw1[k] += x1 * d1;
-  }
-}
-
-template <int S>
-__device__ __forceinline__ void pool_bwd_small_body(const PoolBwdSmall& g, int which, int bh,
-                                                    int group, int split, unsigned char* smem) {
-  const svit_pool_dgrad_args& a = g.d[which];
-  const int tid = threadIdx.x, cp = tid % 12, tl = tid / 12;      // 192 threads: 12 pairs x 16
-  const int c = group * 24 + 2 * cp;
-  const int s = a.stride_hw;
-  const int Ho = pooled(a.H, s), Wo = pooled(a.W, s);
-  const int L = a.T * a.H * a.W, Lo = a.T * Ho * Wo;
-  const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
-  const int b = bh / a.heads, head = bh % a.heads;
-  bf16_t* dp = (bf16_t*)smem;                                     // [Nout][24]
-  const bf16_t* dsrc = (const bf16_t*)a.dpre + (size_t)bh * Nout * HD + group * 24;
-  for (int i = tid; i < Nout * 3; i += 192) {
-    const int tok = i / 3, ch = i % 3;
-    *(uint4*)(dp + (size_t)tok * 24 + ch * 8) = *(const uint4*)(dsrc + (size_t)tok * HD + ch * 8);
-  }
-  float w0[27], w1[27], dw0[27], dw1[27];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    w0[k] = a.conv_w[(size_t)c * 27 + k];
-    w1[k] = a.conv_w[(size_t)(c + 1) * 27 + k];
-    dw0[k] = 0.f; dw1[k] = 0.f;
-  }
-  float nt[3], nh[3], ipt, iph;
-  obj_counts(1, nt, &ipt);
-  obj_counts(s, nh, &iph);
-  const float onorm = ipt * iph * iph;
-  float g0 = 0.f, g1 = 0.f;                 // object gain of the two channels
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    const float coef = nt[k / 9] * nh[(k / 3) % 3] * nh[k % 3] * onorm;
-    g0 += w0[k] * coef; g1 += w1[k] * coef;
-  }
-  __syncthreads();
-  const size_t tok_stride = (size_t)3 * a.heads * HD;
-  const size_t col = ((size_t)which * a.heads + head) * HD + c;
-  const bf16_t* xin = (const bf16_t*)g.qkv + (size_t)b * N * tok_stride + col;
-  bf16_t* dxo = (bf16_t*)a.dqkv + (size_t)b * N * tok_stride + col;
-  const int per = (N + g.nsplit[which] - 1) / g.nsplit[which];
-  const int begin = split * per, end = min(N, begin + per);
-  float go0 = 0.f, go1 = 0.f;
-  // x of the NEXT token is fetched while the current one is processed: one exposed global round
-  // trip per token would otherwise dominate (a wave has a SIMD almost to itself here)
-  uint32_t xnext = 0u;
-  if (begin + tl < end) xnext = *(const uint32_t*)(xin + (size_t)(begin + tl) * tok_stride);
-  for (int tok = begin + tl; tok < end; tok += 16) {
-    const uint32_t xv = xnext;
-    if (tok + 16 < end) xnext = *(const uint32_t*)(xin + (size_t)(tok + 16) * tok_stride);
-    float a0 = 0.f, a1 = 0.f;
-    if (tok == 0) {
-      const uint32_t v = *(const uint32_t*)(dp + 2 * cp);
-      a0 = lo_bf16(v); a1 = hi_bf16(v);
-    } else if (tok > L) {
-      const uint32_t v = *(const uint32_t*)(dp + (size_t)(1 + Lo + (tok - 1 - L)) * 24 + 2 * cp);
-      const float d0 = lo_bf16(v), d1 = hi_bf16(v);
-      a0 = d0 * g0; a1 = d1 * g1;
-      go0 += d0 * lo_bf16(xv); go1 += d1 * hi_bf16(xv);
-    } else {
-      const int p = tok - 1, x = p % a.W, y = (p / a.W) % a.H, t = p / (a.W * a.H);
-      const float x0 = lo_bf16(xv), x1 = hi_bf16(xv);
-      if (S == 1) {
-        pbs_taps<1, 0, 0>(dp, cp, t, y, x, a.T, Ho, Wo, x0, x1, w0, w1, dw0, dw1, a0, a1);
-      } else {
-        const int py = (y + 1) & 1, px = (x + 1) & 1;   // taps with ky = py (mod 2), kx = px (mod 2)
-        if (py == 0 && px == 0) pbs_taps<2, 0, 0>(dp, cp, t, y, x, a.T, Ho, Wo, x0, x1, w0, w1, dw0, dw1, a0, a1);
-        else if (py == 0) pbs_taps<2, 0, 1>(dp, cp, t, y, x, a.T, Ho, Wo, x0, x1, w0, w1, dw0, dw1, a0, a1);
-        else if (px == 0) pbs_taps<2, 1, 0>(dp, cp, t, y, x, a.T, Ho, Wo, x0, x1, w0, w1, dw0, dw1, a0, a1);
-        else pbs_taps<2, 1, 1>(dp, cp, t, y, x, a.T, Ho, Wo, x0, x1, w0, w1, dw0, dw1, a0, a1);
-      }
-    }
-    *(uint32_t*)(dxo + (size_t)tok * tok_stride) = pack_bf16x2(a0, a1);
-  }
-  // object tokens' closed-form share of dw, then the 16 token lanes meet in LDS
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    const float coef = nt[k / 9] * nh[(k / 3) % 3] * nh[k % 3] * onorm;
-    dw0[k] += go0 * coef; dw1[k] += go1 * coef;
-  }
-  __syncthreads();                              // everyone is done reading dp
-  float* red = (float*)smem;                    // [16][12][54]
-#pragma unroll
-  for (int k = 0; k < 27; ++k) {
-    red[(tl * 12 + cp) * 54 + k] = dw0[k];
-    red[(tl * 12 + cp) * 54 + 27 + k] = dw1[k];
-  }
-  __syncthreads();
-  // one partial row per (batch*head, split): plain stores, summed in a fixed order by the
-  // second-stage reduce (round 1 used fp32 atomics here: <= 64 adders per address, any order)
-  float* prow = g.partial + (((size_t)bh * 2 + split) * 3 + which) * (27 * HD);
-  for (int o = tid; o < 12 * 54; o += 192) {
-    float sum = 0.f;
-#pragma unroll
-    for (int l = 0; l < 16; ++l) sum += red[l * 648 + o];
-    const int pair = o / 54, k2 = o % 54;
-    const int ch = group * 24 + 2 * pair + (k2 >= 27 ? 1 : 0);
-    prow[(size_t)ch * 27 + (k2 % 27)] = sum;
-  }
-}
-
-__global__ __launch_bounds__(192) void pool_bwd_small_kernel(PoolBwdSmall g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_pbs[];
-  const int which = blockIdx.y, group = blockIdx.z >> 1, split = blockIdx.z & 1;
-  if (split >= g.nsplit[which]) {     // unsplit tensor: this row segment contributes zeros
-    float* prow = g.partial + (((size_t)blockIdx.x * 2 + split) * 3 + which) * (27 * HD) + group * 24 * 27;
-    for (int o = threadIdx.x; o < 24 * 27; o += 192) prow[o] = 0.f;
-    return;
-  }
-  if (g.d[which].stride_hw == 1) pool_bwd_small_body<1>(g, which, blockIdx.x, group, split, smem_pbs);
-  else pool_bwd_small_body<2>(g, which, blockIdx.x, group, split, smem_pbs);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1814,10 +1580,12 @@ __device__ __forceinline__ void pool_mfma_body(const svit_pool_args& a, int whic
   float* w_lds = g_lds + 16;
   if (tid < 16 * 27) w_lds[tid] = a.conv_w[(size_t)cb * 16 * 27 + tid];
   // ---- zero halo planes t = -1 and t = T of the 16 channels -------------------------------------------
-  const int ppc = PP / 16;                           // 16-byte chunks per plane
+  // (8-byte stores: the channel stride CS = (T + 2) * H * 32 + 8 is a multiple of 8, NOT of 16 -- the +8 skew that
+  //  spreads a half-wave's channels over the bank pairs -- so a 16-byte store would be misaligned for odd channels)
+  const int ppc = PP / 8;                            // 8-byte chunks per plane
   for (int i = tid; i < 16 * 2 * ppc; i += PM_NT) {
     const int c = i / (2 * ppc), r = i % (2 * ppc);
-    *(uint4*)(lds + c * CS + (r < ppc ? 0 : (T + 1) * PP) + (r % ppc) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    *(uint2*)(lds + c * CS + (r < ppc ? 0 : (T + 1) * PP) + (r % ppc) * 8) = make_uint2(0u, 0u);
   }
   // ---- fill: task = (row of the volume, slot pair m, channel half); the loads of FB tasks per thread are requested
   // together (one memory round trip per batch instead of one per task) ------------------------------------------
@@ -2576,12 +2344,11 @@ extern "C" int svit_pool_ln_bwd_qkv(const svit_pool_ln_bwd_args* a3, void* strea
   return SVIT_OK;
 }
 
-static int pool_conv_dgrad_qkv_impl(const svit_pool_dgrad_args* a3, const uint32_t* const* sel3, void* stream) {
+extern "C" int svit_pool_conv_dgrad_qkv(const svit_pool_dgrad_args* a3, void* stream) {
   if (!a3) return SVIT_ERR_ARG;
   PoolDgrad3 g;
   const int N = 1 + a3[0].T * a3[0].H * a3[0].W + a3[0].n_obj;
-  unsigned gx = persistent_x((N + 63) / 64, a3[0].B * a3[0].heads * 3);
-  size_t lds = 0;
+  const unsigned gx = persistent_x((N + 63) / 64, a3[0].B * a3[0].heads * 3);
   for (int i = 0; i < 3; ++i) {
     const svit_pool_dgrad_args* a = &a3[i];
     if (!a->dpre || !a->conv_w || !a->dqkv || a->which < 0 || a->which > 2) return SVIT_ERR_ARG;
@@ -2591,26 +2358,10 @@ static int pool_conv_dgrad_qkv_impl(const svit_pool_dgrad_args* a3, const uint32
         a->W != a3[0].W || a->n_obj != a3[0].n_obj)
       return SVIT_ERR_SHAPE;
     g.p[i] = *a;
-    g.sel[i] = sel3 ? sel3[i] : nullptr;
-    g.plan[i].tiled = 0;
-    if (a->stride_hw == 1 && g.sel[i]) {
-      g.plan[i] = plan_tiled(a->T, a->H, a->W, a->n_obj, a->B * a->heads);
-      const unsigned x = (unsigned)(g.plan[i].n_wgs + g.plan[i].n_special);
-      if (x > gx) gx = x;
-      const size_t need = tiled_lds_bytes(a->W);
-      if (need > lds) lds = need;
-    }
   }
-  static SvitOnce once;
-  if (int rc = svit_max_lds_once(once, (const void*)pool_dgrad3_kernel, 64 * 1024)) return rc;
-  hipLaunchKernelGGL(pool_dgrad3_kernel, dim3(gx, a3[0].B * a3[0].heads, 3), dim3(256), lds,
-                     (hipStream_t)stream, g);
+  hipLaunchKernelGGL(pool_dgrad3_kernel, dim3(gx, a3[0].B * a3[0].heads, 3), dim3(256), 0, (hipStream_t)stream, g);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
-}
-
-extern "C" int svit_pool_conv_dgrad_qkv(const svit_pool_dgrad_args* a3, void* stream) {
-  return pool_conv_dgrad_qkv_impl(a3, nullptr, stream);
 }
 
 extern "C" int svit_pool_conv_wgrad_qkv(const svit_pool_wgrad_args* a3, void* stream) {
@@ -2657,17 +2408,6 @@ extern "C" int svit_pool_conv_wgrad_qkv(const svit_pool_wgrad_args* a3, void* st
   return SVIT_OK;
 }
 
-static int pool_conv_bwd_qkv_impl(const svit_pool_dgrad_args* d3, const svit_pool_wgrad_args* w3,
-                                  const uint32_t* const* sel3, void* stream);
-extern "C" int svit_pool_conv_bwd_qkv(const svit_pool_dgrad_args* d3, const svit_pool_wgrad_args* w3,
-                                      void* stream) {
-  return pool_conv_bwd_qkv_impl(d3, w3, nullptr, stream);
-}
-extern "C" int svit_pool_conv_bwd_qkv_sel(const svit_pool_dgrad_args* d3, const svit_pool_wgrad_args* w3,
-                                          const uint32_t* const* sel3, void* stream) {
-  if (!sel3) return SVIT_ERR_ARG;
-  return pool_conv_bwd_qkv_impl(d3, w3, sel3, stream);
-}
 // Planner of the fused conv backward: input planes (n) and unit rows (R) per chunk for each tensor, so that the items (one per
 // batch*head, tensor, 32-channel group, t-chunk, y-chunk) are about equally long and fill the chip's slots (two workgroups
 // per CU).  Item time, from the in-kernel stamps of round 5 (profiles/r05_pool_bwd_stamps.txt, MI355X): staging 3 us + 0.08 us
@@ -2796,8 +2536,7 @@ static bool plan_bwd_fused_cached(const svit_pool_dgrad_args* d3, PoolBwdFused* 
   return e.ok;
 }
 
-static int pool_conv_bwd_qkv_impl(const svit_pool_dgrad_args* d3, const svit_pool_wgrad_args* w3,
-                                  const uint32_t* const* sel3, void* stream) {
+extern "C" int svit_pool_conv_bwd_qkv(const svit_pool_dgrad_args* d3, const svit_pool_wgrad_args* w3, void* stream) {
   if (!d3 || !w3) return SVIT_ERR_ARG;
   for (int i = 0; i < 3; ++i) {
     const svit_pool_dgrad_args& d = d3[i];
@@ -2817,7 +2556,7 @@ static int pool_conv_bwd_qkv_impl(const svit_pool_dgrad_args* d3, const svit_poo
   const int64_t prows = fused ? (int64_t)d3[0].B * d3[0].heads * g.max_chunks : 0;
   if (fused && (!w3[0].workspace || w3[0].workspace_floats < prows * 3 * 27 * HD || prows > 4096)) fused = false;
   if (!fused) {   // large planes (pooled planes past 14x14, strides > 2): the streaming / tiled kernels
-    int rc = pool_conv_dgrad_qkv_impl(d3, sel3, stream);
+    int rc = svit_pool_conv_dgrad_qkv(d3, stream);
     if (rc) return rc;
     return svit_pool_conv_wgrad_qkv(w3, stream);
   }

@@ -413,18 +413,14 @@ def pool_conv_wgrad_qkv(dpres, qkv, dws, B, heads, thw, n_obj, strides, ws=None)
     hip.call("svit_pool_conv_wgrad_qkv", arr)
 
 
-def pool_conv_bwd_qkv(dpres, conv_ws, dqkv, qkv, dws, B, heads, thw, n_obj, strides, ws=None, sels=None):
-    """conv dgrad + conv wgrad of q, k, v: one fused kernel for small planes, else two launches
-    (with sels, the stride-1 dgrads run the LDS-tiled stencil)."""
+def pool_conv_bwd_qkv(dpres, conv_ws, dqkv, qkv, dws, B, heads, thw, n_obj, strides, ws=None):
+    """conv dgrad + conv wgrad of q, k, v: one fused launch (csrc/pool.hip::pool_bwd_fused_kernel)."""
     da = (hip.PoolDgradArgs * 3)()
     wa = (hip.PoolWgradArgs * 3)()
     for i in range(3):
         _pool_dgrad_args(da[i], dpres[i], conv_ws[i], dqkv, i, B, heads, thw, n_obj, strides[i])
         _pool_wgrad_args(wa[i], dpres[i], qkv, i, dws[i], B, heads, thw, n_obj, strides[i], ws)
-    if sels is None:
-        hip.call("svit_pool_conv_bwd_qkv", da, wa)
-    else:
-        hip.call("svit_pool_conv_bwd_qkv_sel", da, wa, _sel_ptrs(sels))
+    hip.call("svit_pool_conv_bwd_qkv", da, wa)
 
 
 def relpos_q_fwd(qa, tabs, idx, B, heads, q_thw, k_thw, n_obj, inv_scale):

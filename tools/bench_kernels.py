@@ -512,7 +512,7 @@ def bench_pool_tiled():
         dqkv = torch.empty_like(qkv)
         dws = [torch.zeros(96, 27, device=DEV) for _ in range(3)]
         b0 = timeit(lambda: ops.pool_conv_bwd_qkv(dpres, ws, dqkv, qkv, dws, B, h, thw, n_obj, strides))
-        b1 = timeit(lambda: ops.pool_conv_bwd_qkv(dpres, ws, dqkv, qkv, dws, B, h, thw, n_obj, strides, sels=sels))
+        b1 = timeit(lambda: ops.pool_conv_bwd_qkv(dpres, ws, dqkv, qkv, dws, B, h, thw, n_obj, strides))
         for i, v in enumerate((f0, f1, b0, b1)):
             tot[i] += v * mult
         print("blk%-2d h=%d N=%6d sq=%d skv=%d  fwd %6.1f | %6.1f   conv bwd %6.1f | %6.1f" %
