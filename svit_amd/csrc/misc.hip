@@ -280,12 +280,13 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
                                    int Wo, int n_obj, int C) {
   const int c4 = C >> 2;
   const int Nin = 1 + T * H * W + n_obj, Nout = 1 + T * Ho * Wo + n_obj;
-  const int64_t total = (int64_t)B * Nout * c4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int cc = (int)(i % c4);
-    const int tok = (int)((i / c4) % Nout);
-    const int b = (int)(i / ((int64_t)c4 * Nout));
+  // (round 5: blockIdx.y = clip, 32-bit index arithmetic inside it -- the three 64-bit divisions per element of the flat
+  //  index were a third of the kernel's instructions)
+  const int b = blockIdx.y;
+  const unsigned per = (unsigned)Nout * c4;
+  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < per; j += gridDim.x * blockDim.x) {
+    const int tok = (int)(j / (unsigned)c4), cc = (int)(j - (unsigned)tok * c4);
+    const int64_t i = (int64_t)b * per + j;
     const float4* xb = (const float4*)(x + (int64_t)b * Nin * C);
     float4 best;
     uchar4 bi = make_uchar4(255, 255, 255, 255);
@@ -327,12 +328,11 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* 
                                    int Wo, int n_obj, int C) {
   const int c4 = C >> 2;
   const int Nin = 1 + T * H * W + n_obj, Nout = 1 + T * Ho * Wo + n_obj;
-  const int64_t total = (int64_t)B * Nin * c4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int cc = (int)(i % c4);
-    const int tok = (int)((i / c4) % Nin);
-    const int b = (int)(i / ((int64_t)c4 * Nin));
+  const int b = blockIdx.y;
+  const unsigned per = (unsigned)Nin * c4;
+  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < per; j += gridDim.x * blockDim.x) {
+    const int tok = (int)(j / (unsigned)c4), cc = (int)(j - (unsigned)tok * c4);
+    const int64_t i = (int64_t)b * per + j;
     const float4* db = (const float4*)(dy + (int64_t)b * Nout * C);
     const uchar4* ib = (const uchar4*)(idx + (int64_t)b * Nout * C);
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -625,8 +625,9 @@ extern "C" int svit_maxpool_fwd(const float* x, float* y, uint8_t* idx, int B, i
                                 int n_obj, int C, void* stream) {
   if (!x || !y || !idx || C % 4 != 0) return SVIT_ERR_ARG;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  const int64_t total = (int64_t)B * (1 + T * Ho * Wo + n_obj) * (C / 4);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+  const int64_t per = (int64_t)(1 + T * Ho * Wo + n_obj) * (C / 4);
+  if (per >= (1ll << 31) || B > 65535) return SVIT_ERR_SHAPE;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(per, 256, 2048), B), dim3(256), 0,
                      (hipStream_t)stream, x, y, idx, B, T, H, W, Ho, Wo, n_obj, C);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
@@ -636,8 +637,9 @@ extern "C" int svit_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, 
                                 int W, int n_obj, int C, void* stream) {
   if (!dy || !dx || !idx || C % 4 != 0) return SVIT_ERR_ARG;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  const int64_t total = (int64_t)B * (1 + T * H * W + n_obj) * (C / 4);
-  hipLaunchKernelGGL(maxpool_bwd_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0,
+  const int64_t per = (int64_t)(1 + T * H * W + n_obj) * (C / 4);
+  if (per >= (1ll << 31) || B > 65535) return SVIT_ERR_SHAPE;
+  hipLaunchKernelGGL(maxpool_bwd_kernel<false>, dim3(grid_for(per, 256, 2048), B), dim3(256), 0,
                      (hipStream_t)stream, dy, idx, (void*)dx, B, T, H, W, Ho, Wo, n_obj, C);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
@@ -646,8 +648,9 @@ extern "C" int svit_maxpool_bwd_bf16(const float* dy, const uint8_t* idx, void* 
                                      int W, int n_obj, int C, void* stream) {
   if (!dy || !dx_bf16 || !idx || C % 4 != 0) return SVIT_ERR_ARG;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  const int64_t total = (int64_t)B * (1 + T * H * W + n_obj) * (C / 4);
-  hipLaunchKernelGGL(maxpool_bwd_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0,
+  const int64_t per = (int64_t)(1 + T * H * W + n_obj) * (C / 4);
+  if (per >= (1ll << 31) || B > 65535) return SVIT_ERR_SHAPE;
+  hipLaunchKernelGGL(maxpool_bwd_kernel<true>, dim3(grid_for(per, 256, 2048), B), dim3(256), 0,
                      (hipStream_t)stream, dy, idx, dx_bf16, B, T, H, W, Ho, Wo, n_obj, C);
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
