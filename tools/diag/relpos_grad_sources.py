@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Where the rel-pos table gradients lose their 0.5 % (cosine ~0.995 vs the fp32 oracle for EVERY table, every block, any batch:
+profiles/r05_relpos_cos.txt).  Block 0 of the smoke model: the inputs of the HIP attention backward are captured and the
+bias gradient d(relq) is recomputed from them in fp64.  Three table gradients against the oracle's:
+  (a) the HIP path's own;  (b) D (HIP, bf16) through an fp64 D^T q;  (c) fp64 attention backward of the SAME bf16 inputs.
+(c) ~ (a) means the loss is already in the inputs (bf16 q / k / v / dO of the block), not in the kernel's arithmetic.  GPU box."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import procedural as P
+from oracle import svit_ref as R
+from svit_amd import ops
+from tests import smoke_impl as S
+
+cap = []
+orig = ops.attn_bwd
+
+
+def spy(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0, bias_cols=0, reld=None):
+    out = orig(qa, ka, v, ctx, dctx, lse2, scale, q_splits=q_splits, bias_cols=bias_cols, reld=reld)
+    cap.append(dict(qa=qa.double().cpu(), ka=ka.double().cpu(), v=v.double().cpu(), ctx=ctx.double().cpu(),
+                    dctx=dctx.double().cpu(), J=bias_cols, cmap=reld[0].cpu(), ldd=reld[1], D=out[3].double().cpu()))
+    return out
+
+
+ops.attn_bwd = spy
+frames, crop, batch = 4, 64, 2
+cfg, model, spec, sd = S.build_hip_model(frames, crop)
+x, y = P.frames(batch, frames, crop), P.labels(batch)
+logits, _ = model([x.cuda()], {})
+model.zero_grad(set_to_none=True)
+torch.nn.functional.cross_entropy(logits, y.cuda()).backward()
+torch.cuda.synchronize()
+p = {k: t.clone().requires_grad_(True) for k, t in sd.items()}
+lg, ex = R.forward(p, spec, x, training=True)
+R.video_loss(lg, y).backward()
+c = cap[-1]                                    # block 0 is the last attention backward of the step
+qa, ka, v, dctx, D = c["qa"], c["ka"], c["v"], c["dctx"], c["D"]
+B, h, Nq, DA = qa.shape
+J = c["J"]
+S2 = qa @ ka.transpose(2, 3)                   # log2-domain logits incl. the bias columns
+Pm = torch.softmax(S2 * 0.6931471805599453, -1)
+dO = dctx.view(B, Nq, h, 96).permute(0, 2, 1, 3)
+O = Pm @ v
+dS = Pm * (dO @ v.transpose(2, 3) - (dO * O).sum(-1, keepdim=True))
+dbias = dS @ ka[..., 96:96 + J]                # one-hot key columns: group sums over the keys of a row / column / frame
+cmap = c["cmap"][:, :J].long()                 # [Nq, J] -> column of D (-1: none)
+Dref = torch.zeros(B * h * Nq, c["ldd"], dtype=torch.float64)
+rows = torch.arange(B * h * Nq).view(B * h, Nq)
+for j in range(J):
+    ok = cmap[:, j] >= 0
+    Dref[rows[:, ok].reshape(-1), cmap[ok, j].repeat(B * h)] += dbias[..., j].reshape(B * h, Nq)[:, ok].reshape(-1)
+q96 = qa[..., :96].reshape(B * h * Nq, 96)
+cos = lambda a, b: float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
+valid = Dref != 0
+print("D: HIP (bf16) vs fp64 recomputation from the same inputs: cosine %.6f over %d entries" % (cos(D[valid], Dref[valid]), int(valid.sum())))
+named = dict(model.named_parameters())
+offs = model.engine.flat.rel_slots["blocks.0."][2]
+for a, o in zip("hwt", offs):
+    name = "blocks.0.attn.rel_pos_" + a
+    ref = p[name].grad.double()
+    n = ref.shape[0]
+    g_hip = named[name].grad.detach().double().cpu()
+    g_b = D[:, o:o + n].t() @ q96
+    g_c = Dref[:, o:o + n].t() @ q96
+    print("%s: (a) HIP %.5f   (b) HIP D, fp64 D^T q %.5f   (c) fp64 backward of the HIP inputs %.5f   [(a) vs (c): %.5f]"
+          % (name, cos(g_hip, ref), cos(g_b, ref), cos(g_c, ref), cos(g_hip, g_c)))
+
+# ---- sensitivity: one more bf16 rounding's worth of noise (relative 2^-9, uniform in the rounding interval) on ONE input at a
+# time, everything else exact fp64: which input do the table gradients hang on?
+def table_grads(qa_, ka_, v_, dO_):
+    S2_ = qa_ @ ka_.transpose(2, 3)
+    P_ = torch.softmax(S2_ * 0.6931471805599453, -1)
+    O_ = P_ @ v_
+    dS_ = P_ * (dO_ @ v_.transpose(2, 3) - (dO_ * O_).sum(-1, keepdim=True))
+    db = dS_ @ ka_[..., 96:96 + J]
+    Dr = torch.zeros(B * h * Nq, c["ldd"], dtype=torch.float64)
+    for j in range(J):
+        ok = cmap[:, j] >= 0
+        Dr[rows[:, ok].reshape(-1), cmap[ok, j].repeat(B * h)] += db[..., j].reshape(B * h, Nq)[:, ok].reshape(-1)
+    return Dr.t() @ qa_[..., :96].reshape(B * h * Nq, 96), (dS_ @ ka_[..., :96]).reshape(-1)
+
+
+torch.manual_seed(0)
+noise = lambda t: t * (1.0 + (torch.rand_like(t) - 0.5) * 2.0 ** -8)
+base, dq_base = table_grads(qa, ka, v, dO)
+for nm, args in (("dO", (qa, ka, v, noise(dO))), ("q (96 cols)", (torch.cat([noise(qa[..., :96]), qa[..., 96:]], -1), ka, v, dO)),
+                 ("rel-pos bias cols of q", (torch.cat([qa[..., :96], noise(qa[..., 96:])], -1), ka, v, dO)),
+                 ("k", (qa, torch.cat([noise(ka[..., :96]), ka[..., 96:]], -1), v, dO)), ("v", (qa, ka, noise(v), dO))):
+    g, dq = table_grads(*args)
+    print("one bf16 rounding of %-24s -> table gradients cosine %.5f, dq cosine %.6f" % (nm, cos(g, base), cos(dq, dq_base)))
