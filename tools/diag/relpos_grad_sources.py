@@ -36,7 +36,10 @@ model.zero_grad(set_to_none=True)
 torch.nn.functional.cross_entropy(logits, y.cuda()).backward()
 torch.cuda.synchronize()
 p = {k: t.clone().requires_grad_(True) for k, t in sd.items()}
-lg, ex = R.forward(p, spec, x, training=True)
+taps = {}
+lg, ex = R.forward(p, spec, x, training=True, taps=taps)
+for nm in ("q", "k", "v", "ctx"):
+    taps["blocks.0.attn." + nm].retain_grad()
 R.video_loss(lg, y).backward()
 c = cap[-1]                                    # block 0 is the last attention backward of the step
 qa, ka, v, dctx, D = c["qa"], c["ka"], c["v"], c["dctx"], c["D"]
@@ -93,3 +96,33 @@ for nm, args in (("dO", (qa, ka, v, noise(dO))), ("q (96 cols)", (torch.cat([noi
                  ("k", (qa, torch.cat([noise(ka[..., :96]), ka[..., 96:]], -1), v, dO)), ("v", (qa, ka, noise(v), dO))):
     g, dq = table_grads(*args)
     print("one bf16 rounding of %-24s -> table gradients cosine %.5f, dq cosine %.6f" % (nm, cos(g, base), cos(dq, dq_base)))
+
+
+# ---- attribution: the same fp64 backward fed with the ORACLE's block-0 tensors (sanity: must reproduce the oracle's table
+# gradients), then with ONE of them swapped for the HIP path's bf16 tensor
+K_SCALE = 96 ** -0.5 * 1.4426950408889634
+oq, ok_, ov = (taps["blocks.0.attn." + n].detach().double() for n in ("q", "k", "v"))
+odO = taps["blocks.0.attn.ctx"].grad.double().view(B, Nq, h, 96).permute(0, 2, 1, 3)
+# oracle q / k in the kernel's operand convention: qa = [q | log2e * relq], ka = [k * scale * log2e | one-hot]
+Rcat = torch.zeros(c["ldd"], 96, dtype=torch.float64)
+for a_, o in zip("hwt", offs):
+    t_ = sd["blocks.0.attn.rel_pos_" + a_].double()
+    Rcat[o:o + t_.shape[0]] = t_
+relq = torch.zeros(B, h, Nq, DA - 96, dtype=torch.float64)
+P_all = oq @ Rcat.t()                                          # [B, h, Nq, ldd]
+for j in range(J):
+    okj = cmap[:, j] >= 0
+    relq[:, :, okj, j] = P_all[:, :, okj][..., torch.arange(int(okj.sum())), cmap[okj, j]] * 1.4426950408889634
+oqa = torch.cat([oq, relq], -1)
+oka = torch.cat([ok_ * K_SCALE, ka[..., 96:]], -1)
+print("HIP vs oracle block-0 tensors (cosine): q %.6f  k %.6f  v %.6f  dO %.6f  bias columns %.6f" %
+      (cos(qa[..., :96], oq), cos(ka[..., :96], ok_ * K_SCALE), cos(v, ov), cos(dO, odO), cos(qa[..., 96:96 + J], relq[..., :J])))
+ref_all = torch.cat([p["blocks.0.attn.rel_pos_" + a_].grad.double() for a_ in "hwt"])
+def tables(g_):
+    return torch.cat([g_[o:o + p["blocks.0.attn.rel_pos_" + a_].shape[0]] for a_, o in zip("hwt", offs)])
+g0, _ = table_grads(oqa, oka, ov, odO)
+print("fp64 backward of the ORACLE's tensors vs the oracle's table gradients: cosine %.6f (sanity)" % cos(tables(g0), ref_all))
+for nm, args in (("q (and its bias columns)", (qa, oka, ov, odO)), ("k", (oqa, ka, ov, odO)), ("v", (oqa, oka, v, odO)),
+                 ("dO", (oqa, oka, ov, dO)), ("all four", (qa, ka, v, dO))):
+    g, _ = table_grads(*args)
+    print("   HIP's %-26s -> %.5f" % (nm, cos(tables(g), ref_all)))
