@@ -189,17 +189,18 @@ int svit_pool_ln_fwd(const svit_pool_args* a, void* stream);
 
 /* backward, step 1: LayerNorm(96) backward per pooled token.
  * dout: up to three addends: d_main (bf16 or f32, row stride ld_main), d_res (bf16 ctx grad for
- * the residual-pooling path, rows [B, Nout, h*96], skipped for cls), d_extra (f32 [..,96]).
+ * the residual-pooling path, rows [B, Nout, h*96], skipped for cls), d_extra (f32, or bf16 with extra_is_bf16, [..,96]).
  * writes dpre bf16 [B,h,Nout,96]; dgamma/dbeta accumulated (two-stage via workspace). */
 typedef struct {
   const void* d_main; int32_t main_is_f32; int32_t ld_main;
-  const void* d_res; const float* d_extra;
+  const void* d_res; const void* d_extra;
   const void* pre; const float* mean; const float* rstd; const float* gamma;
   void* dpre; float* dgamma; float* dbeta;
   int32_t B, heads, Nout;
   float* workspace; int64_t workspace_floats;   /* scratch for the two-stage dgamma/dbeta sum */
   int32_t main_parts; int64_t main_part_stride; /* f32 d_main only: sum of main_parts planes, main_part_stride
                                                  * floats apart (svit_attn_bwd's dk / dv); 0 / 1 = one plane */
+  int32_t extra_is_bf16;                        /* d_extra holds bf16 (the rel-pos D . R^T GEMM's bf16 epilogue: half the bytes) */
 } svit_pool_ln_bwd_args;
 int svit_pool_ln_bwd(const svit_pool_ln_bwd_args* a, void* stream);
 /* backward, step 2: depthwise-conv dgrad (gather form) + cls/object rows ->

@@ -573,8 +573,17 @@ __device__ __forceinline__ void pool_ln_bwd_body(const svit_pool_ln_bwd_args& a,
           for (int e = 0; e < 8; ++e) d[v * 8 + e] += f[e];
         }
       }
-      if (a.d_extra) {
-        const float* p = a.d_extra + row * HD + c0;
+      if (a.d_extra && a.extra_is_bf16) {
+        const bf16_t* p = (const bf16_t*)a.d_extra + row * HD + c0;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+          float f[8];
+          unpack8(*(const uint4*)(p + v * GS), f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d[v * 8 + e] += f[e];
+        }
+      } else if (a.d_extra) {
+        const float* p = (const float*)a.d_extra + row * HD + c0;
 #pragma unroll
         for (int v = 0; v < 6; ++v) {
           const float4 f = *(const float4*)(p + (v >> 1) * GS + (v & 1) * 4);

@@ -221,7 +221,7 @@ class Engine:
         self._side_keep = []
         self._side_active = False
         # weight-gradient GEMMs on a side stream beside the dgrad chain: off (round-1 measurement: the TN GEMM beside
-        # the chain cost more than it hid); SVIT_OVERLAP_WGRAD=1 is the A/B knob for re-measuring it
+        # the chain cost more than it hid); tools set `engine.overlap_wgrad = True` to re-measure it
         self.overlap_wgrad = False
         self.attn_q_splits = 0      # 0 = heuristic; 1 = no query split in the dk/dv kernel
         # regression-diff mode: every reduction that normally meets in fp32 atomics (attention
@@ -547,7 +547,7 @@ class Engine:
                 qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE,
                 q_splits=1 if self.deterministic else self.attn_q_splits, bias_cols=sum(sv["k_thw"]),
                 reld=(dmap, lpad, LOG2E, rcat_t if rcat_t.is_contiguous() else None, "fold"))
-        else:   # (A/B knob for measurements: SVIT_FUSED_SCATTER=0)
+        else:   # (measurements only: engine.fused_scatter = False)
             dqa, dk, dv = ops.attn_bwd(qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE,
                                        q_splits=1 if self.deterministic else self.attn_q_splits,
                                        bias_cols=sum(sv["k_thw"]))
@@ -563,7 +563,9 @@ class Engine:
                 ops.gemm_tn(D[:, o:o + rows], qa2[:, :HD], d, splits=1 if self.deterministic else 0)
                 f.g(n).add_(m.t() @ d)
         if dq_extra is None:      # wide tables (56x56 / 28x28 stages) or the A/B path: dq = D R as its own GEMM
-            dq_extra = ops.gemm_nt(D, rcat_t, None, hip.EPI_F32)
+            # (bf16 epilogue since round 5: the pooled-LN backward adds it to two other bf16 addends -- dq of the attention
+            #  kernel, the residual-pooling dctx -- and reads half the bytes: 77 MB less each way at block 0)
+            dq_extra = ops.gemm_nt(D, rcat_t, None, hip.EPI_BF16)
         elif isinstance(dq_extra, str):     # "folded": dqa[..., :96] already holds it (narrow tables)
             dq_extra = None
         Nk = ka.shape[2]

@@ -47,7 +47,7 @@ class PoolLnBwdArgs(C.Structure):
                 ("d_extra", vp), ("pre", vp), ("mean", vp), ("rstd", vp), ("gamma", vp),
                 ("dpre", vp), ("dgamma", vp), ("dbeta", vp), ("B", i32), ("heads", i32),
                 ("Nout", i32), ("workspace", vp), ("workspace_floats", i64), ("main_parts", i32),
-                ("main_part_stride", i64)]
+                ("main_part_stride", i64), ("extra_is_bf16", i32)]
 
 
 class PoolDgradArgs(C.Structure):

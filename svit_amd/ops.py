@@ -350,6 +350,7 @@ def _pool_ln_bwd_args(a, pre, mean, rstd, gamma, dgamma, dbeta, B, heads, Nout, 
         assert d_main.dtype == F32
         a.main_parts, a.main_part_stride = d_main.shape[0], d_main.stride(0)
     a.d_res, a.d_extra = ptr(d_res), ptr(d_extra)
+    a.extra_is_bf16 = int(d_extra is not None and d_extra.dtype == BF16)
     a.pre, a.mean, a.rstd, a.gamma = ptr(pre), ptr(mean), ptr(rstd), ptr(gamma)
     a.dpre, a.dgamma, a.dbeta = ptr(dpre), ptr(dgamma), ptr(dbeta)
     a.B, a.heads, a.Nout = B, heads, Nout

@@ -1,4 +1,7 @@
 #!/usr/bin/env python3
+# NOTE (round 5): svit_attn_debug_set(2, m) -- "run only one of the two backward kernels" -- left the product library (it leaves outputs
+# unwritten).  Build the two timing variants instead:  python tools/diag/build_variant.py dqonly attn_bwd.hip -DSVIT_DIAG_BWD_ONLY=1  (and =2 for dkv only)
+# and run this script with SVIT_HIP_LIB pointing at them; the calls below then return SVIT_ERR_ARG and change nothing.
 """Upper bound for running the dq and the dkv kernel of an attention backward side by side (today: two dependent launches,
 the dq kernel writes the delta rows the dkv kernel reads): 20 dq launches on one stream beside 20 dkv launches on another
 against the serial pair, per block shape.  (Timing only: the dkv launches read the delta rows of an earlier iteration.)

@@ -1,4 +1,7 @@
 #!/usr/bin/env python3
+# NOTE (round 5): svit_attn_debug_set(2, m) -- "run only one of the two backward kernels" -- left the product library (it leaves outputs
+# unwritten).  Build the two timing variants instead:  python tools/diag/build_variant.py dqonly attn_bwd.hip -DSVIT_DIAG_BWD_ONLY=1  (and =2 for dkv only)
+# and run this script with SVIT_HIP_LIB pointing at them; the calls below then return SVIT_ERR_ARG and change nothing.
 """What the rel-pos fold (svit_attn_bwd_args.relD / relR: scatter matrix D, D . R^T on the matrix pipe, added into dq) costs the
 dq kernel at the 14x14-stage shape, dq kernel alone (svit_attn_debug_set(2, 2)) and the whole backward.  GPU box."""
 import ctypes as C, os, sys

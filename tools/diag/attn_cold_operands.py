@@ -1,4 +1,7 @@
 #!/usr/bin/env python3
+# NOTE (round 5): svit_attn_debug_set(2, m) -- "run only one of the two backward kernels" -- left the product library (it leaves outputs
+# unwritten).  Build the two timing variants instead:  python tools/diag/build_variant.py dqonly attn_bwd.hip -DSVIT_DIAG_BWD_ONLY=1  (and =2 for dkv only)
+# and run this script with SVIT_HIP_LIB pointing at them; the calls below then return SVIT_ERR_ARG and change nothing.
 """Attention kernels at the 14x14-stage shape with COLD operands (the caches are swept between launches, as inside the
 training step where the saved activations come from HBM) against warm ones (isolated loop) and against cold ones that a
 read-only touch kernel pulled into the Infinity Cache just before.  GPU box: python tools/diag/attn_cold_operands.py"""
