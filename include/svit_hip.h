@@ -449,7 +449,8 @@ int svit_debug_set_tn_tile(int mode);
 /* pooling (csrc/pool.hip): key 0 = forward path of the small planes: 0 streaming kernels, 1 VALU slab conv, 2 (default)
  * MFMA conv where it is ahead (blocks 4-13 of 16x224^2) and the slab elsewhere, 3 MFMA conv wherever its geometry holds;
  * key 1 = backward path of the small planes: 1 (default) the fused plane-walk kernel (LayerNorm backward + conv dgrad +
- * conv wgrad in one launch) where it fits, 0 the three streaming launches. */
+ * conv wgrad in one launch) where it fits, 0 the three streaming launches; key 2 = forward of the planes past 14x14
+ * (blocks 0-3): 1 (default) the staged conv (input staged once in LDS) + the row-wise LayerNorm launch, 0 the streaming kernel. */
 int svit_debug_set_pool(int key, int val);
 /* attention: key 0 = dkv kernel form (0 heuristic, 1 four waves, 2 eight waves with query halves), key 1 = backward
  * launch form (0 heuristic, 1 two launches: dq then dkv, 2 one launch with both kinds of workgroup), key 3 = the

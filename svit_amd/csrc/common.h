@@ -49,6 +49,7 @@ enum SvitKnob {
   SVIT_K_TN_TILE,           // grouped TN tile mode: 0 128x96 only, 1 isolated-launch heuristic, 2 128x192 everywhere, 3 128x192 where K % 192 == 0
   SVIT_K_POOL_FWD,          // small-plane pooling forward: 0 streaming, 1 VALU slab conv, 2 MFMA conv where ahead (default), 3 MFMA conv wherever it fits
   SVIT_K_POOL_BWD,          // small-plane pooling backward: 0 the three streaming launches, 1 (default) the fused plane-walk kernel where it fits
+  SVIT_K_POOL_FWD_LARGE,    // large-plane pooling forward (blocks 0-3): 1 (default) staged conv + row-wise LayerNorm launch, 0 the streaming kernel
   SVIT_K_ATTN_DKV_FORM,     // attention dkv kernel: 0 heuristic, 1 four waves, 2 eight waves with query halves
   SVIT_K_ATTN_FWD_SHORT,    // attention forward T' = 1 tile for Nk <= 64: 1 on (default), 0 generic kernel
   SVIT_K_ATTN_BWD_FORM,     // attention backward: 0 heuristic, 1 two launches (dq, dkv), 2 one launch with both roles

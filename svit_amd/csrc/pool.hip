@@ -1379,6 +1379,145 @@ __global__ __launch_bounds__(PF_NT, 2) void pool_bwd_fused_kernel(PoolBwdFused g
 }
 
 // ---------------------------------------------------------------------------------------
+// Staged conv FORWARD of the large planes (round 5): the depthwise 3x3x3 conv of q, k, v of a block
+// in one launch with the INPUT staged once in LDS -- the mirror image of pool_bwd_fused_kernel -- for the blocks whose
+// planes are too large for the slab / MFMA stencils (blocks 0-3 of 16x224^2), where the streaming kernel pulls every tap
+// through L2 (FETCH 2.6x its operands; 116 / 105 us at the stride-2 blocks 1 / 3).  LayerNorm stays pool_slab_ln_kernel
+// (a second, row-wise launch over `pre`: a 32-channel workgroup cannot normalise 96 channels).
+//   * workgroup = (batch*head, tensor, 32-channel group, t-chunk, y-chunk of OUTPUT rows): 64-byte segments of qkv in,
+//     64-byte segments of `pre` out -- whole cache lines, nothing shared between workgroups;
+//   * the image holds exactly the cells the chunk's windows touch: stride 1 / 2: input rows s*yo0-1 .. s*(yo1-1)+1, every
+//     x (pitch W + 1: the left halo column doubles as the previous row's right halo); stride >= 3 (windows do not overlap):
+//     only the 3 rows / 3 columns of each window, packed (3 R rows x 3 Wo cells).  Either way the 27 taps of output (yo, xo)
+//     are the 3 x 3 cells from base (SE (yo - yo0), SE xo), SE = 1 / 2 / 3, in the slots of planes t-1, t, t+1: ONE code path
+//     for every stride, unconditional reads (out-of-volume cells are staged as zeros through the buffer descriptor's end);
+//   * thread = (channel pair, unit slot): 27 ds_read_b32 feed 54 v_dot2 (selector weights in registers), one 4-byte store.
+#ifndef SVIT_PS_NT
+#define SVIT_PS_NT 512
+#endif
+constexpr int PS_NT = SVIT_PS_NT, PS_SLOTS = PS_NT / 16;
+struct PoolFwdStaged {
+  svit_pool_args p[3];
+  int n_per[3], t_chunks[3], r_per[3], y_chunks[3];
+  int order[3], first_item[4];
+};
+__host__ __device__ inline int ps_plane_bytes(int se, int R, int W, int Wo) {
+  return se < 3 ? ((se * (R - 1) + 3) * (W + 1) + 1) * PF_ROWB : (3 * R) * (3 * Wo) * PF_ROWB;
+}
+
+template <int SE>
+__device__ __forceinline__ void pool_fwd_staged_body(const PoolFwdStaged& g, int which, int bh, int group, int tchunk,
+                                                     int ychunk, unsigned char* smem) {
+  const svit_pool_args& a = g.p[which];
+  const int tid = threadIdx.x, cp = tid & 15, ts = tid >> 4, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = group * 32 + 2 * cp;
+  const int s = a.stride_hw, T = a.T, H = a.H, W = a.W;
+  const int Ho = pooled(H, s), Wo = pooled(W, s);
+  const int L = T * H * W, Lo = T * Ho * Wo;
+  const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
+  const int b = bh / a.heads, head = bh % a.heads;
+  const int t0 = tchunk * g.n_per[which], t1 = min(T, t0 + g.n_per[which]), np = t1 - t0;
+  const int yo0 = ychunk * g.r_per[which], yo1 = min(Ho, yo0 + g.r_per[which]), Rc = yo1 - yo0;
+  const int P = SE < 3 ? W + 1 : 3 * Wo, RR = SE < 3 ? SE * (Rc - 1) + 3 : 3 * Rc;
+  const int cells = RR * P + (SE < 3 ? 1 : 0), plane_b = cells * PF_ROWB, rowb = P * PF_ROWB;
+  const size_t tok_stride = (size_t)3 * a.heads * HD;
+  const unsigned stride_b = (unsigned)(tok_stride * 2);
+  const size_t span = (size_t)N * tok_stride * 2;
+  const unsigned grp_b = (unsigned)((((size_t)a.which * a.heads + head) * HD + group * 32) * 2);
+  const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.qkv + (size_t)b * span), 0, (int)span, 0x00020000);
+  // ---- stage input planes t0-1 .. t1 (slot sl = plane t0 - 1 + sl): 1-KiB LDS-DMA pieces, every piece of a wave in flight
+  {
+    const unsigned mP = fdiv_magic_dev(P), mC = fdiv_magic_dev(cells);
+    const int pieces = ((np + 2) * plane_b + 1023) >> 10;
+    for (int q = wave; q < pieces; q += PS_NT / 64) {
+      const int o = q * 1024 + lane * 16;
+      const int cell = o >> 6, part = (o >> 4) & 3;
+      const int sl = fdiv(cell, mC), cr = cell - sl * cells;
+      const int iy = fdiv(cr, mP), ix = cr - iy * P;
+      int y, x;
+      if (SE < 3) { y = s * yo0 - 1 + iy; x = ix - 1; }
+      else { const int wy = fdiv(iy, 0x55555556u), wx = fdiv(ix, 0x55555556u); y = s * (yo0 + wy) - 1 + (iy - 3 * wy); x = s * wx - 1 + (ix - 3 * wx); }
+      const int t = t0 - 1 + sl;
+      const bool ok = sl < np + 2 && iy < RR && t >= 0 && t < T && y >= 0 && y < H && x >= 0 && x < W;
+      const unsigned voff = ok ? (unsigned)(1 + (t * H + y) * W + x) * stride_b + grp_b + part * 16 : 0x7ffffff0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(smem + q * 1024), 16, voff, 0, 0, 0);
+    }
+  }
+  // ---- weights: bf16-rounded selectors (like every stencil of this file); object gains from the fp32 values
+  uint32_t w0[27], w1[27];
+  float nt[3], nh[3], ipt, iph;
+  obj_counts(1, nt, &ipt);
+  obj_counts(s, nh, &iph);
+  const float onorm = ipt * iph * iph;
+  float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const float f0 = a.conv_w[(size_t)c * 27 + k], f1 = a.conv_w[(size_t)(c + 1) * 27 + k];
+    const float coef = nt[k / 9] * nh[(k / 3) % 3] * nh[k % 3] * onorm;
+    g0 += f0 * coef; g1 += f1 * coef;
+    w0[k] = (uint32_t)f32_to_bf16(f0);
+    w1[k] = (uint32_t)f32_to_bf16(f1) << 16;
+  }
+  bf16_t* preb = (bf16_t*)a.pre + (size_t)bh * Nout * HD;
+  const auto prs = __builtin_amdgcn_make_buffer_rsrc((void*)preb, 0, (int)((size_t)Nout * HD * 2), 0x00020000);
+  // cls / object rows ride on chunk 0: pre[cls] = x[cls], pre[obj] = x[obj] * g(w)  (requested before the wait)
+  if (tchunk == 0 && ychunk == 0) {
+    for (int i = ts; i <= a.n_obj; i += PS_SLOTS) {
+      const int tin = i == 0 ? 0 : L + i, tout = i == 0 ? 0 : Lo + i;
+      const uint32_t xv = __builtin_amdgcn_raw_buffer_load_b32(xrs, (unsigned)tin * stride_b + grp_b + cp * 4, 0, 0);
+      float x0 = lo_bf16(xv), x1 = hi_bf16(xv);
+      if (i > 0) { x0 *= g0; x1 *= g1; }
+      __builtin_amdgcn_raw_buffer_store_b32(pack_bf16x2(x0, x1), prs, (unsigned)(tout * HD + c) * 2, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // ---- the walk over output tokens: unit f = slot + 16 i
+  const int U = Rc * Wo, total = np * U;
+  const unsigned mU = fdiv_magic_dev(U), mW = fdiv_magic_dev(Wo);
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  for (int f = ts; f < total; f += PS_SLOTS) {
+    const int pl = fdiv(f, mU), u = f - pl * U;
+    const int r = fdiv(u, mW), xo = u - r * Wo;
+    const unsigned lb = lds0 + (unsigned)(pl * plane_b + (SE * r) * rowb + (SE * xo) * PF_ROWB + cp * 4);
+    uint32_t v[27];
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+          v[(kt * 3 + ky) * 3 + kx] = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(
+              lb + kt * plane_b + ky * rowb + kx * PF_ROWB);
+    __builtin_amdgcn_sched_barrier(0);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      a0 = dot2_sel(v[k], w0[k], a0);
+      a1 = dot2_sel(v[k], w1[k], a1);
+    }
+    const int tok = 1 + ((t0 + pl) * Ho + yo0 + r) * Wo + xo;
+    __builtin_amdgcn_raw_buffer_store_b32(pack_bf16x2(a0, a1), prs, (unsigned)(tok * HD + c) * 2, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(PS_NT, PS_NT == 256 ? 3 : PS_NT == 512 ? 4 : 2) void pool_fwd_staged_kernel(PoolFwdStaged g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_ps[];
+  const int item = blockIdx.x;
+  const int j = (item >= g.first_item[1]) + (item >= g.first_item[2]);
+  const int which = g.order[j];
+  const int local = item - g.first_item[j];
+  const int BH = g.p[0].B * g.p[0].heads;
+  const int bh = local % BH, rest = local / BH, group = rest % 3, ch = rest / 3;
+  const int ychunk = ch % g.y_chunks[which], tchunk = ch / g.y_chunks[which];
+  const int s = g.p[which].stride_hw;
+  if (s == 1) pool_fwd_staged_body<1>(g, which, bh, group, tchunk, ychunk, smem_ps);
+  else if (s == 2) pool_fwd_staged_body<2>(g, which, bh, group, tchunk, ychunk, smem_ps);
+  else pool_fwd_staged_body<3>(g, which, bh, group, tchunk, ychunk, smem_ps);
+}
+
+// ---------------------------------------------------------------------------------------
 // query side of the decomposed relative-position bias
 __global__ __launch_bounds__(256) void relq_fwd_kernel(svit_relq_args a) {
   const int extra = a.ld - HD;               // 32 or 64 columns
@@ -2175,6 +2314,116 @@ static SlabPlan plan_slab(const svit_pool_args& a) {
   return pl;
 }
 
+// (chunking of one tensor; memo key of a plan: batch*heads, T, H, W, the three strides, kind)
+struct PfTensorPlan { int n, r; };
+struct PfPlanKey { int v[8]; bool operator==(const PfPlanKey& o) const { for (int i = 0; i < 8; ++i) if (v[i] != o.v[i]) return false; return true; } };
+// Planner of the staged conv forward (pool_fwd_staged_kernel): output planes (n) and output rows (R) per chunk and tensor so
+// that (n + 2) planes of the R-row image fit LDS at three workgroups per CU and the items fill the chip about evenly.
+// Item time: staging 3 us + 0.08 us per 1-KiB piece and wave, 0.27 us per 16-output step (27 reads + 54 dot2), ~1 us of tail.
+// Memoised per geometry like the backward's plan.  false: some tensor's smallest image does not fit.
+struct PsPlanEntry { PfPlanKey key; bool ok; PoolFwdStaged plan; size_t lds; };
+static std::mutex g_ps_plan_mu;
+static std::vector<PsPlanEntry> g_ps_plans;
+#ifndef SVIT_PS_LDS_KB      // LDS budget of a staged-forward workgroup / resident workgroups the planner counts on.  Swept in
+#define SVIT_PS_LDS_KB 79   // diagnostic builds (profiles/r05_pool_fwd_staged.txt): 256 threads x 52 KB x 3 per CU 255 us over blocks 0-3,
+#define SVIT_PS_SLOTS 512   // 256 x 79 KB x 2: 238, 512 x 79 KB x 2: 232 (default), 1024 x 156 KB x 1: 287
+#endif
+static bool plan_fwd_staged(const svit_pool_args* a3, PoolFwdStaged* g, size_t* lds_out) {
+  constexpr size_t LDS_MAX = SVIT_PS_LDS_KB * 1024;
+  constexpr double SLOTS = SVIT_PS_SLOTS;
+  const int T = a3[0].T, BH = a3[0].B * a3[0].heads;
+  const PfPlanKey key = {{BH, T, a3[0].H, a3[0].W, a3[0].stride_hw, a3[1].stride_hw, a3[2].stride_hw, 1}};
+  {
+    std::lock_guard<std::mutex> lk(g_ps_plan_mu);
+    for (const auto& e : g_ps_plans)
+      if (e.key == key) { *g = e.plan; *lds_out = e.lds; return e.ok; }
+  }
+  int se[3], Ho[3], Wo[3];
+  for (int i = 0; i < 3; ++i) {
+    const int s = a3[i].stride_hw;
+    se[i] = s >= 3 ? 3 : s;
+    Ho[i] = (a3[i].H - 1) / s + 1;
+    Wo[i] = (a3[i].W - 1) / s + 1;
+  }
+  auto lds_of = [&](int i, int n, int r) { return ((size_t)(n + 2) * ps_plane_bytes(se[i], r, a3[i].W, Wo[i]) + 1023) / 1024 * 1024; };
+  auto item_us = [&](int i, int n, int r) {
+    return 3.0 + 0.08 * (double)(lds_of(i, n, r) / 1024) / 4.0 + std::ceil((double)n * r * Wo[i] / PS_SLOTS) * 0.27 + 1.0;
+  };
+  auto candidates = [&](int i, std::vector<PfTensorPlan>* out) {
+    for (int n = 1; n <= T; ++n) {
+      int last_r = -1;
+      for (int k = 1; k <= Ho[i]; ++k) {
+        const int r = (Ho[i] + k - 1) / k;
+        if (r == last_r) continue;
+        last_r = r;
+        if (lds_of(i, n, r) <= LDS_MAX) out->push_back({n, r});
+      }
+    }
+  };
+  PsPlanEntry e;
+  e.key = key;
+  e.lds = 0;
+  e.ok = false;
+  std::vector<PfTensorPlan> cq, c1, c2, ckv;
+  candidates(0, &cq);
+  candidates(1, &c1);
+  candidates(2, &c2);
+  for (const auto& x : c1)
+    for (const auto& y : c2)
+      if (x.n == y.n && x.r == y.r) ckv.push_back(x);
+  if (se[1] != se[2] || Ho[1] != Ho[2]) ckv = c1.size() < c2.size() ? c1 : c2;
+  if (!cq.empty() && !ckv.empty()) {
+    double best = 1e300;
+    PfTensorPlan bq = cq[0], bkv = ckv[0];
+    for (const auto& pq : cq)
+      for (const auto& pkv : ckv) {
+        const PfTensorPlan pl[3] = {pq, pkv, pkv};
+        double items = 0, sum = 0, longest = 0;
+        bool fits = true;
+        for (int i = 0; i < 3; ++i) {
+          if (lds_of(i, pl[i].n, pl[i].r) > LDS_MAX) { fits = false; break; }
+          const int tc = (T + pl[i].n - 1) / pl[i].n, yc = (Ho[i] + pl[i].r - 1) / pl[i].r;
+          items += 3.0 * BH * tc * yc;
+          sum += 3.0 * BH * tc * yc * item_us(i, pl[i].n, pl[i].r);
+          longest = std::max(longest, item_us(i, pl[i].n, pl[i].r));
+        }
+        if (!fits) continue;
+        const double est = items <= SLOTS ? std::max(longest, sum / SLOTS) : sum / SLOTS + 0.5 * longest;
+        if (est < best) { best = est; bq = pq; bkv = pkv; }
+      }
+    if (best < 1e300) {
+      const PfTensorPlan pl[3] = {bq, bkv, bkv};
+      double len[3];
+      size_t lds = 0;
+      for (int i = 0; i < 3; ++i) {
+        e.plan.n_per[i] = pl[i].n;
+        e.plan.r_per[i] = pl[i].r;
+        e.plan.t_chunks[i] = (T + pl[i].n - 1) / pl[i].n;
+        e.plan.y_chunks[i] = (Ho[i] + pl[i].r - 1) / pl[i].r;
+        lds = std::max(lds, lds_of(i, pl[i].n, pl[i].r));
+        len[i] = item_us(i, pl[i].n, pl[i].r);
+      }
+      int ord[3] = {0, 1, 2};
+      std::sort(ord, ord + 3, [&](int x, int y) { return len[x] > len[y] || (len[x] == len[y] && x < y); });
+      int first = 0;
+      for (int j = 0; j < 3; ++j) {
+        e.plan.order[j] = ord[j];
+        e.plan.first_item[j] = first;
+        first += 3 * BH * e.plan.t_chunks[ord[j]] * e.plan.y_chunks[ord[j]];
+      }
+      e.plan.first_item[3] = first;
+      e.lds = lds;
+      e.ok = true;
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_ps_plan_mu);
+    if (g_ps_plans.size() < 256) g_ps_plans.push_back(e);
+  }
+  *g = e.plan; *lds_out = e.lds;
+  return e.ok;
+}
+
 static int pool_ln_fwd_qkv_kernels(const svit_pool_args* a3, const uint32_t* const* sel3, void* stream, int* q_on_slab);
 
 // rel-pos columns of the q tensor (svit_pool_args.relq_*): the slab LayerNorm kernel writes them itself; on any
@@ -2274,6 +2523,34 @@ static int pool_ln_fwd_qkv_kernels(const svit_pool_args* a3, const uint32_t* con
                        (hipStream_t)stream, sg);
     SVIT_LAUNCH_CHECK();
     if (n_slab == 3) return SVIT_OK;
+  }
+  // round 5: no tensor took the slab path (planes past 14x14: blocks 0-3) and every tensor saves `pre` (a training step):
+  // the staged conv forward (input staged once in LDS, every stride) + the row-wise LayerNorm launch of the slab path;
+  // svit_debug_set_pool(2, 0) keeps the streaming kernel below (A/B)
+  if (n_slab == 0 && a3[0].H * a3[0].W > 196 && svit_knob(SVIT_K_POOL_FWD_LARGE) != 0 && a3[0].pre && a3[1].pre && a3[2].pre &&
+      a3[1].T == a3[0].T && a3[2].T == a3[0].T && a3[1].H == a3[0].H && a3[2].H == a3[0].H && a3[1].W == a3[0].W &&
+      a3[2].W == a3[0].W && a3[1].n_obj == a3[0].n_obj && a3[2].n_obj == a3[0].n_obj) {
+    PoolFwdStaged fg;
+    size_t flds = 0;
+    if (plan_fwd_staged(a3, &fg, &flds)) {
+      for (int i = 0; i < 3; ++i) fg.p[i] = a3[i];
+      static SvitOnce once_ps;
+      if (int rc = svit_max_lds_once(once_ps, (const void*)pool_fwd_staged_kernel, SVIT_PS_LDS_KB * 1024)) return rc;
+      hipLaunchKernelGGL(pool_fwd_staged_kernel, dim3((unsigned)fg.first_item[3]), dim3(PS_NT), flds, (hipStream_t)stream, fg);
+      SVIT_LAUNCH_CHECK();
+      int blocks = 1;
+      for (int i = 0; i < 3; ++i) {
+        const int s = a3[i].stride_hw;
+        const int nout = 1 + a3[i].T * ((a3[i].H - 1) / s + 1) * ((a3[i].W - 1) / s + 1) + a3[i].n_obj;
+        blocks = std::max(blocks, (int)persistent_x((nout + 63) / 64, a3[0].B * a3[0].heads * 3, 2048));
+        sg.plan[i].on = 1;
+      }
+      *q_on_slab = sg.p[0].relq_R != nullptr;       // (already cleared above when the product tile does not fit)
+      const size_t ln_lds = sg.p[0].relq_R ? (size_t)64 * SLN_QROW + (size_t)64 * a3[0].relq_lpad * 2 : 0;
+      hipLaunchKernelGGL(pool_slab_ln_kernel, dim3(blocks, a3[0].B * a3[0].heads, 3), dim3(256), ln_lds, (hipStream_t)stream, sg);
+      SVIT_LAUNCH_CHECK();
+      return SVIT_OK;
+    }
   }
   for (int i = 0; i < 3; ++i) {
     g.p[i] = a3[i];
@@ -2424,7 +2701,6 @@ extern "C" int svit_pool_conv_wgrad_qkv(const svit_pool_wgrad_args* a3, void* st
 // (stride 2: four tokens -- four loads and four stores -- per unit) or ~2 us (stride >= 3: nine), 2.5 us of tail (+ 1.5 us for
 // the cls / object rows of chunk 0).  Estimate of the launch = the longest item if everything is resident at once, else the
 // average load of a slot plus half an item.  Returns false where not even one unit row of three planes fits.
-struct PfTensorPlan { int n, r; };
 static bool plan_bwd_fused(const svit_pool_dgrad_args* d3, PoolBwdFused* g, size_t* lds_out) {
   constexpr size_t LDS_MAX = 79 * 1024;       // two workgroups per CU (the image is staged in whole 1-KiB pieces)
   constexpr double SLOTS = 512.0;
@@ -2522,7 +2798,6 @@ static bool plan_bwd_fused(const svit_pool_dgrad_args* d3, PoolBwdFused* g, size
 
 // The search above costs ~1 ms of host time: its result is a pure function of the geometry, so it is memoised (a training
 // step has at most 16 distinct geometries; the table is append-only, mutex-guarded, and holds no device state).
-struct PfPlanKey { int v[8]; bool operator==(const PfPlanKey& o) const { for (int i = 0; i < 8; ++i) if (v[i] != o.v[i]) return false; return true; } };
 struct PfPlanEntry { PfPlanKey key; bool ok; PoolBwdFused plan; size_t lds; };
 static std::mutex g_pf_plan_mu;
 static std::vector<PfPlanEntry> g_pf_plans;

@@ -585,7 +585,8 @@ def test_pool_ln_bwd_three_inputs(ops):
 @pytest.mark.parametrize("B,h,thw,sq,skv,n_obj,slab", [
     (2, 4, (8, 14, 14), 1, 2, 64, True),       # blocks 4-13: the slab LayerNorm kernel multiplies q . R^T itself
     (2, 8, (8, 14, 14), 2, 1, 64, True),       # block 14 (q pooled to 7x7, 36 key coordinates: DA = 160)
-    (1, 4, (8, 28, 28), 2, 2, 64, False),      # 28x28: not a slab plane -> the entry point adds the GEMM launch
+    (1, 4, (8, 28, 28), 2, 2, 64, False),      # 28x28: not a slab plane -> staged conv + the same LayerNorm kernel (round 5)
+    (1, 1, (2, 56, 56), 1, 8, 8, False),       # block 0: 240 table rows (Lpad 288), the widest product tile the kernel takes
     (2, 4, (8, 14, 14), 1, 2, 64, None),       # no selector tables at all (streaming kernels) -> GEMM launch
 ])
 def test_pool_qkv_writes_the_relpos_columns(ops, B, h, thw, sq, skv, n_obj, slab):
@@ -906,6 +907,64 @@ def test_pool_slab_forward_vs_conv3d(ops, B, h, thw, sq, skv, n_obj):
         pm, ps = res[2][which][1].float(), res[1][which][1].float()
         assert rel_err(pm, ps) < 8e-3
         assert float(((pm - ps).abs() > 0.02 * ps.abs().max()).float().mean()) == 0.0
+
+
+@pytest.mark.parametrize("B,h,thw,sq,skv,n_obj", [
+    (1, 1, (2, 56, 56), 1, 8, 8),       # block 0 (two of its planes): 56x56 cut in y, stride-8 windows packed
+    (1, 2, (3, 56, 56), 2, 4, 12),      # block 1
+    (2, 2, (3, 28, 28), 1, 4, 12),      # block 2
+    (1, 4, (4, 28, 28), 2, 2, 16),      # block 3
+    (2, 1, (1, 56, 56), 1, 8, 4),       # image rank, block 0 (T' = 1)
+    (1, 2, (2, 19, 26), 1, 3, 8),       # odd plane, stride 3
+    (1, 2, (2, 23, 17), 2, 2, 8),       # odd plane, stride 2
+])
+def test_pool_forward_staged_large_planes(ops, B, h, thw, sq, skv, n_obj):
+    """Round 5: the staged conv forward of the planes past 14x14 (csrc/pool.hip::pool_fwd_staged_kernel + the row-wise
+    LayerNorm launch) against torch's depthwise conv3d on the same bf16 operands, the closed form of the object / cls rows,
+    and the streaming kernel of the same library (svit_debug_set_pool(2, 0)) incl. the rel-pos columns of q."""
+    import ctypes as C
+    from svit_amd import hip
+    lib = hip.load()
+    T, H, W = thw
+    L = T * H * W
+    N = 1 + L + n_obj
+    qkv = rnd("fs%d%d%d%d" % (T, H, W, h), (B, N, 3, h, 96), 0.5, BF16)
+    ws = [rnd("fw%d%d" % (i, H), (96, 27), 0.2) for i in range(3)]
+    g = [rnd("fg%d" % i, (96,), 0.3) + 1.0 for i in range(3)]
+    b = [rnd("fb%d" % i, (96,), 0.1) for i in range(3)]
+    J = ops.pooled(H, skv) + ops.pooled(W, skv) + T
+    da = 128 if J <= 32 else 160
+    if J > 64:
+        pytest.skip("key grid too large for the in-MFMA rel-pos columns")
+    res = []
+    try:
+        for on in (0, 1):
+            assert lib.svit_debug_set_pool(2, on) == 0
+            r = ops.pool_ln_fwd_qkv(qkv, ws, g, b, B, h, thw, n_obj, (sq, skv, skv), (da, da, 96), (0, 1, 0),
+                                    out_scales=(1.0, KSC, 1.0))
+            torch.cuda.synchronize()
+            res.append(r)
+    finally:
+        lib.svit_debug_reset()
+    for which, s in ((0, sq), (1, skv), (2, skv)):
+        x = qkv[:, 1:1 + L, which].float()
+        vol = x.reshape(B, T, H, W, h, 96).permute(0, 4, 5, 1, 2, 3).reshape(B * h, 96, T, H, W)
+        w = ws[which].to(BF16).float().reshape(96, 1, 3, 3, 3)
+        ref = F.conv3d(vol, w, None, stride=(1, s, s), padding=1, groups=96)
+        Lo = ref.shape[2] * ref.shape[3] * ref.shape[4]
+        ref = ref.reshape(B, h, 96, -1).transpose(2, 3)
+        gain = R.object_gain(ws[which].to(BF16).float().cpu().reshape(96, 1, 3, 3, 3), (1, s, s))
+        obj = qkv[:, 1 + L:, which].float().cpu().permute(0, 2, 1, 3) * gain
+        so, sp, sm, sr = res[0][which]
+        out, pre, mean, rstd = res[1][which]
+        assert rel_err(pre[:, :, 1:1 + Lo], ref) < 1e-2          # bf16 rounding of the stored value
+        assert rel_err(pre[:, :, 1 + Lo:], obj) < 2e-2
+        assert torch.equal(pre[:, :, 0].cpu(), qkv[:, 0, which].cpu())
+        assert rel_err(out[..., :96], so[..., :96]) < 2e-2 and cos(out[..., :96], so[..., :96]) > 0.9999
+        if which == 1:      # the one-hot key coordinates are copied: exactly equal
+            assert torch.equal(out[..., 96:], so[..., 96:])
+        assert rel_err(mean, sm) < 1e-3 and rel_err(rstd, sr) < 1e-3
+        assert rel_err(pre.float(), sp.float()) < 8e-3
 
 
 # -------------------------------------------------------------------- fused attention ----
