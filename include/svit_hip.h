@@ -83,6 +83,11 @@ int svit_colsum_bf16(const void* A, int lda, float* out, int M, int N, void* str
 
 /* ------------------------------------------------------------- elementwise / casts ---- */
 int svit_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* Rel-pos tables at another resolution (attention.py:84-137 interpolates rel_pos_h / _w / _t with F.interpolate when the
+ * query / key grid differs from the table's): out[r][c] = sum_j M[r][j] * tables[j][c], c < 96, with M [rows, J] the
+ * fp32 matrix of linear-interpolation weights (zero rows pad to a multiple of 96) and tables [J, 96] the block's three
+ * adjacent fp32 tables.  out32 (fp32 [rows, 96]) and / or out16 (bf16 [rows, 96]) may be NULL (not both). */
+int svit_table_interp(const float* M, int rows, int J, const float* tables, float* out32, void* out16, void* stream);
 /* batched fp32 [R,C] -> bf16 [C,R] transposes described by a device table of
  * {src_off, dst_off, R, C, ldd} int64 quintuples: dst[c*ldd + r] (the W^T copies used by
  * dgrad; ldd > R places a table inside a wider row, e.g. the concatenated rel-pos tables). */
@@ -448,12 +453,13 @@ int svit_debug_set_tn(int step_us_x100, int atomic_tbs_x100);
 int svit_debug_set_tn_tile(int mode);
 /* pooling (csrc/pool.hip): key 0 = forward path of the small planes: 0 streaming kernels, 1 VALU slab conv, 2 (default)
  * MFMA conv where it is ahead (blocks 4-13 of 16x224^2) and the slab elsewhere, 3 MFMA conv wherever its geometry holds;
- * key 1 = backward path of the small planes: 1 (default) the fused plane-walk kernel (LayerNorm backward + conv dgrad +
- * conv wgrad in one launch) where it fits, 0 the three streaming launches; key 2 = forward of the planes past 14x14
- * (blocks 0-3): 1 (default) the staged conv (input staged once in LDS) + the row-wise LayerNorm launch, 0 the streaming kernel. */
+ * key 1 = conv backward: 1 (default) the fused plane-walk kernel (conv dgrad + conv wgrad in one launch) where it fits,
+ * 0 the two streaming launches; key 2 = forward of the planes past 14x14 (blocks 0-3): 1 (default) the staged conv (input
+ * staged once in LDS) + the row-wise LayerNorm launch, 0 the streaming kernel; key 3 = one-plane volumes (T = 1):
+ * conv + LayerNorm in one launch from an LDS-staged plane -- 1 (default) in no-grad passes (the frames pass), 2 also where
+ * pre / mean / rstd are saved for a backward (image ranks), 0 never. */
 int svit_debug_set_pool(int key, int val);
-/* attention: key 0 = dkv kernel form (0 heuristic, 1 four waves, 2 eight waves with query halves), key 1 = backward
- * launch form (0 heuristic, 1 two launches: dq then dkv, 2 one launch with both kinds of workgroup), key 3 = the
+/* attention: key 0 = dkv kernel form (0 heuristic, 1 four waves, 2 eight waves with query halves), key 3 = the
  * forward's T' = 1 tile for Nk <= 64 (1 on (default), 0 the generic kernel). */
 int svit_attn_debug_set(int key, int val);
 /* every knob above back to its default */

@@ -488,15 +488,39 @@ inline unsigned grid_for(int64_t work_items, int block, unsigned cap = 8192) {
   if (b > cap) b = cap;
   return (unsigned)b;
 }
+// out[r][c] = sum_j M[r][j] * T[j][c]  (c < 96): the rel-pos tables of a block at another resolution -- M is the cached
+// [Lpad, h + w + t rows] matrix of resize blocks / identities (engine._rel), T the block's three adjacent fp32 tables.  fp32
+// result (the backward's operand) and / or its bf16 copy (the forward's q . R^T operand) in ONE launch: the frames pass and
+// the 312^2 eval path ran a library GEMM (13 us for ~2 MFLOP) plus a cast per block.
+__global__ __launch_bounds__(128) void table_interp_kernel(const float* __restrict__ M, int J, const float* __restrict__ T,
+                                                           float* __restrict__ out32, bf16_t* __restrict__ out16) {
+  const int r = blockIdx.x, c = threadIdx.x;
+  if (c >= 96) return;
+  const float* m = M + (size_t)r * J;
+  float acc = 0.f;
+  for (int j = 0; j < J; ++j) {
+    const float w = m[j];                    // (uniform: a scalar load)
+    if (w != 0.f) acc += w * T[(size_t)j * 96 + c];
+  }
+  if (out32) out32[(size_t)r * 96 + c] = acc;
+  if (out16) out16[(size_t)r * 96 + c] = f32_to_bf16(acc);
+}
 }  // namespace
 
 extern "C" int svit_version(void) { return 1; }
 
+extern "C" int svit_table_interp(const float* M, int rows, int J, const float* tables, float* out32, void* out16, void* stream) {
+  if (!M || !tables || (!out32 && !out16) || rows <= 0 || J <= 0) return SVIT_ERR_ARG;
+  hipLaunchKernelGGL(table_interp_kernel, dim3(rows), dim3(128), 0, (hipStream_t)stream, M, J, tables, out32, (bf16_t*)out16);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
 // ---- the knob table (common.h: SvitKnob) -----------------------------------------------------------------------
 static const int k_knob_default[SVIT_K_COUNT] = {
     /* NT_STAGES */ 0, /* NT_CFG */ -1, /* NT_BK */ 0, /* TN_STEP_US_X100 */ 85, /* TN_ATOMIC_TBS_X100 */ 75, /* TN_TILE */ 2,
-    /* POOL_FWD */ 2, /* POOL_BWD */ 1, /* POOL_FWD_LARGE */ 1, /* ATTN_DKV_FORM */ 0, /* ATTN_FWD_SHORT */ 1, /* ATTN_BWD_FORM */ 0};
-static int g_knob[SVIT_K_COUNT] = {0, -1, 0, 85, 75, 2, 2, 1, 1, 0, 1, 0};     // (= k_knob_default; accessed through __atomic builtins)
+    /* POOL_FWD */ 2, /* POOL_BWD */ 1, /* POOL_FWD_LARGE */ 1, /* ATTN_DKV_FORM */ 0, /* ATTN_FWD_SHORT */ 1, /* POOL_FRAME */ 1};
+static int g_knob[SVIT_K_COUNT] = {0, -1, 0, 85, 75, 2, 2, 1, 1, 0, 1, 1};     // (= k_knob_default; accessed through __atomic builtins)
 int svit_knob(int k) { return __atomic_load_n(&g_knob[k], __ATOMIC_RELAXED); }
 int svit_knob_set(int k, int v) {
   if (k < 0 || k >= SVIT_K_COUNT) return SVIT_ERR_ARG;
@@ -525,11 +549,11 @@ extern "C" int svit_debug_set_pool(int key, int val) {
   if (key == 0) return (val >= 0 && val <= 3) ? svit_knob_set(SVIT_K_POOL_FWD, val) : SVIT_ERR_ARG;
   if (key == 1) return (val == 0 || val == 1) ? svit_knob_set(SVIT_K_POOL_BWD, val) : SVIT_ERR_ARG;
   if (key == 2) return (val == 0 || val == 1) ? svit_knob_set(SVIT_K_POOL_FWD_LARGE, val) : SVIT_ERR_ARG;
+  if (key == 3) return (val >= 0 && val <= 2) ? svit_knob_set(SVIT_K_POOL_FRAME, val) : SVIT_ERR_ARG;
   return SVIT_ERR_ARG;
 }
 extern "C" int svit_attn_debug_set(int key, int val) {
   if (key == 0) return (val >= 0 && val <= 2) ? svit_knob_set(SVIT_K_ATTN_DKV_FORM, val) : SVIT_ERR_ARG;
-  if (key == 1) return (val >= 0 && val <= 2) ? svit_knob_set(SVIT_K_ATTN_BWD_FORM, val) : SVIT_ERR_ARG;
   if (key == 3) return (val == 0 || val == 1) ? svit_knob_set(SVIT_K_ATTN_FWD_SHORT, val) : SVIT_ERR_ARG;
   return SVIT_ERR_ARG;
 }

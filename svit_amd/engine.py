@@ -352,12 +352,11 @@ class Engine:
         if mcat is None:
             tabs = self._tables(pre, mats)
             rcat, rows_off = f.rel_cat(pre)
-        else:   # interpolated tables (odd crops, T=1 frames pass): one matmul + one cast
-            r32 = mcat @ f.rel_tables32(pre)
-            rcat = r32.to(BF16)
+        else:   # interpolated tables (odd crops, T=1 frames pass): one small launch (fp32 for the backward + the bf16 operand)
+            r32, rcat = ops.table_interp(mcat, f.rel_tables32(pre), want_f32=save)
             rows_off = (0, need[0], need[0] + need[1])
-            tabs = [r32[rows_off[0]:rows_off[0] + need[0]], r32[rows_off[1]:rows_off[1] + need[1]],
-                    r32[rows_off[2]:rows_off[2] + need[2]]]
+            tabs = None if r32 is None else [r32[rows_off[0]:rows_off[0] + need[0]], r32[rows_off[1]:rows_off[1] + need[1]],
+                                             r32[rows_off[2]:rows_off[2] + need[2]]]
         pools = ops.pool_ln_fwd_qkv(
             qkv, [f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
             [f.p(pre + "attn.norm_%s.weight" % r) for r in "qkv"],

@@ -174,6 +174,18 @@ def transpose_bf16_batched(src16_flat, dst_flat, table, n_mats, max_tiles):
              max_tiles)
 
 
+def table_interp(mcat, tables, want_f32=True):
+    """rel-pos tables at another resolution: (mcat f32 [Lp, J]) @ (tables f32 [J, 96]) -> (f32 [Lp, 96] or None, bf16 [Lp, 96])
+    in one launch."""
+    _chk_dev(mcat, tables)
+    assert mcat.dtype == F32 and tables.dtype == F32 and mcat.is_contiguous() and tables.is_contiguous()
+    assert mcat.shape[1] == tables.shape[0] and tables.shape[1] == HD
+    r32 = torch.empty((mcat.shape[0], HD), device=mcat.device, dtype=F32) if want_f32 else None
+    r16 = torch.empty((mcat.shape[0], HD), device=mcat.device, dtype=BF16)
+    hip.call("svit_table_interp", ptr(mcat), mcat.shape[0], mcat.shape[1], ptr(tables), ptr(r32), ptr(r16))
+    return r32, r16
+
+
 def pad_cast_rows(src, dst):
     """dst bf16 [R,ldd] = [src f32 [R,C] | 0]."""
     _chk_dev(src, dst)

@@ -967,6 +967,92 @@ def test_pool_forward_staged_large_planes(ops, B, h, thw, sq, skv, n_obj):
         assert rel_err(pre.float(), sp.float()) < 8e-3
 
 
+def test_table_interp_matches_matmul(ops):
+    """svit_table_interp (rel-pos tables at another resolution: attention.py:84-137's F.interpolate as one matrix) against
+    torch's fp32 matmul, fp32 and bf16 outputs, zero pad rows included."""
+    m = torch.zeros((96, 27 + 27 + 15), device=DEV)
+    m[:55, :27] = rnd("ti0", (55, 27), 1.0).abs()
+    m[55:80, 27:54] = rnd("ti1", (25, 27), 1.0)
+    m[80:81, 54:] = rnd("ti2", (1, 15), 1.0)
+    t = rnd("ti3", (69, 96), 0.7)
+    ref = m.double() @ t.double()
+    r32, r16 = ops.table_interp(m, t)
+    assert rel_err(r32, ref) < 1e-6
+    assert torch.equal(r16, r32.to(BF16))
+    assert float(r32[81:].abs().max()) == 0.0
+    none32, r16b = ops.table_interp(m, t, want_f32=False)
+    assert none32 is None and torch.equal(r16b, r16)
+
+
+@pytest.mark.parametrize("B,h,hw,sq,skv,n_obj,save", [
+    (6, 1, (56, 56), 1, 8, 4, False),     # frames pass, block 0: bands of 4 output rows, packed stride-8 windows
+    (3, 2, (56, 56), 2, 4, 4, False),     # block 1
+    (5, 2, (28, 28), 1, 4, 4, True),      # block 2 (an image rank keeps pre / mean / rstd)
+    (3, 4, (28, 28), 2, 2, 4, False),     # block 3
+    (9, 4, (14, 14), 1, 2, 4, False),     # blocks 4-13: whole planes
+    (4, 8, (14, 14), 2, 1, 4, True),      # block 14
+    (7, 8, (7, 7), 1, 1, 4, False),       # block 15
+    (2, 2, (19, 26), 1, 3, 3, True),      # odd plane, stride 3
+    (2, 3, (23, 17), 2, 2, 0, False),     # odd plane, no object tokens
+])
+def test_pool_forward_one_plane_volumes(ops, B, h, hw, sq, skv, n_obj, save):
+    """Round 5: T = 1 volumes (frames pass, image ranks) take csrc/pool.hip::pool_frame_fwd_kernel -- conv + LayerNorm in one
+    launch from an LDS-staged plane.  Against torch's depthwise conv3d + layer_norm on the same bf16 operands, the closed
+    form of the object / cls rows, and the other paths of the same library (svit_debug_set_pool(3, 0)) incl. q's rel-pos
+    columns and the keys' one-hot coordinates; with and without the saved-for-backward trio."""
+    from svit_amd import hip
+    lib = hip.load()
+    H, W = hw
+    thw = (1, H, W)
+    L = H * W
+    N = 1 + L + n_obj
+    qkv = rnd("fr%d%d%d%d" % (B, H, W, h), (B, N, 3, h, 96), 0.5, BF16)
+    ws = [rnd("frw%d%d" % (i, H), (96, 27), 0.2) for i in range(3)]
+    g = [rnd("frg%d" % i, (96,), 0.3) + 1.0 for i in range(3)]
+    b = [rnd("frb%d" % i, (96,), 0.1) for i in range(3)]
+    J = ops.pooled(H, skv) + ops.pooled(W, skv) + 1
+    if J > 64:
+        pytest.skip("key grid too large for the in-MFMA rel-pos columns")
+    da = 128 if J <= 32 else 160
+    res = []
+    try:
+        for on in (0, 2):        # 2: also where the trio is saved (the default takes the kernel in no-grad passes only)
+            assert lib.svit_debug_set_pool(3, on) == 0
+            r = ops.pool_ln_fwd_qkv(qkv, ws, g, b, B, h, thw, n_obj, (sq, skv, skv), (da, da, 96), (0, 1, 0),
+                                    out_scales=(1.0, KSC, 1.0), save=save)
+            torch.cuda.synchronize()
+            res.append(r)
+    finally:
+        lib.svit_debug_reset()
+    for which, s in ((0, sq), (1, skv), (2, skv)):
+        x = qkv[:, 1:1 + L, which].float()
+        vol = x.reshape(B, 1, H, W, h, 96).permute(0, 4, 5, 1, 2, 3).reshape(B * h, 96, 1, H, W)
+        w = ws[which].to(BF16).float().reshape(96, 1, 3, 3, 3)
+        ref = F.conv3d(vol, w, None, stride=(1, s, s), padding=1, groups=96)
+        Lo = ref.shape[3] * ref.shape[4]
+        ref = ref.reshape(B, h, 96, -1).transpose(2, 3)
+        gain = R.object_gain(ws[which].to(BF16).float().cpu().reshape(96, 1, 3, 3, 3), (1, s, s)).to(ref.device)
+        obj = qkv[:, 1 + L:, which].float().permute(0, 2, 1, 3) * gain
+        cls = qkv[:, :1, which].float().permute(0, 2, 1, 3)
+        pre_ref = torch.cat([cls, ref, obj], dim=2).to(BF16).float()
+        sc = KSC if which == 1 else 1.0
+        ln_ref = F.layer_norm(pre_ref, (96,), g[which], b[which], 1e-6) * sc
+        so, sp, sm, sr = res[0][which]
+        out, pre, mean, rstd = res[1][which]
+        assert out.shape == so.shape == (B, h, 1 + Lo + n_obj, da if which < 2 else 96)
+        assert rel_err(out[..., :96], ln_ref) < 2e-2 and cos(out[..., :96], ln_ref) > 0.9999
+        assert rel_err(out[..., :96], so[..., :96]) < 2e-2 and cos(out[..., :96], so[..., :96]) > 0.9999
+        if which == 1:      # the one-hot key coordinates: exactly equal
+            assert torch.equal(out[..., 96:], so[..., 96:])
+        if save:
+            assert rel_err(pre[:, :, 1:1 + Lo], ref) < 1e-2
+            assert torch.equal(pre[:, :, 0].cpu(), qkv[:, 0, which].cpu())
+            assert rel_err(mean, sm) < 1e-3 and rel_err(rstd, sr) < 1e-3
+            assert rel_err(pre.float(), sp.float()) < 8e-3
+        else:
+            assert pre is None and mean is None and rstd is None
+
+
 # -------------------------------------------------------------------- fused attention ----
 KSC = (96 ** -0.5) * math.log2(math.e)   # what the pooling kernel multiplies the keys by (engine.K_SCALE)
 
