@@ -498,10 +498,8 @@ __global__ __launch_bounds__(128) void table_interp_kernel(const float* __restri
   if (c >= 96) return;
   const float* m = M + (size_t)r * J;
   float acc = 0.f;
-  for (int j = 0; j < J; ++j) {
-    const float w = m[j];                    // (uniform: a scalar load)
-    if (w != 0.f) acc += w * T[(size_t)j * 96 + c];
-  }
+#pragma unroll 8
+  for (int j = 0; j < J; ++j) acc += m[j] * T[(size_t)j * 96 + c];      // (m[j] is uniform: scalar loads; eight rows of T in flight)
   if (out32) out32[(size_t)r * 96 + c] = acc;
   if (out16) out16[(size_t)r * 96 + c] = f32_to_bf16(acc);
 }
