@@ -284,6 +284,12 @@ def pooled(n, s):
     return (n - 1) // s + 1
 
 
+# no-grad passes over clips (T > 1: eval, multi-view test) hand the kernels a scratch pre / mean / rstd so that the pooling
+# forward takes the same staged / slab launches as a training step (they hand `pre` from the conv launch to the LayerNorm
+# launch); one-plane volumes (the frames pass) have their own kernel and keep nothing
+NOGRAD_SCRATCH = True
+
+
 def _pool_fwd_args(a, qkv, which, conv_w, gamma, beta, B, heads, thw, n_obj, stride_hw, ld_out, mode,
                    eps, save=True, out_scale=1.0):
     _chk_dev(qkv, conv_w, gamma, beta)
@@ -291,14 +297,16 @@ def _pool_fwd_args(a, qkv, which, conv_w, gamma, beta, B, heads, thw, n_obj, str
     Nout = 1 + T * pooled(H, stride_hw) * pooled(W, stride_hw) + n_obj
     dev = qkv.device
     out = torch.empty((B, heads, Nout, ld_out), device=dev, dtype=BF16)
-    pre = torch.empty((B, heads, Nout, HD), device=dev, dtype=BF16) if save else None
-    mean = torch.empty(B * heads * Nout, device=dev, dtype=F32) if save else None
-    rstd = torch.empty(B * heads * Nout, device=dev, dtype=F32) if save else None
+    keep = save or (NOGRAD_SCRATCH and T > 1)
+    pre = torch.empty((B, heads, Nout, HD), device=dev, dtype=BF16) if keep else None
+    mean = torch.empty(B * heads * Nout, device=dev, dtype=F32) if keep else None
+    rstd = torch.empty(B * heads * Nout, device=dev, dtype=F32) if keep else None
     a.qkv, a.which, a.conv_w, a.gamma, a.beta = ptr(qkv), which, ptr(conv_w), ptr(gamma), ptr(beta)
     a.out, a.ld_out, a.pre, a.mean, a.rstd = ptr(out), ld_out, ptr(pre), ptr(mean), ptr(rstd)
     a.B, a.heads, a.T, a.H, a.W, a.n_obj = B, heads, T, H, W, n_obj
     a.stride_hw, a.mode, a.eps, a.out_scale = stride_hw, mode, eps, out_scale
-    return out, pre, mean, rstd
+    return out, pre, mean, rstd       # (scratch included: the caller drops it AFTER the launch -- freed earlier, the next
+                                      # tensor's `out` could be carved from the same block)
 
 
 def pool_ln_fwd(qkv, which, conv_w, gamma, beta, B, heads, thw, n_obj, stride_hw, ld_out=HD,
@@ -348,6 +356,8 @@ def pool_ln_fwd_qkv(qkv, conv_ws, gammas, betas, B, heads, thw, n_obj, strides, 
         hip.call("svit_pool_ln_fwd_qkv", arr)
     else:
         hip.call("svit_pool_ln_fwd_qkv_sel", arr, _sel_ptrs(sels))
+    if not save:
+        res = [(r[0], None, None, None) for r in res]
     return res
 
 

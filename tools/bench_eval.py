@@ -22,8 +22,10 @@ def main():
     ap.add_argument("--videos", type=int, default=4, help="videos per batch (x3 crops)")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nograd-scratch", type=int, default=1, help="0: no-grad pooling on the streaming kernels (A/B)")
     args = ap.parse_args()
-    from svit_amd import config, evaluate
+    from svit_amd import config, evaluate, ops
+    ops.NOGRAD_SCRATCH = bool(args.nograd_scratch)
     from svit_amd.model import build_model
     cfg = config.ssv2_cfg(num_frames=args.frames, crop=args.crop)
     torch.manual_seed(0)
