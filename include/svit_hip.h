@@ -88,6 +88,16 @@ int svit_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
  * fp32 matrix of linear-interpolation weights (zero rows pad to a multiple of 96) and tables [J, 96] the block's three
  * adjacent fp32 tables.  out32 (fp32 [rows, 96]) and / or out16 (bf16 [rows, 96]) may be NULL (not both). */
 int svit_table_interp(const float* M, int rows, int J, const float* tables, float* out32, void* out16, void* stream);
+/* The same for every block of a forward pass in one launch: `jobs_dev` = n_jobs descriptors in DEVICE memory (the caller
+ * caches the table per input geometry: the pointers are those of its persistent buffers), max_rows = the largest `rows`. */
+typedef struct svit_table_interp_job {
+  const float* M;        /* [rows, J] interpolation weights */
+  const float* tables;   /* [J, 96] */
+  float* out32;          /* [rows, 96] or NULL */
+  void* out16;           /* bf16 [rows, 96] or NULL */
+  int32_t rows, J;
+} svit_table_interp_job;
+int svit_table_interp_batched(const svit_table_interp_job* jobs_dev, int n_jobs, int max_rows, void* stream);
 /* batched fp32 [R,C] -> bf16 [C,R] transposes described by a device table of
  * {src_off, dst_off, R, C, ldd} int64 quintuples: dst[c*ldd + r] (the W^T copies used by
  * dgrad; ldd > R places a table inside a wider row, e.g. the concatenated rel-pos tables). */

@@ -503,9 +503,28 @@ __global__ __launch_bounds__(128) void table_interp_kernel(const float* __restri
   if (out32) out32[(size_t)r * 96 + c] = acc;
   if (out16) out16[(size_t)r * 96 + c] = f32_to_bf16(acc);
 }
+// every block of a forward pass in ONE launch (blockIdx.y = job; the jobs live in device memory: a cached table per geometry)
+__global__ __launch_bounds__(128) void table_interp_batched_kernel(const svit_table_interp_job* __restrict__ jobs) {
+  const svit_table_interp_job j = jobs[blockIdx.y];
+  const int r = blockIdx.x, c = threadIdx.x;
+  if (r >= j.rows || c >= 96) return;
+  const float* m = j.M + (size_t)r * j.J;
+  float acc = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < j.J; ++k) acc += m[k] * j.tables[(size_t)k * 96 + c];
+  if (j.out32) j.out32[(size_t)r * 96 + c] = acc;
+  if (j.out16) ((bf16_t*)j.out16)[(size_t)r * 96 + c] = f32_to_bf16(acc);
+}
 }  // namespace
 
 extern "C" int svit_version(void) { return 1; }
+
+extern "C" int svit_table_interp_batched(const svit_table_interp_job* jobs_dev, int n_jobs, int max_rows, void* stream) {
+  if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535 || max_rows <= 0) return SVIT_ERR_ARG;
+  hipLaunchKernelGGL(table_interp_batched_kernel, dim3(max_rows, n_jobs), dim3(128), 0, (hipStream_t)stream, jobs_dev);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
 
 extern "C" int svit_table_interp(const float* M, int rows, int J, const float* tables, float* out32, void* out16, void* stream) {
   if (!M || !tables || (!out32 && !out16) || rows <= 0 || J <= 0) return SVIT_ERR_ARG;

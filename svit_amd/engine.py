@@ -197,6 +197,9 @@ class Engine:
         self.plan, self.flat = plan, flat
         self.dev = flat.data.device
         self._rel_cache = {}
+        self._interp_cache = {}     # (thw of the first block, save) -> the batched table-interpolation launch of a forward pass
+        self._interp_out = {}       # block index -> (r32 or None, rcat bf16) of the forward pass that is running
+        self.batch_interp = True    # False: one svit_table_interp launch per block (A/B: tools/diag/interp_ab.py)
         self._relq_cache = {}
         self.fused_scatter = True     # (False = the stand-alone rel-pos scatter launch; tests / tools flip the attribute)
         self.patch_w16 = torch.zeros((plan.embed_dim, 448), device=self.dev, dtype=BF16)
@@ -263,6 +266,36 @@ class Engine:
             self._rel_cache[key] = ent
         return ent
 
+    def _interp_tables(self, thw, save):
+        """Rel-pos tables of every block whose grid differs from its tables' (odd crops, the T' = 1 frames pass, 312^2 test
+        crops): ONE launch at the start of the pass (sixteen 6-us launches otherwise).  The descriptor table and the output
+        buffers are cached per geometry; the fp32 results (the backward's operand) exist only when the pass saves."""
+        if not self.batch_interp:
+            self._interp_out = {}
+            return
+        key = (tuple(thw), bool(save))
+        ent = self._interp_cache.get(key)
+        if ent is None:
+            entries, outs, cur = [], {}, tuple(thw)
+            for blk in self.plan.blocks:
+                sq, skv = blk.stride_q[1], blk.stride_kv[1]
+                q_thw = (cur[0], arch.pooled(cur[1], sq), arch.pooled(cur[2], sq))
+                k_thw = (cur[0], arch.pooled(cur[1], skv), arch.pooled(cur[2], skv))
+                _, _, mcat, _ = self._rel(blk, q_thw, k_thw)
+                if mcat is not None:
+                    r32 = torch.empty((mcat.shape[0], HD), device=self.dev, dtype=F32) if save else None
+                    r16 = torch.empty((mcat.shape[0], HD), device=self.dev, dtype=BF16)
+                    entries.append((mcat, self.flat.rel_tables32("blocks.%d." % blk.index), r32, r16))
+                    outs[blk.index] = (r32, r16)
+                cur = q_thw
+            jobs = ops.table_interp_jobs(entries, self.dev) if entries else None
+            ent = (jobs, max((e[0].shape[0] for e in entries), default=0), outs, entries)
+            self._interp_cache[key] = ent
+        jobs, max_rows, outs, _ = ent
+        if jobs is not None:
+            ops.table_interp_batched(jobs, max_rows)
+        self._interp_out = outs
+
     def _relq_map(self, blk, q_thw, k_thw, idx, rows_off, n_obj, extra):
         """i32 [Nq, extra]: the column of P = q . Rcat^T that (token, j) reads, -1 for cls / object
         rows and for the padding columns j >= kh + kw + kt (svit_gemm_args.relq_map)."""
@@ -317,6 +350,7 @@ class Engine:
         st = {"B": B, "Tx": Tx, "n_obj": n_obj, "L0": L, "cols": cols if save else None,
               "blocks": []}
         thw = (T, Ho, Wo)
+        self._interp_tables(thw, save)
         hip.mark("stem")
         for blk in plan.blocks:
             ds = drop_scales[blk.index] if drop_scales is not None else None
@@ -353,7 +387,10 @@ class Engine:
             tabs = self._tables(pre, mats)
             rcat, rows_off = f.rel_cat(pre)
         else:   # interpolated tables (odd crops, T=1 frames pass): one small launch (fp32 for the backward + the bf16 operand)
-            r32, rcat = ops.table_interp(mcat, f.rel_tables32(pre), want_f32=save)
+            if blk.index in self._interp_out:             # (computed for all blocks at the start of the pass)
+                r32, rcat = self._interp_out[blk.index]
+            else:
+                r32, rcat = ops.table_interp(mcat, f.rel_tables32(pre), want_f32=save)
             rows_off = (0, need[0], need[0] + need[1])
             tabs = None if r32 is None else [r32[rows_off[0]:rows_off[0] + need[0]], r32[rows_off[1]:rows_off[1] + need[1]],
                                              r32[rows_off[2]:rows_off[2] + need[2]]]

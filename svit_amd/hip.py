@@ -129,6 +129,7 @@ _SIGS = {
     "svit_colsum_bf16": (i32, [vp, i32, vp, i32, i32, vp]),
     "svit_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
     "svit_table_interp": (i32, [vp, i32, i32, vp, vp, vp, vp]),
+    "svit_table_interp_batched": (i32, [vp, i32, i32, vp]),
     "svit_transpose_cast_batched": (i32, [vp, vp, vp, i32, i32, vp]),
     "svit_transpose_bf16_batched": (i32, [vp, vp, vp, i32, i32, vp]),
     "svit_scale_cast": (i32, [vp, vp, vp, i32, i64, i32, i32, i32, i32, vp]),

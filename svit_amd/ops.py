@@ -186,6 +186,19 @@ def table_interp(mcat, tables, want_f32=True):
     return r32, r16
 
 
+def table_interp_jobs(entries, device):
+    """entries: [(mcat f32 [Lp, J], tables f32 [J, 96], out32 f32 [Lp, 96] or None, out16 bf16 [Lp, 96])] -> the device
+    descriptor table of svit_table_interp_batched (uint8 [n, 40]; keep it and every tensor it names alive)."""
+    import struct
+    raw = b"".join(struct.pack("<QQQQii", ptr(m), ptr(t), ptr(o32) or 0, ptr(o16) or 0, m.shape[0], m.shape[1])
+                   for m, t, o32, o16 in entries)
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).view(len(entries), 40).to(device)
+
+
+def table_interp_batched(jobs, max_rows):
+    hip.call("svit_table_interp_batched", ptr(jobs), jobs.shape[0], max_rows)
+
+
 def pad_cast_rows(src, dst):
     """dst bf16 [R,ldd] = [src f32 [R,C] | 0]."""
     _chk_dev(src, dst)

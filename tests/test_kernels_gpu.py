@@ -982,6 +982,16 @@ def test_table_interp_matches_matmul(ops):
     assert float(r32[81:].abs().max()) == 0.0
     none32, r16b = ops.table_interp(m, t, want_f32=False)
     assert none32 is None and torch.equal(r16b, r16)
+    # the batched form (every block of a forward pass in one launch): two jobs of different sizes, one without fp32 output
+    m2 = rnd("ti4", (192, 40), 1.0)
+    t2 = rnd("ti5", (40, 96), 0.7)
+    o32 = torch.full((96, 96), 7.0, device=DEV)
+    o16 = torch.empty((96, 96), device=DEV, dtype=BF16)
+    p16 = torch.empty((192, 96), device=DEV, dtype=BF16)
+    jobs = ops.table_interp_jobs([(m, t, o32, o16), (m2, t2, None, p16)], DEV)
+    ops.table_interp_batched(jobs, 192)
+    assert torch.equal(o32, r32) and torch.equal(o16, r16)
+    assert torch.equal(p16, ops.table_interp(m2, t2)[1])
 
 
 @pytest.mark.parametrize("B,h,hw,sq,skv,n_obj,save", [
