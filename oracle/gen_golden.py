@@ -677,6 +677,67 @@ def run_module_cases(out_dir, manifest):
           {k: "%.2e" % v for k, v in agree.items() if v > 1e-4}, flush=True)
 
 
+def _cos(a, b):
+    a, b = a.detach().double().flatten(), b.detach().double().flatten()
+    return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30))
+
+
+def run_yardstick_cases(manifest):
+    """Round 6: the noise floor of the gradient tolerances.  The reference's backward once in fp32
+    and once under ref_shim.autocast_emulation() (bf16 operands / results of every matrix op); per-tensor cosine of the
+    two gradients = what a correct bf16-GEMM implementation scores.  Same inputs as the parity tests that use them:
+    tiny (the smoke), tiny_frames (T' = 1 path), tiny_image (tests/test_model_gpu.py::test_image_rank_step_parity_vs_oracle),
+    c2 (the headline clip)."""
+    ref_shim.install()
+    from slowfast.models import losses as L
+    from slowfast.utils import misc
+    out = {}
+    for name, nf, crop, batch, kind in (("tiny", 4, 64, 2, "video"), ("tiny_frames", 4, 64, 3, "frames"),
+                                        ("tiny_image", 4, 64, 3, "image"), ("c2", 16, 224, 1, "video")):
+        torch.manual_seed(0)
+        cfg, model, shapes, sd = build_reference(nf, crop)
+        model.train()
+        x = P.frames(batch, nf if kind == "video" else 1, crop)
+        y = P.labels(batch)
+        meta = P.haog_meta(batch)
+        lam = misc.get_lambdas_dict(cfg)
+        lf = L.VideoImageLoss(cfg)
+        lf._is_vid = False
+        lf.train()
+
+        def step():
+            model.zero_grad()
+            logits, extra = model([x], {})
+            if kind == "image":
+                parts = lf(logits, extra, None, meta)
+                loss = sum(lam[k] * v for k, v in parts.items())
+            else:
+                loss = torch.nn.functional.cross_entropy(logits, y)
+            loss.backward()
+            return logits.detach().clone(), {k: v.grad.detach().clone() for k, v in model.named_parameters()}
+        lg32, g32 = step()
+        mode = ref_shim.autocast_emulation()
+        with mode:
+            lg16, g16 = step()
+        gmax = max(float(v.abs().max()) for v in g32.values())
+        cos = {k: round(_cos(g16[k], g32[k]), 6) for k in g32 if float(g32[k].abs().max()) >= 1e-4 * gmax}
+        num = sum(float((g16[k].double() * g32[k].double()).sum()) for k in g32)
+        da = sum(float((g16[k].double() ** 2).sum()) for k in g32) ** 0.5
+        db = sum(float((g32[k].double() ** 2).sum()) for k in g32) ** 0.5
+        worst = min(cos, key=cos.get)
+        out[name] = {"num_frames": nf, "crop": crop, "batch": batch, "kind": kind,
+                     "rounded_ops": type(mode).calls, "logits_maxabs": float((lg16 - lg32).abs().max()),
+                     "logits_cos": _cos(lg16, lg32), "grad_cos_global": num / (da * db),
+                     "grad_cos_worst": [worst, cos[worst]], "autocast_emulation_cos": cos}
+        type(mode).calls = 0
+        rel = sorted((v, k) for k, v in cos.items() if "rel_pos" in k)[:4]
+        print("yardstick", name, "worst", worst, cos[worst], "global %.5f" % out[name]["grad_cos_global"],
+              "logits maxabs %.4f" % out[name]["logits_maxabs"], "rel-pos worst:", rel, flush=True)
+    manifest["yardstick"] = {
+        "note": "per-tensor cosine (bf16-emulated reference backward vs the fp32 reference backward): the noise floor "
+                "of a correct bf16-GEMM implementation; oracle/ref_shim.py::autocast_emulation", "cases": out}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(HERE, "..", "tests", "golden"))
@@ -736,6 +797,8 @@ def main():
     if on("c2_frames"):
         run_model_case("c2_frames", 16, 224, 2, args.out, manifest, backward=False,
                        frames_path=True)
+    if on("yardstick"):
+        run_yardstick_cases(manifest)
     json.dump(manifest, open(mpath, "w"), indent=1, sort_keys=True)
     print("wrote", mpath)
 

@@ -216,3 +216,48 @@ def reference_cfg(num_frames=16, crop=224, overrides=()):
     if overrides:
         cfg.merge_from_list(list(overrides))
     return cfg
+
+
+# ---- bf16 yardstick (round 6): the reference under an emulation of CUDA autocast, on CPU ---------------------
+# tests/golden/manifest.json["yardstick"] records what a CORRECT bf16-GEMM implementation of the step scores against
+# the fp32 reference, per gradient tensor -- the noise floor the HIP path's per-tensor tolerances are set against.
+# Plumbing only: the reference's modules run unmodified; a TorchFunctionMode rounds the operands and the result of
+# every op CUDA autocast runs in bf16 (linear, matmul / bmm / einsum, conv3d) to bf16, forward and backward (the
+# incoming gradient is rounded as a bf16 output's gradient is, the operand gradients as bf16 tensors' are);
+# accumulation, LayerNorm, softmax, GELU and the residual stream stay fp32.  Elementwise ops on bf16 intermediates
+# (q * scale, attn + rel-pos bias) are NOT re-rounded here, which autocast would do: the yardstick is a lower bound
+# on autocast's own noise.
+def autocast_emulation():
+    import torch
+    import torch.nn.functional as F
+    from torch.overrides import TorchFunctionMode
+    from torch.utils._pytree import tree_map
+
+    class _Round(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.to(torch.bfloat16).to(torch.float32)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g.to(torch.bfloat16).to(torch.float32)
+
+    def rnd(t):
+        if isinstance(t, torch.Tensor) and t.dtype == torch.float32:
+            return _Round.apply(t)
+        return t
+
+    ops = {F.linear, torch.matmul, torch.Tensor.matmul, torch.Tensor.__matmul__, torch.bmm, torch.einsum,
+           torch.conv3d, F.conv3d}
+
+    class Mode(TorchFunctionMode):
+        calls = 0
+
+        def __torch_function__(self, func, types, args=(), kwargs=None):
+            kwargs = kwargs or {}
+            if func in ops:
+                Mode.calls += 1
+                return rnd(func(*tree_map(rnd, args), **tree_map(rnd, kwargs)))
+            return func(*args, **kwargs)
+
+    return Mode()

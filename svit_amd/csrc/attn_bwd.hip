@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
 #pragma unroll
   for (int r = 0; r < 16; ++r) { s_init[r] = CINIT ? -lse_p : 0.f; dp_init[r] = CINIT ? -dlt_p : 0.f; }
 
+  static_prio(blockIdx.y * gridDim.x + blockIdx.x, wave, 4);
   BSTAMP(3);
   for (int t = 0; t < nt; ++t) {
     if (t < 4) BSTAMP(8 + 4 * t);
@@ -511,6 +512,7 @@ __global__ __launch_bounds__(256 * NH, NH == 2 ? 1 : 2) void attn_bwd_dkv_kernel
   fa.init((unsigned)(size_t)smem + (NH == 2 ? qh * 2048 : 0), lane);
   const unsigned cba = (unsigned)(size_t)smem + Q_BYTES + O_BYTES + 16 * hh + (NH == 2 ? qh * 128 : 0);   // row 4*hh of the planes
 
+  static_prio((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, wave, 4 * NH);
   for (int t = t_begin; t < t_end; ++t) {
     if (t - t_begin < 4) BSTAMP(44 + 4 * (t - t_begin));
     if (NSTAGE == 3 && t + 1 < t_end) wait_vmcnt<PER_STAGE>();   // all but the youngest stage's loads are done

@@ -405,6 +405,22 @@ struct RowStage {
   }
 };
 
+// Static wave priority for the tile loops (MI355X guide, "Two waves per SIMD" items 2 and 4): two waves share a SIMD --
+// the two halves of an 8-wave workgroup, or one wave of each of two co-resident 4-wave workgroups -- and at equal
+// priority the older one wins every VALU arbitration.  One s_setprio before the loop, never flipped.
+// Diagnostic builds pick the rule with -DSVIT_ATTN_PRIO=<n> (tools/diag/build_variant.py); 0 = no priority.
+#ifndef SVIT_ATTN_PRIO
+#define SVIT_ATTN_PRIO 0
+#endif
+__device__ __forceinline__ void static_prio(int lin_wg, int wave, int nwaves) {
+  bool hi = false;
+  if (nwaves == 8) hi = (SVIT_ATTN_PRIO & 8) ? false : wave >= 4;   // the younger half of an 8-wave workgroup
+  else if ((SVIT_ATTN_PRIO & 7) == 1) hi = lin_wg & 1;               // workgroup parity
+  else if ((SVIT_ATTN_PRIO & 7) == 2) hi = (lin_wg >> 3) & 1;        // parity inside the XCD's dispatch order
+  else if ((SVIT_ATTN_PRIO & 7) == 3) hi = (lin_wg >> 8) & 1;        // every second round of 256 workgroups
+  if (SVIT_ATTN_PRIO != 0 && hi) __builtin_amdgcn_s_setprio(1);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
