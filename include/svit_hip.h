@@ -470,9 +470,7 @@ int svit_debug_set_tn_tile(int mode);
  * pre / mean / rstd are saved for a backward (image ranks), 0 never. */
 int svit_debug_set_pool(int key, int val);
 /* attention: key 0 = dkv kernel form (0 heuristic, 1 four waves, 2 eight waves with query halves), key 3 = the
- * forward's T' = 1 tile for Nk <= 64 (1 on (default), 0 the generic kernel); key 4 = the anti-phase 8-wave forward
- * (round 6): the fewest 64-key tiles a launch must have to take it (default 12, 0 = never, 1..4 = from 4 tiles on);
- * key 5 = the fewest 256-query workgroups such a launch must have (default 192). */
+ * forward's T' = 1 tile for Nk <= 64 (1 on (default), 0 the generic kernel). */
 int svit_attn_debug_set(int key, int val);
 /* every knob above back to its default */
 int svit_debug_reset(void);

@@ -535,351 +535,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_short_kernel(svit_attn_fwd_ar
 #endif
 }
 
-// ---------------------------------------------------------------------------------------
-// Anti-phase 8-wave forward for long key ranges (round 6; MI355X guide, "Two waves per SIMD").
-// The two waves that share a SIMD (wave w of half 0 = waves 0-3, and wave w + 4 of half 1) never run the same kind of
-// segment: while one half is in its MATRIX segment C(t) = [P.V of tile t-1 ; QK^T of tile t] (34-36 back-to-back MFMAs fed by
-// hand-pipelined LDS reads) the other half is in its VECTOR segment L(t) = [max / re-base / exp2 / pack of tile t ; issue of
-// the LDS-DMA pieces of tiles t+2 / t+3], with one s_barrier between segments; half 1 starts one segment late.  The
-// generic kernel's two waves per SIMD run the SAME phase after every barrier (matrix beside matrix, exp2 beside exp2: the
-// matrix pipe reads 54 % busy on the 26-tile launches).  Rotating the loop so that P.V(t-1) and QK^T(t) form ONE matrix
-// segment is what makes the two segment kinds of comparable length (~1100 cycles of matrix pipe against ~75 VALU + 5 DMA).
-//   * workgroup = 8 waves x 32 queries; K ring and V ring of NS = 4 tiles each (they are consumed one segment apart: C(t)
-//     reads K(t) and V(t-1)); L(t) issues V(t+2) and K(t+3) into the slots of V(t-2) / K(t-1), which both halves have
-//     left two barriers earlier;
-//   * every wave issues its share of every tile and waits for it (counted vmcnt, in issue order) at the END of its matrix
-//     segment, one barrier before the first reader needs it: group order  Q | K0 | V0 K1 | V1 K2 | V2 K3 (L(0)) | ...
-//   * arithmetic, operand images, softmax (log2 domain, -m as the accumulator init, defer-max) are the generic kernel's.
-#ifndef SVIT_ATTN_AP_PRIO       // 1: static s_setprio 1 for the later-started half (guide item 4); 0 in a diagnostic build
-#define SVIT_ATTN_AP_PRIO 1
-#endif
-#ifdef SVIT_ATTN_STAMPS   // tools/attn_ap_stamps.py: cycle stamps of workgroup 0, waves 0 and 4 (one of each half); the value of
-                          // the macro is the bit mask of the per-tile stamp points that are compiled in (every stamp costs
-                          // ~100-150 cycles: an s_memtime round trip + a store)
-__device__ unsigned long long g_ap_stamps[2 * 64 * 8 + 8];
-extern "C" int svit_debug_attn_ap_stamps(unsigned long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ap_stamps), sizeof(unsigned long long) * n);
-}
-#define APSTAMP(t, i)                                                                                   \
-  do {                                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                                  \
-    if (ap_stamp_on && (t) < 64 && ((SVIT_ATTN_STAMPS >> (i)) & 1))                                     \
-      g_ap_stamps[(half * 64 + (t)) * 8 + (i)] = __builtin_readcyclecounter();                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                  \
-  } while (0)
-#else
-#define APSTAMP(t, i) do {} while (0)
-#endif
-// Diagnostic builds only (-DSVIT_AP_ABL=<mask>, tools/diag/build_variant.py): anatomy of the anti-phase loop by ablation --
-// 1: no softmax arithmetic (max / exp2 / row sum), 2: no K / V DMA after the prologue, 4: no P.V stream, 8: no QK^T stream.
-// Results are wrong by construction; never defined in the product build.
-#ifndef SVIT_AP_ABL
-#define SVIT_AP_ABL 0
-#endif
-#ifndef SVIT_AP_DK          // read-ahead depths of the K row-fragment stream / the V^T fragment stream (fragments in flight)
-#define SVIT_AP_DK 4
-#endif
-#ifndef SVIT_AP_DV
-#define SVIT_AP_DV 3
-#endif
-#ifndef SVIT_AP_CHAIN       // 1 in a diagnostic build: the key blocks' QK^T chains one after the other (the generic kernel's order)
-#define SVIT_AP_CHAIN 0
-#endif
-template <int KSU>
-__global__ __launch_bounds__(512, 1) void attn_fwd_ap_kernel(svit_attn_fwd_args a) {
-#if __HIP_DEVICE_COMPILE__
-  constexpr int NW = 8, NS = 4;
-  constexpr int NP = (KSU + 1) / 2, KCOLS = NP * 32;
-  constexpr int K_BYTES = KT * KCOLS * 2, V_BYTES = KT * HD * 2;
-  constexpr int V_RING = NS * K_BYTES;        // [K ring | V ring]
-  using KLoad = BufTile<KT, KCOLS, NW>;
-  using VLoad = BufTile<KT, HD, NW>;
-  constexpr int PK = KLoad::PER_WAVE, PV = VLoad::PER_WAVE, P = PK + PV;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, half = wave >> 2;
-#ifdef SVIT_ATTN_STAMPS
-  const bool ap_stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave & 3) == 0;
-  if (ap_stamp_on && half == 0) { g_ap_stamps[1024] = __builtin_readcyclecounter(); g_ap_stamps[1025] = wall_clock64(); }
-#endif
-  const int DA = a.DA;
-  const int wgid = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-  const int bh = wgid / gridDim.x, b = bh / a.heads, head = bh % a.heads;
-  const int q0 = (wgid % gridDim.x) * (NW * 32) + wave * 32;
-  const int qi = q0 + (lane & 31);
-  const int qc = min(qi, a.Nq - 1);
-  const bf16_t* qa = (const bf16_t*)a.qa + ((size_t)bh * a.Nq) * DA;
-  const bf16_t* ka = (const bf16_t*)a.ka + ((size_t)bh * a.Nk) * DA;
-  const bf16_t* vv = (const bf16_t*)a.v + ((size_t)bh * a.Nk) * HD;
-
-  // the wave's Q fragments, row per lane: the oldest vector-memory operations of the wave, so the wait for them leaves
-  // the tiles issued right behind them in flight (Nk >= 4 tiles amortises the uncoalesced rows)
-  bf16x8_t qf[KSU];
-#pragma unroll
-  for (int ks = 0; ks < KSU; ++ks) qf[ks] = *(const bf16x8_t*)(qa + (size_t)qc * DA + ks * 16 + hh * 8);
-
-  const int nt = (a.Nk + KT - 1) / KT;      // >= 4 (launcher)
-  KLoad kload;
-  VLoad vload;
-  kload.init(DA, wave, lane);
-  vload.init(HD, wave, lane);
-  const auto krs = __builtin_amdgcn_make_buffer_rsrc((void*)ka, 0, a.Nk * DA * 2, 0x00020000);
-  const auto vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vv, 0, a.Nk * HD * 2, 0x00020000);
-  auto issue_k = [&](int t) {
-    if (t >= nt || ((SVIT_AP_ABL & 2) && t > 2)) return;
-    const unsigned k0 = (unsigned)t * KT;
-    kload.issue_auto(krs, k0 * DA * 2u, DA, a.Nk - (int)k0, smem + (t % NS) * K_BYTES, wave, lane);
-  };
-  auto issue_v = [&](int t) {
-    if (t >= nt || ((SVIT_AP_ABL & 2) && t > 1)) return;
-    const unsigned k0 = (unsigned)t * KT;
-    vload.issue_auto(vrs, k0 * HD * 2u, HD, a.Nk - (int)k0, smem + V_RING + (t % NS) * V_BYTES, wave, lane);
-  };
-  issue_k(0);
-  issue_v(0); issue_k(1);
-  issue_v(1); issue_k(2);
-
-  f32x16_t o[3], negm;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
-  // the row sums of P stay on the vector ALU here (32 v_add per tile in the VECTOR segment, which has the slack): the
-  // generic kernel's four row-sum MFMAs per tile would be 12 % of this kernel's matrix segment
-  float m_run = 0.f, l_run = 0.f;      // l_run: this lane's 16 key rows of every block; the halves meet in the epilogue
-
-  const unsigned lds0 = (unsigned)(size_t)smem;
-  unsigned kaddr0[2], vaddr0[2];
-  {
-    const int row = lane & 31, sw = (row >> 2) & 3;
-    kaddr0[0] = lds0 + row * 64 + 16 * ((0 + hh) ^ sw);
-    kaddr0[1] = lds0 + row * 64 + 16 * ((2 + hh) ^ sw);
-    const int cg = (lane >> 4) & 1, i = lane & 15, q = i >> 2, pp = i & 3;
-    const int r0 = 4 * hh, ch = 2 * cg + (pp >> 1);
-    const unsigned vb = lds0 + V_RING + 8 * (pp & 1);
-    vaddr0[0] = vb + (r0 + q) * 64 + 16 * (ch ^ ((r0 >> 2) & 3));
-    vaddr0[1] = vb + (r0 + 8 + q) * 64 + 16 * (ch ^ (((r0 + 8) >> 2) & 3));
-  }
-#pragma unroll
-  for (int ks = 0; ks < KSU; ++ks) asm volatile("" : "+v"(qf[ks]));    // (first use outside the loop: see the generic kernel)
-  if (SVIT_ATTN_AP_PRIO && half == 1) __builtin_amdgcn_s_setprio(1);
-
-  f32x16_t s[2];
-  bf16x8_t pf[4];
-  // ---- matrix segment, part 1: O^T += V^T . P^T (and l += 1^T P^T) of tile t, P in pf -------------------------------
-  auto seg_pv = [&](int t, auto HalfTag) {
-    constexpr int NKB = decltype(HalfTag)::value == 1 ? 1 : 2;
-    const unsigned so = (t % NS) * V_BYTES;
-    const unsigned vaddr[2] = {vaddr0[0] + so, vaddr0[1] + so};
-    TrStream<6 * NKB, (SVIT_AP_DV < 6 * NKB ? SVIT_AP_DV : 6 * NKB)> vs;
-    auto rdv = [&](auto J, s16x4_t& lo, s16x4_t& hi) {
-      constexpr int i = decltype(J)::value, g = i / 3, j = i % 3;
-      lds_read_tr<g * 16 * 64 + j * KT * 64>(lo, vaddr[0]);
-      lds_read_tr<g * 16 * 64 + j * KT * 64>(hi, vaddr[1]);
-    };
-    vs.prologue(rdv);
-    vs.run(rdv, [&](auto J, const bf16x8_t& f) {
-      constexpr int i = decltype(J)::value, g = i / 3, j = i % 3;
-      o[j] = mfma32(f, pf[g], o[j]);
-    });
-  };
-  // ---- matrix segment, part 2: S^T = ka . qa^T - m of tile t ---------------------------------------------------------
-  auto seg_qk = [&](int t, auto HalfTag) {
-    constexpr int NKB = decltype(HalfTag)::value == 1 ? 1 : 2;
-    const unsigned so = (t % NS) * K_BYTES;
-    const unsigned kaddr[2] = {kaddr0[0] + so, kaddr0[1] + so};
-    RowStream<KSU * NKB, (SVIT_AP_DK < KSU * NKB ? SVIT_AP_DK : KSU * NKB)> ks_;
-    // the two key blocks' accumulation chains are INTERLEAVED (item j = k-step j / 2 of block j % 2): with one wave per SIMD
-    // in its matrix segment nobody else fills the pipe while an MFMA waits for the accumulator of the one before it
-    auto rdk = [&](auto J, bf16x8_t& d) {
-      constexpr int j = decltype(J)::value, kb = SVIT_AP_CHAIN ? j / KSU : j % NKB, ks = SVIT_AP_CHAIN ? j % KSU : j / NKB;
-      lds_read128<kb * 2048 + (ks >> 1) * KT * 64>(d, kaddr[ks & 1]);
-    };
-    ks_.prologue(rdk);
-    ks_.run(rdk, [&](auto J, const bf16x8_t& f) {
-      constexpr int j = decltype(J)::value, kb = SVIT_AP_CHAIN ? j / KSU : j % NKB, ks = SVIT_AP_CHAIN ? j % KSU : j / NKB;
-      s[kb] = mfma32(f, qf[ks], ks == 0 ? negm : s[kb]);
-    });
-  };
-  // this wave's share of K(t+1) and V(t) has landed: everything but the youngest group [V(t+1) K(t+2)]
-  auto end_c = [&](int t) {
-    APSTAMP(t, 2);
-    if constexpr ((SVIT_AP_ABL & 2) != 0) wait_vmcnt<0>();
-    else if (t + 2 < nt) wait_vmcnt<P>();
-    else if (t + 2 == nt) wait_vmcnt<PV>();
-    else wait_vmcnt<0>();
-    APSTAMP(t, 3);
-    __builtin_amdgcn_s_barrier();
-    APSTAMP(t, 4);
-  };
-  // ---- vector segment: online softmax of tile t (s -> pf), then the DMA pieces of the tiles three segments ahead ------
-  auto seg_l = [&](int t, auto HalfTag) {
-    constexpr bool HALF = decltype(HalfTag)::value == 1;
-    constexpr int NKB = HALF ? 1 : 2;
-    const int kbase = t * KT;
-    if (kbase + KT > a.Nk) {  // ragged last tile (uniform branch): rows >= Nk hold re-read data
-      asm volatile("; ragged key rows" ::: "memory");
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kbase + kb * 32 + acc_row(r, lane) >= a.Nk) s[kb][r] = -INFINITY;
-    }
-    float mx;
-    if constexpr ((SVIT_AP_ABL & 1) != 0) {
-      mx = s[0][0];
-    } else if constexpr (HALF) {
-      mx = max3(s[0][0], s[0][1], s[0][2]);
-#pragma unroll
-      for (int r = 3; r < 15; r += 2) mx = max3(mx, s[0][r], s[0][r + 1]);
-      mx = fmaxf(mx, s[0][15]);
-    } else {
-      mx = max3(s[0][0], s[1][0], s[0][1]);
-      mx = max3(mx, s[1][1], s[0][2]);
-#pragma unroll
-      for (int r = 2; r < 15; ++r) mx = max3(mx, s[1][r], s[0][r + 1]);
-      mx = fmaxf(mx, s[1][15]);
-    }
-    mx = fmaxf(mx, other_half(mx));
-    constexpr float RESCALE_THR = 6.0f;          // defer-max (see the generic kernel); P.V of tile t-1 is complete here
-    if (((SVIT_AP_ABL & 1) == 0 || t == 0) && (t == 0 || !__all(mx <= RESCALE_THR))) {
-      asm volatile("; re-base" ::: "memory");
-      const float shift = t == 0 ? mx : fmaxf(mx, 0.f);
-      if (t > 0) {
-        const float alpha = fast_exp2(-shift);
-        l_run *= alpha;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[j][r] *= alpha;
-      }
-      m_run += shift;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) negm[r] = -m_run;
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] -= shift;
-    }
-    if constexpr ((SVIT_AP_ABL & 1) == 0) {
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = fast_exp2(s[kb][r]);
-    }
-    if constexpr ((SVIT_AP_ABL & 1) == 0) {
-      float l4[4] = {s[0][0], s[0][1], s[0][2], s[0][3]};
-#pragma unroll
-      for (int r = 4; r < 16; ++r) l4[r & 3] += s[0][r];
-      if constexpr (!HALF) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) l4[r & 3] += s[1][r];
-      }
-      l_run += (l4[0] + l4[1]) + (l4[2] + l4[3]);
-    }
-    pf[0] = acc_to_frag(s[0], 0);
-    pf[1] = acc_to_frag(s[0], 1);
-    pf[2] = HALF ? pf[0] : acc_to_frag(s[1], 0);
-    pf[3] = HALF ? pf[1] : acc_to_frag(s[1], 1);
-    APSTAMP(t, 5);
-    issue_v(t + 2);
-    issue_k(t + 3);
-    APSTAMP(t, 6);
-    __builtin_amdgcn_s_barrier();
-    APSTAMP(t, 7);
-  };
-
-  wait_vmcnt<2 * P>();                 // K(0): everything older than [V0 K1 | V1 K2]
-  __builtin_amdgcn_s_barrier();        // every wave's share of K(0) has landed
-  if (half == 1) __builtin_amdgcn_s_barrier();      // half 1 runs one segment behind
-  const bool half_tile = a.Nk - (nt - 1) * KT <= 32;    // a last tile of <= 32 keys multiplies one key block
-  for (int t = 0; t < nt; ++t) {
-    APSTAMP(t, 0);
-    if ((SVIT_AP_ABL & 4) == 0 && t > 0) seg_pv(t - 1, Int<0>{});
-    APSTAMP(t, 1);
-    if (t + 1 == nt && half_tile) {
-      seg_qk(t, Int<1>{});
-      end_c(t);
-      seg_l(t, Int<1>{});
-    } else {
-      if constexpr ((SVIT_AP_ABL & 8) == 0) seg_qk(t, Int<0>{});
-      end_c(t);
-      seg_l(t, Int<0>{});
-    }
-  }
-  if (half_tile) seg_pv(nt - 1, Int<1>{});
-  else seg_pv(nt - 1, Int<0>{});
-  if (half == 0) __builtin_amdgcn_s_barrier();      // (pairs with half 1's last segment barrier)
-#ifdef SVIT_ATTN_STAMPS
-  if (ap_stamp_on && half == 0) { g_ap_stamps[1026] = __builtin_readcyclecounter(); g_ap_stamps[1027] = wall_clock64(); }
-#endif
-  if (SVIT_ATTN_AP_PRIO && half == 1) __builtin_amdgcn_s_setprio(0);
-
-  // ---- epilogue (the generic kernel's): the staging rows live in the K ring, which nobody reads any more -- half 1's
-  // last matrix segment, possibly still running, reads the V ring only -----------------------------------------------
-  uint4 qres[6];
-#pragma unroll
-  for (int it = 0; it < 6; ++it) {
-    const int id = it * 64 + lane, row = id / 12, ch = id % 12;
-    const int q = min(q0 + row, a.Nq - 1);
-    qres[it] = *(const uint4*)(qa + (size_t)q * DA + ch * 8);
-  }
-  const float l_lo = l_run + other_half(l_run);
-  const float inv = 1.f / l_lo;
-  if (hh == 0 && qi < a.Nq) a.lse2[(size_t)bh * a.Nq + qi] = m_run + log2f(l_lo);
-  constexpr int OROW = 208;
-  static_assert(NW * 32 * OROW <= NS * K_BYTES, "output staging fits the K ring");
-  unsigned char* ost = smem + wave * (32 * OROW);
-  {
-    unsigned char* orow = ost + (lane & 31) * OROW;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int dv = j * 32 + 8 * g + 4 * hh;
-        uint2 pk;
-        pk.x = pack_bf16x2(o[j][4 * g] * inv, o[j][4 * g + 1] * inv);
-        pk.y = pack_bf16x2(o[j][4 * g + 2] * inv, o[j][4 * g + 3] * inv);
-        *(uint2*)(orow + dv * 2) = pk;
-      }
-  }
-#pragma unroll
-  for (int it = 0; it < 6; ++it) {
-    const int id = it * 64 + lane, row = id / 12, ch = id % 12;
-    const int q = q0 + row;
-    if (q < a.Nq) {
-      uint4 ov = *(const uint4*)(ost + row * OROW + ch * 16);
-      if (q > 0) {
-        const uint4 qq = qres[it];
-        ov.x = pack_bf16x2(lo_bf16(ov.x) + lo_bf16(qq.x), hi_bf16(ov.x) + hi_bf16(qq.x));
-        ov.y = pack_bf16x2(lo_bf16(ov.y) + lo_bf16(qq.y), hi_bf16(ov.y) + hi_bf16(qq.y));
-        ov.z = pack_bf16x2(lo_bf16(ov.z) + lo_bf16(qq.z), hi_bf16(ov.z) + hi_bf16(qq.z));
-        ov.w = pack_bf16x2(lo_bf16(ov.w) + lo_bf16(qq.w), hi_bf16(ov.w) + hi_bf16(qq.w));
-      }
-      *(uint4*)((bf16_t*)a.ctx + ((size_t)b * a.Nq + q) * a.heads * HD + head * HD + ch * 8) = ov;
-    }
-  }
-#ifdef SVIT_ATTN_STAMPS
-  __builtin_amdgcn_s_waitcnt(0);
-  if (ap_stamp_on && half == 0) g_ap_stamps[1028] = __builtin_readcyclecounter();
-#endif
-#endif
-}
-
-template <int KSU>
-int launch_ap(const svit_attn_fwd_args& a, hipStream_t st) {
-  constexpr int NP = (KSU + 1) / 2;
-  const size_t lds = (size_t)4 * (KT * NP * 32 * 2 + KT * HD * 2);
-  static SvitOnce once;
-  if (int rc = svit_max_lds_once(once, (const void*)attn_fwd_ap_kernel<KSU>, lds)) return rc;
-  dim3 grid((a.Nq + 255) / 256, a.B * a.heads);
-  hipLaunchKernelGGL((attn_fwd_ap_kernel<KSU>), grid, dim3(512), lds, st, a);
-  SVIT_LAUNCH_CHECK();
-  return SVIT_OK;
-}
-
 #ifndef SVIT_ATTN_SHORT_WGS     // workgroups the T' = 1 launch aims at (swept inside the frames-pass step in round 4)
 #define SVIT_ATTN_SHORT_WGS 512
 #endif
@@ -920,14 +575,6 @@ int launch_cfg(const svit_attn_fwd_args& a, hipStream_t st) {
 
 template <int KSU>
 int launch_fwd(const svit_attn_fwd_args& a, hipStream_t st) {
-  // round 6: the anti-phase 8-wave kernel where the key range is long enough to amortise its prologue (knob = fewest key
-  // tiles, 0 = never) and the 256-query workgroups still cover most of the chip (knob; one workgroup per CU)
-  {
-    const int min_tiles = svit_knob(SVIT_K_ATTN_FWD_AP), min_wgs = svit_knob(SVIT_K_ATTN_FWD_AP_WGS);
-    const long wgs = (long)((a.Nq + 255) / 256) * a.B * a.heads;
-    const int nt = (a.Nk + KT - 1) / KT;
-    if (min_tiles > 0 && nt >= std::max(4, min_tiles) && wgs >= min_wgs) return launch_ap<KSU>(a, st);
-  }
   // 8-wave workgroups once they still cover the chip (one per CU)
   // measured (tools/bench_kernels.py attn): the 8-wave form wins 3-4 % on the long-key blocks
   // (Nk = 1633, DA = 160) and loses on the short ones, where the 8-wave barrier dominates
@@ -936,6 +583,11 @@ int launch_fwd(const svit_attn_fwd_args& a, hipStream_t st) {
   return wide ? launch_cfg<KSU, 8, 3>(a, st) : launch_cfg<KSU, 4, 2>(a, st);
 }
 }  // namespace
+// (round 6: an 8-wave ANTI-PHASE forward -- halves of the workgroup alternating a matrix segment [P.V(t-1) ; QK^T(t)] and a vector
+// segment [softmax(t) ; LDS-DMA issue] between barriers, K / V rings four tiles deep -- was built, parity-tested and measured 0.95-0.98
+// of these kernels on its best shapes, 0.67-0.92 elsewhere: its vector segment (five LDS-DMA pieces at ~140 cycles of issue each beside a
+// partner streaming MFMAs) is longer than its matrix segment, and the form pays two barriers per tile.  Anatomy by ablation:
+// profiles/r06_attn_anti_phase.txt; the kernel, its tests and tools: tools/diag/variants/attn_fwd_anti_phase.patch)
 // (the one-wave-per-SIMD, 64-rows-per-wave forward of round 4 measured 1.5x slower on every shape of the model --
 // profiles/r04_attn_w64.txt -- and lives on as tools/diag/variants/attn_fwd64.hip, no longer part of the library)
 extern "C" int svit_attn_fwd(const svit_attn_fwd_args* a, void* stream) {

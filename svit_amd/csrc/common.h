@@ -53,8 +53,6 @@ enum SvitKnob {
   SVIT_K_ATTN_DKV_FORM,     // attention dkv kernel: 0 heuristic, 1 four waves, 2 eight waves with query halves
   SVIT_K_ATTN_FWD_SHORT,    // attention forward T' = 1 tile for Nk <= 64: 1 on (default), 0 generic kernel
   SVIT_K_POOL_FRAME,        // one-plane volumes (T = 1): conv + LayerNorm from an LDS-staged plane -- 1 (default) in no-grad passes (frames pass), 2 also when saving for a backward, 0 never
-  SVIT_K_ATTN_FWD_AP,       // attention forward, anti-phase 8-wave kernel: fewest 64-key tiles it takes (default 12: Nk >= 705), 0 never
-  SVIT_K_ATTN_FWD_AP_WGS,   // ... and the fewest 256-query workgroups of the launch (default 192)
   SVIT_K_COUNT
 };
 int svit_knob(int k);                 // misc.hip

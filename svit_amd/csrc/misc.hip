@@ -536,9 +536,8 @@ extern "C" int svit_table_interp(const float* M, int rows, int J, const float* t
 // ---- the knob table (common.h: SvitKnob) -----------------------------------------------------------------------
 static const int k_knob_default[SVIT_K_COUNT] = {
     /* NT_STAGES */ 0, /* NT_CFG */ -1, /* NT_BK */ 0, /* TN_STEP_US_X100 */ 85, /* TN_ATOMIC_TBS_X100 */ 75, /* TN_TILE */ 2,
-    /* POOL_FWD */ 2, /* POOL_BWD */ 1, /* POOL_FWD_LARGE */ 1, /* ATTN_DKV_FORM */ 0, /* ATTN_FWD_SHORT */ 1, /* POOL_FRAME */ 1,
-    /* ATTN_FWD_AP */ 0, /* ATTN_FWD_AP_WGS */ 192};
-static int g_knob[SVIT_K_COUNT] = {0, -1, 0, 85, 75, 2, 2, 1, 1, 0, 1, 1, 0, 192};     // (= k_knob_default; accessed through __atomic builtins)
+    /* POOL_FWD */ 2, /* POOL_BWD */ 1, /* POOL_FWD_LARGE */ 1, /* ATTN_DKV_FORM */ 0, /* ATTN_FWD_SHORT */ 1, /* POOL_FRAME */ 1};
+static int g_knob[SVIT_K_COUNT] = {0, -1, 0, 85, 75, 2, 2, 1, 1, 0, 1, 1};     // (= k_knob_default; accessed through __atomic builtins)
 int svit_knob(int k) { return __atomic_load_n(&g_knob[k], __ATOMIC_RELAXED); }
 int svit_knob_set(int k, int v) {
   if (k < 0 || k >= SVIT_K_COUNT) return SVIT_ERR_ARG;
@@ -573,8 +572,6 @@ extern "C" int svit_debug_set_pool(int key, int val) {
 extern "C" int svit_attn_debug_set(int key, int val) {
   if (key == 0) return (val >= 0 && val <= 2) ? svit_knob_set(SVIT_K_ATTN_DKV_FORM, val) : SVIT_ERR_ARG;
   if (key == 3) return (val == 0 || val == 1) ? svit_knob_set(SVIT_K_ATTN_FWD_SHORT, val) : SVIT_ERR_ARG;
-  if (key == 4) return (val >= 0 && val <= 4096) ? svit_knob_set(SVIT_K_ATTN_FWD_AP, val) : SVIT_ERR_ARG;
-  if (key == 5) return (val >= 0 && val <= 65536) ? svit_knob_set(SVIT_K_ATTN_FWD_AP_WGS, val) : SVIT_ERR_ARG;
   return SVIT_ERR_ARG;
 }
 extern "C" int svit_debug_reset(void) { svit_knob_reset(); return SVIT_OK; }

@@ -1200,72 +1200,6 @@ def test_attention_fwd_short_key_tile(ops, B, h, Nq, Nk, J):
     assert rel_err(lse2, torch.logsumexp(s, dim=-1) * math.log2(math.e)) < 1e-3
 
 
-@pytest.mark.parametrize("B,h,Nq,Nk,DA,J", [
-    (8, 4, 1633, 1633, 160, 36),   # block 3 of the step: 26 tiles (ragged, > 32 keys in the last), 9 k-steps, 224 workgroups
-    (2, 2, 700, 256, 128, 22),     # exactly 4 full tiles (the fewest the kernel takes), 8 k-steps, ragged query tile
-    (1, 2, 300, 276, 128, 15),     # 5 tiles, 20 keys in the last: the half-tile arm, 7 k-steps
-    (2, 1, 130, 300, 160, 64),     # 5 tiles, 44 keys in the last; every bias column (10 k-steps); fewer queries than one workgroup
-    (1, 1, 257, 913, 128, 30),     # C4's key count: 15 tiles, 17 keys in the last; one query in the second workgroup
-    (1, 3, 513, 457, 160, 29),     # 8 tiles at DA 160 with J <= 32 (8 k-steps)
-])
-def test_attention_fwd_anti_phase_kernel(ops, B, h, Nq, Nk, DA, J):
-    """Round 6: the anti-phase 8-wave forward (csrc/attn_fwd.hip::attn_fwd_ap_kernel -- halves of the workgroup alternate
-    matrix and vector segments, K / V rings four tiles deep, row sums on the vector ALU) forced on for every launch of
-    >= 4 key tiles: against the fp32 reference, and against the generic kernel on the same operands (same arithmetic but
-    for the row sum's summation order and its unrounded addends)."""
-    from svit_amd import hip
-    lib = hip.load()
-    scale = 96 ** -0.5
-    qa = rnd("apq%d_%d" % (Nq, DA), (B, h, Nq, DA), 1.0, BF16)
-    ka = rnd("apk%d_%d" % (Nk, DA), (B, h, Nk, DA), KSC, BF16)
-    v = rnd("apv%d" % Nk, (B, h, Nk, 96), 1.0, BF16)
-    if J:
-        qa[..., 96 + J:] = 0
-        ka[..., 96 + J:] = 0
-    try:
-        assert lib.svit_attn_debug_set(4, 0) == 0
-        ctx0, lse0 = ops.attn_fwd(qa, ka, v, scale, bias_cols=J)
-        torch.cuda.synchronize()
-        assert lib.svit_attn_debug_set(4, 1) == 0 and lib.svit_attn_debug_set(5, 0) == 0
-        ctx, lse2 = ops.attn_fwd(qa, ka, v, scale, bias_cols=J)
-        torch.cuda.synchronize()
-    finally:
-        lib.svit_debug_reset()
-    assert not torch.equal(lse2, lse0) or Nk < 256      # (the other kernel really ran)
-    ref, s = _attn_ref(qa.float().cpu(), ka.float().cpu(), v.float().cpu(), scale)
-    assert rel_err(ctx, ref) < 2e-2 and cos(ctx, ref) > 0.9999
-    assert rel_err(lse2, torch.logsumexp(s, dim=-1) * math.log2(math.e)) < 1e-3
-    assert rel_err(ctx, ctx0.float()) < 1e-2 and rel_err(lse2, lse0) < 1e-4
-
-
-def test_attention_fwd_anti_phase_rebase_and_ragged_reads(ops):
-    """The anti-phase kernel's re-base path (one key dominates late in the sweep: the running maximum jumps twice, O and
-    the vector-ALU row sum are rescaled) and its ragged last tile on NaN-filled K / V buffers (nothing is read past Nk)."""
-    from svit_amd import hip
-    lib = hip.load()
-    B, h, Nq, Nk, DA = 2, 2, 300, 470, 128
-    scale = 96 ** -0.5
-    qa = rnd("arq", (B, h, Nq, DA), 1.0, BF16)
-    kbuf = torch.full((B * h * Nk * DA + 64 * DA,), float("nan"), device=DEV, dtype=BF16)
-    vbuf = torch.full((B * h * Nk * 96 + 64 * 96,), float("nan"), device=DEV, dtype=BF16)
-    ka = kbuf[:B * h * Nk * DA].view(B, h, Nk, DA)
-    v = vbuf[:B * h * Nk * 96].view(B, h, Nk, 96)
-    ka.copy_(rnd("ark", (B, h, Nk, DA), KSC, BF16))
-    v.copy_(rnd("arv", (B, h, Nk, 96), 1.0, BF16))
-    ka[:, :, 150] = qa[:, :, 5] * (6 * KSC)
-    ka[:, :, 399] = qa[:, :, 9] * (9 * KSC)
-    try:
-        assert lib.svit_attn_debug_set(4, 1) == 0 and lib.svit_attn_debug_set(5, 0) == 0
-        ctx, lse2 = ops.attn_fwd(qa, ka, v, scale)
-        torch.cuda.synchronize()
-    finally:
-        lib.svit_debug_reset()
-    ref, s = _attn_ref(qa.cpu(), ka.cpu(), v.cpu(), scale)
-    assert bool(torch.isfinite(ctx.float()).all()) and bool(torch.isfinite(lse2).all())
-    assert rel_err(ctx, ref) < 2e-2
-    assert rel_err(lse2, torch.logsumexp(s, dim=-1) * math.log2(math.e)) < 1e-3
-
-
 @pytest.mark.parametrize("Nk,DA", [(9, 128), (54, 128), (100, 160), (457, 128)])
 def test_attention_ragged_tile_reads_nothing_past_the_keys(ops, Nk, DA):
     """K and V are views into larger NaN-filled buffers (including behind the LAST (batch, head)):

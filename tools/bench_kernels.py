@@ -158,36 +158,6 @@ def bench_attn_fwd():
           (tot_us, tot_alg / tot_us / 1e6, tot_alg / tot_us / 1e6 / 2500))
 
 
-def bench_attn_ap(cfg="c2"):
-    """round 6: forward per block shape, generic kernels (anti-phase knob off) against the anti-phase 8-wave kernel forced
-    on every shape (svit_attn_debug_set(4, 1), (5, 0)); the `attnap` mode of this tool."""
-    blocks, Bc = (BLOCKS_C4, 4) if cfg == "c4" else (BLOCKS, 8)
-    lib = hip.load()
-    print("== attention fwd, generic | anti-phase, %s B = %d ==" % (cfg, Bc))
-    for blk, Nin, Nq, Nk, Ci, Co, h, DA in blocks:
-        J = (30 if DA == 128 else 44) if cfg == "c4" else (22 if DA == 128 else 36)
-        qa, ka, v = rnd(Bc, h, Nq, DA), (rnd(Bc, h, Nk, DA).float() * KSC).to(BF16), rnd(Bc, h, Nk, 96)
-        qa[..., 96 + J:] = 0
-        ka[..., 96 + J:] = 0
-        scale = 96 ** -0.5
-        alg = 2.0 * Bc * h * Nq * Nk * 192
-        out = []
-        for ap in (0, 1, 0, 1):
-            lib.svit_attn_debug_set(4, ap)
-            lib.svit_attn_debug_set(5, 0)
-            out.append(timeit(lambda: ops.attn_fwd(qa, ka, v, scale, bias_cols=J), iters=50))
-        lib.svit_debug_reset()
-        g, a = min(out[0], out[2]), min(out[1], out[3])
-        wgs = (Nq + 255) // 256 * Bc * h
-        print("blk%-2d h=%d Nq=%6d Nk=%5d DA=%d  generic %7.1f us (%.3f)  anti-phase %7.1f us (%.3f)  x%.2f   [%d workgroups of 256 queries]" %
-              (blk, h, Nq, Nk, DA, g, alg / g / 1e6 / 2500, a, alg / a / 1e6 / 2500, g / a, wgs), flush=True)
-
-
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "attnap":
-    bench_attn_ap(sys.argv[2] if len(sys.argv) > 2 else "c2")
-    sys.exit(0)
-
-
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "attnfwd":
     hip.load()
     bench_attn_fwd()
