@@ -46,7 +46,7 @@ enum SvitKnob {
   SVIT_K_NT_BK,             // NT GEMM forced K-step: 32 / 64, 0 = heuristic
   SVIT_K_TN_STEP_US_X100,   // grouped TN planner: microseconds per k-step x 100
   SVIT_K_TN_ATOMIC_TBS_X100,  // grouped TN planner: TB/s of the fp32-atomic flush x 100
-  SVIT_K_TN_TILE,           // grouped TN tile mode: 0 128x96 only, 1 isolated-launch heuristic, 2 128x192 everywhere, 3 128x192 where K % 192 == 0, 4 256x192 on 8-wave workgroups (round 6)
+  SVIT_K_TN_TILE,           // grouped TN tile mode: 0 128x96 only, 1 isolated-launch heuristic, 2 128x192 everywhere, 3 128x192 where K % 192 == 0
   SVIT_K_POOL_FWD,          // small-plane pooling forward: 0 streaming, 1 VALU slab conv, 2 MFMA conv where ahead (default), 3 MFMA conv wherever it fits
   SVIT_K_POOL_BWD,          // small-plane pooling backward: 0 the three streaming launches, 1 (default) the fused plane-walk kernel where it fits
   SVIT_K_POOL_FWD_LARGE,    // large-plane pooling forward (blocks 0-3): 1 (default) staged conv + row-wise LayerNorm launch, 0 the streaming kernel

@@ -79,13 +79,6 @@ using TnSmallD = TnDma<1, 4, 1, 64, 2>;     // 128 x 96 tiles, 64 rows per stage
 #endif
 using TnBigD = TnDma<2, 2, 2, SVIT_TN_BIG_BM, SVIT_TN_BIG_NS>;       // 128 x 192 tiles, 32 rows per stage, 3 stages (60 KB)
 constexpr int TN_DMA_LDS = 2 * TnSmallD::STAGE > SVIT_TN_BIG_NS * TnBigD::STAGE ? 2 * TnSmallD::STAGE : SVIT_TN_BIG_NS * TnBigD::STAGE;
-// round 6: 256 x 192 tiles on EIGHT waves (4 along n x 2 along k, 64 x 96 per wave as in the 128 x 192 tile), 64 reduction rows
-// per stage, 2 stages (112 KB: one workgroup per CU, two waves per SIMD as before).  The grouped launch is paced by the
-// bytes it pulls L2 -> LDS per flop (rounds 4-5: FETCH 1.6x the operands, three workgroups per CU slower): this tile
-// re-reads the X panel once per 256 output rows instead of once per 128 -- (256 + 192) / (256 x 192) against
-// (128 + 192) / (128 x 192) staged bytes per MAC, -30 % -- with the SAME 24 MFMAs per wave and 64 rows; unlike the 128 x 384
-// forms of round 4 it keeps dY's 192-column k tile (the longer operand rows are the ones that re-read least).
-using TnWideD = TnDma<2, 4, 2, 64, 2>;
 
 template <int OFF>
 __device__ __forceinline__ void tn_read_tr(s16x4_t& d, unsigned addr) {
@@ -333,27 +326,6 @@ __global__ __launch_bounds__(256, SVIT_TN_WPE) void gemm_tn_grouped_kernel(const
                           p.dbias, tk == 0);
 }
 
-// the same grid logic on 8-wave workgroups and 256 x 192 tiles for EVERY problem of the group (narrow problems -- the rel-pos
-// table gradients, N < 256 -- run on clamped, partly idle tiles: they are a few per cent of a group's rows)
-__global__ __launch_bounds__(512, 1) void gemm_tn_grouped_wide_kernel(const TnGroup g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
-  const int nwg = gridDim.x, lin = blockIdx.x;
-  const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
-  int pi = 0;
-  const int bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
-#pragma unroll
-  for (int i = 1; i < SVIT_TN_GROUP_MAX; ++i)
-    if (i < g.count && bid >= g.first_block[i]) pi = i;
-  const int local = bid - g.first_block[pi];
-  const int tile = local % g.tiles[pi], split = local / g.tiles[pi];
-  const svit_tn_problem& p = g.p[pi];
-  const int tn = tile % g.tiles_n[pi], tk = tile / g.tiles_n[pi];
-  const int m_begin = split * g.rows_per_split[pi];
-  tn_tile_dma<TnWideD>(lds_dyn, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.dW, p.lddw, p.M, p.N, p.K,
-                       tn * TnWideD::TN, tk * TnWideD::TK, m_begin, min(p.M, m_begin + g.rows_per_split[pi]),
-                       p.dbias, tk == 0);
-}
-
 __global__ void colsum_kernel(const bf16_t* __restrict__ A, int lda, float* __restrict__ out,
                               int M, int N, int rows_per_block) {
   // block (64 x 4): lane -> 2 adjacent columns (one dword), 4 row phases; grid.x = column
@@ -460,10 +432,8 @@ static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void
     g.count = count - base < SVIT_TN_GROUP_MAX ? count - base : SVIT_TN_GROUP_MAX;
     long max_steps = 1;
     const int big_mode = svit_knob(SVIT_K_TN_TILE);
-    const bool wide = big_mode == 4;   // 256 x 192 tiles on 8-wave workgroups, every problem of the group
-    // (a 64-row step of the wide tile = two 32-row steps of the 128 x 192 tile on the same eight waves per CU)
-    const double step_us = svit_knob(SVIT_K_TN_STEP_US_X100) * 0.01 * (wide ? 2.0 : 1.0), atomic_tbs = svit_knob(SVIT_K_TN_ATOMIC_TBS_X100) * 0.01;
-    const long slots = wide ? 256 : 512;      // resident workgroups the planner counts on
+    const double step_us = svit_knob(SVIT_K_TN_STEP_US_X100) * 0.01, atomic_tbs = svit_knob(SVIT_K_TN_ATOMIC_TBS_X100) * 0.01;
+    constexpr long slots = 512;      // resident 4-wave workgroups the planner counts on
     int bm[SVIT_TN_GROUP_MAX];
     double tile_bytes[SVIT_TN_GROUP_MAX];
     for (int i = 0; i < g.count; ++i) {
@@ -477,8 +447,8 @@ static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void
                                   (g.p[i].M <= 4096 || (g.p[i].M >= 32768 && g.p[i].M < 131072)))
                  : big_mode == 3 ? (g.p[i].K % TnBig::TK == 0 && g.p[i].N >= 128)
                                  : (big_mode == 2);
-      const int tn = wide ? TnWideD::TN : g.big[i] ? TnBig::TN : TnSmall::TN, tk = wide ? TnWideD::TK : g.big[i] ? TnBig::TK : TnSmall::TK;
-      bm[i] = wide ? TnWideD::BM : g.big[i] ? TnBigD::BM : TnSmall::BM;
+      const int tn = g.big[i] ? TnBig::TN : TnSmall::TN, tk = g.big[i] ? TnBig::TK : TnSmall::TK;
+      bm[i] = g.big[i] ? TnBigD::BM : TnSmall::BM;
       tile_bytes[i] = (double)tn * tk * 4.0;
       g.tiles_n[i] = (g.p[i].N + tn - 1) / tn;
       g.tiles[i] = g.tiles_n[i] * ((g.p[i].K + tk - 1) / tk);
@@ -513,14 +483,7 @@ static int tn_grouped(const svit_tn_problem* probs, int count, int ordered, void
       total += g.tiles[i] * splits;
     }
     for (int i = g.count; i <= SVIT_TN_GROUP_MAX; ++i) g.first_block[i] = total;
-    if (wide) {
-      constexpr size_t lds_wide = (size_t)TnWideD::NS * TnWideD::STAGE;
-      static SvitOnce once;
-      if (int rc = svit_max_lds_once(once, (const void*)gemm_tn_grouped_wide_kernel, lds_wide)) return rc;
-      hipLaunchKernelGGL(gemm_tn_grouped_wide_kernel, dim3(total), dim3(512), lds_wide, (hipStream_t)stream, g);
-    } else {
-      hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, g);
-    }
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, g);
     SVIT_LAUNCH_CHECK();
   }
   return SVIT_OK;

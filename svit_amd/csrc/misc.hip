@@ -560,7 +560,7 @@ extern "C" int svit_debug_set_tn(int step_us_x100, int atomic_tbs_x100) {
   return SVIT_OK;
 }
 extern "C" int svit_debug_set_tn_tile(int mode) {
-  return (mode >= 0 && mode <= 4) ? svit_knob_set(SVIT_K_TN_TILE, mode) : SVIT_ERR_ARG;
+  return (mode >= 0 && mode <= 3) ? svit_knob_set(SVIT_K_TN_TILE, mode) : SVIT_ERR_ARG;
 }
 extern "C" int svit_debug_set_pool(int key, int val) {
   if (key == 0) return (val >= 0 && val <= 3) ? svit_knob_set(SVIT_K_POOL_FWD, val) : SVIT_ERR_ARG;

@@ -161,12 +161,12 @@ def test_gemm_tn(ops, M, N, K, splits):
     assert rel_err(db, a.float().sum(0) + 1.0) < 2e-4
 
 
-@pytest.mark.parametrize("tile_mode", [1, 0, 2, 4])
+@pytest.mark.parametrize("tile_mode", [1, 0, 2])
 @pytest.mark.parametrize("count", [1, 5, 11])
 def test_gemm_tn_grouped(ops, count, tile_mode):
     """several wgrads per launch (incl. strided column slices, K tail inside a padded ldb, no
     bias) == the same GEMMs one by one; tile_mode: 1 = the heuristic (128x192 tiles where K is a
-    multiple of 192), 0 = 128x96 everywhere, 2 = 128x192 everywhere (partial tiles masked), 4 = 256x192 tiles on 8-wave workgroups (round 6)"""
+    multiple of 192), 0 = 128x96 everywhere, 2 = 128x192 everywhere (partial tiles masked)"""
     import ctypes as C
     from svit_amd import hip
     lib = hip.load()
