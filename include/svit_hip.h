@@ -466,9 +466,12 @@ int svit_debug_set_tn_tile(int mode);
  * key 1 = conv backward: 1 (default) the fused plane-walk kernel (conv dgrad + conv wgrad in one launch) where it fits,
  * 0 the two streaming launches; key 2 = forward of the planes past 14x14 (blocks 0-3): 1 (default) the staged conv (input
  * staged once in LDS) + the row-wise LayerNorm launch, 0 the streaming kernel; key 3 = one-plane volumes (T = 1):
- * conv + LayerNorm in one launch from an LDS-staged plane -- 1 (default) in no-grad passes (the frames pass), 2 also where
- * pre / mean / rstd are saved for a backward (image ranks), 0 never. */
+ * conv + LayerNorm in one launch from an LDS-staged plane -- 2 (default since round 6) in every T = 1 pass, also where
+ * pre / mean / rstd are saved for a backward (image ranks), 1 in no-grad passes only (the frames pass), 0 never. */
 int svit_debug_set_pool(int key, int val);
+/* which path the last svit_pool_conv_bwd_qkv call took: 1 = the fused plane-walk kernel, 0 = the two streaming launches (planes that
+ * do not fit its LDS plan, a workspace smaller than the plan's partial rows, key 1 = 0), -1 = no call yet. */
+int svit_debug_pool_bwd_path(void);
 /* attention: key 0 = dkv kernel form (0 heuristic, 1 four waves, 2 eight waves with query halves), key 3 = the
  * forward's T' = 1 tile for Nk <= 64 (1 on (default), 0 the generic kernel). */
 int svit_attn_debug_set(int key, int val);

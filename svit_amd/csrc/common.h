@@ -52,7 +52,7 @@ enum SvitKnob {
   SVIT_K_POOL_FWD_LARGE,    // large-plane pooling forward (blocks 0-3): 1 (default) staged conv + row-wise LayerNorm launch, 0 the streaming kernel
   SVIT_K_ATTN_DKV_FORM,     // attention dkv kernel: 0 heuristic, 1 four waves, 2 eight waves with query halves
   SVIT_K_ATTN_FWD_SHORT,    // attention forward T' = 1 tile for Nk <= 64: 1 on (default), 0 generic kernel
-  SVIT_K_POOL_FRAME,        // one-plane volumes (T = 1): conv + LayerNorm from an LDS-staged plane -- 1 (default) in no-grad passes (frames pass), 2 also when saving for a backward, 0 never
+  SVIT_K_POOL_FRAME,        // one-plane volumes (T = 1): conv + LayerNorm from an LDS-staged plane -- 2 (default since round 6) every T = 1 pass, 1 no-grad passes only (frames pass), 0 never
   SVIT_K_COUNT
 };
 int svit_knob(int k);                 // misc.hip

@@ -536,8 +536,8 @@ extern "C" int svit_table_interp(const float* M, int rows, int J, const float* t
 // ---- the knob table (common.h: SvitKnob) -----------------------------------------------------------------------
 static const int k_knob_default[SVIT_K_COUNT] = {
     /* NT_STAGES */ 0, /* NT_CFG */ -1, /* NT_BK */ 0, /* TN_STEP_US_X100 */ 85, /* TN_ATOMIC_TBS_X100 */ 75, /* TN_TILE */ 2,
-    /* POOL_FWD */ 2, /* POOL_BWD */ 1, /* POOL_FWD_LARGE */ 1, /* ATTN_DKV_FORM */ 0, /* ATTN_FWD_SHORT */ 1, /* POOL_FRAME */ 1};
-static int g_knob[SVIT_K_COUNT] = {0, -1, 0, 85, 75, 2, 2, 1, 1, 0, 1, 1};     // (= k_knob_default; accessed through __atomic builtins)
+    /* POOL_FWD */ 2, /* POOL_BWD */ 1, /* POOL_FWD_LARGE */ 1, /* ATTN_DKV_FORM */ 0, /* ATTN_FWD_SHORT */ 1, /* POOL_FRAME */ 2};
+static int g_knob[SVIT_K_COUNT] = {0, -1, 0, 85, 75, 2, 2, 1, 1, 0, 1, 2};     // (= k_knob_default; accessed through __atomic builtins)
 int svit_knob(int k) { return __atomic_load_n(&g_knob[k], __ATOMIC_RELAXED); }
 int svit_knob_set(int k, int v) {
   if (k < 0 || k >= SVIT_K_COUNT) return SVIT_ERR_ARG;

@@ -360,6 +360,11 @@ class Engine:
         y16, y32, mean, rstd = ops.layernorm_fwd(x, f.p("norm.weight"), f.p("norm.bias"),
                                                  want_f32=True, want_bf16=False, save_stats=save)
         st.update(x_last=x if save else None, mean=mean, rstd=rstd, thw=thw)
+        # the batched interpolation results belong to THIS pass: a stand-alone _block_fwd afterwards (tests, tools) interpolates
+        # its own tables.  The fp32 / bf16 buffers are cached per (geometry, save) and the saved `tabs` of a pass are views of
+        # them: at most ONE saved forward per geometry may be awaiting its backward (the step's passes all differ in geometry
+        # or in `save`; two saved forwards of one geometry with a weight update between them would share the operand).
+        self._interp_out = {}
         return y32, st
 
     def _block_fwd(self, blk, x, thw, n_obj, ds, save):

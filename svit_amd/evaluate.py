@@ -67,9 +67,13 @@ class TestMeter:
                  0 if self.ensemble_method == "sum" else 1, int(repeat), ptr(self.video_preds),
                  ptr(self.video_labels), ptr(self.clip_count), ptr(self.errors))
 
-    def all_reduce(self, group=None):
-        """Merge the accumulators of data-parallel ranks (each saw a disjoint set of clips)."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    def all_reduce(self, group=None, force=False):
+        """Merge the accumulators of data-parallel ranks (each saw a disjoint set of clips).  `force`: launch the four
+        collectives on a one-rank group too (a rehearsal switch like DataParallel(force_collectives=True): the production
+        backend's merge runs on the one GPU a test box has; SUM / MAX over one rank are the identity)."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        if dist.get_world_size(group) == 1 and not force:
             return
         op = dist.ReduceOp.SUM if self.ensemble_method == "sum" else dist.ReduceOp.MAX
         dist.all_reduce(self.video_preds, op=op, group=group)
@@ -147,7 +151,7 @@ def spatial_crops(video, size, num_crops=3):
 
 
 @torch.no_grad()
-def perform_test(test_loader, model, test_meter, cfg, dedupe=True):
+def perform_test(test_loader, model, test_meter, cfg, dedupe=True, force_collectives=False):
     """tools/test_net.py:25-170, classification branch.  `test_loader` yields
     (inputs, labels, video_idx, meta) like the reference's loader; with `dedupe` it is expected to
     yield only the unique views (clip index = video * NUM_SPATIAL_CROPS + crop) and the meter is
@@ -160,6 +164,6 @@ def perform_test(test_loader, model, test_meter, cfg, dedupe=True):
         if isinstance(preds, tuple):
             preds, _extra = preds
         test_meter.update_stats(preds, labels, video_idx, repeat=repeat)
-    test_meter.all_reduce()
+    test_meter.all_reduce(force=force_collectives)
     test_meter.finalize_metrics(ks=ks)
     return test_meter

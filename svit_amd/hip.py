@@ -180,6 +180,7 @@ _SIGS = {
     "svit_debug_set_pool": (i32, [i32, i32]),
     "svit_attn_debug_set": (i32, [i32, i32]),
     "svit_debug_reset": (i32, []),
+    "svit_debug_pool_bwd_path": (i32, []),
 }
 EXPORTS = tuple(sorted(_SIGS))
 

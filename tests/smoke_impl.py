@@ -74,6 +74,7 @@ def compare_step(num_frames=4, crop=64, batch=2, frames_path=False, verbose=Fals
     # absolute criterion that follows each tensor's own measured bf16 noise and sample count
     # (a [15, 96] rel-pos table with cosine 0.993 gets 3 % + 1.3 %, a 2-D weight 3 % + ~0).
     scale_excess, scale_name, scale_worst = -1.0, "", (1.0, 0.0)
+    per_tensor = {}
     ref_total = sum(float((v.grad.double() ** 2).sum()) for v in p.values() if v.grad is not None) ** 0.5
     num = den_a = den_b = 0.0
     for k, v in p.items():
@@ -87,6 +88,7 @@ def compare_step(num_frames=4, crop=64, batch=2, frames_path=False, verbose=Fals
             assert float(got.abs().max()) < 2e-2 * gmax, (k, float(got.abs().max()), gmax)
             continue
         c = cosine(got, ref)
+        per_tensor[k] = c
         if c < worst:
             worst, worst_name = c, k
         rn = float(ref.double().norm())
@@ -99,6 +101,7 @@ def compare_step(num_frames=4, crop=64, batch=2, frames_path=False, verbose=Fals
             print("%-40s cos %.5f  scale %.4f (tol %.4f)  |ref| %.3e |got| %.3e"
                   % (k, c, sc, tol, float(ref.norm()), float(got.norm())))
     out["grad_cos_worst"] = worst
+    out["grad_cos_per_tensor"] = per_tensor
     out["grad_cos_worst_name"] = worst_name
     out["grad_cos_global"] = num / ((den_a ** 0.5) * (den_b ** 0.5) + 1e-30)
     out["grad_scale_excess"] = scale_excess            # <= 0: every tensor's scale is inside its band
@@ -117,11 +120,43 @@ TOL = {"logits_maxabs": 0.05, "logits_cos": 0.999, "grad_cos": 0.99, "obj_desc_c
        "grad_scale": SCALE_TOL, "grad_norm_ratio_global": (0.99, 1.01)}
 
 
-def check(res):
+# Per-tensor gradient criterion where the golden manifest holds a YARDSTICK for the case (round 6):
+# manifest["yardstick"]["cases"][name]["autocast_emulation_cos"][tensor] = cosine, against the fp32 reference, of the REFERENCE's own
+# backward with every matrix op's operands and results rounded to bf16 (oracle/ref_shim.py::autocast_emulation) -- what a correct
+# bf16-GEMM implementation scores.  The HIP path must stay within YARD_RATIO x that noise power per tensor (+ an absolute floor for
+# tensors both compute almost exactly).  Measured on MI355X (profiles/r06_yardstick.txt): median ratio 0.8-0.9, maximum 2.0 over the
+# 405 tensors of the four cases; the rel-pos tables -- always the worst tensors of a step -- read 0.9938 / 0.9950 / 0.9917 / 0.9893
+# against the yardstick's 0.9930 / 0.9951 / 0.9932 / 0.9789 (c2, tiny, tiny_frames, tiny_image).  Cases without a yardstick keep
+# the flat per-tensor bar TOL["grad_cos"].
+YARD_RATIO, YARD_FLOOR = 3.0, 2e-4
+YARD_CASES = {(4, 64, 2, False, False): "tiny", (4, 64, 3, True, False): "tiny_frames", (4, 64, 3, False, True): "tiny_image",
+              (16, 224, 1, False, False): "c2"}
+
+
+def yardstick_for(num_frames, crop, batch, frames_path=False, image=False):
+    """the manifest's yardstick case for these step arguments, or None"""
+    import json
+    import os
+    name = YARD_CASES.get((num_frames, crop, batch, bool(frames_path), bool(image)))
+    if name is None:
+        return None
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manifest.json")
+    with open(path) as f:
+        return json.load(f)["yardstick"]["cases"][name]
+
+
+def check(res, yardstick=None):
     assert res["logits_maxabs"] <= TOL["logits_maxabs"], res
     assert res["logits_cos"] >= TOL["logits_cos"], res
     assert res["obj_desc_cos"] >= TOL["obj_desc_cos"], res
-    assert res["grad_cos_worst"] >= TOL["grad_cos"], res
+    if yardstick is None:
+        assert res["grad_cos_worst"] >= TOL["grad_cos"], res
+    else:
+        yc = yardstick["autocast_emulation_cos"]
+        bad = [(k, c, yc[k]) for k, c in res["grad_cos_per_tensor"].items()
+               if k in yc and (1.0 - c) > YARD_RATIO * (1.0 - yc[k]) + YARD_FLOOR]
+        assert not bad, ("gradient tensors noisier than %.1f x the bf16 yardstick" % YARD_RATIO, bad[:8])
+        assert res["grad_cos_worst"] >= 0.97, res        # (a backstop no tensor of any case comes near)
     assert res["grad_cos_global"] >= 0.995, res
     assert res["grad_scale_excess"] <= 0.0, res
     lo, hi = TOL["grad_norm_ratio_global"]
@@ -130,5 +165,5 @@ def check(res):
 
 def run():
     res = compare_step(4, 64, 2)
-    print("smoke:", res)
-    check(res)
+    print("smoke:", {k: v for k, v in res.items() if k != "grad_cos_per_tensor"})
+    check(res, yardstick_for(4, 64, 2))

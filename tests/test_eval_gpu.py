@@ -173,6 +173,59 @@ def test_two_ranks_merge_with_one_allreduce(tmp_path, golden_dir, manifest):
     assert res["stats"]["top1_acc"] == want["top1_acc"] and res["stats"]["top5_acc"] == want["top5_acc"]
 
 
+def _rccl_eval_worker(port, out, use_rccl):
+    """perform_test of a tiny model on 3 videos x 3 crops; with `use_rccl` inside a ONE-rank process group of the production
+    backend (nccl = RCCL) with the meter's merge forced."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    if use_rccl:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from svit_amd import evaluate
+    cfg, model, spec, sd = S.build_hip_model(4, 64, train=False)
+    V, crops = 3, cfg.TEST.NUM_SPATIAL_CROPS
+    wide = P.tensor("input:wide", (V, 3, 4, 64, 85), amp=1.0)
+    labels_v = torch.tensor([5, 17, 101])
+    clips = evaluate.spatial_crops(wide.cuda(), 64, crops)
+    ids = torch.arange(V * crops)
+    loader = [([clips[a:a + 4]], labels_v[ids[a:a + 4] // crops].cuda(), ids[a:a + 4].cuda(), {})
+              for a in range(0, V * crops, 4)]
+    meter = evaluate.TestMeter(V, crops, cfg.MODEL.NUM_CLASSES, len(loader))
+    evaluate.perform_test(loader, model, meter, cfg, force_collectives=use_rccl)
+    info = {"preds": meter.video_preds.cpu(), "count": meter.clip_count.cpu(), "labels": meter.video_labels.cpu(),
+            "stats": meter.stats, "backend": dist.get_backend() if use_rccl else "none"}
+    if use_rccl:
+        info["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        dist.barrier()
+        dist.destroy_process_group()
+    torch.save(info, out)
+
+
+def test_eval_leg_on_the_production_backend_with_one_rank(tmp_path):
+    """Round 6: the eval leg of BASELINE config C5 -- `perform_test`'s end-of-loop merge of the device-resident
+    ensemble (tools/test_net.py:128-150 replaced by ONE set of all-reduces, TestMeter.all_reduce) -- executed on the production
+    backend: init_process_group("nccl", world_size=1, device_id=...) in a child process, the four collectives (SUM of the
+    per-video scores and clip counts, MAX of the labels, SUM of the error flags) forced on the one-rank group.  A merge over one
+    rank is the identity: scores, counts, labels and the top-k strings must be BIT-equal to the same loop with no process
+    group.  Says that RCCL accepts the meter's dtypes / ops (fp32 SUM, int64 SUM / MAX, int32 SUM) beside libsvit_hip.so;
+    N > 1 over xGMI stays the driver's to run."""
+    ctx = mp.get_context("spawn")
+    outs = {}
+    for use_rccl in (False, True):
+        out = str(tmp_path / ("ev%d.pt" % use_rccl))
+        p = ctx.Process(target=_rccl_eval_worker, args=(_free_port(), out, use_rccl))
+        p.start()
+        p.join(600)
+        assert p.exitcode == 0, (use_rccl, p.exitcode)
+        outs[use_rccl] = torch.load(out)
+    a, b = outs[False], outs[True]
+    assert b["backend"] == "nccl" and b["nccl_version"]
+    assert torch.equal(a["preds"], b["preds"]) and torch.equal(a["count"], b["count"]) and torch.equal(a["labels"], b["labels"])
+    assert a["stats"] == b["stats"] and int(b["count"].min()) == 30
+
+
 def test_uint8_frames_equal_reference_normalised_clips():
     """model([U8Clips]) == model([fp32 crops normalised like
     datasets/utils.py:287-303]) -- identical patch-embed operand, hence identical probabilities --

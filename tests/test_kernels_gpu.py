@@ -501,6 +501,7 @@ def test_pool_conv_bwd_fused_small_planes(ops, sq, skv, thw, B, h):
     d_got = torch.full_like(qkv, 7.0)                       # every element must be overwritten
     dw_got = [torch.full((96, 27), 0.5, device=DEV) for _ in range(3)]
     ops.pool_conv_bwd_qkv(dpres, ws, d_got, qkv, dw_got, B, h, thw, O, strides)
+    assert lib.svit_debug_pool_bwd_path() == 1, "the fused kernel did not run (silent fallback to the streaming launches)"
     assert rel_err(d_got.float(), d_ref.float()) < 1e-2
     assert float((d_got.float() - d_ref.float()).abs().max()) < 0.05 * float(d_ref.float().abs().max())
     for i in range(3):
@@ -511,6 +512,7 @@ def test_pool_conv_bwd_fused_small_planes(ops, sq, skv, thw, B, h):
         d_off = torch.full_like(qkv, 7.0)
         dw_off = [torch.zeros((96, 27), device=DEV) for _ in range(3)]
         ops.pool_conv_bwd_qkv(dpres, ws, d_off, qkv, dw_off, B, h, thw, O, strides)
+        assert lib.svit_debug_pool_bwd_path() == 0
         assert torch.equal(d_off, d_ref)
     finally:
         lib.svit_debug_reset()
@@ -553,6 +555,8 @@ def test_pool_backward_vs_oracle_at_the_step_shapes(ops, sq, skv, thw, h):
     dqkv = torch.full_like(qkv, 7.0)
     dws = [torch.zeros((96, 27), device=DEV) for _ in range(3)]
     ops.pool_conv_bwd_qkv(dpres, ws, dqkv, qkv, dws, B, h, thw, O, strides)
+    from svit_amd import hip
+    assert hip.load().svit_debug_pool_bwd_path() == 1, "the step's shapes must take the fused kernel"
     for i in range(3):
         gx, gw, gg, gb = refs[i]
         got = dqkv[:, :, i].permute(0, 2, 1, 3)

@@ -26,8 +26,10 @@ from tests import smoke_impl as S
 ])
 def test_step_parity_vs_oracle(frames, crop, batch, frames_path):
     res = S.compare_step(frames, crop, batch, frames_path)
-    print(res)
-    S.check(res)
+    print({k: v for k, v in res.items() if k != "grad_cos_per_tensor"})
+    # per-tensor gradient bar: the manifest's bf16 yardstick where the case has one (tiny, the T = 1 path, the headline clip),
+    # the flat 0.99 elsewhere (tests/smoke_impl.py::check)
+    S.check(res, S.yardstick_for(frames, crop, batch, frames_path))
 
 
 def test_image_rank_step_parity_vs_oracle():
@@ -35,8 +37,8 @@ def test_image_rank_step_parity_vs_oracle():
     (fused svit_haog_loss) -- losses and every parameter gradient against the fp32 oracle, whose
     image loss is itself pinned by the reference's numbers (tests/test_oracle_golden.py)."""
     res = S.compare_step(4, 64, 3, image=True)
-    print(res)
-    S.check(res)
+    print({k: v for k, v in res.items() if k != "grad_cos_per_tensor"})
+    S.check(res, S.yardstick_for(4, 64, 3, image=True))
     assert res["loss_rel"] < 2e-2, res
     assert all(v < 2e-2 for v in res["parts_abs"].values()), res
 

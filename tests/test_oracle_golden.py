@@ -412,3 +412,51 @@ def test_reference_yaml_merges_to_the_recorded_tree(golden_dir):
             assert got == v, (sec, k, got, v)
             assert want[sec][k] == v
     assert cfg.NUM_GPUS == 8 and "AUG" in cfg and "MIXUP" in cfg
+
+
+def test_bf16_yardstick_is_recorded(manifest):
+    """Round 6: the golden manifest carries, for the four step cases the GPU parity tests use it for, the per-tensor cosine of the
+    REFERENCE's own backward under bf16 matrix operands against its fp32 backward (oracle/gen_golden.py::run_yardstick_cases) --
+    the noise floor tests/smoke_impl.py::check measures the HIP path against.  Here: present, complete, and in the band a bf16
+    step lives in (every tensor >= 0.97, the worst tensors are rel-pos tables, the global cosine >= 0.99)."""
+    from tests import smoke_impl as S
+    y = manifest["yardstick"]["cases"]
+    assert set(y) == {"tiny", "tiny_frames", "tiny_image", "c2"}
+    for name, c in y.items():
+        cos = c["autocast_emulation_cos"]
+        assert len(cos) >= 370, (name, len(cos))             # 405 tensors minus the mathematically-zero gradients (norm_k.bias, unused heads)
+        assert min(cos.values()) >= 0.97 and max(cos.values()) <= 1.0 + 1e-9, (name, min(cos.values()))
+        assert "rel_pos" in c["grad_cos_worst"][0], c["grad_cos_worst"]
+        assert c["grad_cos_global"] >= 0.99 and c["rounded_ops"] > 100
+    # the test-side lookup finds exactly these cases
+    assert S.yardstick_for(4, 64, 2) is y["tiny"] or S.yardstick_for(4, 64, 2) == y["tiny"]
+    assert S.yardstick_for(4, 64, 3, frames_path=True) == y["tiny_frames"]
+    assert S.yardstick_for(4, 64, 3, image=True) == y["tiny_image"]
+    assert S.yardstick_for(16, 224, 1) == y["c2"] and S.yardstick_for(8, 224, 1) is None
+
+
+def test_autocast_emulation_rounds_matrix_ops_only():
+    """oracle/ref_shim.py::autocast_emulation (the yardstick's mode): linear / matmul / einsum / conv3d see bf16-rounded operands,
+    return bf16-rounded results and bf16-rounded gradients; everything else stays fp32."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import ref_shim
+    torch.manual_seed(0)
+    x = torch.randn(5, 16, requires_grad=True)
+    w = torch.randn(8, 16, requires_grad=True)
+    r = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    mode = ref_shim.autocast_emulation()
+    with mode:
+        y = F.linear(x, w)
+        z = (x @ w.t()) + 1.0 / 3.0            # the add is not a matrix op: not re-rounded
+        e = torch.einsum("ik,jk->ij", x, w)
+        s = torch.softmax(x, -1)
+    assert type(mode).calls == 3
+    ref = r(F.linear(r(x), r(w)))
+    assert torch.equal(y, ref) and torch.equal(e, ref) and torch.equal(z, ref + 1.0 / 3.0)
+    assert torch.equal(s, torch.softmax(x, -1))
+    g = torch.randn_like(y)
+    y.backward(g)
+    gx = r(r(g) @ r(w).detach())
+    assert torch.equal(x.grad, gx)
+    assert torch.equal(w.grad, r(r(g).t() @ r(x).detach()))

@@ -9,6 +9,17 @@ against the serial pair, per block shape.  (Timing only: the dkv launches read t
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
+
+def _need_bwd_only_switch(lib):
+    """svit_attn_debug_set(2, m) ("run only one of the two backward kernels") left every library in round 5 -- the
+    product refuses it, the diagnostic builds select the kernel at COMPILE time (-DSVIT_DIAG_BWD_ONLY=1 dq / 2 dkv).  Without the
+    switch this tool would print "dq only" / "dkv only" timings that are really both kernels: refuse to run instead."""
+    import sys
+    if lib.svit_attn_debug_set(2, 0) != 0:
+        sys.exit("%s: the loaded library has no run-one-backward-kernel switch (svit_attn_debug_set(2, .) -> SVIT_ERR_ARG); "
+                 "time the -DSVIT_DIAG_BWD_ONLY=1 / =2 variants of tools/diag/build_variant.py with tools/bench_kernels.py attn "
+                 "instead.  Not producing numbers." % sys.argv[0])
+
 import torch
 from svit_amd import ops, hip
 from tools.bench_kernels import rnd, BLOCKS, BLOCKS_C4, KSC, BF16
@@ -16,6 +27,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 blocks, B = (BLOCKS_C4, 4) if cfg == "c4" else (BLOCKS, 8)
 lib = hip.load()
 lib.svit_attn_debug_set.restype, lib.svit_attn_debug_set.argtypes = C.c_int32, [C.c_int32, C.c_int32]
+_need_bwd_only_switch(lib)
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 tot = [0.0, 0.0]
 for blk, Nin, Nq, Nk, Ci, Co, h, DA in blocks:

@@ -12,6 +12,9 @@ from svit_amd.engine import rel_sections
 from oracle import svit_ref as R
 from tools.bench_kernels import rnd, timeit, KSC, BF16, DEV
 lib = hip.load()
+if lib.svit_attn_debug_set(2, 0) != 0:      # the run-one-backward-kernel switch left every library in round 5
+    sys.exit("%s: the loaded library refuses svit_attn_debug_set(2, .): its 'dq only' / 'dkv only' timings would really be both kernels. "
+             "Time the -DSVIT_DIAG_BWD_ONLY=1 / =2 variants (tools/diag/build_variant.py) with tools/bench_kernels.py attn instead." % sys.argv[0])
 for (B, h, q_thw, k_thw, O) in [(8, 4, (8, 14, 14), (8, 7, 7), 64), (8, 4, (8, 14, 14), (8, 14, 14), 64)]:
     Lq, Lk = q_thw[0] * q_thw[1] * q_thw[2], k_thw[0] * k_thw[1] * k_thw[2]
     Nq, Nk, J = 1 + Lq + O, 1 + Lk + O, sum(k_thw)

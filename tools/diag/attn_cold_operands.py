@@ -11,6 +11,9 @@ import torch
 from svit_amd import hip, ops
 from tools.bench_kernels import rnd, KSC, BF16, DEV
 lib = hip.load()
+if lib.svit_attn_debug_set(2, 0) != 0:      # the run-one-backward-kernel switch left every library in round 5
+    sys.exit("%s: the loaded library refuses svit_attn_debug_set(2, .): its 'dq only' / 'dkv only' timings would really be both kernels. "
+             "Time the -DSVIT_DIAG_BWD_ONLY=1 / =2 variants (tools/diag/build_variant.py) with tools/bench_kernels.py attn instead." % sys.argv[0])
 B, h, Nq, Nk, DA, J = 8, 4, 1633, 457, 128, 22
 qa, ka, v = rnd(B, h, Nq, DA), (rnd(B, h, Nk, DA).float() * KSC).to(BF16), rnd(B, h, Nk, 96)
 qa[..., 96 + J:] = 0; ka[..., 96 + J:] = 0

@@ -11,7 +11,8 @@ fam_of = lambda k: ("svit_gemm_nt" if "gemm_nt_v2" in k or "gemm_nt_ring" in k e
                     "svit_attn_fwd" if "attn_fwd_kernel" in k or "attn_fwd2_kernel" in k else
                     "svit_attn_bwd" if "attn_bwd_" in k else
                     "svit_gemm_tn_grouped" if "gemm_tn_grouped" in k else
-                    "svit_pool_ln_fwd_qkv" if "pool_ln_fwd3" in k else
+                    "svit_pool_ln_fwd_qkv" if any(t in k for t in ("pool_ln_fwd3", "pool_fwd_staged", "pool_slab_", "pool_mfma_fwd",
+                                                                    "pool_frame_fwd")) else
                     "svit_pool_conv_bwd_qkv" if "pool_dgrad3" in k or "pool_wgrad3" in k or "pool_bwd_fused" in k else None)
 agg = {}
 for line in open(src):
