@@ -326,8 +326,10 @@ def main():
     else:
         x, y = synth_batch(cfg, args.batch, dev, seed=cfg.RNG_SEED + rank)
 
-        def ce(preds, extra, labels):
-            return torch.nn.functional.cross_entropy(preds, labels)
+        from svit_amd import losses
+
+        def ce(preds, extra, labels):            # VideoImageLoss's loss_ce on a video rank (one launch each way since round 6)
+            return losses.cross_entropy(preds, labels)
     if args.u8:
         if is_image or args.frames_pass:
             raise SystemExit("--u8 is wired for the clip step only")

@@ -427,6 +427,19 @@ int svit_haog_loss_bwd(const float* upstream, const float* g_l1, const float* g_
                        const float* g_giou, const float* g_contact, float* dpred,
                        float* dcontact, int R, int Rc, void* stream);
 
+/* Video-rank classification loss (round 6): nn.CrossEntropyLoss(reduction="mean") of VideoImageLoss
+ * (slowfast/models/losses.py:121,158) and its unit gradient in one launch -- replaces log_softmax + nll_loss and their
+ * backward kernels.  logits f32 [B,C], labels int64 [B] (-100 = ignored row, as torch's default ignore_index; any other
+ * label outside [0,C) makes the loss NaN); loss f32 [1] = mean over the counted rows, dlogits f32 [B,C] = d loss / d logits. */
+int svit_ce_loss(const float* logits, const int64_t* labels, int B, int C, float* loss, float* dlogits, void* stream);
+/* The step's random draws in one launch (round 6; replaces torch.rand + add + floor + div of DropPath,
+ * slowfast/models/common.py:46-59, and the head's nn.Dropout mask): scales f32 [n_blocks, per_block] =
+ * floor(keep[b] + U) / keep[b], drop f32 [n_drop] in {0, 1/(1-p_drop)}.  Philox-4x32-10 keyed by state[0], draw number
+ * state[1] advanced by the launch itself (state: uint64 [3] in device memory = {seed, draw, 0}), so a replayed HIP graph
+ * draws fresh numbers every replay. */
+int svit_step_draws(uint64_t* state, const float* keep, int n_blocks, int per_block, float* scales,
+                    int n_drop, float p_drop, float* drop, void* stream);
+
 /* ---------------------------------------- multi-view test ensemble ---------- */
 /* TestMeter.update_stats (slowfast/utils/meters.py:303-336) for one batch, on the device: clip n
  * belongs to video clip_ids[n] / num_clips; video_preds[v] (f32 [V,C]) += preds[n] (mode 0, "sum")

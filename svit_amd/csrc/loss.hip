@@ -200,3 +200,151 @@ extern "C" int svit_haog_loss_bwd(const float* upstream, const float* g_l1, cons
   SVIT_LAUNCH_CHECK();
   return SVIT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Video-rank classification loss (round 6): nn.CrossEntropyLoss(reduction="mean") of VideoImageLoss
+// (slowfast/models/losses.py:121,158) forward AND its unit gradient in ONE launch -- the replayed step spent four
+// stock launches (log-softmax, NLL, and their backward kernels) plus autograd's fills on [B, 174] numbers.
+//   loss = mean over the rows with label != -100 of (logsumexp(x) - x[label]);  dlogits = (softmax(x) - onehot) / #rows
+// (ignore_index = -100 as torch's default; any other label outside [0, C) poisons the loss with NaN: fail loudly).
+// One workgroup; a wave per row (rows wave, wave + 4, ...); the row losses meet in LDS and are added in row order.
+namespace {
+__global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ x, const int64_t* __restrict__ lab, int B, int C,
+                                                      float* __restrict__ loss, float* __restrict__ dx) {
+  extern __shared__ float ce_rows[];      // [B] row losses, then [1] the count
+  __shared__ int ce_cnt[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int cnt = 0;
+  for (int r = wave; r < B; r += 4) {
+    const float* xr = x + (size_t)r * C;
+    const long y = lab[r];
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, xr[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += __expf(xr[c] - m);
+    s = wave_sum(s);
+    const bool ign = y == -100, bad = !ign && (y < 0 || y >= C);
+    const float lse = m + __logf(s);
+    if (lane == 0) {
+      float v = 0.f;
+      if (bad) v = __builtin_nanf("");
+      else if (!ign) v = lse - xr[y];
+      ce_rows[r] = v;
+    }
+    cnt += ign ? 0 : 1;
+  }
+  if (lane == 0) ce_cnt[wave] = cnt;
+  __syncthreads();
+  const int n = ce_cnt[0] + ce_cnt[1] + ce_cnt[2] + ce_cnt[3];
+  const float inv = n > 0 ? 1.f / (float)n : __builtin_nanf("");       // (all rows ignored: NaN, as torch)
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int r = 0; r < B; ++r) t += ce_rows[r];
+    *loss = t * inv;
+  }
+  for (int r = wave; r < B; r += 4) {
+    const float* xr = x + (size_t)r * C;
+    const long y = lab[r];
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, xr[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += __expf(xr[c] - m);
+    s = wave_sum(s);
+    const float is = inv / s;
+    for (int c = lane; c < C; c += 64)
+      dx[(size_t)r * C + c] = y == -100 ? 0.f : (__expf(xr[c] - m) * is - (c == y ? inv : 0.f));
+  }
+}
+}  // namespace
+
+extern "C" int svit_ce_loss(const float* logits, const int64_t* labels, int B, int C, float* loss, float* dlogits, void* stream) {
+  if (!logits || !labels || !loss || !dlogits) return SVIT_ERR_ARG;
+  if (B <= 0 || C <= 0 || B > 8192) return SVIT_ERR_SHAPE;
+  hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), (size_t)B * sizeof(float), (hipStream_t)stream, logits, labels, B, C, loss, dlogits);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The step's random draws in ONE launch (round 6): the stochastic-depth factors of every block, floor(keep_b + U) / keep_b per
+// (block, branch, sample) (slowfast/models/common.py:46-59), and the head's dropout factors, {0, 1 / (1 - p)} per element
+// (nn.Dropout, slowfast/models/head_helper / video_model_builder.py head) -- five stock launches before (rand, add, floor,
+// div, dropout).  Philox-4x32-10 keyed by `state[0]` (the seed), counter = (element / 4, draw number state[1]); the LAST
+// workgroup to finish advances state[1], so a replayed HIP graph draws fresh numbers every replay with no host involvement
+// (state lives in device memory).  Not torch's stream: the masks are as random, not the same numbers.
+namespace {
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+}
+__device__ __forceinline__ void philox4(uint64_t seed, uint64_t draw, uint32_t idx, float (&u)[4]) {
+  uint32_t c[4] = {idx, 0u, (uint32_t)draw, (uint32_t)(draw >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = (float)(c[i] >> 8) * (1.0f / 16777216.0f);      // [0, 1) on a 2^-24 grid
+}
+__global__ __launch_bounds__(256) void step_draws_kernel(unsigned long long* __restrict__ state, const float* __restrict__ keep,
+                                                         int n_scale, int per_block, float* __restrict__ scales,
+                                                         int n_drop, float p_drop, float* __restrict__ drop) {
+  const uint64_t seed = state[0], draw = state[1];
+  const int n4 = (n_scale + 3) / 4 + (n_drop + 3) / 4;
+  const int s4 = (n_scale + 3) / 4;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += gridDim.x * blockDim.x) {
+    float u[4];
+    philox4(seed, draw, (uint32_t)q, u);
+    if (q < s4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * q + e;
+        if (i < n_scale) {
+          const float k = keep[i / per_block];
+          scales[i] = floorf(k + u[e]) / k;
+        }
+      }
+    } else {
+      const float on = 1.f / (1.f - p_drop);
+      const int i0 = 4 * (q - s4);
+      const float4 v = make_float4(u[0] >= p_drop ? on : 0.f, u[1] >= p_drop ? on : 0.f, u[2] >= p_drop ? on : 0.f, u[3] >= p_drop ? on : 0.f);
+      if (i0 + 3 < n_drop && ((uintptr_t)drop & 15) == 0) {
+        *(float4*)(drop + i0) = v;
+      } else {
+        const float ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (i0 + e < n_drop) drop[i0 + e] = ve[e];
+      }
+    }
+  }
+  // the last workgroup out advances the draw number and re-arms the ticket.  Every workgroup has READ the draw number before it
+  // takes its ticket (the barrier below orders its threads' loads in front of the atomic), and the two plain stores only have to be
+  // visible to the NEXT launch -- no device-scope fence (on a multi-XCD part a release fence writes the XCD's L2 back: ~15 us here)
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(&state[2], 1ull) == (unsigned long long)gridDim.x - 1) {
+    state[1] = draw + 1;
+    state[2] = 0;
+  }
+}
+}  // namespace
+
+extern "C" int svit_step_draws(uint64_t* state, const float* keep, int n_blocks, int per_block, float* scales,
+                               int n_drop, float p_drop, float* drop, void* stream) {
+  if (!state || n_blocks < 0 || per_block < 0 || n_drop < 0) return SVIT_ERR_ARG;
+  const int n_scale = n_blocks * per_block;
+  if ((n_scale > 0 && (!keep || !scales)) || (n_drop > 0 && !drop) || p_drop < 0.f || p_drop >= 1.f) return SVIT_ERR_ARG;
+  const int n4 = (n_scale + 3) / 4 + (n_drop + 3) / 4;
+  if (n4 == 0) return SVIT_OK;
+  int blocks = (n4 + 255) / 256;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(step_draws_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)state, keep, n_scale,
+                     per_block, scales, n_drop, p_drop, drop);
+  SVIT_LAUNCH_CHECK();
+  return SVIT_OK;
+}

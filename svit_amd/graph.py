@@ -63,7 +63,8 @@ class GraphedTrainStep:
         Tx = x.shape[2] if x.dim() == 5 else 1
         eng.refresh_weights()
         flat.grad.zero_()
-        ds = core.sample_drop_scales(x.shape[0], x.device)
+        ds = core.sample_drop_scales(x.shape[0], x.device, Tx=Tx)      # (+ the head's dropout factors: one launch)
+        head_keep, core._head_keep = core._head_keep, None
         with torch.no_grad():
             y, st = eng.forward(x, ds, save=True)
         n_obj = Tx * core.O
@@ -82,7 +83,7 @@ class GraphedTrainStep:
             # step, which a stream capture cannot follow), no slice / cat plumbing either
             yt = y.detach().requires_grad_(True)
             with torch.enable_grad():
-                preds, extra = core.head_train(yt, Tx)
+                preds, extra = core.head_train(yt, Tx, dropout_keep=head_keep)
                 if frames_out is not None:
                     extra = dict(extra)
                     extra["frames_output"] = frames_out

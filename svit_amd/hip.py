@@ -171,6 +171,8 @@ _SIGS = {
     "svit_head_bwd": (i32, [C.POINTER(HeadBwdArgs), vp]),
     "svit_haog_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "svit_haog_loss_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "svit_ce_loss": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+    "svit_step_draws": (i32, [vp, vp, i32, i32, vp, i32, C.c_float, vp, vp]),
     "svit_ensemble_update": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "svit_topk_correct": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, vp]),
     # diagnostics block of the header: knobs for tools/ (never called by the product path)

@@ -1,6 +1,8 @@
 """Losses of the SViT recipe (slowfast/models/losses.py:50-93,119-168; slowfast/utils/box_ops.py:
-10-77; slowfast/utils/misc.py:412-423).  A few hundred scalars per step: plain fp32 torch ops on
-the device, numerically exact -- not a hot spot and deliberately not a kernel.
+10-77; slowfast/utils/misc.py:412-423).  A few hundred scalars per step.  On the device the two losses a
+step really computes are one launch each way -- the image ranks' HAOG losses (round 1) and, since round 6, the video ranks'
+cross entropy (`cross_entropy` below: the replayed step spent four stock launches + autograd's fills on [B, 174] numbers);
+host tensors (configuration / unit tests of the plumbing) take plain fp32 torch ops.
 """
 import torch
 import torch.nn as nn
@@ -79,6 +81,29 @@ class _HaogLossHip(torch.autograd.Function):
         return dpred, None, dcontact, None
 
 
+class _CrossEntropyHip(torch.autograd.Function):
+    """nn.CrossEntropyLoss(reduction="mean") forward + unit gradient in one launch (svit_ce_loss, include/svit_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        from . import ops
+        loss, dlogits = ops.ce_loss(logits, labels)
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * d_loss, None
+
+
+def cross_entropy(logits, labels):
+    """F.cross_entropy(logits, labels) (mean, ignore_index -100) -- the fused launch for fp32 logits on the GPU."""
+    if logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and labels.dtype == torch.int64:
+        return _CrossEntropyHip.apply(logits, labels)
+    return F.cross_entropy(logits, labels)
+
+
 class VideoImageLoss(nn.Module):
     """losses.py:119-168.  `is_video_rank` replaces the reference's local-rank test
     (`du.get_local_rank() not in cfg.IMAGE_TRAIN.GPU_IDS`)."""
@@ -125,7 +150,7 @@ class VideoImageLoss(nn.Module):
     def forward(self, x, extra_preds, y, metadata):
         ret = {}
         if self.is_vid():
-            ret["loss_ce"] = self.ce_loss(x, y)
+            ret["loss_ce"] = cross_entropy(x, y) if self.reduction == "mean" else self.ce_loss(x, y)
             if self.cfg.TRAIN.FORWARD_VIDEO_FRAMES and "frames_output" in extra_preds:
                 ret.update(self._consistency_loss(extra_preds,
                                                   extra_preds["frames_output"]["extra_preds"]))

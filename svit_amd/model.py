@@ -192,6 +192,9 @@ class SViT(nn.Module):
         self.engine = None
         self.fused_head = True      # (False = the ATen head in training too; tests / tools flip the attribute)
         self._head_ones = None
+        self._rng_state = None      # int64 [3] on the device: {seed, draw number, ticket} of svit_step_draws
+        self._head_keep = None      # the head's dropout factors drawn together with the stochastic-depth factors
+        self.fused_draws = True     # (False = torch's own rand / floor / dropout launches; tests / tools flip the attribute)
         self.flat = None
         self._grad_ready_hook = None   # set by the data-parallel wrapper (svit_amd/dp.py)
         self._grad_ready_ranks = None  # ranks at which that hook launches collectives
@@ -286,15 +289,32 @@ class SViT(nn.Module):
             p.grad = v
 
     # -- forward ---------------------------------------------------------------------------------
-    def sample_drop_scales(self, batch, device):
-        """Per-sample stochastic-depth factors floor(keep + U[0,1)) / keep (common.py:46-59)."""
+    def sample_drop_scales(self, batch, device, Tx=None):
+        """Per-sample stochastic-depth factors floor(keep + U[0,1)) / keep (common.py:46-59).  Round 6: ONE launch
+        (svit_step_draws) that also draws the training head's dropout factors when `Tx` says how many tokens the head
+        will see (head_train picks them up) -- five stock launches before.  Philox keyed by torch.initial_seed() at the
+        first draw; the draw number lives on the device and advances with every launch, also under HIP-graph replay."""
         blocks = self.plan.blocks
+        self._head_keep = None
         if not self.training or all(b.drop_path <= 0.0 for b in blocks):
             return [None] * len(blocks)
         if self._keep is None or self._keep.device != torch.device(device):
             self._keep = torch.tensor([1.0 - b.drop_path for b in blocks], device=device).view(-1, 1, 1)
-        # one launch chain for all blocks: rows (attention branch, MLP branch) per block
-        m = torch.floor(self._keep + torch.rand((len(blocks), 2, batch), device=device)) / self._keep
+        if not self.fused_draws:
+            # one launch chain for all blocks: rows (attention branch, MLP branch) per block
+            m = torch.floor(self._keep + torch.rand((len(blocks), 2, batch), device=device)) / self._keep
+        else:
+            if self._rng_state is None or self._rng_state.device != torch.device(device):
+                self._rng_state = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64, device=device)
+            shp, p = None, float(self.head.dropout_rate)
+            if Tx is not None and self.fused_head and p > 0.0:
+                shp = (batch, 1 + Tx * self.O, self.plan.final_dim)
+            from . import ops
+            m, drop = ops.step_draws(self._rng_state, self._keep.view(-1), 2 * batch,
+                                     n_drop=shp[0] * shp[1] * shp[2] if shp else 0, p_drop=p)
+            m = m.view(len(blocks), 2, batch)
+            if shp:
+                self._head_keep = drop.view(shp)
         return [(m[i, 0], m[i, 1]) if b.drop_path > 0.0 else None for i, b in enumerate(blocks)]
 
     def head_train(self, tokens, Tx, dropout_keep=None):
@@ -303,8 +323,10 @@ class SViT(nn.Module):
         graph.GraphedTrainStep calls."""
         n_obj = Tx * self.O
         keep = dropout_keep
-        if keep is None and self.head.dropout_rate > 0.0:
-            shp = (tokens.shape[0], 1 + n_obj, tokens.shape[2])
+        shp = (tokens.shape[0], 1 + n_obj, tokens.shape[2])
+        if keep is None and self._head_keep is not None and tuple(self._head_keep.shape) == shp:
+            keep, self._head_keep = self._head_keep, None          # drawn with this pass's stochastic-depth factors
+        elif keep is None and self.head.dropout_rate > 0.0:
             if self._head_ones is None or tuple(self._head_ones.shape) != shp:
                 self._head_ones = torch.ones(shp, device=tokens.device)
             keep = F.dropout(self._head_ones, self.head.dropout_rate, True)     # mask / (1 - p), one launch
@@ -323,7 +345,7 @@ class SViT(nn.Module):
         Tx = x.shape[2]
         self.engine.refresh_weights()
         if drop_scales is None:
-            drop_scales = self.sample_drop_scales(x.shape[0], x.device)
+            drop_scales = self.sample_drop_scales(x.shape[0], x.device, Tx=Tx)
         need_grad = torch.is_grad_enabled()
         tokens = _Backbone.apply(self, x, drop_scales, need_grad, self._anchor)
         n_obj = Tx * self.O

@@ -684,3 +684,26 @@ def haog_loss_bwd(upstream, unit, pred_shape, contact_shape):
     hip.call("svit_haog_loss_bwd", ptr(upstream), ptr(g_l1), ptr(g_bce), ptr(g_giou),
              ptr(g_contact), ptr(dpred), ptr(dcontact), R, Rc)
     return dpred, dcontact
+
+
+def ce_loss(logits, labels):
+    """mean cross entropy over the rows (ignore_index -100) and d loss / d logits in one launch (svit_ce_loss)."""
+    _chk_dev(logits, labels)
+    assert logits.dtype == F32 and logits.dim() == 2 and labels.dtype == torch.int64 and labels.numel() == logits.shape[0]
+    logits, labels = logits.contiguous(), labels.contiguous()
+    loss = torch.empty((), device=logits.device, dtype=F32)
+    dlogits = torch.empty_like(logits)
+    hip.call("svit_ce_loss", ptr(logits), ptr(labels), logits.shape[0], logits.shape[1], ptr(loss), ptr(dlogits))
+    return loss, dlogits
+
+
+def step_draws(state, keep, per_block, n_drop=0, p_drop=0.0):
+    """state int64 [3] = {seed, draw number, 0} (advanced by the launch); keep f32 [n_blocks] -> scales f32 [n_blocks, per_block] =
+    floor(keep + U) / keep and drop f32 [n_drop] in {0, 1 / (1 - p)} (svit_step_draws; one launch)."""
+    _chk_dev(state, keep)
+    assert state.dtype == torch.int64 and state.numel() == 3 and keep.dtype == F32
+    nb = keep.numel()
+    scales = torch.empty((nb, per_block), device=state.device, dtype=F32)
+    drop = torch.empty((n_drop,), device=state.device, dtype=F32) if n_drop else None
+    hip.call("svit_step_draws", ptr(state), ptr(keep), nb, per_block, ptr(scales), n_drop, float(p_drop), ptr(drop))
+    return scales, drop

@@ -108,3 +108,17 @@ def test_nan_checks():
     for v in (1.0, 2.0, 3.0, 4.0):
         ok.update(torch.tensor(v))
     ok.check()
+
+
+def test_cross_entropy_host_path_is_torch():
+    """losses.cross_entropy: host tensors (and anything that is not fp32 [B, C] on the GPU) take F.cross_entropy; the fused launch
+    (svit_ce_loss) is the device path only -- tests/test_kernels_gpu.py::test_ce_loss_fused."""
+    import torch
+    import torch.nn.functional as F
+    from svit_amd import losses
+    x = torch.randn(5, 11, requires_grad=True)
+    y = torch.tensor([0, 3, 10, -100, 7])
+    a = losses.cross_entropy(x, y)
+    assert torch.equal(a, F.cross_entropy(x, y))
+    a.backward()
+    assert x.grad is not None and float(x.grad[3].abs().max()) == 0.0

@@ -1362,3 +1362,72 @@ def test_im2col_patch_u8_bit_exact(ops, V, T, Hs, Ws, S, table):
         U8Clips(u8.cuda(), S, torch.tensor([[0, Hs - S + 1, 0]], dtype=torch.int32))
     with pytest.raises(ValueError):
         U8Clips(u8.float().cuda(), S)
+
+
+# ------------------------------------------------------------ round 6: CE loss / the step's random draws ----
+@pytest.mark.parametrize("B,C", [(8, 174), (3, 174), (9, 5), (130, 1000)])
+def test_ce_loss_fused(ops, B, C):
+    """svit_ce_loss (csrc/loss.hip): nn.CrossEntropyLoss(reduction="mean") of VideoImageLoss (losses.py:121,158) and its gradient in one
+    launch, against F.cross_entropy on the same fp32 logits -- incl. ignored rows (label -100, torch's default ignore_index) and, through
+    svit_amd.losses.cross_entropy, an upstream gradient other than 1."""
+    from svit_amd import losses
+    x = rnd("ce%d_%d" % (B, C), (B, C), 3.0)
+    y = torch.from_numpy(np.arange(B) * 7 % C).to(DEV)
+    if B > 4:
+        y[2] = -100
+    xr = x.cpu().clone().requires_grad_(True)
+    ref = F.cross_entropy(xr, y.cpu())
+    (ref * 0.37).backward()
+    loss, dl = ops.ce_loss(x, y)
+    assert abs(float(loss) - float(ref)) < 2e-6 * max(1.0, abs(float(ref)))
+    assert rel_err(dl * 0.37, xr.grad) < 1e-5
+    xg = x.clone().requires_grad_(True)
+    out = losses.cross_entropy(xg, y)
+    (out * 0.37).backward()
+    assert float(out) == float(loss) and rel_err(xg.grad, xr.grad) < 1e-5
+    # a label outside [0, C) that is not the ignore index poisons the loss (fail loudly), every row ignored too
+    y2 = y.clone(); y2[0] = C
+    assert bool(torch.isnan(ops.ce_loss(x, y2)[0]))
+    assert bool(torch.isnan(ops.ce_loss(x, torch.full_like(y, -100))[0]))
+
+
+def test_step_draws(ops):
+    """svit_step_draws (csrc/loss.hip): stochastic-depth factors floor(keep + U) / keep (common.py:46-59) and the head's dropout factors in
+    one launch -- values, means, the draw number advancing by itself (also under HIP-graph replay), reproducibility from (seed, draw)."""
+    keep = torch.tensor([1.0, 0.9, 0.6, 0.75], device=DEV)
+    st = torch.tensor([1234, 0, 0], dtype=torch.int64, device=DEV)
+    per, nd, p = 4096, 65 * 768 * 3, 0.5
+    s0, d0 = ops.step_draws(st, keep, per, nd, p)
+    assert st.tolist() == [1234, 1, 0]
+    assert bool((s0[0] == 1.0).all())
+    for b in range(1, 4):
+        k = float(keep[b])
+        on = s0[b] != 0
+        assert bool(((s0[b] == 0) | ((s0[b] - 1.0 / k).abs() < 1e-6)).all())
+        assert abs(float(on.float().mean()) - k) < 4 * (k * (1 - k) / per) ** 0.5 + 1e-3
+    assert bool(((d0 == 0) | (d0 == 2.0)).all()) and abs(float((d0 != 0).float().mean()) - 0.5) < 5e-3
+    s1, d1 = ops.step_draws(st, keep, per, nd, p)
+    assert st.tolist() == [1234, 2, 0] and not torch.equal(s1, s0) and not torch.equal(d1, d0)
+    # same (seed, draw number) -> same numbers; the drop stream does not depend on how many scale values precede it being a multiple of 4
+    st2 = torch.tensor([1234, 0, 0], dtype=torch.int64, device=DEV)
+    s2, d2 = ops.step_draws(st2, keep, per, nd, p)
+    assert torch.equal(s2, s0) and torch.equal(d2, d0)
+    st3 = torch.tensor([99, 0, 0], dtype=torch.int64, device=DEV)
+    assert not torch.equal(ops.step_draws(st3, keep, per, nd, p)[0], s0)
+    # successive draws are uncorrelated (|corr| of two 196k-element masks ~ 1 / sqrt(n))
+    a, b = (d0 != 0).float() - 0.5, (d1 != 0).float() - 0.5
+    assert abs(float((a * b).mean()) / 0.25) < 0.02
+    # under HIP-graph replay every replay draws fresh numbers
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.step_draws(st, keep, per, nd, p)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            sg, dg = ops.step_draws(st, keep, per, nd, p)
+    torch.cuda.current_stream().wait_stream(side)
+    before = int(st[1])
+    g.replay(); torch.cuda.synchronize(); r1 = dg.clone()
+    g.replay(); torch.cuda.synchronize(); r2 = dg.clone()
+    assert int(st[1]) == before + 2 and not torch.equal(r1, r2) and abs(float((r2 != 0).float().mean()) - 0.5) < 5e-3
