@@ -218,20 +218,18 @@ typedef struct {
   int32_t extra_is_bf16;                        /* d_extra holds bf16 (the rel-pos D . R^T GEMM's bf16 epilogue: half the bytes) */
 } svit_pool_ln_bwd_args;
 int svit_pool_ln_bwd(const svit_pool_ln_bwd_args* a, void* stream);
-/* backward, step 2: depthwise-conv dgrad (gather form) + cls/object rows ->
- * dqkv bf16 [B,N,3,h,96] slice `which`. */
+/* backward, step 2: depthwise-conv dgrad + cls/object rows -> dqkv bf16 [B,N,3,h,96] slice `which`;
+ * step 3: depthwise-conv wgrad incl. the object-gain path; dw f32 [96,27] accumulated.
+ * (argument blocks of svit_pool_conv_bwd_qkv below, one pair per tensor) */
 typedef struct {
   const void* dpre; const float* conv_w; void* dqkv; int32_t which;
   int32_t B, heads, T, H, W, n_obj, stride_hw;
 } svit_pool_dgrad_args;
-int svit_pool_conv_dgrad(const svit_pool_dgrad_args* a, void* stream);
-/* backward, step 3: depthwise-conv wgrad incl. the object-gain path; dw f32 [96,27] accumulated. */
 typedef struct {
   const void* dpre; const void* qkv; int32_t which; float* dw;
   int32_t B, heads, T, H, W, n_obj, stride_hw;
   float* workspace; int64_t workspace_floats;
 } svit_pool_wgrad_args;
-int svit_pool_conv_wgrad(const svit_pool_wgrad_args* a, void* stream);
 /* The four pooling entry points for q, k and v of one block in ONE launch each (args[0..2] =
  * which 0, 1, 2; same qkv / B / heads / T / H / W / n_obj, individual strides and outputs).
  * This is what the engine calls: at the 14x14 and 7x7 stages each stencil is a short latency
@@ -251,13 +249,22 @@ int svit_pool_weight_sel(const float* src_base, const int64_t* src_off, uint32_t
                          void* stream);
 int svit_pool_ln_fwd_qkv_sel(const svit_pool_args* args3, const uint32_t* const* sel3, void* stream);
 int svit_pool_ln_bwd_qkv(const svit_pool_ln_bwd_args* args3, void* stream);
+#ifdef SVIT_DIAG_POOL_STREAMING
+/* DIAGNOSTIC BUILD ONLY (round 6: csrc/pool.hip compiled with -DSVIT_DIAG_POOL_STREAMING, tools/diag/build_variant.py): the
+ * streaming conv backward of rounds 1-4 -- gather-form dgrad and LDS-tiled wgrad, per tensor and for q, k, v in one launch
+ * each.  The product library does not export them: svit_pool_conv_bwd_qkv takes every block of every configuration the suite
+ * runs (tools/diag/pool_bwd_paths.py) and fails loudly where its plan does not fit. */
+int svit_pool_conv_dgrad(const svit_pool_dgrad_args* a, void* stream);
+int svit_pool_conv_wgrad(const svit_pool_wgrad_args* a, void* stream);
 int svit_pool_conv_dgrad_qkv(const svit_pool_dgrad_args* args3, void* stream);
 int svit_pool_conv_wgrad_qkv(const svit_pool_wgrad_args* args3, void* stream);
+#endif
 /* Steps 2 + 3 together (what the engine calls; round 5): conv dgrad AND conv wgrad of q, k, v in ONE launch for every
  * stride and plane of the model (csrc/pool.hip::pool_bwd_fused_kernel: a workgroup stages the dpre halo of its chunk of
  * planes / rows once in LDS and walks its input tokens once, producing dqkv and per-workgroup partial rows of the three dw
- * that the second-stage reduce sums in a fixed order); where not even one unit row of three padded planes fits LDS, or
- * with svit_debug_set_pool(1, 0), it falls through to the two streaming launches above.
+ * that the second-stage reduce sums in a fixed order).  Since round 6 the ONLY conv backward of the product library: where
+ * not even one unit row of three padded planes fits LDS, the workspace is smaller than the plan's partial rows, or with
+ * svit_debug_set_pool(1, 0), it returns SVIT_ERR_SHAPE (a diagnostic build falls through to the streaming launches).
  * dgrad3[i] / wgrad3[i] describe the same `which` = i (same dpre, stride, dims); wgrad3[0].workspace >=
  * B * heads * chunks * 3 * 27 * 96 floats. */
 int svit_pool_conv_bwd_qkv(const svit_pool_dgrad_args* dgrad3, const svit_pool_wgrad_args* wgrad3,
@@ -476,14 +483,15 @@ int svit_debug_set_tn(int step_us_x100, int atomic_tbs_x100);
 int svit_debug_set_tn_tile(int mode);
 /* pooling (csrc/pool.hip): key 0 = forward path of the small planes: 0 streaming kernels, 1 VALU slab conv, 2 (default)
  * MFMA conv where it is ahead (blocks 4-13 of 16x224^2) and the slab elsewhere, 3 MFMA conv wherever its geometry holds;
- * key 1 = conv backward: 1 (default) the fused plane-walk kernel (conv dgrad + conv wgrad in one launch) where it fits,
- * 0 the two streaming launches; key 2 = forward of the planes past 14x14 (blocks 0-3): 1 (default) the staged conv (input
+ * key 1 = conv backward: 1 (default) the fused plane-walk kernel (conv dgrad + conv wgrad in one launch),
+ * 0 refuse it (the two streaming launches in a -DSVIT_DIAG_POOL_STREAMING build, SVIT_ERR_SHAPE in the product library); key 2 = forward of the planes past 14x14 (blocks 0-3): 1 (default) the staged conv (input
  * staged once in LDS) + the row-wise LayerNorm launch, 0 the streaming kernel; key 3 = one-plane volumes (T = 1):
  * conv + LayerNorm in one launch from an LDS-staged plane -- 2 (default since round 6) in every T = 1 pass, also where
  * pre / mean / rstd are saved for a backward (image ranks), 1 in no-grad passes only (the frames pass), 0 never. */
 int svit_debug_set_pool(int key, int val);
-/* which path the last svit_pool_conv_bwd_qkv call took: 1 = the fused plane-walk kernel, 0 = the two streaming launches (planes that
- * do not fit its LDS plan, a workspace smaller than the plan's partial rows, key 1 = 0), -1 = no call yet. */
+/* which path the last svit_pool_conv_bwd_qkv call took: 1 = the fused plane-walk kernel, 0 = not (planes that do not fit its LDS
+ * plan, a workspace smaller than the plan's partial rows, key 1 = 0: SVIT_ERR_SHAPE in the product library, the two streaming
+ * launches in a -DSVIT_DIAG_POOL_STREAMING build), -1 = no call yet. */
 int svit_debug_pool_bwd_path(void);
 /* attention: key 0 = dkv kernel form (0 heuristic, 1 four waves, 2 eight waves with query halves), key 3 = the
  * forward's T' = 1 tile for Nk <= 64 (1 on (default), 0 the generic kernel). */

@@ -656,381 +656,18 @@ __global__ __launch_bounds__(256) void pool_ln_bwd3_kernel(PoolLnBwd3 g) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Gather form: one input token sums the taps of the output positions that saw it.  Per axis an
-// input coordinate y is hit through ky with (y + 1 - ky) % s == 0: all 3 taps for s = 1, taps
-// {0,2} or {1} for s = 2, at most one tap for s >= 3 -- so the candidate list per axis has
-// NC = 3 / 2 / 1 entries (template S = 1 / 2 / 3 for "any s >= 3") and a lane issues the loads
-// of KTB t-planes (NC*NC candidates each) before it consumes the first one.
-// the tap loop of one input token: NCY x NCX candidate (ky, kx) pairs per t-plane, KTB planes of
-// loads in flight
-template <int S, int NCY, int NCX>
-__device__ __forceinline__ void dgrad_taps(const bf16_t* dp, const float* w_lds, int c0, int t, int T,
-                                           int Ho, int Wo, const int* kyc, const int* yoc,
-                                           const bool* yv, const int* kxc, const int* xoc,
-                                           const bool* xv, float (&acc)[24]) {
-  constexpr int KTB = (S == 1) ? 1 : 3;
-#pragma unroll 1
-  for (int kt0 = 0; kt0 < 3; kt0 += KTB) {
-    uint4 v[KTB][NCY * NCX][3];
-    bool ok[KTB][NCY * NCX];
-    if (KTB == 1) {                    // whole wave outside the volume (T' = 1; clip borders)
-      const int to0 = t + 1 - kt0;
-      if (!__any(to0 >= 0 && to0 < T)) continue;
-    }
-#pragma unroll
-    for (int kk = 0; kk < KTB; ++kk) {
-      const int to = t + 1 - (kt0 + kk);
-      const bool tv = to >= 0 && to < T;
-#pragma unroll
-      for (int j = 0; j < NCY * NCX; ++j) {
-        ok[kk][j] = tv && yv[j / NCX] && xv[j % NCX];
-        const int ti = ok[kk][j] ? 1 + (to * Ho + yoc[j / NCX]) * Wo + xoc[j % NCX] : 0;
-        const bf16_t* src = dp + (size_t)ti * HD;
-#pragma unroll
-        for (int u = 0; u < 3; ++u) v[kk][j][u] = *(const uint4*)(src + u * 8);
-      }
-    }
-#pragma unroll
-    for (int kk = 0; kk < KTB; ++kk)
-#pragma unroll
-      for (int j = 0; j < NCY * NCX; ++j) {
-        if (!ok[kk][j]) continue;
-        const float* w = w_lds + (((kt0 + kk) * 3 + kyc[j / NCX]) * 3 + kxc[j % NCX]) * HD + c0;
-#pragma unroll
-        for (int u = 0; u < 3; ++u) fma8_sel(acc, u, v[kk][j][u], w);
-      }
-  }
-}
-
-template <int S>
-__device__ __forceinline__ void pool_dgrad_body(const svit_pool_dgrad_args& a, const float* w_lds,
-                                                const float* g_lds, int tb) {
-  constexpr int NC = (S == 1) ? 3 : (S == 2 ? 2 : 1);
-  const int s = a.stride_hw;
-  const int Ho = pooled(a.H, s), Wo = pooled(a.W, s);
-  const int L = a.T * a.H * a.W, Lo = a.T * Ho * Wo;
-  const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
-  const int bh = blockIdx.y, b = bh / a.heads, head = bh % a.heads;
-  int tok = tb * 64 + (threadIdx.x >> 2);
-  const int sub = threadIdx.x & 3, c0 = sub * 24;
-  if (tok >= N) return;
-  // stride 2, even planes: walk the patch tokens parity class by parity class ((y+1)&1, (x+1)&1),
-  // so that (almost) every wave holds tokens of ONE class and loads only that class's taps
-  // (2x2, 2x1, 1x2 or 1x1 per t-plane instead of the generic 2x2 with half of them dummies)
-  const bool classed = S == 2 && !(a.H & 1) && !(a.W & 1);
-  if (classed && tok >= 1 && tok <= L) {
-    const int Lq = L >> 2, cls = (tok - 1) / Lq, i = (tok - 1) % Lq;
-    const int W2 = a.W >> 1, H2 = a.H >> 1;
-    const int x2 = i % W2, y2 = (i / W2) % H2, tt = i / (W2 * H2);
-    tok = 1 + (tt * a.H + 2 * y2 + (cls >> 1)) * a.W + 2 * x2 + (cls & 1);
-  }
-  const bf16_t* dp = (const bf16_t*)a.dpre + (size_t)bh * Nout * HD + c0;
-  float acc[24];
-#pragma unroll
-  for (int i = 0; i < 24; ++i) acc[i] = 0.f;
-  if (tok == 0 || tok > L) {
-    const int src = (tok == 0) ? 0 : (1 + Lo + (tok - 1 - L));
-#pragma unroll
-    for (int v = 0; v < 3; ++v) {
-      float f[8];
-      unpack8(*(const uint4*)(dp + (size_t)src * HD + v * 8), f);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[v * 8 + e] = (tok == 0) ? f[e] : f[e] * g_lds[c0 + v * 8 + e];
-    }
-  } else {
-    const int p = tok - 1, x = p % a.W, y = (p / a.W) % a.H, t = p / (a.W * a.H);
-    // candidate taps / output coordinates per axis
-    int kyc[NC], yoc[NC], kxc[NC], xoc[NC];
-    bool yv[NC], xv[NC];
-#pragma unroll
-    for (int j = 0; j < NC; ++j) {
-      if (S == 1) { kyc[j] = j; kxc[j] = j; }
-      else if (S == 2) { kyc[j] = ((y + 1) & 1) + 2 * j; kxc[j] = ((x + 1) & 1) + 2 * j; }
-      else { kyc[j] = (y + 1) % s; kxc[j] = (x + 1) % s; }
-      const int yn = y + 1 - kyc[j], xn = x + 1 - kxc[j];
-      yoc[j] = yn / s; xoc[j] = xn / s;
-      yv[j] = kyc[j] <= 2 && yn >= 0 && yoc[j] < Ho;
-      xv[j] = kxc[j] <= 2 && xn >= 0 && xoc[j] < Wo;
-    }
-    if (S == 2) {
-      const int py = (y + 1) & 1, px = (x + 1) & 1;
-      const int fy = __builtin_amdgcn_readfirstlane(py), fx = __builtin_amdgcn_readfirstlane(px);
-      if (__all(py == fy && px == fx)) {       // one parity class in this wave (the common case)
-        if (fy == 0 && fx == 0) dgrad_taps<S, NC, NC>(dp, w_lds, c0, t, a.T, Ho, Wo, kyc, yoc, yv, kxc, xoc, xv, acc);
-        else if (fy == 0) dgrad_taps<S, NC, 1>(dp, w_lds, c0, t, a.T, Ho, Wo, kyc, yoc, yv, kxc, xoc, xv, acc);
-        else if (fx == 0) dgrad_taps<S, 1, NC>(dp, w_lds, c0, t, a.T, Ho, Wo, kyc, yoc, yv, kxc, xoc, xv, acc);
-        else dgrad_taps<S, 1, 1>(dp, w_lds, c0, t, a.T, Ho, Wo, kyc, yoc, yv, kxc, xoc, xv, acc);
-      } else {
-        dgrad_taps<S, NC, NC>(dp, w_lds, c0, t, a.T, Ho, Wo, kyc, yoc, yv, kxc, xoc, xv, acc);
-      }
-    } else {
-      dgrad_taps<S, NC, NC>(dp, w_lds, c0, t, a.T, Ho, Wo, kyc, yoc, yv, kxc, xoc, xv, acc);
-    }
-  }
-  const size_t tok_stride = (size_t)3 * a.heads * HD;
-  bf16_t* o = (bf16_t*)a.dqkv + ((size_t)b * N + tok) * tok_stride + ((size_t)a.which * a.heads + head) * HD + c0;
-#pragma unroll
-  for (int v = 0; v < 3; ++v) *(uint4*)(o + v * 8) = pack8(&acc[v * 8]);
-}
-
-template <int S>
-__device__ __forceinline__ void pool_dgrad_loop(const svit_pool_dgrad_args& a, float* w_lds,
-                                                float* g_lds) {
-  load_weights(a.conv_w, w_lds, g_lds, a.stride_hw);       // once per (persistent) workgroup
-  const int N = 1 + a.T * a.H * a.W + a.n_obj;
-  for (int tb = blockIdx.x; tb * 64 < N; tb += gridDim.x) pool_dgrad_body<S>(a, w_lds, g_lds, tb);
-}
-template <int S>
-__global__ __launch_bounds__(256) void pool_dgrad_kernel(svit_pool_dgrad_args a) {
-  __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];
-  __shared__ __attribute__((aligned(16))) float g_lds[HD];
-  pool_dgrad_loop<S>(a, w_lds, g_lds);
-}
-struct PoolDgrad3 { svit_pool_dgrad_args p[3]; };
-__global__ __launch_bounds__(256) void pool_dgrad3_kernel(PoolDgrad3 g) {
-  __shared__ __attribute__((aligned(16))) float w_lds[27 * HD];
-  __shared__ __attribute__((aligned(16))) float g_lds[HD];
-  const svit_pool_dgrad_args& a = g.p[blockIdx.z];
-  if (a.stride_hw == 1) pool_dgrad_loop<1>(a, w_lds, g_lds);
-  else if (a.stride_hw == 2) pool_dgrad_loop<2>(a, w_lds, g_lds);
-  else pool_dgrad_loop<3>(a, w_lds, g_lds);
-}
-
-// ---------------------------------------------------------------------------------------
-// wgrad, LDS-tiled: a block owns an (R x TX) patch of output positions of one (b, head) and
-// walks t; the input halo of three consecutive planes lives in an LDS ring (one new plane slab
-// per step, fetched with coalesced 16-byte loads, zero-filled outside the volume), so every
-// input element is fetched ~2x instead of 27x, and the 27 taps are read from LDS by one lane
-// per channel (2-byte conflict-free reads) into 27 register accumulators.
-// Block = R(2) x 96 threads.  S = 1 / 2: dense halo; S = 3 stands for any stride >= 3 (only the
-// 3 rows/columns each output touches are staged).  Each block stores one [c][tap] partial row.
-template <int S>
-struct WgradTile {
-  static constexpr int R = 2;
-  static constexpr int TX = (S == 1) ? 14 : 7;
-  static constexpr bool SPARSE = (S >= 3);
-  static constexpr int CS = SPARSE ? 3 : S;
-  static constexpr int RI = (R - 1) * CS + 3;
-  static constexpr int CI = (TX - 1) * CS + 3;
-  static constexpr int PLANE = RI * CI * HD;          // bf16 elements per plane slab
-  static constexpr int LDS_BYTES = (3 * PLANE + R * TX * HD) * 2;
-};
-
-template <int S>
-__device__ __forceinline__ void pool_wgrad_body(const svit_pool_wgrad_args& a, int n_tiles,
-                                                int tiles_x, int tiles_y, int t_chunks, int t_len,
-                                                float* prow_base) {
-  using TL = WgradTile<S>;
-  constexpr int R = TL::R, TX = TL::TX, CS = TL::CS, RI = TL::RI, CI = TL::CI, PLANE = TL::PLANE;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
-  bf16_t* ring = (bf16_t*)smem_w;                 // [3][RI][CI][96]
-  bf16_t* dyt = ring + 3 * PLANE;                 // [R][TX][96]
-  const int s = a.stride_hw;
-  const int Ho = pooled(a.H, s), Wo = pooled(a.W, s);
-  const int L = a.T * a.H * a.W, Lo = a.T * Ho * Wo;
-  const int N = 1 + L + a.n_obj, Nout = 1 + Lo + a.n_obj;
-  const int tid = threadIdx.x, c = tid % HD, r = tid / HD;
-  const size_t tok_stride = (size_t)3 * a.heads * HD;
-  const bf16_t* qkv = (const bf16_t*)a.qkv + (size_t)a.which * a.heads * HD;
-  const bf16_t* dpre = (const bf16_t*)a.dpre;
-  float acc[27];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
-
-  constexpr int SLAB_CH = RI * CI * 12;                  // 16-byte chunks per plane slab
-  constexpr int SLAB_PER = (SLAB_CH + 191) / 192;
-  constexpr int DY_CH = R * TX * 12;
-  constexpr int DY_PER = (DY_CH + 191) / 192;
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int xc = tile % tiles_x, yc = (tile / tiles_x) % tiles_y;
-    const int tc = (tile / (tiles_x * tiles_y)) % t_chunks, bh = tile / (tiles_x * tiles_y * t_chunks);
-    const int b = bh / a.heads, head = bh % a.heads;
-    const int yo0 = yc * R, xo0 = xc * TX;
-    const int t_begin = tc * t_len, t_end = min(a.T, t_begin + t_len);
-    const bf16_t* xin = qkv + (size_t)b * N * tok_stride + (size_t)head * HD;
-    uint4 sreg[SLAB_PER], sreg_a[SLAB_PER], sreg_b[SLAB_PER], dreg[DY_PER];
-    auto fetch_plane_to = [&](int tp, uint4 (&dst)[SLAB_PER]) {   // global -> registers (zero outside the volume)
-#pragma unroll
-      for (int u = 0; u < SLAB_PER; ++u) {
-        const int q = tid + u * 192;
-        const int tok = q / 12, cc = q % 12, j = tok / CI, i = tok % CI;
-        const int y = TL::SPARSE ? (yo0 + j / 3) * s - 1 + j % 3 : yo0 * s - 1 + j;
-        const int x = TL::SPARSE ? (xo0 + i / 3) * s - 1 + i % 3 : xo0 * s - 1 + i;
-        dst[u] = make_uint4(0, 0, 0, 0);
-        if (q < SLAB_CH && tp >= 0 && tp < a.T && y >= 0 && y < a.H && x >= 0 && x < a.W)
-          dst[u] = *(const uint4*)(xin + (size_t)(1 + (tp * a.H + y) * a.W + x) * tok_stride + cc * 8);
-      }
-    };
-    auto store_plane_from = [&](int tp, const uint4 (&src)[SLAB_PER]) {   // registers -> ring slot (tp+1) % 3
-      bf16_t* dst = ring + ((tp + 1) % 3) * PLANE;
-#pragma unroll
-      for (int u = 0; u < SLAB_PER; ++u) {
-        const int q = tid + u * 192;
-        if (q < SLAB_CH) *(uint4*)(dst + (size_t)(q / 12) * HD + (q % 12) * 8) = src[u];
-      }
-    };
-    auto fetch_plane = [&](int tp) { fetch_plane_to(tp, sreg); };
-    auto store_plane = [&](int tp) { store_plane_from(tp, sreg); };
-    auto fetch_dy = [&](int t) {
-#pragma unroll
-      for (int u = 0; u < DY_PER; ++u) {
-        const int q = tid + u * 192;
-        const int tok = q / 12, cc = q % 12, rr = tok / TX, xo = tok % TX;
-        dreg[u] = make_uint4(0, 0, 0, 0);
-        if (q < DY_CH && t < t_end && yo0 + rr < Ho && xo0 + xo < Wo)
-          dreg[u] = *(const uint4*)(dpre + ((size_t)bh * Nout + 1 + (size_t)(t * Ho + yo0 + rr) * Wo +
-                                            xo0 + xo) * HD + cc * 8);
-      }
-    };
-    auto store_dy = [&]() {
-#pragma unroll
-      for (int u = 0; u < DY_PER; ++u) {
-        const int q = tid + u * 192;
-        if (q < DY_CH) *(uint4*)(dyt + (size_t)(q / 12) * HD + (q % 12) * 8) = dreg[u];
-      }
-    };
-    // all four loads of the tile's first step leave together (one memory round trip, not three in a row);
-    // they do not touch LDS, so they may fly above the barrier that protects the ring
-    if constexpr (!TL::SPARSE) {
-      fetch_plane_to(t_begin - 1, sreg_a);
-      fetch_plane_to(t_begin, sreg_b);
-      fetch_plane(t_begin + 1);
-      fetch_dy(t_begin);
-      __syncthreads();            // previous tile's readers are done with the ring
-      store_plane_from(t_begin - 1, sreg_a);
-      store_plane_from(t_begin, sreg_b);
-    } else {                      // (the sparse slabs are twice as large: three register sets would spill)
-      __syncthreads();
-      fetch_plane(t_begin - 1); store_plane(t_begin - 1);
-      fetch_plane(t_begin);     store_plane(t_begin);
-      fetch_plane(t_begin + 1);
-      fetch_dy(t_begin);
-    }
-    for (int t = t_begin; t < t_end; ++t) {
-      store_plane(t + 1);       // slot of plane t-2: its readers passed the barrier below
-      store_dy();
-      __syncthreads();
-      if (t + 1 < t_end) {      // next step's data travels while this step computes
-        fetch_plane(t + 2);
-        fetch_dy(t + 1);
-      }
-      const bf16_t* p0 = ring + ((t + 0) % 3) * PLANE + c;   // plane t-1
-      const bf16_t* p1 = ring + ((t + 1) % 3) * PLANE + c;   // plane t
-      const bf16_t* p2 = ring + ((t + 2) % 3) * PLANE + c;   // plane t+1
-#pragma unroll 2
-      for (int xo = 0; xo < TX; ++xo) {
-        const float d = bf16_to_f32(dyt[(r * TX + xo) * HD + c]);
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int off = ((r * CS + ky) * CI + xo * CS + kx) * HD;
-            acc[0 * 9 + ky * 3 + kx] += d * bf16_to_f32(p0[off]);
-            acc[1 * 9 + ky * 3 + kx] += d * bf16_to_f32(p1[off]);
-            acc[2 * 9 + ky * 3 + kx] += d * bf16_to_f32(p2[off]);
-          }
-      }
-      __syncthreads();          // ring slot of plane t-1 and dyt are overwritten next step
-    }
-  }
-  // object tokens: dw[c][tap] += ncoef[tap] * sum_obj dy*x  (closed form of the cube branch)
-  if (a.n_obj > 0) {
-    float g = 0.f;
-    const int n_obj_rows = a.B * a.heads * a.n_obj;
-    for (int i = blockIdx.x * R + r; i < n_obj_rows; i += gridDim.x * R) {
-      const int o = i % a.n_obj, bh = i / a.n_obj, b = bh / a.heads, head = bh % a.heads;
-      const float d = bf16_to_f32(dpre[((size_t)bh * Nout + 1 + Lo + o) * HD + c]);
-      const float x = bf16_to_f32(qkv[((size_t)b * N + 1 + L + o) * tok_stride + (size_t)head * HD + c]);
-      g += d * x;
-    }
-    float nt[3], nh[3], ipt, iph;
-    obj_counts(1, nt, &ipt);
-    obj_counts(s, nh, &iph);
-    g *= ipt * iph * iph;
-#pragma unroll
-    for (int k = 0; k < 27; ++k) acc[k] += g * nt[k / 9] * nh[(k / 3) % 3] * nh[k % 3];
-  }
-  __syncthreads();
-  float* comb = (float*)smem_w;   // [27][96]
-  if (r == 1) {
-#pragma unroll
-    for (int k = 0; k < 27; ++k) comb[k * HD + c] = acc[k];
-  }
-  __syncthreads();
-  if (r == 0) {
-    float* prow = prow_base + c * 27;   // [c][tap]
-#pragma unroll
-    for (int k = 0; k < 27; ++k) prow[k] = acc[k] + comb[k * HD + c];
-  }
-}
-
-template <int S>
-__global__ __launch_bounds__(192) void pool_wgrad_kernel(svit_pool_wgrad_args a, int n_tiles,
-                                                         int tiles_x, int tiles_y, int t_chunks,
-                                                         int t_len) {
-  pool_wgrad_body<S>(a, n_tiles, tiles_x, tiles_y, t_chunks, t_len,
-                     a.workspace + (size_t)blockIdx.x * 27 * HD);
-}
-struct WgradPlan { int n_tiles, tiles_x, tiles_y, t_chunks, t_len, sclass; };
-struct PoolWgrad3 { svit_pool_wgrad_args p[3]; WgradPlan plan[3]; };
-// HAS_SPARSE = false: no tensor of the launch has a stride >= 3 (blocks 3-15).  The sparse body needs 208
-// VGPRs and, compiled into the same kernel, held every launch at two waves per SIMD; without it the
-// kernel fits three (163 VGPRs), i.e. three resident workgroups per CU instead of two.
-template <bool HAS_SPARSE>
-__global__ __launch_bounds__(192, HAS_SPARSE ? 2 : 3) void pool_wgrad3_kernel(PoolWgrad3 g) {
-  const svit_pool_wgrad_args& a = g.p[blockIdx.y];
-  const WgradPlan& pl = g.plan[blockIdx.y];
-  // partial rows [block][which][c][tap] in the first entry's workspace
-  float* prow = g.p[0].workspace + ((size_t)blockIdx.x * 3 + blockIdx.y) * 27 * HD;
-  if (pl.sclass == 1)
-    pool_wgrad_body<1>(a, pl.n_tiles, pl.tiles_x, pl.tiles_y, pl.t_chunks, pl.t_len, prow);
-  else if (pl.sclass == 2 || !HAS_SPARSE)
-    pool_wgrad_body<2>(a, pl.n_tiles, pl.tiles_x, pl.tiles_y, pl.t_chunks, pl.t_len, prow);
-  else
-    pool_wgrad_body<3>(a, pl.n_tiles, pl.tiles_x, pl.tiles_y, pl.t_chunks, pl.t_len, prow);
-}
-
-template <int S>
-static WgradPlan plan_wgrad(const svit_pool_wgrad_args& a, int Ho, int Wo) {
-  using TL = WgradTile<S>;
-  WgradPlan pl;
-  pl.tiles_x = (Wo + TL::TX - 1) / TL::TX;
-  pl.tiles_y = (Ho + TL::R - 1) / TL::R;
-  // split the t walk when the (y, x) tiling alone gives too few workgroups
-  int t_chunks = 1;
-  // (round 3: 768 -> 224.  Every t chunk re-fetches two halo planes and writes its own 31-KB partial row;
-  // un-chunked walks were 20-35 % faster wherever (y, x, batch, head) alone gives ~1 workgroup per CU:
-  // tools/_run_pool2.sh sweep, profiles/r03_pool_slab.txt)
-  constexpr long want = 224;
-  while (t_chunks < a.T && (long)pl.tiles_x * pl.tiles_y * a.B * a.heads * t_chunks < want &&
-         a.T / (t_chunks * 2) >= 2)
-    t_chunks *= 2;
-  pl.t_chunks = t_chunks;
-  pl.t_len = (a.T + t_chunks - 1) / t_chunks;
-  pl.n_tiles = pl.tiles_x * pl.tiles_y * a.B * a.heads * t_chunks;
-  pl.sclass = S;
-  return pl;
-}
-
-template <int S>
-static int launch_wgrad(const svit_pool_wgrad_args& a, int Ho, int Wo, hipStream_t st) {
-  using TL = WgradTile<S>;
-  const WgradPlan pl = plan_wgrad<S>(a, Ho, Wo);
-  int64_t blocks = pl.n_tiles;
-  if (blocks > 1024) blocks = 1024;
-  if (blocks > a.workspace_floats / (27 * HD)) blocks = a.workspace_floats / (27 * HD);
-  if (blocks < 1) return SVIT_ERR_ARG;
-  static SvitOnce once;
-  if (int rc = svit_max_lds_once(once, (const void*)pool_wgrad_kernel<S>, TL::LDS_BYTES)) return rc;
-  hipLaunchKernelGGL(pool_wgrad_kernel<S>, dim3((unsigned)blocks), dim3(192), TL::LDS_BYTES, st, a,
-                     pl.n_tiles, pl.tiles_x, pl.tiles_y, pl.t_chunks, pl.t_len);
-  SVIT_LAUNCH_CHECK();
-  SvitReduceDst dst = {{a.dw, a.dw, a.dw, a.dw, a.dw, a.dw}, {27 * HD, 27 * HD, 27 * HD, 27 * HD, 27 * HD, 27 * HD}};
-  svit_launch_reduce(a.workspace, (int)blocks, 27 * HD, dst, st);
-  SVIT_LAUNCH_CHECK();
-  return SVIT_OK;
-}
-
+// DIAGNOSTIC BUILD ONLY (-DSVIT_DIAG_POOL_STREAMING, tools/diag/build_variant.py; round 6): the streaming conv backward of
+// rounds 1-4 -- pool_dgrad3 (gather form) + pool_wgrad3 (LDS-tiled) and their single-tensor forms.  Since round 5 the fused
+// plane-walk kernel below takes EVERY block of every configuration the suite runs (tools/diag/pool_bwd_paths.py: 9 configs x 16
+// blocks, no fallback), and it is pinned against autograd of the oracle (tests/test_kernels_gpu.py::
+// test_pool_backward_vs_oracle_at_the_step_shapes, ::test_pool_conv_bwd_fused_small_planes), so these kernels are no longer a
+// product path nor its comparator: the product library does not contain them, svit_pool_conv_bwd_qkv fails loudly
+// (SVIT_ERR_SHAPE) where the fused plan does not fit, and the four streaming entry points exist only in this build.
+#ifdef SVIT_DIAG_POOL_STREAMING
+#define SVIT_POOL_STREAMING_PART 1
+#include "../../tools/diag/variants/pool_streaming.inc"
+#undef SVIT_POOL_STREAMING_PART
+#endif
 // ---------------------------------------------------------------------------------------
 // Fused conv backward (round 5): conv dgrad AND conv wgrad of q, k, v in ONE launch, replacing
 // pool_dgrad3 (27-tap gather of dpre through L2: 5x its bytes fetched) + pool_wgrad3 (x halo ring + dpre re-read).
@@ -2748,7 +2385,10 @@ static int pool_ln_fwd_qkv_kernels(const svit_pool_args* a3, const uint32_t* con
       if (need > slds) slds = need;
       if ((unsigned)(pl.nt * pl.ny) > sgx) sgx = pl.nt * pl.ny;
       const int nout = 1 + a3[i].T * ((a3[i].H - 1) / s + 1) * ((a3[i].W - 1) / s + 1) + a3[i].n_obj;
-      constexpr long ln_want = 2048;    // (in-step A/B of round 4: 1024 -> 2048 is -0.02..-0.04 ms)
+#ifndef SVIT_SLAB_LN_WANT
+#define SVIT_SLAB_LN_WANT 2048
+#endif
+      constexpr long ln_want = SVIT_SLAB_LN_WANT;    // (in-step A/B of round 4: 1024 -> 2048 is -0.02..-0.04 ms)
       ln_blocks = std::max(ln_blocks, (int)persistent_x((nout + 63) / 64, a3[0].B * a3[0].heads * 3, ln_want));
       ++n_slab;
     }
@@ -2863,7 +2503,7 @@ static int pool_ln_fwd_qkv_kernels(const svit_pool_args* a3, const uint32_t* con
       for (int i = 0; i < 3; ++i) {
         const int s = a3[i].stride_hw;
         const int nout = 1 + a3[i].T * ((a3[i].H - 1) / s + 1) * ((a3[i].W - 1) / s + 1) + a3[i].n_obj;
-        blocks = std::max(blocks, (int)persistent_x((nout + 63) / 64, a3[0].B * a3[0].heads * 3, 2048));
+        blocks = std::max(blocks, (int)persistent_x((nout + 63) / 64, a3[0].B * a3[0].heads * 3, SVIT_SLAB_LN_WANT));
         sg.plan[i].on = 1;
       }
       *q_on_slab = sg.p[0].relq_R != nullptr;       // (already cleared above when the product tile does not fit)
@@ -2951,69 +2591,11 @@ extern "C" int svit_pool_ln_bwd_qkv(const svit_pool_ln_bwd_args* a3, void* strea
   return SVIT_OK;
 }
 
-extern "C" int svit_pool_conv_dgrad_qkv(const svit_pool_dgrad_args* a3, void* stream) {
-  if (!a3) return SVIT_ERR_ARG;
-  PoolDgrad3 g;
-  const int N = 1 + a3[0].T * a3[0].H * a3[0].W + a3[0].n_obj;
-  const unsigned gx = persistent_x((N + 63) / 64, a3[0].B * a3[0].heads * 3);
-  for (int i = 0; i < 3; ++i) {
-    const svit_pool_dgrad_args* a = &a3[i];
-    if (!a->dpre || !a->conv_w || !a->dqkv || a->which < 0 || a->which > 2) return SVIT_ERR_ARG;
-    const int rc = check_pool_dims(a->B, a->heads, a->T, a->H, a->W, a->n_obj, a->stride_hw);
-    if (rc) return rc;
-    if (a->B != a3[0].B || a->heads != a3[0].heads || a->T != a3[0].T || a->H != a3[0].H ||
-        a->W != a3[0].W || a->n_obj != a3[0].n_obj)
-      return SVIT_ERR_SHAPE;
-    g.p[i] = *a;
-  }
-  hipLaunchKernelGGL(pool_dgrad3_kernel, dim3(gx, a3[0].B * a3[0].heads, 3), dim3(256), 0, (hipStream_t)stream, g);
-  SVIT_LAUNCH_CHECK();
-  return SVIT_OK;
-}
-
-extern "C" int svit_pool_conv_wgrad_qkv(const svit_pool_wgrad_args* a3, void* stream) {
-  if (!a3 || !a3[0].workspace) return SVIT_ERR_ARG;
-  PoolWgrad3 g;
-  int64_t blocks = 1;
-  size_t lds = 0;
-  for (int i = 0; i < 3; ++i) {
-    const svit_pool_wgrad_args* a = &a3[i];
-    if (!a->dpre || !a->qkv || !a->dw || a->which < 0 || a->which > 2) return SVIT_ERR_ARG;
-    const int rc = check_pool_dims(a->B, a->heads, a->T, a->H, a->W, a->n_obj, a->stride_hw);
-    if (rc) return rc;
-    const int Ho = (a->H - 1) / a->stride_hw + 1, Wo = (a->W - 1) / a->stride_hw + 1;
-    g.p[i] = *a;
-    size_t need;
-    if (a->stride_hw == 1) { g.plan[i] = plan_wgrad<1>(*a, Ho, Wo); need = WgradTile<1>::LDS_BYTES; }
-    else if (a->stride_hw == 2) { g.plan[i] = plan_wgrad<2>(*a, Ho, Wo); need = WgradTile<2>::LDS_BYTES; }
-    else { g.plan[i] = plan_wgrad<3>(*a, Ho, Wo); need = WgradTile<3>::LDS_BYTES; }
-    if (need > lds) lds = need;
-    if (g.plan[i].n_tiles > blocks) blocks = g.plan[i].n_tiles;
-  }
-  if (blocks > 1024) blocks = 1024;
-  if (blocks > a3[0].workspace_floats / (3 * 27 * HD)) blocks = a3[0].workspace_floats / (3 * 27 * HD);
-  if (blocks < 1) return SVIT_ERR_ARG;
-  bool sparse = false;
-  for (int i = 0; i < 3; ++i) sparse = sparse || g.plan[i].sclass >= 3;
-  {
-    size_t mx = WgradTile<1>::LDS_BYTES;
-    if ((size_t)WgradTile<2>::LDS_BYTES > mx) mx = WgradTile<2>::LDS_BYTES;
-    if ((size_t)WgradTile<3>::LDS_BYTES > mx) mx = WgradTile<3>::LDS_BYTES;
-    static SvitOnce once[2];
-    if (int rc = svit_max_lds_once(once[0], (const void*)pool_wgrad3_kernel<false>, mx)) return rc;
-    if (int rc = svit_max_lds_once(once[1], (const void*)pool_wgrad3_kernel<true>, mx)) return rc;
-  }
-  if (sparse)
-    hipLaunchKernelGGL(pool_wgrad3_kernel<true>, dim3((unsigned)blocks, 3), dim3(192), lds, (hipStream_t)stream, g);
-  else
-    hipLaunchKernelGGL(pool_wgrad3_kernel<false>, dim3((unsigned)blocks, 3), dim3(192), lds, (hipStream_t)stream, g);
-  SVIT_LAUNCH_CHECK();
-  SvitReduceDst dst = {{a3[0].dw, a3[1].dw, a3[2].dw, a3[2].dw, a3[2].dw, a3[2].dw},
-                       {27 * HD, 2 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD, 3 * 27 * HD}};
-  svit_launch_reduce(a3[0].workspace, (int)blocks, 3 * 27 * HD, dst, (hipStream_t)stream);
-  SVIT_LAUNCH_CHECK();
-  return SVIT_OK;
-}
+#ifdef SVIT_DIAG_POOL_STREAMING
+#define SVIT_POOL_STREAMING_PART 2
+#include "../../tools/diag/variants/pool_streaming.inc"
+#undef SVIT_POOL_STREAMING_PART
+#endif
 
 // Planner of the fused conv backward: input planes (n) and unit rows (R) per chunk for each tensor, so that the items (one per
 // batch*head, tensor, 32-channel group, t-chunk, y-chunk) are about equally long and fill the chip's slots (two workgroups
@@ -3168,10 +2750,16 @@ extern "C" int svit_pool_conv_bwd_qkv(const svit_pool_dgrad_args* d3, const svit
   const int64_t prows = fused ? (int64_t)d3[0].B * d3[0].heads * g.max_chunks : 0;
   if (fused && (!w3[0].workspace || w3[0].workspace_floats < prows * 3 * 27 * HD || prows > 4096)) fused = false;
   __atomic_store_n(&g_pool_bwd_last_path, fused ? 1 : 0, __ATOMIC_RELAXED);
-  if (!fused) {   // large planes (pooled planes past 14x14, strides > 2): the streaming / tiled kernels
+  if (!fused) {
+#ifdef SVIT_DIAG_POOL_STREAMING      // (diagnostic build: the two streaming launches of rounds 1-4, also the knob-off arm)
     int rc = svit_pool_conv_dgrad_qkv(d3, stream);
     if (rc) return rc;
     return svit_pool_conv_wgrad_qkv(w3, stream);
+#else
+    // no plan (a volume whose unit row of three planes does not fit 79 KB of LDS, a clip past the 2-GiB descriptor span), a
+    // workspace smaller than the plan's partial rows, or key 1 = 0: the product library has no other conv backward -- fail loudly
+    return SVIT_ERR_SHAPE;
+#endif
   }
   for (int i = 0; i < 3; ++i) g.d[i] = d3[i];
   g.qkv = w3[0].qkv;
@@ -3207,34 +2795,11 @@ extern "C" int svit_pool_ln_bwd(const svit_pool_ln_bwd_args* a, void* stream) {
   return SVIT_OK;
 }
 
-extern "C" int svit_pool_conv_dgrad(const svit_pool_dgrad_args* a, void* stream) {
-  if (!a || !a->dpre || !a->conv_w || !a->dqkv || a->which < 0 || a->which > 2) return SVIT_ERR_ARG;
-  int rc = check_pool_dims(a->B, a->heads, a->T, a->H, a->W, a->n_obj, a->stride_hw);
-  if (rc) return rc;
-  const int N = 1 + a->T * a->H * a->W + a->n_obj;
-  const dim3 grid(persistent_x((N + 63) / 64, a->B * a->heads), a->B * a->heads);
-  if (a->stride_hw == 1)
-    hipLaunchKernelGGL(pool_dgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-  else if (a->stride_hw == 2)
-    hipLaunchKernelGGL(pool_dgrad_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-  else
-    hipLaunchKernelGGL(pool_dgrad_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-  SVIT_LAUNCH_CHECK();
-  return SVIT_OK;
-}
-
-extern "C" int svit_pool_conv_wgrad(const svit_pool_wgrad_args* a, void* stream) {
-  if (!a || !a->dpre || !a->qkv || !a->dw || a->which < 0 || a->which > 2) return SVIT_ERR_ARG;
-  int rc = check_pool_dims(a->B, a->heads, a->T, a->H, a->W, a->n_obj, a->stride_hw);
-  if (rc) return rc;
-  const int Ho = (a->H - 1) / a->stride_hw + 1, Wo = (a->W - 1) / a->stride_hw + 1;
-  const int64_t total = (int64_t)a->B * a->heads * (1 + a->T * Ho * Wo + a->n_obj);
-  if (!a->workspace) return SVIT_ERR_ARG;
-  (void)total;
-  if (a->stride_hw == 1) return launch_wgrad<1>(*a, Ho, Wo, (hipStream_t)stream);
-  if (a->stride_hw == 2) return launch_wgrad<2>(*a, Ho, Wo, (hipStream_t)stream);
-  return launch_wgrad<3>(*a, Ho, Wo, (hipStream_t)stream);
-}
+#ifdef SVIT_DIAG_POOL_STREAMING
+#define SVIT_POOL_STREAMING_PART 3
+#include "../../tools/diag/variants/pool_streaming.inc"
+#undef SVIT_POOL_STREAMING_PART
+#endif
 
 static int check_relq(int ld, int kh, int kw, int kt) {
   const int extra = ld - HD;

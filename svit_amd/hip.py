@@ -146,14 +146,10 @@ _SIGS = {
     "svit_special_token_grads": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "svit_pool_ln_fwd": (i32, [C.POINTER(PoolArgs), vp]),
     "svit_pool_ln_bwd": (i32, [C.POINTER(PoolLnBwdArgs), vp]),
-    "svit_pool_conv_dgrad": (i32, [C.POINTER(PoolDgradArgs), vp]),
-    "svit_pool_conv_wgrad": (i32, [C.POINTER(PoolWgradArgs), vp]),
     "svit_pool_ln_fwd_qkv": (i32, [C.POINTER(PoolArgs), vp]),
     "svit_pool_ln_fwd_qkv_sel": (i32, [C.POINTER(PoolArgs), C.POINTER(vp), vp]),
     "svit_pool_weight_sel": (i32, [vp, vp, vp, i32, vp]),
     "svit_pool_ln_bwd_qkv": (i32, [C.POINTER(PoolLnBwdArgs), vp]),
-    "svit_pool_conv_dgrad_qkv": (i32, [C.POINTER(PoolDgradArgs), vp]),
-    "svit_pool_conv_wgrad_qkv": (i32, [C.POINTER(PoolWgradArgs), vp]),
     "svit_pool_conv_bwd_qkv": (i32, [C.POINTER(PoolDgradArgs), C.POINTER(PoolWgradArgs), vp]),
     "svit_relpos_q_fwd": (i32, [C.POINTER(RelqArgs), vp]),
     "svit_relpos_q_bwd": (i32, [C.POINTER(RelqBwdArgs), vp]),

@@ -411,22 +411,13 @@ def pool_ln_bwd_qkv(entries, ws=None):
     return res
 
 
+# (the four streaming conv-backward entry points left the product library in round 6: their wrappers live in
+#  tools/diag/pool_streaming.py and need a -DSVIT_DIAG_POOL_STREAMING build)
 def _pool_dgrad_args(a, dpre, conv_w, dqkv, which, B, heads, thw, n_obj, stride_hw):
     a.dpre, a.conv_w, a.dqkv, a.which = ptr(dpre), ptr(conv_w), ptr(dqkv), which
     a.B, a.heads, (a.T, a.H, a.W), a.n_obj, a.stride_hw = B, heads, thw, n_obj, stride_hw
 
 
-def pool_conv_dgrad(dpre, conv_w, dqkv, which, B, heads, thw, n_obj, stride_hw):
-    a = hip.PoolDgradArgs()
-    _pool_dgrad_args(a, dpre, conv_w, dqkv, which, B, heads, thw, n_obj, stride_hw)
-    hip.call("svit_pool_conv_dgrad", C.byref(a))
-
-
-def pool_conv_dgrad_qkv(dpres, conv_ws, dqkv, B, heads, thw, n_obj, strides):
-    arr = (hip.PoolDgradArgs * 3)()
-    for i in range(3):
-        _pool_dgrad_args(arr[i], dpres[i], conv_ws[i], dqkv, i, B, heads, thw, n_obj, strides[i])
-    hip.call("svit_pool_conv_dgrad_qkv", arr)
 
 
 def _pool_wgrad_args(a, dpre, qkv, which, dw, B, heads, thw, n_obj, stride_hw, ws=None):
@@ -436,17 +427,6 @@ def _pool_wgrad_args(a, dpre, qkv, which, dw, B, heads, thw, n_obj, stride_hw, w
     a.workspace, a.workspace_floats = ptr(ws), ws.numel()
 
 
-def pool_conv_wgrad(dpre, qkv, which, dw, B, heads, thw, n_obj, stride_hw):
-    a = hip.PoolWgradArgs()
-    _pool_wgrad_args(a, dpre, qkv, which, dw, B, heads, thw, n_obj, stride_hw)
-    hip.call("svit_pool_conv_wgrad", C.byref(a))
-
-
-def pool_conv_wgrad_qkv(dpres, qkv, dws, B, heads, thw, n_obj, strides, ws=None):
-    arr = (hip.PoolWgradArgs * 3)()
-    for i in range(3):
-        _pool_wgrad_args(arr[i], dpres[i], qkv, i, dws[i], B, heads, thw, n_obj, strides[i], ws)
-    hip.call("svit_pool_conv_wgrad_qkv", arr)
 
 
 def pool_conv_bwd_qkv(dpres, conv_ws, dqkv, qkv, dws, B, heads, thw, n_obj, strides, ws=None):

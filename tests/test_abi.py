@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_functions():
     text = open(os.path.join(ROOT, "include", "svit_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    # declarations of DIAGNOSTIC builds (#ifdef SVIT_DIAG_... blocks: entry points the product library does not export)
+    text = re.sub(r"#ifdef SVIT_DIAG_\w+.*?#endif", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(svit_[a-z0-9_]+)\s*\(", text)))
 
 

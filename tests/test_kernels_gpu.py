@@ -373,14 +373,18 @@ def test_pool_ln_fwd_bwd(ops, stride, thw):
     dgam, dbet = torch.zeros(96, device=DEV), torch.zeros(96, device=DEV)
     dpre = ops.pool_ln_bwd(pre, mean, rstd, g, dgam, dbet, B, h, Nout, d_main=dout, ld_main=96)
     assert rel_err(dgam, gc.grad) < 2e-2 and rel_err(dbet, bc.grad) < 2e-2
-    dqkv = torch.zeros_like(qkv)
-    ops.pool_conv_dgrad(dpre, w.reshape(96, 27).contiguous(), dqkv, which, B, h, thw, O, stride)
+    # conv dgrad + wgrad: the fused q-k-v entry point (the product's only conv backward since round 6) with this tensor's
+    # dpre / weight / stride in all three slots -- slice `which` of dqkv and its dw are what autograd of the oracle gives
+    dqkv = torch.full_like(qkv, 7.0)
+    w27 = w.reshape(96, 27).contiguous()
+    dws = [torch.zeros((96, 27), device=DEV) for _ in range(3)]
+    ops.pool_conv_bwd_qkv([dpre] * 3, [w27] * 3, dqkv, qkv, dws, B, h, thw, O, (stride,) * 3)
+    from svit_amd import hip
+    assert hip.load().svit_debug_pool_bwd_path() == 1
     got = dqkv[:, :, which].permute(0, 2, 1, 3)
     assert cos(got, x.grad) > 0.9995 and rel_err(got, x.grad) < 3e-2
-    assert float(dqkv[:, :, 0].float().abs().max()) == 0
-    dw = torch.zeros((96, 27), device=DEV)
-    ops.pool_conv_wgrad(dpre, qkv, which, dw, B, h, thw, O, stride)
-    assert cos(dw, wc.grad.reshape(96, 27)) > 0.9995 and rel_err(dw, wc.grad.reshape(96, 27)) < 3e-2
+    assert torch.equal(dqkv[:, :, 0], dqkv[:, :, which])         # (dx depends on dpre and w only)
+    assert cos(dws[which], wc.grad.reshape(96, 27)) > 0.9995 and rel_err(dws[which], wc.grad.reshape(96, 27)) < 3e-2
 
 
 @pytest.mark.parametrize("sq,skv,thw", [(1, 1, (2, 8, 8)), (1, 2, (3, 7, 7)), (2, 1, (2, 16, 16)),
@@ -450,17 +454,6 @@ def test_pool_qkv_fused_equals_single(ops, sq, skv, thw):
     for i in range(3):
         assert torch.equal(dpres[i], refs[i])
         assert rel_err(dgs[i], dgs[3 + i]) < 1e-5 and rel_err(dbs[i], dbs[3 + i]) < 1e-5
-    d1, d2 = torch.zeros_like(qkv), torch.zeros_like(qkv)
-    ops.pool_conv_dgrad_qkv(dpres, ws, d1, B, h, thw, O, strides)
-    for i in range(3):
-        ops.pool_conv_dgrad(dpres[i], ws[i], d2, i, B, h, thw, O, strides[i])
-    assert torch.equal(d1, d2)
-    dw1 = [torch.zeros((96, 27), device=DEV) for _ in range(3)]
-    dw2 = [torch.zeros((96, 27), device=DEV) for _ in range(3)]
-    ops.pool_conv_wgrad_qkv(dpres, qkv, dw1, B, h, thw, O, strides)
-    for i in range(3):
-        ops.pool_conv_wgrad(dpres[i], qkv, i, dw2[i], B, h, thw, O, strides[i])
-        assert rel_err(dw1[i], dw2[i]) < 1e-5
 
 
 @pytest.mark.parametrize("sq,skv,thw,B,h", [(1, 2, (4, 14, 14), 2, 4), (2, 1, (2, 14, 14), 2, 8),
@@ -481,39 +474,46 @@ def test_pool_qkv_fused_equals_single(ops, sq, skv, thw):
                                              (2, 3, (2, 19, 26), 1, 2)])     # stride 3
 def test_pool_conv_bwd_fused_small_planes(ops, sq, skv, thw, B, h):
     """Round 5: conv dgrad + conv wgrad of q, k, v in ONE launch with the dpre halo staged once in LDS
-    (csrc/pool.hip::pool_bwd_fused_kernel; every stride, planes cut in t and y) == the streaming launches it replaces
-    (svit_debug_set_pool(1, 0) runs them through the same entry point)"""
-    import ctypes as C
+    (csrc/pool.hip::pool_bwd_fused_kernel; every stride, planes cut in t and y).  Round 6: against fp32 autograd of the
+    pre-LayerNorm pooling on the CPU (depthwise Conv3d + the object-gain rows + the cls row: attention.py:13-65 as
+    oracle.svit_ref.pool_tokens restates it, without its LayerNorm) on the same bf16 dpre -- the streaming kernels this test
+    used as its comparator in round 5 left the product library."""
     from svit_amd import hip
     lib = hip.load()
     O = 5
     qkv = _qkv(B, h, thw, O, "s%d%d" % (sq, skv))
     ws = [rnd("sw%d" % i, (96, 27), 0.3) for i in range(3)]
     strides = (sq, skv, skv)
-    dpres = []
-    for i, s in enumerate(strides):
-        Nout = 1 + thw[0] * ops.pooled(thw[1], s) * ops.pooled(thw[2], s) + O
-        dpres.append(rnd("sd%d%d" % (i, s), (B, h, Nout, 96), 1.0, BF16))
-    d_ref = torch.zeros_like(qkv)
-    ops.pool_conv_dgrad_qkv(dpres, ws, d_ref, B, h, thw, O, strides)
-    dw_ref = [torch.zeros((96, 27), device=DEV) for _ in range(3)]
-    ops.pool_conv_wgrad_qkv(dpres, qkv, dw_ref, B, h, thw, O, strides)
+    T, H, W = thw
+    L = T * H * W
+    dpres, refs = [], []
+    for i, s_ in enumerate(strides):
+        Nout = 1 + T * ops.pooled(H, s_) * ops.pooled(W, s_) + O
+        dpres.append(rnd("sd%d%d" % (i, s_), (B, h, Nout, 96), 1.0, BF16))
+        x = qkv[:, :, i].permute(0, 2, 1, 3).float().cpu().requires_grad_(True)       # [B, h, N, 96]
+        wc = ws[i].cpu().reshape(96, 1, 3, 3, 3).clone().requires_grad_(True)
+        vol = x[:, :, 1:1 + L].reshape(B * h, T, H, W, 96).permute(0, 4, 1, 2, 3)
+        vol = F.conv3d(vol, wc, None, stride=(1, s_, s_), padding=1, groups=96)
+        pre = torch.cat([x[:, :, :1], vol.reshape(B, h, 96, -1).transpose(2, 3),
+                         x[:, :, 1 + L:] * R.object_gain(wc, (1, s_, s_))], dim=2)
+        pre.backward(dpres[i].float().cpu())
+        refs.append((x.grad, wc.grad.reshape(96, 27)))
     d_got = torch.full_like(qkv, 7.0)                       # every element must be overwritten
     dw_got = [torch.full((96, 27), 0.5, device=DEV) for _ in range(3)]
     ops.pool_conv_bwd_qkv(dpres, ws, d_got, qkv, dw_got, B, h, thw, O, strides)
-    assert lib.svit_debug_pool_bwd_path() == 1, "the fused kernel did not run (silent fallback to the streaming launches)"
-    assert rel_err(d_got.float(), d_ref.float()) < 1e-2
-    assert float((d_got.float() - d_ref.float()).abs().max()) < 0.05 * float(d_ref.float().abs().max())
+    assert lib.svit_debug_pool_bwd_path() == 1, "the fused kernel did not run"
     for i in range(3):
-        assert rel_err(dw_got[i] - 0.5, dw_ref[i]) < 2e-4
-    # and the same entry point with the fused kernel switched off: the two paths stay interchangeable
+        gx, gw = refs[i]
+        got = d_got[:, :, i].permute(0, 2, 1, 3)
+        assert cos(got, gx) > 0.9999 and rel_err(got, gx) < 1.5e-2, i      # bf16 weights in the dgrad taps, bf16 output
+        assert rel_err(dw_got[i] - 0.5, gw) < 2e-3 and cos(dw_got[i] - 0.5, gw) > 0.99999, i
+    # the product library has no other conv backward: with the fused kernel refused the entry point fails loudly
     try:
         assert lib.svit_debug_set_pool(1, 0) == 0
-        d_off = torch.full_like(qkv, 7.0)
-        dw_off = [torch.zeros((96, 27), device=DEV) for _ in range(3)]
-        ops.pool_conv_bwd_qkv(dpres, ws, d_off, qkv, dw_off, B, h, thw, O, strides)
+        with pytest.raises(hip.SvitHipError):
+            ops.pool_conv_bwd_qkv(dpres, ws, torch.empty_like(qkv), qkv, [torch.zeros((96, 27), device=DEV) for _ in range(3)],
+                                  B, h, thw, O, strides)
         assert lib.svit_debug_pool_bwd_path() == 0
-        assert torch.equal(d_off, d_ref)
     finally:
         lib.svit_debug_reset()
 

@@ -5,6 +5,13 @@ import json
 import os
 import sys
 
+
+def _streaming():
+    """the streaming conv-backward wrappers (diagnostic build only since round 6: tools/diag/pool_streaming.py)"""
+    from tools.diag import pool_streaming
+    return pool_streaming
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
@@ -198,9 +205,9 @@ def bench_pool():
             t_l = timeit(lambda: ops.pool_ln_bwd(pre, mean, rstd, g, dg, db, B, h, Nout, d_main=dout, ld_main=96))
             dpre = ops.pool_ln_bwd(pre, mean, rstd, g, dg, db, B, h, Nout, d_main=dout, ld_main=96)
             dqkv = torch.empty_like(qkv)
-            t_d = timeit(lambda: ops.pool_conv_dgrad(dpre, w, dqkv, which, B, h, thw, n_obj, s))
+            t_d = timeit(lambda: _streaming().pool_conv_dgrad(dpre, w, dqkv, which, B, h, thw, n_obj, s))
             dw = torch.zeros(96, 27, device=DEV)
-            t_w = timeit(lambda: ops.pool_conv_wgrad(dpre, qkv, which, dw, B, h, thw, n_obj, s))
+            t_w = timeit(lambda: _streaming().pool_conv_wgrad(dpre, qkv, which, dw, B, h, thw, n_obj, s))
             print("blk%-2d h=%d in=%6d out=%6d which=%d s=%d  fwd %7.1f  ln_bwd %7.1f  dgrad %7.1f  wgrad %7.1f" %
                   (blk, h, N, Nout, which, s, t_f, t_l, t_d, t_w))
 
@@ -449,8 +456,8 @@ def bench_pool_bwd():
         dpres = [rnd(B, h, 1 + thw[0] * ops.pooled(thw[1], s) * ops.pooled(thw[2], s) + n_obj, 96) for s in strides]
         dqkv = torch.empty_like(qkv)
         dws = [torch.zeros(96, 27, device=DEV) for _ in range(3)]
-        t_d = timeit(lambda: ops.pool_conv_dgrad_qkv(dpres, ws, dqkv, B, h, thw, n_obj, strides))
-        t_w = timeit(lambda: ops.pool_conv_wgrad_qkv(dpres, qkv, dws, B, h, thw, n_obj, strides))
+        t_d = timeit(lambda: _streaming().pool_conv_dgrad_qkv(dpres, ws, dqkv, B, h, thw, n_obj, strides))
+        t_w = timeit(lambda: _streaming().pool_conv_wgrad_qkv(dpres, qkv, dws, B, h, thw, n_obj, strides))
         t_f = timeit(lambda: ops.pool_conv_bwd_qkv(dpres, ws, dqkv, qkv, dws, B, h, thw, n_obj, strides))
         print("blk%-2d h=%d N=%5d sq=%d skv=%d  dgrad3 %6.1f + wgrad3 %6.1f | fused %6.1f" % (blk, h, N, sq, skv, t_d, t_w, t_f))
 

@@ -7,6 +7,13 @@ import torch
 from svit_amd import hip, ops
 from tools.bench_kernels import rnd, timeit, DEV
 B, n_obj = 8, 64
+
+def _streaming():
+    """the streaming conv-backward wrappers (diagnostic build only since round 6: tools/diag/pool_streaming.py)"""
+    from tools.diag import pool_streaming
+    return pool_streaming
+
+
 side = torch.cuda.Stream()
 for blk, h, thw, sq, skv in [(4, 4, (8, 14, 14), 1, 2), (2, 2, (8, 28, 28), 1, 4), (14, 8, (8, 14, 14), 2, 1)]:
     N = 1 + thw[0] * thw[1] * thw[2] + n_obj
@@ -17,8 +24,8 @@ for blk, h, thw, sq, skv in [(4, 4, (8, 14, 14), 1, 2), (2, 2, (8, 28, 28), 1, 4
     dqkv = torch.empty_like(qkv)
     dws = [torch.zeros(96, 27, device=DEV) for _ in range(3)]
     wsp = torch.empty(8 << 20, device=DEV)
-    dg = lambda: ops.pool_conv_dgrad_qkv(dpres, ws, dqkv, B, h, thw, n_obj, strides)
-    wg = lambda: ops.pool_conv_wgrad_qkv(dpres, qkv, dws, B, h, thw, n_obj, strides, wsp)
+    dg = lambda: _streaming().pool_conv_dgrad_qkv(dpres, ws, dqkv, B, h, thw, n_obj, strides)
+    wg = lambda: _streaming().pool_conv_wgrad_qkv(dpres, qkv, dws, B, h, thw, n_obj, strides, wsp)
     def serial():
         dg(); wg()
     def forked():

@@ -7,6 +7,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from svit_amd import ops
 from tools.bench_kernels import rnd, B, DEV
+
+def _streaming():
+    """the streaming conv-backward wrappers (diagnostic build only since round 6: tools/diag/pool_streaming.py)"""
+    from tools.diag import pool_streaming
+    return pool_streaming
+
+
 cfgs = {0: (1, (8, 56, 56), 1, 8), 1: (2, (8, 56, 56), 2, 4), 2: (2, (8, 28, 28), 1, 4), 3: (4, (8, 28, 28), 2, 2),
         4: (4, (8, 14, 14), 1, 2), 14: (8, (8, 14, 14), 2, 1)}
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
@@ -23,8 +30,8 @@ for blk, (h, thw, sq, skv) in cfgs.items():
     dws = [torch.zeros(96, 27, device=DEV) for _ in range(3)]
     dqkv = torch.zeros_like(qkv)
     wsp = torch.empty(8 << 20, device=DEV)
-    def dg(): ops.pool_conv_dgrad_qkv(dpres, ws, dqkv, B, h, thw, n_obj, strides)
-    def wg(): ops.pool_conv_wgrad_qkv(dpres, qkv, dws, B, h, thw, n_obj, strides, ws=wsp)
+    def dg(): _streaming().pool_conv_dgrad_qkv(dpres, ws, dqkv, B, h, thw, n_obj, strides)
+    def wg(): _streaming().pool_conv_wgrad_qkv(dpres, qkv, dws, B, h, thw, n_obj, strides, ws=wsp)
     def timed(fn, n=20):
         for _ in range(3): fn()
         torch.cuda.synchronize()

@@ -43,6 +43,13 @@ ROW = 3 * 27 * 96          # floats per workgroup row: [which][c][tap]
 WS_ROWS = 1024
 
 
+
+def _streaming():
+    """the streaming conv-backward wrappers (diagnostic build only since round 6: tools/diag/pool_streaming.py)"""
+    from tools.diag import pool_streaming
+    return pool_streaming
+
+
 def partner(kind):
     if kind == "nt":
         ops.gemm_nt(a16, w16, None, hip.EPI_BF16, out=nt_out)
@@ -59,7 +66,7 @@ def partner(kind):
 def victim(ws):
     ws.fill_(-7.0)                 # rows no workgroup writes stay recognisable
     dws = [torch.zeros(96, 27, device=DEV) for _ in range(3)]
-    ops.pool_conv_wgrad_qkv(dpres, qkv, dws, B, h, thw, O, strides, ws=ws)
+    _streaming().pool_conv_wgrad_qkv(dpres, qkv, dws, B, h, thw, O, strides, ws=ws)
     return ws[:WS_ROWS * ROW].clone(), torch.stack(dws)
 
 

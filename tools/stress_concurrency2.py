@@ -10,6 +10,13 @@ import torch
 from svit_amd import hip, ops
 
 torch.manual_seed(0)
+
+def _streaming():
+    """the streaming conv-backward wrappers (diagnostic build only since round 6: tools/diag/pool_streaming.py)"""
+    from tools.diag import pool_streaming
+    return pool_streaming
+
+
 DEV = "cuda"
 RUNS = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 B, h, thw, O = 8, 4, (8, 14, 14), 64
@@ -57,11 +64,11 @@ def victim(kind, ws):
     ws.fill_(-7.0)
     if kind == "qkv122":       # fused launch, strides (1, 2, 2)
         dws = [torch.zeros(96, 27, device=DEV) for _ in range(3)]
-        ops.pool_conv_wgrad_qkv([dp[1], dp[2], dp[2]], qkv, dws, B, h, thw, O, (1, 2, 2), ws=ws)
+        _streaming().pool_conv_wgrad_qkv([dp[1], dp[2], dp[2]], qkv, dws, B, h, thw, O, (1, 2, 2), ws=ws)
         return ws[:1024 * 7776].clone(), 7776
     if kind == "qkv111":
         dws = [torch.zeros(96, 27, device=DEV) for _ in range(3)]
-        ops.pool_conv_wgrad_qkv([dp[1], dp[1], dp[1]], qkv, dws, B, h, thw, O, (1, 1, 1), ws=ws)
+        _streaming().pool_conv_wgrad_qkv([dp[1], dp[1], dp[1]], qkv, dws, B, h, thw, O, (1, 1, 1), ws=ws)
         return ws[:1024 * 7776].clone(), 7776
     s = 2 if kind == "single_s2" else 1      # the single-tensor kernel
     dw = torch.zeros(96, 27, device=DEV)
