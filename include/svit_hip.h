@@ -248,8 +248,6 @@ int svit_pool_ln_fwd_qkv(const svit_pool_args* args3, void* stream);
 int svit_pool_weight_sel(const float* src_base, const int64_t* src_off, uint32_t* dst, int n_tables,
                          void* stream);
 int svit_pool_ln_fwd_qkv_sel(const svit_pool_args* args3, const uint32_t* const* sel3, void* stream);
-/* (round 6) an entry with Nout == 0 is skipped -- the q tensor when svit_attn_bwd did its LayerNorm backward itself
- * (svit_attn_bwd_args.qln_*); its gamma / dgamma / dbeta must still be valid (zeros are added). */
 int svit_pool_ln_bwd_qkv(const svit_pool_ln_bwd_args* args3, void* stream);
 #ifdef SVIT_DIAG_POOL_STREAMING
 /* DIAGNOSTIC BUILD ONLY (round 6: csrc/pool.hip compiled with -DSVIT_DIAG_POOL_STREAMING, tools/diag/build_variant.py): the
@@ -360,14 +358,6 @@ typedef struct {
    *   the whole gradient of the pooled q and svit_pool_ln_bwd needs no d_extra.
    * relR == NULL = off (the caller runs svit_gemm_nt on relD). */
   const void* relR; float* relX;
-  /* optional (round 6; qln_pre == NULL = off): the dq kernel ALSO does the pooled-q LayerNorm's backward -- what svit_pool_ln_bwd
-   * computes for the q tensor (attention.py:263-304's norm_q under autograd) from d_main = dqa, d_res = dctx -- from the rows it
-   * holds: qln_pre bf16 [B,h,Nq,96] / qln_mean, qln_rstd f32 [B*h*Nq] / qln_gamma f32 [96] in, qln_dpre bf16 [B,h,Nq,96] out,
-   * qln_dgamma / qln_dbeta f32 [96] ACCUMULATED through qln_ws (>= ceil(Nq / 128) * B * h * 192 floats, one partial row per
-   * workgroup + the library's second-stage reduce).  dqa is then NOT written (may be NULL).  Requires the dq rows to be the whole
-   * gradient: "fold" mode above, or no rel-pos outputs at all. */
-  const void* qln_pre; const float* qln_mean; const float* qln_rstd; const float* qln_gamma;
-  void* qln_dpre; float* qln_dgamma; float* qln_dbeta; float* qln_ws; int64_t qln_ws_floats;
 } svit_attn_bwd_args;
 int svit_attn_bwd(const svit_attn_bwd_args* a, void* stream);
 /* number of dk / dv planes svit_attn_bwd will write for these arguments (>= 1; only the shape fields,

@@ -347,89 +347,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(svit_attn_bwd_args 
     }
   }
   constexpr int CPR = DA / 8;          // 16-byte chunks per row
-  if (a.qln_pre == nullptr) {
-    bf16_t* out = (bf16_t*)a.dqa + ((size_t)bh * a.Nq) * DA;
+  bf16_t* out = (bf16_t*)a.dqa + ((size_t)bh * a.Nq) * DA;
 #pragma unroll
-    for (int it = 0; it < CPR / 2; ++it) {
-      const int id = it * 64 + lane, row = id / CPR, ch = id % CPR;
-      if (q0 + row < a.Nq)
-        *(uint4*)(out + (size_t)(q0 + row) * DA + ch * 8) = *(const uint4*)(ost + row * OROW + ch * 16);
-    }
-  } else {
-    // ---- round 6 (fold mode only): the pooled-q LayerNorm's BACKWARD happens here, from the staged rows -- the whole gradient of
-    // LN(pool(q)) is dq[:, 0:96] (with the folded D . R^T) + the residual-pooling path's dctx (every token but cls), and this wave
-    // holds its 32 rows whole.  dqa is not written at all; dpre_q = rstd (g - mean(g) - xhat mean(g xhat)), g = gamma * d, goes out as
-    // whole 192-byte rows, dgamma / dbeta as one partial row per workgroup (the caller's second-stage reduce adds them in a fixed
-    // order).  What svit_pool_ln_bwd did for the q tensor in a launch of its own: dqa written (bf16 [.., DA]) and read back, 27 MB
-    // per 14x14 block, and dctx / pre fetched by a cold kernel.  Same addends, same two roundings (dq to bf16, dpre to bf16).
-    // lane -> (row = 4 it + lane / 16, 16-byte chunk ch = lane % 16 of which 12 carry data): a row sits on one 16-lane DPP row.
-    const int ch = lane & 15, rsub = lane >> 4;
-    const bool cl = ch < 12;
-    float gam[8], dgs[8], dbs[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { gam[e] = cl ? a.qln_gamma[ch * 8 + e] : 0.f; dgs[e] = 0.f; dbs[e] = 0.f; }
-    const bf16_t* dres = (const bf16_t*)a.dctx + (size_t)b * a.Nq * a.heads * HD + head * HD;
-    const bf16_t* preq = (const bf16_t*)a.qln_pre + (size_t)bh * a.Nq * HD;
-    bf16_t* dpq = (bf16_t*)a.qln_dpre + (size_t)bh * a.Nq * HD;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = it * 4 + rsub, q = q0 + row;
-      const bool live = cl && q < a.Nq;
-      float g[8], xh[8], rstd = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { g[e] = 0.f; xh[e] = 0.f; }
-      if (live) {
-        const uint4 dv = *(const uint4*)(ost + row * OROW + ch * 16);
-        const uint4 pv = *(const uint4*)(preq + (size_t)q * HD + ch * 8);
-        uint4 rv = make_uint4(0u, 0u, 0u, 0u);
-        if (q > 0) rv = *(const uint4*)(dres + (size_t)q * a.heads * HD + ch * 8);
-        const float mean = a.qln_mean[(size_t)bh * a.Nq + q];
-        rstd = a.qln_rstd[(size_t)bh * a.Nq + q];
-        const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w}, pw[4] = {pv.x, pv.y, pv.z, pv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
-#pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) {
-          const float d0 = lo_bf16(dw[e2]) + lo_bf16(rw[e2]), d1 = hi_bf16(dw[e2]) + hi_bf16(rw[e2]);
-          xh[2 * e2] = (lo_bf16(pw[e2]) - mean) * rstd;
-          xh[2 * e2 + 1] = (hi_bf16(pw[e2]) - mean) * rstd;
-          dgs[2 * e2] += d0 * xh[2 * e2]; dgs[2 * e2 + 1] += d1 * xh[2 * e2 + 1];
-          dbs[2 * e2] += d0; dbs[2 * e2 + 1] += d1;
-          g[2 * e2] = d0 * gam[2 * e2]; g[2 * e2 + 1] = d1 * gam[2 * e2 + 1];
-        }
-      }
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { s1 += g[e]; s2 += g[e] * xh[e]; }
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-      s1 *= 1.f / HD; s2 *= 1.f / HD;
-      if (live) {
-        uint4 ov;
-        ov.x = pack_bf16x2(rstd * (g[0] - s1 - xh[0] * s2), rstd * (g[1] - s1 - xh[1] * s2));
-        ov.y = pack_bf16x2(rstd * (g[2] - s1 - xh[2] * s2), rstd * (g[3] - s1 - xh[3] * s2));
-        ov.z = pack_bf16x2(rstd * (g[4] - s1 - xh[4] * s2), rstd * (g[5] - s1 - xh[5] * s2));
-        ov.w = pack_bf16x2(rstd * (g[6] - s1 - xh[6] * s2), rstd * (g[7] - s1 - xh[7] * s2));
-        *(uint4*)(dpq + (size_t)q * HD + ch * 8) = ov;
-      }
-    }
-    // dgamma / dbeta: the four row groups of the wave (lanes ch, ch + 16, ch + 32, ch + 48), then the four waves through
-    // their own (no longer used) D-row regions, then one partial row per workgroup
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      dgs[e] += __shfl_xor(dgs[e], 16, 64); dgs[e] += __shfl_xor(dgs[e], 32, 64);
-      dbs[e] += __shfl_xor(dbs[e], 16, 64); dbs[e] += __shfl_xor(dbs[e], 32, 64);
-    }
-    float* wred = (float*)(smem + 4 * (32 * OROW) + wave * (32 * 128 * 2));     // [2][96] floats of this wave
-    if (lane < 12) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { wred[lane * 8 + e] = dgs[e]; wred[HD + lane * 8 + e] = dbs[e]; }
-    }
-    __syncthreads();
-    if (threadIdx.x < 2 * HD) {
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) t += ((const float*)(smem + 4 * (32 * OROW) + w * (32 * 128 * 2)))[threadIdx.x];
-      a.qln_ws[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (2 * HD) + threadIdx.x] = t;
-    }
+  for (int it = 0; it < CPR / 2; ++it) {
+    const int id = it * 64 + lane, row = id / CPR, ch = id % CPR;
+    if (q0 + row < a.Nq)
+      *(uint4*)(out + (size_t)(q0 + row) * DA + ch * 8) = *(const uint4*)(ost + row * OROW + ch * 16);
   }
   // ---- optional: the rel-pos backward's scattered matrix D, rows of this wave (svit_attn_bwd_args.relD).
   // The staged tile still holds d(relq) in its columns 96..DA: they go to registers, then the wave's
@@ -797,17 +720,9 @@ extern "C" int svit_attn_bwd_parts(const svit_attn_bwd_args* a) {
 }
 
 extern "C" int svit_attn_bwd(const svit_attn_bwd_args* a, void* stream) {
-  if (!a || !a->qa || !a->ka || !a->v || !a->ctx || !a->dctx || !a->lse2 || !a->delta || (!a->dqa && !a->qln_pre) ||
+  if (!a || !a->qa || !a->ka || !a->v || !a->ctx || !a->dctx || !a->lse2 || !a->delta || !a->dqa ||
       !a->dk || !a->dv)
     return SVIT_ERR_ARG;
-  if (a->qln_pre) {     // fused pooled-q LayerNorm backward: the dq rows must be the whole gradient (fold mode, or no rel-pos at all)
-    if (!a->qln_mean || !a->qln_rstd || !a->qln_gamma || !a->qln_dpre || !a->qln_dgamma || !a->qln_dbeta || !a->qln_ws)
-      return SVIT_ERR_ARG;
-    if (a->relD && !(a->relR && !a->relX && a->relD_ld <= 128)) return SVIT_ERR_ARG;
-    if (((uintptr_t)a->qln_pre | (uintptr_t)a->qln_dpre) & 15) return SVIT_ERR_ALIGN;
-    const int64_t wgs = (int64_t)((a->Nq + 127) / 128) * a->B * a->heads;
-    if (a->qln_ws_floats < wgs * 2 * attn::HD) return SVIT_ERR_ARG;
-  }
   if (a->B <= 0 || a->heads <= 0 || a->Nq <= 0 || a->Nk <= 0) return SVIT_ERR_SHAPE;
   if (a->B * a->heads > 65535) return SVIT_ERR_SHAPE;
   if (a->DA != 128 && a->DA != 160) return SVIT_ERR_SHAPE;
@@ -829,15 +744,6 @@ extern "C" int svit_attn_bwd(const svit_attn_bwd_args* a, void* stream) {
   const int bias_cols = a->bias_cols > 0 ? a->bias_cols : a->DA - 96;
   const int ksu = 6 + (bias_cols + 15) / 16;
   hipStream_t st = (hipStream_t)stream;
-  int rc;
-  if (a->DA == 128) rc = ksu <= 7 ? launch_bwd<128, 7>(*a, st) : launch_bwd<128, 8>(*a, st);
-  else rc = ksu <= 9 ? launch_bwd<160, 9>(*a, st) : launch_bwd<160, 10>(*a, st);
-  if (rc == SVIT_OK && a->qln_pre) {      // second stage of the fused LayerNorm backward's dgamma / dbeta (queued like every other reduce)
-    const int wgs = ((a->Nq + 127) / 128) * a->B * a->heads;
-    SvitReduceDst dst = {{a->qln_dgamma, a->qln_dbeta, a->qln_dbeta, a->qln_dbeta, a->qln_dbeta, a->qln_dbeta},
-                         {attn::HD, 2 * attn::HD, 2 * attn::HD, 2 * attn::HD, 2 * attn::HD, 2 * attn::HD}};
-    svit_launch_reduce(a->qln_ws, wgs, 2 * attn::HD, dst, st);
-    SVIT_LAUNCH_CHECK();
-  }
-  return rc;
+  if (a->DA == 128) return ksu <= 7 ? launch_bwd<128, 7>(*a, st) : launch_bwd<128, 8>(*a, st);
+  return ksu <= 9 ? launch_bwd<160, 9>(*a, st) : launch_bwd<160, 10>(*a, st);
 }

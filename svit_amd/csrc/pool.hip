@@ -2556,10 +2556,7 @@ extern "C" int svit_pool_weight_sel(const float* src_base, const int64_t* src_of
   return SVIT_OK;
 }
 
-static int check_pool_ln_bwd(const svit_pool_ln_bwd_args* a, bool may_skip = false) {
-  // (q-k-v launch, round 6: an entry with Nout == 0 is SKIPPED -- the q tensor when svit_attn_bwd did its LayerNorm backward
-  //  itself (svit_attn_bwd_args.qln_*); only gamma / dgamma / dbeta must be valid, its partial rows are zeros)
-  if (may_skip && a->Nout == 0) return (a->gamma && a->dgamma && a->dbeta && a->B > 0 && a->heads > 0) ? SVIT_OK : SVIT_ERR_ARG;
+static int check_pool_ln_bwd(const svit_pool_ln_bwd_args* a) {
   if (!a->pre || !a->mean || !a->rstd || !a->gamma || !a->dpre || !a->dgamma || !a->dbeta)
     return SVIT_ERR_ARG;
   if (a->B <= 0 || a->heads <= 0 || a->Nout <= 0) return SVIT_ERR_SHAPE;
@@ -2572,7 +2569,7 @@ extern "C" int svit_pool_ln_bwd_qkv(const svit_pool_ln_bwd_args* a3, void* strea
   PoolLnBwd3 g;
   int64_t max_total = 0;
   for (int i = 0; i < 3; ++i) {
-    const int rc = check_pool_ln_bwd(&a3[i], true);
+    const int rc = check_pool_ln_bwd(&a3[i]);
     if (rc) return rc;
     g.p[i] = a3[i];
     const int64_t total = (int64_t)a3[i].B * a3[i].heads * a3[i].Nout;
@@ -2583,7 +2580,7 @@ extern "C" int svit_pool_ln_bwd_qkv(const svit_pool_ln_bwd_args* a3, void* strea
   if (blocks < 128) blocks = (max_total + 63) / 64 < 128 ? (max_total + 63) / 64 : 128;
   if (blocks > 1024) blocks = 1024;
   if (blocks > a3[0].workspace_floats / (6 * HD)) blocks = a3[0].workspace_floats / (6 * HD);
-  if (blocks < 1) return SVIT_ERR_ARG;     // (every entry skipped, or no workspace)
+  if (blocks < 1) return SVIT_ERR_ARG;
   hipLaunchKernelGGL(pool_ln_bwd3_kernel, dim3((unsigned)blocks, 3), dim3(256), 0,
                      (hipStream_t)stream, g);
   SVIT_LAUNCH_CHECK();

@@ -209,17 +209,13 @@ class Engine:
         # round 4: RED_GROUP consecutive blocks share ONE deferred launch (17 -> 5 reduce launches per step): every
         # block of a group owns its own copy of the scratch, the queue is run when the group's last block is done --
         # in front of the gradient-ready callback of the data-parallel buckets, which are four blocks wide as well
-        # (1 = one launch per block, the round-3 schedule).  Scratch: RED_GROUP x 76 MB of fp32 partial rows.
+        # (1 = one launch per block, the round-3 schedule).  Scratch: RED_GROUP x 72 MB of fp32 partial rows.
         self.RED_GROUP = max(1, int(red_group))
         M1 = 1024 * 1024
-        self._red_ws = torch.empty(self.RED_GROUP * 19 * M1, device=self.dev, dtype=F32)
+        self._red_ws = torch.empty(self.RED_GROUP * 18 * M1, device=self.dev, dtype=F32)
         self._red_slot = 0
         self._red_regions = {"ln2": (0, 4 * M1), "ln1": (4 * M1, 8 * M1), "pln": (8 * M1, 9 * M1),
-                             "wgrad": (9 * M1, 18 * M1), "qln": (18 * M1, 19 * M1)}
-        # round 6: the pooled-q LayerNorm backward inside the attention dq kernel wherever that kernel holds the whole dq
-        # (the "fold" blocks: rel-pos tables of <= 128 padded rows, i.e. every block but the 56x56 one); False = the q tensor
-        # stays in svit_pool_ln_bwd_qkv's launch (tests / tools flip the attribute)
-        self.fused_qln = True
+                             "wgrad": (9 * M1, 18 * M1)}
         # the grouped weight-gradient GEMM leaves the dgrad chain: it runs on a second stream next
         # to the latency-bound kernels of the chain (its fp32 atomics execute at the memory side,
         # so nothing of the chain depends on it) and is joined only where gradients must be final
@@ -492,7 +488,7 @@ class Engine:
 
     def _rws(self, key):
         a, b = self._red_regions[key]
-        o = self._red_slot * 19 * 1024 * 1024
+        o = self._red_slot * 18 * 1024 * 1024
         return self._red_ws[o + a:o + b]
 
     def _fork(self, fn, keep):
@@ -586,19 +582,12 @@ class Engine:
                 rcat[o:o + t.shape[0]] = t
             rcat_t = rcat.t().contiguous().to(BF16)
         # the dq kernel writes D itself (its epilogue holds d(relq) of whole rows): no scatter launch
-        qln_done = False
         if self.fused_scatter:
             dmap = self._relq_map(blk, q_thw, k_thw, sv["idx"], offs, n_obj, qa.shape[-1] - HD)
-            rt = rcat_t if rcat_t.is_contiguous() else None
-            # the kernel folds D . R^T into dq for tables of <= 128 padded rows: dq is then the whole gradient of the pooled q
-            # and the kernel does norm_q's backward too (round 6) -- dqa is never written, the first result is dpre_q
-            qln_done = self.fused_qln and rt is not None and lpad <= 128 and lpad % 16 == 0
             dqa, dk, dv, D, dq_extra = ops.attn_bwd(
                 qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE,
                 q_splits=1 if self.deterministic else self.attn_q_splits, bias_cols=sum(sv["k_thw"]),
-                reld=(dmap, lpad, LOG2E, rt, "fold"),
-                qln=(preq, mq, rq, f.p(pre + "attn.norm_q.weight"), f.g(pre + "attn.norm_q.weight"),
-                     f.g(pre + "attn.norm_q.bias"), self._rws("qln")) if qln_done else None)
+                reld=(dmap, lpad, LOG2E, rcat_t if rcat_t.is_contiguous() else None, "fold"))
         else:   # (measurements only: engine.fused_scatter = False)
             dqa, dk, dv = ops.attn_bwd(qa, ka, v, sv["ctx"], dctx.view(B, Nq, Co), sv["lse2"], SCALE,
                                        q_splits=1 if self.deterministic else self.attn_q_splits,
@@ -628,16 +617,10 @@ class Engine:
                                              d_extra=dq_extra)),
                 ("k", prek, mk, rk, Nk, dict(d_main=dk, ld_main=HD)),
                 ("v", prev, mv, rv, Nk, dict(d_main=dv, ld_main=HD))):
-            if r == "q" and qln_done:
-                entries.append(("skip", f.p(pre + "attn.norm_q.weight"), f.g(pre + "attn.norm_q.weight"),
-                                f.g(pre + "attn.norm_q.bias"), B, h))
-                continue
             entries.append(((pre_t, mean, rstd, f.p(pre + "attn.norm_%s.weight" % r),
                              f.g(pre + "attn.norm_%s.weight" % r),
                              f.g(pre + "attn.norm_%s.bias" % r), B, h, nout), kw))
         dpres = ops.pool_ln_bwd_qkv(entries, ws=self._rws("pln"))   # q, k, v: one launch per stage
-        if qln_done:
-            dpres[0] = dqa          # (= dpre_q, written by the dq kernel)
         strides = (sq, skv, skv)
         # conv dgrad + conv wgrad: one kernel with dpre in LDS for the small planes (blocks >= 4),
         # the two streaming launches otherwise (decided inside the library)

@@ -103,9 +103,7 @@ class AttnBwdArgs(C.Structure):
                 ("delta", vp), ("dqa", vp), ("dk", vp), ("dv", vp), ("B", i32), ("heads", i32),
                 ("Nq", i32), ("Nk", i32), ("DA", i32), ("q_splits", i32), ("scale", f32),
                 ("bias_cols", i32), ("relD", vp), ("relD_ld", i32), ("relD_map", vp), ("relD_scale", f32),
-                ("relR", vp), ("relX", vp),
-                ("qln_pre", vp), ("qln_mean", vp), ("qln_rstd", vp), ("qln_gamma", vp), ("qln_dpre", vp),
-                ("qln_dgamma", vp), ("qln_dbeta", vp), ("qln_ws", vp), ("qln_ws_floats", i64)]
+                ("relR", vp), ("relX", vp)]
 
 
 class HeadArgs(C.Structure):

@@ -404,22 +404,9 @@ def pool_ln_bwd(pre, mean, rstd, gamma, dgamma, dbeta, B, heads, Nout, d_main=No
 
 
 def pool_ln_bwd_qkv(entries, ws=None):
-    """entries: 3 x (args tuple, kwargs dict) of pool_ln_bwd -> [dpre] * 3, one launch.  An entry may be
-    ("skip", gamma, dgamma, dbeta, B, heads): that tensor's LayerNorm backward was done elsewhere (the q tensor inside
-    svit_attn_bwd, round 6) -- its result slot is None."""
+    """entries: 3 x (args tuple, kwargs dict) of pool_ln_bwd -> [dpre] * 3, one launch."""
     arr = (hip.PoolLnBwdArgs * 3)()
-    res = []
-    for i in range(3):
-        e = entries[i]
-        if e[0] == "skip":
-            _, gamma, dgamma, dbeta, B, heads = e
-            a = arr[i]
-            a.gamma, a.dgamma, a.dbeta, a.B, a.heads, a.Nout = ptr(gamma), ptr(dgamma), ptr(dbeta), B, heads, 0
-            w = scratch(gamma.device) if ws is None else ws
-            a.workspace, a.workspace_floats = ptr(w), w.numel()
-            res.append(None)
-        else:
-            res.append(_pool_ln_bwd_args(arr[i], *e[0], ws=ws, **e[1]))
+    res = [_pool_ln_bwd_args(arr[i], *entries[i][0], ws=ws, **entries[i][1]) for i in range(3)]
     hip.call("svit_pool_ln_bwd_qkv", arr)
     return res
 
@@ -528,17 +515,14 @@ def attn_fwd(qa, ka, v, scale, bias_cols=0):
     return ctx, lse2
 
 
-def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0, bias_cols=0, reld=None, qln=None):
+def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0, bias_cols=0, reld=None):
     """-> dqa bf16 [B,h,Nq,DA], dk f32 [parts,B,h,Nk,96], dv f32 [parts,B,h,Nk,96]: the gradients of k
     and v are the SUMS over the leading axis (one plane per chunk of the query range; pool_ln_bwd
     adds them while it reads).  reld = (map i32 [Nq, DA - 96], ldd, scale[, rt]): the dq kernel also writes the
     rel-pos backward's scattered matrix D bf16 [B*h*Nq, ldd] (what relpos_scatter builds), returned 4th, and --
     given rt = the transposed tables bf16 [96, ldd], ldd <= 128 -- dq_extra = D . rt^T f32 [B*h*Nq, 96], returned
     5th (None when it was not computed: the caller then runs the GEMM); with a fifth element "fold" the product
-    is added into dqa[..., :96] inside the kernel instead and the 5th result is the string "folded".
-    qln = (pre bf16 [B,h,Nq,96], mean, rstd, gamma, dgamma, dbeta, ws) (round 6; needs the "fold" mode or no reld at all): the dq
-    kernel also does the pooled-q LayerNorm's backward (d_main = its dq rows, d_res = dctx) -- the FIRST result is then dpre_q
-    bf16 [B,h,Nq,96] instead of dqa, which is never written; dgamma / dbeta are accumulated."""
+    is added into dqa[..., :96] inside the kernel instead and the 5th result is the string "folded"."""
     _chk_dev(qa, ka, v, ctx, dctx, lse2)
     B, heads, Nq, DA = qa.shape
     Nk = ka.shape[2]
@@ -549,7 +533,7 @@ def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0, bias_cols=0, reld=No
     parts = hip.load().svit_attn_bwd_parts(C.byref(a))
     if parts < 1:
         raise hip.SvitHipError("svit_attn_bwd_parts failed: %d" % parts)
-    dqa = torch.empty((B, heads, Nq, DA), device=dev, dtype=BF16) if qln is None else None
+    dqa = torch.empty((B, heads, Nq, DA), device=dev, dtype=BF16)
     dkv = torch.empty((2, parts, B, heads, Nk, HD), device=dev, dtype=F32)
     delta = torch.empty((B, heads, Nq, 2), device=dev, dtype=F32)
     a.qa, a.ka, a.v, a.ctx, a.dctx, a.lse2 = (ptr(t) for t in (qa, ka, v, ctx, dctx, lse2))
@@ -575,15 +559,6 @@ def attn_bwd(qa, ka, v, ctx, dctx, lse2, scale, q_splits=0, bias_cols=0, reld=No
     # (the D . R^T product of the rel-pos backward, when this launch carries it: 2 * rows * 96 * ldd flops that the
     # step used to spend in a GEMM launch of its own -- bench.py adds them to this kernel's algorithmic count)
     folded = 2.0 * B * heads * Nq * HD * reld[1] if (reld is not None and X is not None) else 0.0
-    if qln is not None:
-        pre, mean, rstd, gamma, dgamma, dbeta, ws = qln
-        _chk_dev(pre, mean, rstd, gamma, dgamma, dbeta, ws)
-        assert reld is None or X == "folded", "the fused LayerNorm backward needs the whole dq in the kernel (fold mode)"
-        assert pre.dtype == BF16 and pre.is_contiguous() and tuple(pre.shape) == (B, heads, Nq, HD)
-        dqa = torch.empty((B, heads, Nq, HD), device=dev, dtype=BF16)          # = dpre_q
-        a.qln_pre, a.qln_mean, a.qln_rstd, a.qln_gamma = ptr(pre), ptr(mean), ptr(rstd), ptr(gamma)
-        a.qln_dpre, a.qln_dgamma, a.qln_dbeta = ptr(dqa), ptr(dgamma), ptr(dbeta)
-        a.qln_ws, a.qln_ws_floats = ptr(ws), ws.numel()
     hip.call("svit_attn_bwd", C.byref(a), meta=("attn", B, heads, Nq, Nk, DA, folded))
     if reld is not None:
         return dqa, dkv[0], dkv[1], D, X
