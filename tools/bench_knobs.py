@@ -2,7 +2,7 @@
 """bench.py with tuning knobs set first -- the in-step A/B runner (the library reads no environment variable; the
 declared svit_debug_* entry points of include/svit_hip.h are the only switches, and the product bench never calls them).
 
-    python tools/bench_knobs.py --set pool:1=0 --set attn:1=1 -- --steps 20 --warmup 5 --no-cpu-baseline
+    python tools/bench_knobs.py --set pool:0=1 --set attn:0=1 -- --steps 20 --warmup 5 --no-cpu-baseline
 
 families: nt:<key>=<v> (svit_debug_set), tn_tile=<mode>, tn=<step_us_x100>,<tbs_x100>, pool:<key>=<v>
 (svit_debug_set_pool), attn:<key>=<v> (svit_attn_debug_set).  The line bench.py prints gets a "knobs" entry.  GPU box."""

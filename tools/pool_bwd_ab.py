@@ -2,6 +2,9 @@
 """Pooling conv backward of q, k, v at the step's shapes: the fused kernel (pool_bwd_fused_kernel, one launch) against the
 streaming launches it replaces (pool_dgrad3 + pool_wgrad3; svit_debug_set_pool(1, 0)), isolated loops, us per call
 (incl. the second-stage reduce).  GPU box.   python tools/pool_bwd_ab.py [B]"""
+# NOTE (round 6): the knob-off arm (svit_debug_set_pool(1, 0) -> the streaming launches) exists only in a -DSVIT_DIAG_POOL_STREAMING build
+# (python tools/diag/build_variant.py poolstream pool.hip -DSVIT_DIAG_POOL_STREAMING; SVIT_HIP_LIB=tools/diag/libsvit_diag_poolstream.so):
+# against the product library the entry point returns SVIT_ERR_SHAPE with the fused kernel refused, and this tool stops there.
 import os
 import sys
 
