@@ -139,6 +139,11 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return x * cdf;
 }
 __device__ __forceinline__ void gelu_fwd_grad(float x, float* y, float* dydx) {
+#ifdef SVIT_DIAG_GELU_FREE      // (diagnostic build, TIMING ONLY: what the fc1 epilogue's GELU / GELU' arithmetic costs inside the step:
+                                //  0.13-0.17 ms, profiles/r06_gelu_epilogue.txt; a Phi / phi table in LDS was measured 0.10 ms SLOWER than this math)
+  *y = 0.5f * x; *dydx = 0.5f;
+  return;
+#endif
   float cdf, pdf;
   gelu_parts(x, &cdf, &pdf);
   *y = x * cdf;
