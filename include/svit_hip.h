@@ -269,6 +269,9 @@ int svit_pool_conv_wgrad_qkv(const svit_pool_wgrad_args* args3, void* stream);
  * B * heads * chunks * 3 * 27 * 96 floats. */
 int svit_pool_conv_bwd_qkv(const svit_pool_dgrad_args* dgrad3, const svit_pool_wgrad_args* wgrad3,
                            void* stream);
+/* floats of wgrad3[0].workspace that call needs for these tensors (B * heads * chunks of its plan * 3 * 27 * 96; grows with the
+ * batch), -1 = the fused kernel has no plan for them, < -1 = error code.  Only the shape fields of dgrad3 are read. */
+int64_t svit_pool_conv_bwd_workspace(const svit_pool_dgrad_args* dgrad3);
 
 /* ------------------------------------------- decomposed rel-pos bias, query side (K9/K10) */
 /* cal_rel_pos_spatial / cal_rel_pos_temporal (attention.py:84-183) restated as

@@ -2724,6 +2724,19 @@ static bool plan_bwd_fused_cached(const svit_pool_dgrad_args* d3, PoolBwdFused* 
   return e.ok;
 }
 
+// floats of workspace svit_pool_conv_bwd_qkv needs for these three tensors (one partial row of the three dw per (batch, head, chunk) of
+// its plan); -1 where the fused kernel has no plan.  Callers with a fixed scratch region ask first and bring a larger buffer when the
+// batch outgrows it (the entry point refuses a workspace that is too small: the product library has no other conv backward).
+extern "C" int64_t svit_pool_conv_bwd_workspace(const svit_pool_dgrad_args* d3) {
+  if (!d3) return SVIT_ERR_ARG;
+  for (int i = 0; i < 3; ++i)
+    if (check_pool_dims(d3[i].B, d3[i].heads, d3[i].T, d3[i].H, d3[i].W, d3[i].n_obj, d3[i].stride_hw)) return SVIT_ERR_SHAPE;
+  PoolBwdFused g;
+  size_t lds = 0;
+  if (!plan_bwd_fused_cached(d3, &g, &lds)) return -1;
+  return (int64_t)d3[0].B * d3[0].heads * g.max_chunks * 3 * 27 * HD;
+}
+
 // which path the last svit_pool_conv_bwd_qkv call of this process took: 1 the fused plane-walk kernel, 0 the two streaming launches
 // (planes that do not fit, a workspace smaller than the plan's partial rows, the knob), -1 none yet.  Diagnostics / tests: a parity
 // test of the fused kernel must not pass on a silent fallback.
@@ -2748,7 +2761,7 @@ extern "C" int svit_pool_conv_bwd_qkv(const svit_pool_dgrad_args* d3, const svit
   size_t lds = 0;
   bool fused = svit_knob(SVIT_K_POOL_BWD) != 0 && plan_bwd_fused_cached(d3, &g, &lds);
   const int64_t prows = fused ? (int64_t)d3[0].B * d3[0].heads * g.max_chunks : 0;
-  if (fused && (!w3[0].workspace || w3[0].workspace_floats < prows * 3 * 27 * HD || prows > 4096)) fused = false;
+  if (fused && (!w3[0].workspace || w3[0].workspace_floats < prows * 3 * 27 * HD || prows > 65536)) fused = false;
   __atomic_store_n(&g_pool_bwd_last_path, fused ? 1 : 0, __ATOMIC_RELAXED);
   if (!fused) {
 #ifdef SVIT_DIAG_POOL_STREAMING      // (diagnostic build: the two streaming launches of rounds 1-4, also the knob-off arm)

@@ -214,6 +214,7 @@ class Engine:
         M1 = 1024 * 1024
         self._red_ws = torch.empty(self.RED_GROUP * 18 * M1, device=self.dev, dtype=F32)
         self._red_slot = 0
+        self._wgrad_need, self._wgrad_big = {}, {}
         self._red_regions = {"ln2": (0, 4 * M1), "ln1": (4 * M1, 8 * M1), "pln": (8 * M1, 9 * M1),
                              "wgrad": (9 * M1, 18 * M1)}
         # the grouped weight-gradient GEMM leaves the dgrad chain: it runs on a second stream next
@@ -491,6 +492,22 @@ class Engine:
         o = self._red_slot * 18 * 1024 * 1024
         return self._red_ws[o + a:o + b]
 
+    def _wgrad_ws(self, B, h, thw, n_obj, strides):
+        """workspace of the fused pooling backward's partial rows for this block: the slot's fixed 9 M-float region (sized for
+        8 clips of 16x224^2), or -- when the batch outgrows it (round 6: the product library has no streaming fallback any
+        more) -- a buffer of the plan's size kept per scratch slot (the rows are read by the group's DEFERRED reduce)."""
+        key = (B, h, tuple(thw), n_obj, tuple(strides))
+        need = self._wgrad_need.get(key)
+        if need is None:
+            need = self._wgrad_need[key] = ops.pool_conv_bwd_workspace(B, h, thw, n_obj, strides)
+        ws = self._rws("wgrad")
+        if need <= ws.numel():
+            return ws
+        big = self._wgrad_big.get(self._red_slot)
+        if big is None or big.numel() < need:
+            big = self._wgrad_big[self._red_slot] = torch.empty(need, device=self.dev, dtype=F32)
+        return big
+
     def _fork(self, fn, keep):
         """run fn() on the side stream, after everything enqueued so far on the current one"""
         if not self.overlap_wgrad:
@@ -627,7 +644,7 @@ class Engine:
         ops.pool_conv_bwd_qkv(dpres, [f.p(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
                               dqkv, sv["qkv"],
                               [f.g(pre + "attn.pool_%s.weight" % r).view(HD, 27) for r in "qkv"],
-                              B, h, thw, n_obj, strides, ws=self._rws("wgrad"))
+                              B, h, thw, n_obj, strides, ws=self._wgrad_ws(B, h, thw, n_obj, strides))
         # (bf16 unless the dim-change projection accumulates into it below)
         dxn = self._linear_bwd(dqkv, sv["xn"], pre + "attn.qkv.weight", pre + "attn.qkv.bias", True,
                                epilogue=hip.EPI_F32 if blk.has_proj else hip.EPI_BF16)

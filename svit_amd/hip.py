@@ -151,6 +151,7 @@ _SIGS = {
     "svit_pool_weight_sel": (i32, [vp, vp, vp, i32, vp]),
     "svit_pool_ln_bwd_qkv": (i32, [C.POINTER(PoolLnBwdArgs), vp]),
     "svit_pool_conv_bwd_qkv": (i32, [C.POINTER(PoolDgradArgs), C.POINTER(PoolWgradArgs), vp]),
+    "svit_pool_conv_bwd_workspace": (i64, [C.POINTER(PoolDgradArgs)]),
     "svit_relpos_q_fwd": (i32, [C.POINTER(RelqArgs), vp]),
     "svit_relpos_q_bwd": (i32, [C.POINTER(RelqBwdArgs), vp]),
     "svit_relpos_scatter": (i32, [C.POINTER(RelqScatterArgs), vp]),

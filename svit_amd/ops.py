@@ -429,8 +429,21 @@ def _pool_wgrad_args(a, dpre, qkv, which, dw, B, heads, thw, n_obj, stride_hw, w
 
 
 
+def pool_conv_bwd_workspace(B, heads, thw, n_obj, strides):
+    """floats of workspace pool_conv_bwd_qkv needs for this geometry (grows with the batch); -1 = no plan."""
+    da = (hip.PoolDgradArgs * 3)()
+    for i in range(3):
+        da[i].B, da[i].heads, (da[i].T, da[i].H, da[i].W), da[i].n_obj, da[i].stride_hw, da[i].which = B, heads, thw, n_obj, strides[i], i
+    return int(hip.load().svit_pool_conv_bwd_workspace(da))
+
+
 def pool_conv_bwd_qkv(dpres, conv_ws, dqkv, qkv, dws, B, heads, thw, n_obj, strides, ws=None):
-    """conv dgrad + conv wgrad of q, k, v: one fused launch (csrc/pool.hip::pool_bwd_fused_kernel)."""
+    """conv dgrad + conv wgrad of q, k, v: one fused launch (csrc/pool.hip::pool_bwd_fused_kernel).  ws: the workspace of its
+    partial rows (>= pool_conv_bwd_workspace(...) floats; it must outlive the deferred second-stage reduce); None = a per-device
+    scratch of the needed size."""
+    if ws is None:
+        need = pool_conv_bwd_workspace(B, heads, thw, n_obj, strides)
+        ws = scratch(dpres[0].device, max(8 * 1024 * 1024, need), tag="poolbwd")
     da = (hip.PoolDgradArgs * 3)()
     wa = (hip.PoolWgradArgs * 3)()
     for i in range(3):

@@ -343,3 +343,44 @@ def test_grouped_second_stage_reductions_equal_ungrouped():
         grads.append(model.flat.grad.clone())
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
     assert float(grads[0].abs().max()) > 0
+
+
+def test_batch_that_outgrows_the_fixed_pooling_scratch():
+    """Round 6: the product library has no streaming fallback for the pooling conv backward, so a step whose fused-kernel plan needs
+    more partial rows than the engine's fixed scratch region (9 M floats: 8 clips of 16x224^2; 16 clips outgrow it) must get a
+    buffer of the plan's size (svit_pool_conv_bwd_workspace, Engine._wgrad_ws) instead of an error.  Here the fixed region is
+    shrunk to 1000 floats on the tiny model so that EVERY block takes the grown buffers: the gradient must be bit-equal to the
+    default engine's (deterministic mode); `bench.py --batch 16 / 32` is the full-size run (profiles/r06_throughput_vs_batch.txt)."""
+    grads = []
+    for shrink in (False, True):
+        cfg, model, spec, sd = S.build_hip_model(4, 64)
+        eng = model.engine
+        eng.deterministic = True
+        if shrink:
+            lo, _ = eng._red_regions["wgrad"]
+            eng._red_regions["wgrad"] = (lo, lo + 1000)
+        model.flat.grad.zero_()
+        logits, _ = model([P.frames(3, 4, 64).cuda()], {})
+        torch.nn.functional.cross_entropy(logits, P.labels(3).cuda()).backward()
+        torch.cuda.synchronize()
+        assert bool(eng._wgrad_big) == shrink and all(n > 1000 for n in eng._wgrad_need.values())
+        grads.append(model.flat.grad.clone())
+    assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().max()) > 0
+
+
+def test_pool_conv_bwd_refuses_a_workspace_that_is_too_small():
+    """svit_pool_conv_bwd_workspace is exact: a workspace of that many floats runs the fused kernel, one float less is refused
+    (SVIT_ERR_SHAPE: the product library has no other conv backward -- a silent fallback used to hide this)."""
+    from svit_amd import hip, ops
+    B, h, thw, O, strides = 2, 4, (8, 14, 14), 5, (1, 2, 2)
+    need = ops.pool_conv_bwd_workspace(B, h, thw, O, strides)
+    assert need > 0 and need % (3 * 27 * 96) == 0
+    N = 1 + thw[0] * thw[1] * thw[2] + O
+    qkv = torch.randn(B, N, 3, h, 96, device="cuda").bfloat16()
+    ws_ = [torch.randn(96, 27, device="cuda") * 0.2 for _ in range(3)]
+    dpres = [torch.randn(B, h, 1 + thw[0] * ops.pooled(thw[1], s) * ops.pooled(thw[2], s) + O, 96, device="cuda").bfloat16() for s in strides]
+    dws = [torch.zeros(96, 27, device="cuda") for _ in range(3)]
+    ops.pool_conv_bwd_qkv(dpres, ws_, torch.empty_like(qkv), qkv, dws, B, h, thw, O, strides, ws=torch.empty(need, device="cuda"))
+    assert hip.load().svit_debug_pool_bwd_path() == 1
+    with pytest.raises(hip.SvitHipError):
+        ops.pool_conv_bwd_qkv(dpres, ws_, torch.empty_like(qkv), qkv, dws, B, h, thw, O, strides, ws=torch.empty(need - 1, device="cuda"))
